@@ -1,0 +1,99 @@
+/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v1") and of the packed data layout.
+ *
+ * The reference delegates gene-vs-contig alignment to the third-party rammappy 0.1.3 wheel
+ * (src/kaptive/serotyping/core.py:147-155), whose source is not in the reference tree; parity at that stage is
+ * UNPINNED. This header is therefore the specification of the replacement: the HIP kernels
+ * (kaptive_amd/csrc) and the CPU restatement (oracle/kp_oracle.c) both include it and must agree bit for bit.
+ * Parameters follow minimap2's documented defaults where the design has an equivalent (k, scoring, -s 80 peak score,
+ * >=3 seeds and >=40 seeded bases per chain); DESIGN.md lists every deviation.
+ */
+#ifndef KP_SPEC_H
+#define KP_SPEC_H
+
+#include <stdint.h>
+
+/* ---- base codes -------------------------------------------------------------------------------------------------
+ * A C G T(U) = 0 1 2 3, case-insensitive; every other byte is "N" (code 4).  Packed streams hold 2 bits per base,
+ * 16 bases per little-endian uint32 (base i of a word at bits 2i..2i+1); N positions are stored as code 0 and listed
+ * separately as sorted, disjoint [start,end) runs in the same coordinate space. */
+#define KP_CODE_N 4
+
+/* ---- assembly layout --------------------------------------------------------------------------------------------
+ * An assembly is one padded coordinate space: contig c occupies [ctg_start[c], ctg_start[c]+ctg_len[c]) and every
+ * ctg_start is a multiple of KP_CONTIG_ALIGN; the gap up to the next contig is code 0.  Assemblies of a batch are
+ * laid back to back, each starting on a KP_ASM_ALIGN boundary. */
+#define KP_CONTIG_ALIGN 32u
+#define KP_ASM_ALIGN 64u
+
+/* ---- seeding ----------------------------------------------------------------------------------------------------
+ * A k-mer starts at position p of a sequence iff the context-free rule
+ *        (c[p] ^ c[p+1] ^ c[p+3]) == KP_SEED_RULE_VALUE              (c = 2-bit codes)
+ * holds, p+K <= sequence end, and no N lies in [p, p+K).  Contigs are scanned on their forward strand only; the
+ * database side indexes every gene twice (forward sequence and its reverse complement) under the same rule, so a
+ * shared k-mer gives the anchor its strand.  Expected density 1/4. */
+#define KP_K 15
+#define KP_KMER_MASK 0x3FFFFFFFu
+#define KP_SEED_RULE_VALUE 1u
+#define KP_MAX_GENE_LEN 65535 /* q positions are stored in 16 bits */
+#define KP_MAX_GENES 131071   /* (gene*2+strand) is stored in 18 bits */
+#define KP_MAX_ASM_LEN ((1u << 30) - 65536u)
+
+/* anchor key (sortable): [gs:18][diag:30][qpos:16], diag = tpos - qpos + 65536, gs = gene*2 + (strand<0) */
+#define KP_DIAG_BIAS 65536
+#define KP_ANCHOR_KEY(gs, diag, qpos) (((uint64_t)(gs) << 46) | ((uint64_t)(diag) << 16) | (uint64_t)(qpos))
+#define KP_KEY_GS(k) ((uint32_t)((k) >> 46))
+#define KP_KEY_DIAG(k) ((uint32_t)(((k) >> 16) & 0x3FFFFFFFu))
+#define KP_KEY_QPOS(k) ((uint32_t)((k) & 0xFFFFu))
+
+/* ---- anchors -> DP tasks ----------------------------------------------------------------------------------------
+ * Anchors of one assembly are sorted by key and cut into clusters: a new cluster starts when gs changes, the contig
+ * changes, the diagonal jumps by more than KP_DIAG_GAP, or the cluster would span more than KP_MAX_SPREAD diagonals.
+ * A cluster becomes a task when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases
+ * (qmax - qmin + K).  Its band is the anchors' diagonal range widened by KP_BAND_MARGIN on both sides, rounded up to
+ * 32, 64 or 128 diagonals and centred. */
+#define KP_DIAG_GAP 32
+#define KP_BAND_MARGIN 15
+#define KP_MAX_BAND 128
+#define KP_MAX_SPREAD (KP_MAX_BAND - 2 * KP_BAND_MARGIN - 1)
+#define KP_MIN_ANCHORS 3
+#define KP_MIN_SEED_SPAN 40
+
+/* ---- banded local alignment (Smith-Waterman-Gotoh, int32) ----------------------------------------------------------
+ * H = max(0, Hdiag + s, E, F);  E (gap in query, moves along the target) = max(Hleft - (O+X), Eleft - X);
+ * F (gap in target, moves along the query) = max(Hup - (O+X), Fup - X).  Opening wins ties against extending; the
+ * diagonal wins ties against E, E against F; a cell whose best is <= 0 is a restart cell.  The reported cell is the
+ * first maximum in (query row, target column) order.  Cells outside the band or the contig read as H=0, E=F=-inf.
+ * Hits scoring below KP_MIN_DP_SCORE are dropped. */
+#define KP_SC_MATCH 2
+#define KP_SC_MISMATCH (-4)
+#define KP_SC_N (-1) /* either base is N */
+#define KP_GAP_OPEN 4
+#define KP_GAP_EXT 2
+#define KP_MIN_DP_SCORE 80
+#define KP_NEG_INF (-(1 << 29))
+
+/* ---- protein alignment (restates src/kaptive/core/pairwise.py:395-584) ------------------------------------------------ */
+#define KP_PROT_GAP_OPEN 11
+#define KP_PROT_GAP_EXT 1
+#define KP_PROT_K 20
+#define KP_PROT_NEG_INF (-1000000000)
+#define KP_PROT_FILL (-128) /* BLOSUM62 lookup value for bytes outside ARNDCQEGHILKMFPSTWYVBJZX* */
+
+/* ---- hit record (one per reported alignment; emission order: gene asc, score desc, contig asc, t_start asc,
+ * forward strand first, q_start asc; exact duplicates are emitted once) -------------------------------------------- */
+typedef struct kp_hit {
+    int32_t gene;    /* database gene index */
+    int32_t contig;  /* contig index within the assembly */
+    int32_t q_start; /* on the gene's forward strand, 0-based half-open */
+    int32_t q_end;
+    int32_t t_start; /* on the contig's forward strand, 0-based half-open */
+    int32_t t_end;
+    int32_t score;
+    int32_t matches;   /* identical aligned bases */
+    int32_t block_len; /* alignment columns */
+    int8_t strand;     /* +1 / -1 */
+    uint8_t mapq;      /* 60 for the first (best) hit of a gene in emission order, else 0 */
+    uint8_t pad_[2];
+} kp_hit;
+
+#endif /* KP_SPEC_H */

@@ -1,0 +1,133 @@
+"""GenomeAssembly: contigs of one assembly plus its device-ready packed form.
+
+Interface of the reference's ``kaptive.core.genome`` (src/kaptive/core/genome.py:24-242): ``FastaReader``,
+``GenomeAssembly.ensure/from_file/from_stream/from_records``, ``id_map``. The reference hands the file bytes to
+``rammappy.fasta.parse_fasta_bytes`` and later builds a minimizer index per assembly (genome.py:45, 188-189); here the
+FASTA is split with numpy and, instead of an index, the assembly caches a 2-bit packing of its contigs
+(``packed()``), which is what the HIP aligner streams.
+"""
+
+from __future__ import annotations
+
+import bz2
+import gzip
+import lzma
+import re
+import threading
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import IO, Any, Iterable, Iterator
+
+import numpy as np
+
+from kaptive_amd.core.seq import SeqRecord, Sequences
+
+_WS = np.zeros(256, dtype=bool)
+_WS[[9, 10, 11, 12, 13, 32]] = True
+
+
+def parse_fasta_bytes(data: bytes) -> list[tuple[str, bytes]]:
+    """Split FASTA text into ``(name, sequence)`` pairs: name = first word of the header line, sequence = all
+    following lines up to the next ``>`` with whitespace removed. Text before the first header is ignored."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    if len(buf) == 0:
+        return []
+    line_start = np.r_[0, np.flatnonzero(buf == 10) + 1]
+    line_start = line_start[line_start < len(buf)]
+    headers = line_start[buf[line_start] == 62]
+    out: list[tuple[str, bytes]] = []
+    bounds = np.r_[headers, len(buf)]
+    for h, nxt in zip(bounds[:-1], bounds[1:]):
+        eol = h + int(np.argmax(buf[h:nxt] == 10)) if (buf[h:nxt] == 10).any() else nxt
+        words = data[h + 1 : eol].split()
+        body = buf[min(eol + 1, nxt) : nxt]
+        out.append((words[0].decode("utf-8", "replace") if words else "", body[~_WS[body]].tobytes()))
+    return out
+
+
+class FastaReader(Iterator):
+    """Iterates SeqRecords of a binary FASTA stream (the whole stream is read up front, as the reference does)."""
+
+    def __init__(self, handle: IO[bytes]) -> None:
+        self._handle = handle
+        self._records = iter(SeqRecord(name, seq) for name, seq in parse_fasta_bytes(handle.read()))
+
+    def __enter__(self) -> "FastaReader":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        self._handle.close()
+
+    def __iter__(self) -> "FastaReader":
+        return self
+
+    def __next__(self) -> SeqRecord:
+        return next(self._records)
+
+
+_FASTA_NAME = re.compile(r"\.(?P<ext>f(asta|a|na|fn|as))(\.(?P<compression>gz|bz2|xz))?$")
+_OPENERS = {"gz": gzip.open, "bz2": bz2.open, "xz": lzma.open}
+
+
+@dataclass(slots=True, frozen=True)
+class GenomeAssembly:
+    id: str
+    contigs: Sequences
+    id_map: dict[str, int] = field(init=False, repr=False, hash=False, compare=False)
+    _packed: list = field(default_factory=list, init=False, repr=False, hash=False, compare=False)
+    _lock: threading.Lock = field(default_factory=threading.Lock, init=False, repr=False, hash=False, compare=False)
+
+    def __post_init__(self) -> None:
+        object.__setattr__(self, "id_map", {name: i for i, name in enumerate(self.contigs.ids)})
+
+    def __len__(self) -> int:
+        return len(self.contigs.seqs)
+
+    def __iter__(self) -> Iterator[SeqRecord]:
+        return iter(self.contigs)
+
+    def __str__(self) -> str:
+        return self.id
+
+    def __getitem__(self, item: str) -> bytes:
+        i = self.id_map[item]
+        o, n = self.contigs.offsets[i], self.contigs.lengths[i]
+        return self.contigs.seqs[o : o + n].tobytes()
+
+    def packed(self):
+        """2-bit packing of the contigs (``kaptive_amd.pack.PackedAssembly``), built once under a lock so K and O
+        typers can share one assembly across threads (the reference guards its index the same way,
+        src/kaptive/core/genome.py:177-191)."""
+        if not self._packed:
+            with self._lock:
+                if not self._packed:
+                    from kaptive_amd.pack import pack_contigs
+
+                    self._packed.append(pack_contigs(self.contigs))
+        return self._packed[0]
+
+    @classmethod
+    def ensure(cls, genome: "GenomeAssembly | str | Path | IO[bytes]") -> "GenomeAssembly":
+        if isinstance(genome, cls):
+            return genome
+        if isinstance(genome, (str, Path)):
+            return cls.from_file(genome)
+        return cls.from_stream(genome)
+
+    @classmethod
+    def from_file(cls, filepath: str | Path) -> "GenomeAssembly":
+        filepath = Path(filepath)
+        m = _FASTA_NAME.search(filepath.name)
+        if not m:
+            raise NotImplementedError(f"Unsupported format: {filepath}")
+        with _OPENERS.get(m.group("compression"), open)(filepath, mode="rb") as handle:
+            return cls.from_stream(handle, filepath.name.removesuffix(m.group()))
+
+    @classmethod
+    def from_stream(cls, handle: IO[bytes], id_: str | None = None) -> "GenomeAssembly":
+        with FastaReader(handle) as records:
+            return cls.from_records(id_ or getattr(handle, "name", "unknown"), records)
+
+    @classmethod
+    def from_records(cls, id_: str, records: Iterable[SeqRecord]) -> "GenomeAssembly":
+        return cls(id_, Sequences.from_records(list(records)))

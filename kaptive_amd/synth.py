@@ -1,0 +1,234 @@
+"""Synthetic databases and assemblies shaped like the benchmark configs.
+
+No curated database or genome exists in the build container, so tests and bench use these
+generators; every draw comes from one ``numpy.random.default_rng(seed)``.
+
+* ``make_db("kpsc_k")``  163 loci x 16-30 CDS (600-1800 bp), 8 gene families shared by all loci at 85-99 % identity.
+* ``make_db("kpsc_o")``  13 loci x 6-10 CDS + 10 extra genes + 12 ``extra_genes`` phenotype rules.
+* ``make_db("ab_k")``    240 loci x 18-28 CDS.
+* ``make_assembly``      iid background (GC set per organism) with one mutated locus copy, cut into contigs.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from kaptive_amd.core.genome import GenomeAssembly
+from kaptive_amd.core.seq import COMP_MAP, SeqRecord, Sequences
+from kaptive_amd.db import Database
+
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+_STOPS = {b"TAA", b"TAG", b"TGA"}
+_SHARED = ("galF", "cpsACP", "wzi", "wza", "wzb", "wzc", "gnd", "ugd")
+
+DB_SHAPES = {
+    "kpsc_k": dict(n_loci=163, genes=(16, 30), shared=_SHARED, gc=0.57, n_extra=0, n_rules=0, prefix="KL",
+                   type_prefix="K", organism="Klebsiella pneumoniae species complex", taxon=573, antigen="K"),
+    "kpsc_o": dict(n_loci=13, genes=(6, 10), shared=("wzm", "wzt"), gc=0.57, n_extra=10, n_rules=12, prefix="OL",
+                   type_prefix="O", organism="Klebsiella pneumoniae species complex", taxon=573, antigen="O"),
+    "ab_k": dict(n_loci=240, genes=(18, 28), shared=("fkpA", "wzc", "wzb", "wza", "gna", "galU", "ugd", "gpi"),
+                 gc=0.39, n_extra=0, n_rules=0, prefix="KL", type_prefix="K", organism="Acinetobacter baumannii",
+                 taxon=470, antigen="K"),
+}  # fmt: skip
+
+
+def _base_probs(gc: float) -> np.ndarray:
+    return np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+
+
+def random_dna(rng: np.random.Generator, n: int, gc: float) -> np.ndarray:
+    return _ACGT[rng.choice(4, size=n, p=_base_probs(gc))]
+
+
+def _kill_internal_stops(orf: np.ndarray) -> None:
+    """In place: any in-frame stop before the last codon gets its first base set to C."""
+    body = orf[: len(orf) - 3].reshape(-1, 3)
+    t = body[:, 0] == ord("T")
+    stop = t & (
+        ((body[:, 1] == ord("A")) & ((body[:, 2] == ord("A")) | (body[:, 2] == ord("G"))))
+        | ((body[:, 1] == ord("G")) & (body[:, 2] == ord("A")))
+    )
+    body[stop, 0] = ord("C")
+
+
+def random_orf(rng: np.random.Generator, n_bp: int, gc: float) -> np.ndarray:
+    n_bp -= n_bp % 3
+    orf = random_dna(rng, n_bp, gc)
+    orf[:3] = np.frombuffer(b"ATG", np.uint8)
+    orf[-3:] = np.frombuffer((b"TAA", b"TAG", b"TGA")[rng.integers(3)], np.uint8)
+    _kill_internal_stops(orf)
+    return orf
+
+
+def mutate(rng: np.random.Generator, seq: np.ndarray, sub_rate: float, indel_rate: float = 0.0) -> np.ndarray:
+    out = seq.copy()
+    hit = np.flatnonzero(rng.random(len(out)) < sub_rate)
+    # a substitution always changes the base: add 1..3 in ACGT index space
+    idx = np.searchsorted(_ACGT, out[hit])
+    out[hit] = _ACGT[(idx + rng.integers(1, 4, size=len(hit))) % 4]
+    if indel_rate > 0:
+        sites = np.flatnonzero(rng.random(len(out)) < indel_rate)
+        for s in sites[::-1]:
+            k = int(rng.integers(1, 4))
+            if rng.random() < 0.5:
+                out = np.delete(out, slice(s, s + k))
+            else:
+                out = np.insert(out, s, random_dna(rng, k, 0.5))
+    return out
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    return COMP_MAP[seq[::-1]]
+
+
+def make_db(kind: str = "kpsc_k", seed: int = 100, n_loci: int | None = None, id_threshold: float = 82.5) -> Database:
+    shape = DB_SHAPES[kind]
+    rng = np.random.default_rng(seed)
+    gc = shape["gc"]
+    n_loci = n_loci or shape["n_loci"]
+    families = {name: random_orf(rng, int(rng.integers(600, 1801)), gc) for name in shape["shared"]}
+    loci = []
+    for li in range(n_loci):
+        name = f"{shape['prefix']}{li + 1}"
+        n_genes = int(rng.integers(shape["genes"][0], shape["genes"][1] + 1))
+        # shared families take the outer positions (first half up front, rest at the end), unique genes in between
+        fam = list(shape["shared"])
+        lead, tail = fam[: (len(fam) + 1) // 2], fam[(len(fam) + 1) // 2 :]
+        n_unique = max(n_genes - len(fam), 2)
+        order = lead + [None] * n_unique + tail
+        parts, genes = [random_dna(rng, int(rng.integers(50, 200)), gc)], []
+        pos = len(parts[0])
+        for gi, fam_name in enumerate(order):
+            if fam_name is None:
+                orf = random_orf(rng, int(rng.integers(600, 1801)), gc)
+                gname = f"wc{chr(97 + li % 26)}{chr(97 + gi % 26)}{li // 26}"
+                product = f"hypothetical protein {li}-{gi}"
+            else:
+                orf = mutate(rng, families[fam_name], float(rng.uniform(0.01, 0.15)))
+                orf[:3] = families[fam_name][:3]
+                orf[-3:] = families[fam_name][-3:]
+                _kill_internal_stops(orf)
+                gname, product = fam_name, f"{fam_name} family protein"
+            strand = 1 if (fam_name is not None or rng.random() < 0.8) else -1
+            parts.append(orf if strand == 1 else revcomp(orf))
+            genes.append(dict(start=pos, end=pos + len(orf), strand=strand, gene=gname, product=product))
+            pos += len(orf)
+            spacer = random_dna(rng, int(rng.integers(30, 151)), gc)
+            parts.append(spacer)
+            pos += len(spacer)
+        loci.append(dict(name=name, type=f"{shape['type_prefix']}{li + 1}", extra=False,
+                         seq=np.concatenate(parts).tobytes(), genes=genes))  # fmt: skip
+    logic = {}
+    if shape["n_extra"]:
+        parts, genes, pos = [], [], 0
+        for ei in range(shape["n_extra"]):
+            orf = random_orf(rng, int(rng.integers(600, 1501)), gc)
+            parts += [orf, random_dna(rng, 60, gc)]
+            genes.append(dict(start=pos, end=pos + len(orf), strand=1, gene=f"opx{ei}", product=f"modifier {ei}"))
+            pos += len(orf) + 60
+        loci.append(dict(name="Extra_genes", type="", extra=True, seq=np.concatenate(parts).tobytes(), genes=genes))
+        for ri in range(shape["n_rules"]):
+            li = ri % n_loci
+            logic[f"{shape['type_prefix']}{li + 1}v{ri}"] = dict(
+                loci=[f"{shape['prefix']}{li + 1}"], extra_genes=[f"opx{ri % shape['n_extra']}"], priority=50 + ri
+            )
+    meta = dict(
+        name=f"synthetic {kind}", keyword=kind, genbank=f"{kind}.gbk", organism=shape["organism"],
+        taxon=shape["taxon"], antigen=shape["antigen"], pathway="Wzx/Wzy", version=f"synth-{seed}",
+        id_threshold=id_threshold, doi=[], owner="kaptive_amd", repo="synthetic", branch="main", contact={},
+        phenotype_logic=logic,
+    )  # fmt: skip
+    return Database.from_parts(meta, loci)
+
+
+def make_assembly(
+    db: Database,
+    seed: int,
+    length: float = 5.0e6,
+    gc: float | None = None,
+    median_contigs: int = 120,
+    locus: int | None = None,
+    min_contig: int = 200,
+    p_break: float = 0.3,
+    p_is: float = 0.05,
+    p_stop: float = 0.05,
+    p_extra: float = 0.5,
+    force_split: bool = False,
+    name: str | None = None,
+    sub_rate: float | None = None,
+    second_locus: int | None = None,
+    n_run: int = 0,
+) -> GenomeAssembly:
+    """One synthetic assembly holding a mutated copy of one database locus.
+    ``locus`` < 0 plants no locus at all."""
+    rng = np.random.default_rng(seed)
+    gc = DB_SHAPES.get(db.metadata.keyword, {}).get("gc", 0.5) if gc is None else gc
+    total = int(length * rng.uniform(0.95, 1.05))
+    typed = np.flatnonzero(~_locus_is_extra(db))
+    li = int(rng.choice(typed)) if locus is None else locus
+    genome = random_dna(rng, total, gc)
+    cuts_inside: list[int] = []
+    if li >= 0:
+        o, n = int(db.loci.offsets[li]), int(db.loci.lengths[li])
+        rate = float(rng.uniform(0.0, 0.03)) if sub_rate is None else sub_rate
+        copy = mutate(rng, db.loci.seqs[o : o + n], rate)
+        g0, g1 = int(db.locus_gene_offsets[li]), int(db.locus_gene_offsets[li] + db.locus_gene_lengths[li])
+        for gi in range(g0, g1):  # substitutions that would create an in-frame stop are purged, as selection does
+            s, e = int(db.gene_intervals.starts[gi]), int(db.gene_intervals.ends[gi])
+            if db.gene_intervals.strands[gi] > 0:
+                _kill_internal_stops(copy[s:e])
+            else:
+                orf = revcomp(copy[s:e])
+                _kill_internal_stops(orf)
+                copy[s:e] = revcomp(orf)
+        if rng.random() < p_stop:  # premature stop in one gene (planted on the unmutated coordinates; close enough)
+            gi = int(rng.integers(g0, g1))
+            s, e = int(db.gene_intervals.starts[gi]), int(db.gene_intervals.ends[gi])
+            at = s + 3 * int(rng.integers(5, max(6, (e - s) // 6)))
+            if at + 3 < len(copy):
+                stop = np.frombuffer(b"TAA", np.uint8)
+                copy[at : at + 3] = stop if db.gene_intervals.strands[gi] > 0 else revcomp(stop)
+        copy = mutate(rng, copy, 0.0, indel_rate=2e-5)
+        if rng.random() < p_is:  # IS-like 1.2 kb insertion inside the locus
+            at = int(rng.integers(len(copy) // 4, 3 * len(copy) // 4))
+            copy = np.concatenate([copy[:at], random_dna(rng, 1200, 0.5), copy[at:]])
+        if n_run:  # a scaffold gap inside the locus
+            at = int(rng.integers(len(copy) // 4, 3 * len(copy) // 4))
+            copy[at : at + n_run] = ord("N")
+        if rng.random() < 0.5:
+            copy = revcomp(copy)
+        where = int(rng.integers(total // 10, total - total // 10 - len(copy)))
+        genome[where : where + len(copy)] = copy
+        if second_locus is not None:  # part of another locus elsewhere in the genome
+            o2, n2 = int(db.loci.offsets[second_locus]), int(db.loci.lengths[second_locus])
+            other = mutate(rng, db.loci.seqs[o2 : o2 + n2 // 2], 0.01)
+            at = where - len(other) - 2000
+            if at < 0:
+                at = where + len(copy) + 2000
+            genome[at : at + len(other)] = other[: max(0, total - at)]
+        if force_split or rng.random() < p_break:
+            cuts_inside.append(where + int(rng.integers(len(copy) // 5, 4 * len(copy) // 5)))
+    extra_rows = np.flatnonzero(db.extra_genes)
+    for gi in extra_rows:  # unlinked modifier genes planted elsewhere
+        if rng.random() < p_extra / max(len(extra_rows), 1) * 3:
+            o, n = int(db.genes.offsets[gi]), int(db.genes.lengths[gi])
+            g = mutate(rng, db.genes.seqs[o : o + n], 0.01)
+            at = int(rng.integers(0, total // 12))
+            genome[at : at + len(g)] = g if rng.random() < 0.5 else revcomp(g)
+    # contig lengths: lognormal around total/median_contigs, floored at min_contig
+    n_ctg = max(1, int(rng.lognormal(np.log(median_contigs), 0.3)))
+    w = rng.lognormal(0.0, 1.0, size=n_ctg)
+    cuts = np.unique(np.r_[(np.cumsum(w)[:-1] / w.sum() * total).astype(np.int64), np.array(cuts_inside, np.int64)])
+    cuts = cuts[(cuts > 0) & (cuts < total)]
+    bounds = np.r_[0, cuts, total]
+    keep = np.flatnonzero(np.diff(bounds) >= min_contig)
+    recs = [SeqRecord(f"contig_{k + 1}", genome[bounds[i] : bounds[i + 1]].tobytes()) for k, i in enumerate(keep)]
+    if rng.random() < 0.3 and len(recs) > 1:  # some contigs come out reverse-complemented, as assemblers do
+        for k in rng.choice(len(recs), size=max(1, len(recs) // 3), replace=False):
+            r = recs[k]
+            recs[k] = SeqRecord(r.id, revcomp(np.frombuffer(r.seq, np.uint8)).tobytes())
+    return GenomeAssembly(name or f"asm_{seed}", Sequences.from_records(recs))
+
+
+def _locus_is_extra(db: Database) -> np.ndarray:
+    return db.extra_genes[db.locus_gene_offsets.astype(np.int64)]

@@ -1,0 +1,591 @@
+/* kp_oracle.c -- CPU restatement of the typing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product (kaptive_amd/) may include, link or call this file; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, as the checker.  Plain C, scalar, single-threaded, written for clarity.
+ *
+ * What it restates, and how each part is pinned:
+ *   kpo_protein_align   reference src/kaptive/core/pairwise.py:395-584 (_batched_banded_gotoh, unseeded mode), with
+ *                       the BLOSUM62 lookup of pairwise.py:343-391.  PINNED against tests/golden/protein_dp.npz,
+ *                       produced by running the reference itself (oracle/make_golden.py).
+ *   kpo_cull_overlaps   reference src/kaptive/core/interval.py:698-751.          PINNED (tests/golden/intervals.npz)
+ *   kpo_cluster         reference src/kaptive/core/interval.py:595-639.          PINNED (tests/golden/intervals.npz)
+ *   kpo_translate       reference src/kaptive/core/seq.py:671-741.               PINNED (tests/golden/seqs.npz)
+ *   kpo_extract         reference src/kaptive/core/seq.py:612-668.               PINNED (tests/golden/seqs.npz)
+ *   kpo_align (+ stage entry points kpo_anchors / kpo_tasks / kpo_sw)
+ *                       the gene-vs-contig aligner.  In the reference this stage is the third-party rammappy 0.1.3
+ *                       wheel (call sites src/kaptive/core/genome.py:188-189, src/kaptive/serotyping/core.py:147-155;
+ *                       consumer src/kaptive/core/alignment.py:409-446); its source is not in the reference tree and
+ *                       no reference test pins any alignment.  PARITY UNPINNED for this stage: the specification is
+ *                       include/kp_spec.h, and this file is its executable statement.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/kp_spec.h"
+
+#define KPO_API __attribute__((visibility("default")))
+
+/* ================================================================================================================
+ * Protein banded Smith-Waterman-Gotoh with traceback (pairwise.py:395-584)
+ * ================================================================================================================ */
+
+static int8_t g_blosum[256][256];
+static int g_blosum_ready = 0;
+
+static void blosum_init(void) {
+    /* rows/cols in the order ARNDCQEGHILKMFPSTWYVBJZX*  (pairwise.py:353-383) */
+    static const int8_t m[25][25] = {
+        {4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0, -2, -1, -1, -1, -4},
+        {-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3, -1, -2, 0, -1, -4},
+        {-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3, 4, -3, 0, -1, -4},
+        {-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3, 4, -3, 1, -1, -4},
+        {0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1, -3, -1, -3, -1, -4},
+        {-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2, 0, -2, 4, -1, -4},
+        {-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2, 1, -3, 4, -1, -4},
+        {0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3, -1, -4, -2, -1, -4},
+        {-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3, 0, -3, 0, -1, -4},
+        {-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3, -3, 3, -3, -1, -4},
+        {-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1, -4, 3, -3, -1, -4},
+        {-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2, 0, -3, 1, -1, -4},
+        {-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1, -3, 2, -1, -1, -4},
+        {-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1, -3, 0, -3, -1, -4},
+        {-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2, -2, -3, -1, -1, -4},
+        {1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2, 0, -2, 0, -1, -4},
+        {0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0, -1, -1, -1, -1, -4},
+        {-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3, -4, -2, -2, -1, -4},
+        {-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1, -3, -1, -2, -1, -4},
+        {0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4, -3, 2, -2, -1, -4},
+        {-2, -1, 4, 4, -3, 0, 1, -1, 0, -3, -4, 0, -3, -3, -2, 0, -1, -4, -3, -3, 4, -3, 0, -1, -4},
+        {-1, -2, -3, -3, -1, -2, -3, -4, -3, 3, 3, -3, 2, 0, -3, -2, -1, -2, -1, 2, -3, 3, -3, -1, -4},
+        {-1, 0, 0, 1, -3, 4, 4, -2, 0, -3, -3, 1, -1, -3, -1, 0, -1, -2, -2, -2, 0, -3, 4, -1, -4},
+        {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -4},
+        {-4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, 1},
+    };
+    static const char alphabet[] = "ARNDCQEGHILKMFPSTWYVBJZX*";
+    memset(g_blosum, KP_PROT_FILL, sizeof g_blosum);
+    for (int a = 0; a < 25; a++)
+        for (int b = 0; b < 25; b++) g_blosum[(uint8_t)alphabet[a]][(uint8_t)alphabet[b]] = m[a][b];
+    g_blosum_ready = 1;
+}
+
+KPO_API void kpo_blosum62(int8_t *out /* [256*256] */) {
+    if (!g_blosum_ready) blosum_init();
+    memcpy(out, g_blosum, sizeof g_blosum);
+}
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+/* One pair; follows the reference loop structure (band stored as rows x (2k+3) with per-row origin). */
+static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int k, int go, int ge,
+                         int32_t *out8 /* score, matches, mismatches, gaps, qs, qe, ts, te */) {
+    const int rows = len1 + 1, cols = len2 + 1;
+    int d = len1 - len2;
+    if (d < 0) d = -d;
+    const int kl = imax(k, d + 1);
+    const int bw = 2 * kl + 3;
+    const size_t cells = (size_t)rows * (size_t)bw;
+    int32_t *M = malloc(cells * sizeof(int32_t)), *I = malloc(cells * sizeof(int32_t)),
+            *D = malloc(cells * sizeof(int32_t));
+    uint8_t *tM = malloc(cells), *tD = malloc(cells), *tI = malloc(cells);
+#define AT(i, jm) ((size_t)(i) * (size_t)bw + (size_t)(jm))
+    for (int i = 0; i < rows; i++) { /* band-only initialisation, pairwise.py:466-479 */
+        int sj = imax(0, i - kl - 1), ej = imin(cols, i + kl + 2);
+        if (sj >= cols || ej <= 0) continue;
+        for (int j = sj; j < ej; j++) {
+            int jm = j - sj;
+            M[AT(i, jm)] = 0;
+            I[AT(i, jm)] = KP_PROT_NEG_INF;
+            D[AT(i, jm)] = KP_PROT_NEG_INF;
+            tM[AT(i, jm)] = 3;
+        }
+    }
+    int max_score = 0, max_i = 0, max_j = 0;
+    for (int i = 1; i < rows; i++) { /* fill, pairwise.py:486-535 */
+        int sj = imax(1, i - kl), ej = imin(cols, i + kl + 1);
+        if (sj >= cols || ej <= 1) continue;
+        int sp = imax(0, i - 1 - kl - 1), sc = imax(0, i - kl - 1);
+        for (int j = sj; j < ej; j++) {
+            int jt = j - sp, jm = j - sc, jl = j - 1 - sc, jd = j - 1 - sp;
+            int d_open = M[AT(i - 1, jt)] - go - ge, d_ext = D[AT(i - 1, jt)] - ge;
+            if (d_open >= d_ext) { D[AT(i, jm)] = d_open; tD[AT(i, jm)] = 0; }
+            else { D[AT(i, jm)] = d_ext; tD[AT(i, jm)] = 1; }
+            int i_open = M[AT(i, jl)] - go - ge, i_ext = I[AT(i, jl)] - ge;
+            if (i_open >= i_ext) { I[AT(i, jm)] = i_open; tI[AT(i, jm)] = 0; }
+            else { I[AT(i, jm)] = i_ext; tI[AT(i, jm)] = 2; }
+            int best = M[AT(i - 1, jd)] + g_blosum[s1[i - 1]][s2[j - 1]], tb = 0;
+            if (D[AT(i, jm)] > best) { best = D[AT(i, jm)]; tb = 1; }
+            if (I[AT(i, jm)] > best) { best = I[AT(i, jm)]; tb = 2; }
+            if (best <= 0) { M[AT(i, jm)] = 0; tM[AT(i, jm)] = 3; }
+            else {
+                M[AT(i, jm)] = best; tM[AT(i, jm)] = (uint8_t)tb;
+                if (best > max_score) { max_score = best; max_i = i; max_j = j; }
+            }
+        }
+    }
+    int i = max_i, j = max_j, matches = 0, mism = 0, gaps = 0, state = 0; /* traceback, pairwise.py:538-572 */
+    while (i > 0 && j > 0) {
+        int sc = imax(0, i - kl - 1), jm = j - sc;
+        if (state == 0) {
+            int tb = tM[AT(i, jm)];
+            if (tb == 3) break;
+            if (tb == 0) { if (s1[i - 1] == s2[j - 1]) matches++; else mism++; i--; j--; }
+            else state = tb;
+        } else if (state == 1) { int tb = tD[AT(i, jm)]; gaps++; i--; if (tb == 0) state = 0; }
+        else { int tb = tI[AT(i, jm)]; gaps++; j--; if (tb == 0) state = 0; }
+    }
+#undef AT
+    out8[0] = max_score; out8[1] = matches; out8[2] = mism; out8[3] = gaps;
+    out8[4] = i; out8[5] = max_i; out8[6] = j; out8[7] = max_j;
+    free(M); free(I); free(D); free(tM); free(tD); free(tI);
+}
+
+KPO_API void kpo_protein_align(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                               const int32_t *t_off, const int32_t *t_len, int n, int32_t *out /* [n][8] */) {
+    if (!g_blosum_ready) blosum_init();
+    for (int x = 0; x < n; x++)
+        protein_pair(q + q_off[x], q_len[x], t + t_off[x], t_len[x], KP_PROT_K, KP_PROT_GAP_OPEN, KP_PROT_GAP_EXT,
+                     out + 8 * (size_t)x);
+}
+
+/* ================================================================================================================
+ * Interval reductions (interval.py:595-639, 698-751) and ragged sequence kernels (seq.py:612-741)
+ * ================================================================================================================ */
+
+KPO_API void kpo_cull_overlaps(const int32_t *order, const int32_t *g1, const int32_t *g2, const int32_t *starts,
+                               const int32_t *ends, double max_frac, int n, uint8_t *kept) {
+    memset(kept, 0, (size_t)n);
+    for (int i = 0; i < n; i++) {
+        int idx = order[i], s = starts[idx], e = ends[idx], len = e - s;
+        if (len <= 0) continue;
+        int clash = 0;
+        for (int j = 0; j < i && !clash; j++) {
+            int p = order[j];
+            if (!kept[p] || g1[p] != g1[idx] || g2[p] != g2[idx]) continue;
+            int ov = imin(e, ends[p]) - imax(s, starts[p]);
+            if (ov > 0 && (double)ov / (double)imin(len, ends[p] - starts[p]) > max_frac) clash = 1;
+        }
+        if (!clash) kept[idx] = 1;
+    }
+}
+
+KPO_API void kpo_cluster(const int32_t *starts, const int32_t *ends, const int32_t *groups, int64_t tolerance,
+                         const int32_t *order, int n, int32_t *ids) {
+    if (n == 0) return;
+    int cur = 0, f = order[0];
+    int64_t cur_e = ends[f];
+    int32_t cur_g = groups[f];
+    ids[f] = 0;
+    for (int i = 1; i < n; i++) {
+        int idx = order[i];
+        if (groups[idx] == cur_g && (int64_t)starts[idx] <= cur_e + tolerance) {
+            if (ends[idx] > cur_e) cur_e = ends[idx];
+        } else { cur++; cur_e = ends[idx]; cur_g = groups[idx]; }
+        ids[idx] = cur;
+    }
+}
+
+static uint8_t g_code[256], g_comp[256], g_codon[125];
+static int g_tables_ready = 0;
+
+static void tables_init(void) {
+    memset(g_code, 4, sizeof g_code);
+    const char *acgt = "ACGT";
+    for (int i = 0; i < 4; i++) { g_code[(uint8_t)acgt[i]] = (uint8_t)i; g_code[(uint8_t)acgt[i] + 32] = (uint8_t)i; }
+    g_code['U'] = g_code['u'] = 3;
+    for (int i = 0; i < 256; i++) g_comp[i] = (uint8_t)i;
+    const char *from = "ACGTUacgtu", *to = "TGCAAtgcaa";
+    for (int i = 0; i < 10; i++) g_comp[(uint8_t)from[i]] = (uint8_t)to[i];
+    /* table 11 in TCAG order, re-indexed to ACGT radix-5 (seq.py:418-499) */
+    const char *aa = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    const int tcag[4] = {3, 1, 0, 2};
+    memset(g_codon, 'X', sizeof g_codon);
+    for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++)
+            for (int c = 0; c < 4; c++) g_codon[tcag[a] * 25 + tcag[b] * 5 + tcag[c]] = (uint8_t)aa[a * 16 + b * 4 + c];
+    g_tables_ready = 1;
+}
+
+/* returns total output length; out may be NULL to size */
+KPO_API int64_t kpo_translate(const uint8_t *seqs, const int32_t *off, const int32_t *len, const int8_t *frames,
+                              int n, int to_stop, uint8_t *out, int32_t *out_off, int32_t *out_len) {
+    if (!g_tables_ready) tables_init();
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        int f = frames ? frames[i] : 0, nc = 0;
+        if (len[i] > f) {
+            int adj = len[i] - f, maxc = adj >= 3 ? adj / 3 : 0;
+            const uint8_t *p = seqs + off[i] + f;
+            for (int c = 0; c < maxc; c++, p += 3) {
+                uint8_t a = g_codon[g_code[p[0]] * 25 + g_code[p[1]] * 5 + g_code[p[2]]];
+                if (to_stop && a == 42) break;
+                if (out) out[total + nc] = a;
+                nc++;
+            }
+        }
+        out_off[i] = (int32_t)total;
+        out_len[i] = nc;
+        total += nc;
+    }
+    return total;
+}
+
+KPO_API int64_t kpo_extract(const uint8_t *seqs, const int32_t *off, const int32_t *idx, const int32_t *starts,
+                            const int32_t *ends, const int8_t *strands, int n, uint8_t *out, int32_t *out_off,
+                            int32_t *out_len) {
+    if (!g_tables_ready) tables_init();
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        int l = ends[i] - starts[i];
+        out_off[i] = (int32_t)total;
+        out_len[i] = l;
+        if (out) {
+            int64_t gs = (int64_t)off[idx[i]] + starts[i], ge = (int64_t)off[idx[i]] + ends[i];
+            if (strands[i] >= 0) for (int c = 0; c < l; c++) out[total + c] = seqs[gs + c];
+            else for (int c = 0; c < l; c++) out[total + c] = g_comp[seqs[ge - 1 - c]];
+        }
+        total += l > 0 ? l : 0;
+    }
+    return total;
+}
+
+/* ================================================================================================================
+ * Nucleotide aligner "kp-align v1" (include/kp_spec.h) -- parity UNPINNED against the reference (see header)
+ * ================================================================================================================ */
+
+typedef struct { uint32_t key; uint32_t gs; uint32_t pos; } kpo_posting;
+
+typedef struct kpo_db {
+    int n_genes;
+    const uint8_t *codes; /* borrowed: one byte per base, 0..4 */
+    const int32_t *off;   /* borrowed: n_genes+1 */
+    uint8_t *rc;          /* reverse complements, same offsets */
+    kpo_posting *post;    /* sorted by (key, gs, pos) */
+    int64_t n_post;
+} kpo_db;
+
+static int cmp_posting(const void *a, const void *b) {
+    const kpo_posting *x = a, *y = b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    if (x->gs != y->gs) return x->gs < y->gs ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+static inline int seed_rule(const uint8_t *c) { return ((c[0] ^ c[1] ^ c[3]) & 3u) == KP_SEED_RULE_VALUE; }
+
+/* k-mer value with the first base in the low bits; returns 0 and sets *ok=0 if an N is inside */
+static inline uint32_t kmer_at(const uint8_t *c, int *ok) {
+    uint32_t v = 0;
+    for (int i = 0; i < KP_K; i++) {
+        if (c[i] > 3) { *ok = 0; return 0; }
+        v |= (uint32_t)c[i] << (2 * i);
+    }
+    *ok = 1;
+    return v;
+}
+
+KPO_API kpo_db *kpo_db_create(const uint8_t *codes, const int32_t *off, int n_genes) {
+    kpo_db *db = calloc(1, sizeof *db);
+    db->n_genes = n_genes; db->codes = codes; db->off = off;
+    int64_t total = off[n_genes];
+    db->rc = malloc((size_t)(total > 0 ? total : 1));
+    for (int g = 0; g < n_genes; g++) {
+        int len = off[g + 1] - off[g];
+        for (int i = 0; i < len; i++) {
+            uint8_t c = codes[off[g] + len - 1 - i];
+            db->rc[off[g] + i] = c > 3 ? 4 : (uint8_t)(3 - c);
+        }
+    }
+    int64_t cap = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t n = 0;
+        for (int g = 0; g < n_genes; g++) {
+            int len = off[g + 1] - off[g];
+            for (int s = 0; s < 2; s++) {
+                const uint8_t *c = (s ? db->rc : codes) + off[g];
+                for (int p = 0; p + KP_K <= len; p++) {
+                    if (!seed_rule(c + p)) continue;
+                    int ok; uint32_t v = kmer_at(c + p, &ok);
+                    if (!ok) continue;
+                    if (pass) { db->post[n].key = v; db->post[n].gs = (uint32_t)(2 * g + s); db->post[n].pos = (uint32_t)p; }
+                    n++;
+                }
+            }
+        }
+        if (!pass) { cap = n; db->post = malloc((size_t)(cap > 0 ? cap : 1) * sizeof(kpo_posting)); }
+        db->n_post = n;
+    }
+    qsort(db->post, (size_t)db->n_post, sizeof(kpo_posting), cmp_posting);
+    return db;
+}
+
+KPO_API void kpo_db_free(kpo_db *db) { if (db) { free(db->rc); free(db->post); free(db); } }
+KPO_API int64_t kpo_db_n_postings(const kpo_db *db) { return db->n_post; }
+
+static int64_t lower_bound_key(const kpo_db *db, uint32_t key) {
+    int64_t lo = 0, hi = db->n_post;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (db->post[mid].key < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+typedef struct {
+    const uint32_t *words; int64_t padded_len;
+    const int32_t *ctg_start, *ctg_len; int n_ctg;
+    const int32_t *n_runs; int n_nruns;
+    uint8_t *codes; /* unpacked, N applied (code 4), pad = 0 */
+} kpo_asm;
+
+static void asm_unpack(kpo_asm *a) {
+    a->codes = malloc((size_t)(a->padded_len > 0 ? a->padded_len : 1));
+    for (int64_t i = 0; i < a->padded_len; i++) a->codes[i] = (uint8_t)((a->words[i >> 4] >> (2 * (i & 15))) & 3u);
+    for (int r = 0; r < a->n_nruns; r++)
+        for (int64_t i = a->n_runs[2 * r]; i < a->n_runs[2 * r + 1]; i++) a->codes[i] = 4;
+}
+
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+/* all anchors of one assembly, sorted by key; returns count (caller frees *out) */
+static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **out) {
+    int64_t cap = 1 << 16, n = 0;
+    uint64_t *keys = malloc((size_t)cap * sizeof(uint64_t));
+    for (int c = 0; c < a->n_ctg; c++) {
+        int64_t s = a->ctg_start[c], e = s + a->ctg_len[c];
+        for (int64_t p = s; p + KP_K <= e; p++) {
+            const uint8_t *cd = a->codes + p;
+            /* rule on raw 2-bit values: an N inside the k-mer rejects it below regardless of the rule outcome */
+            if (cd[0] > 3 || cd[1] > 3 || cd[3] > 3 || !seed_rule(cd)) continue;
+            int ok; uint32_t v = kmer_at(cd, &ok);
+            if (!ok) continue;
+            for (int64_t i = lower_bound_key(db, v); i < db->n_post && db->post[i].key == v; i++) {
+                if (n == cap) { cap *= 2; keys = realloc(keys, (size_t)cap * sizeof(uint64_t)); }
+                uint32_t qpos = db->post[i].pos;
+                keys[n++] = KP_ANCHOR_KEY(db->post[i].gs, (uint64_t)(p - qpos + KP_DIAG_BIAS), qpos);
+            }
+        }
+    }
+    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64);
+    *out = keys;
+    return n;
+}
+
+typedef struct kpo_task {
+    int32_t gs;      /* gene*2 + strand */
+    int32_t contig;
+    int32_t lo;      /* lowest diagonal of the band, true value (tpos - qpos, assembly coordinates) */
+    int32_t width;   /* 32, 64 or 128 */
+    int32_t n_anchors;
+    int32_t qmin, qmax;
+} kpo_task;
+
+static int contig_of(const kpo_asm *a, int64_t t) { /* largest c with ctg_start[c] <= t */
+    int lo = 0, hi = a->n_ctg - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (a->ctg_start[mid] <= t) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo_task **out) {
+    int64_t cap = 1024, nt = 0;
+    kpo_task *tasks = malloc((size_t)cap * sizeof(kpo_task));
+    int64_t i = 0;
+    while (i < n) {
+        uint32_t gs = KP_KEY_GS(keys[i]), d0 = KP_KEY_DIAG(keys[i]), q = KP_KEY_QPOS(keys[i]);
+        int ctg = contig_of(a, (int64_t)d0 - KP_DIAG_BIAS + q);
+        uint32_t dprev = d0, dmax = d0, qmin = q, qmax = q;
+        int cnt = 1;
+        int64_t j = i + 1;
+        for (; j < n; j++) {
+            uint32_t g2 = KP_KEY_GS(keys[j]), d2 = KP_KEY_DIAG(keys[j]), q2 = KP_KEY_QPOS(keys[j]);
+            if (g2 != gs || d2 - dprev > KP_DIAG_GAP || d2 - d0 > KP_MAX_SPREAD) break;
+            if (contig_of(a, (int64_t)d2 - KP_DIAG_BIAS + q2) != ctg) break;
+            dprev = d2; dmax = d2; cnt++;
+            if (q2 < qmin) qmin = q2;
+            if (q2 > qmax) qmax = q2;
+        }
+        if (cnt >= KP_MIN_ANCHORS && (int)(qmax - qmin) + KP_K >= KP_MIN_SEED_SPAN) {
+            int need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
+            int w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+            if (nt == cap) { cap *= 2; tasks = realloc(tasks, (size_t)cap * sizeof(kpo_task)); }
+            kpo_task *t = &tasks[nt++];
+            t->gs = (int32_t)gs; t->contig = ctg; t->width = w; t->n_anchors = cnt;
+            t->lo = (int32_t)((int64_t)d0 - KP_DIAG_BIAS - KP_BAND_MARGIN - (w - need) / 2);
+            t->qmin = (int32_t)qmin; t->qmax = (int32_t)qmax;
+        }
+        i = j;
+    }
+    *out = tasks;
+    return nt;
+}
+
+/* Banded local alignment of one task with stored traceback.  out: score, q_start, q_end, t_start, t_end (query in the
+ * orientation given, target in assembly coordinates), matches, block_len. */
+static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstart, int64_t cend, int lo, int w,
+                    int32_t *out7) {
+    const size_t cells = (size_t)qlen * (size_t)w;
+    int32_t *H = malloc(cells * 4), *E = malloc(cells * 4), *F = malloc(cells * 4);
+    uint8_t *tH = malloc(cells), *tE = malloc(cells), *tF = malloc(cells);
+    const int oe = KP_GAP_OPEN + KP_GAP_EXT, ex = KP_GAP_EXT;
+#define AT(r, b) ((size_t)(r) * (size_t)w + (size_t)(b))
+#define VALID(r, b) ((r) >= 0 && (b) >= 0 && (b) < w && (int64_t)(r) + lo + (b) >= cstart && (int64_t)(r) + lo + (b) < cend)
+    int best_s = 0, best_r = -1, best_b = -1;
+    for (int r = 0; r < qlen; r++) {
+        for (int b = 0; b < w; b++) {
+            int64_t t = (int64_t)r + lo + b;
+            if (t < cstart || t >= cend) { H[AT(r, b)] = 0; E[AT(r, b)] = F[AT(r, b)] = KP_NEG_INF; tH[AT(r, b)] = 3; continue; }
+            int hl = 0, el = KP_NEG_INF, hu = 0, fu = KP_NEG_INF, hd = 0;
+            if (VALID(r, b - 1)) { hl = H[AT(r, b - 1)]; el = E[AT(r, b - 1)]; }
+            if (VALID(r - 1, b + 1)) { hu = H[AT(r - 1, b + 1)]; fu = F[AT(r - 1, b + 1)]; }
+            if (VALID(r - 1, b)) hd = H[AT(r - 1, b)];
+            int e_open = hl - oe, e_ext = el - ex, f_open = hu - oe, f_ext = fu - ex;
+            int e = e_open >= e_ext ? e_open : e_ext, f = f_open >= f_ext ? f_open : f_ext;
+            tE[AT(r, b)] = e_open >= e_ext ? 0 : 1;
+            tF[AT(r, b)] = f_open >= f_ext ? 0 : 1;
+            E[AT(r, b)] = e; F[AT(r, b)] = f;
+            uint8_t qc = q[r], cc = tc[t];
+            int s = (qc > 3 || cc > 3) ? KP_SC_N : (qc == cc ? KP_SC_MATCH : KP_SC_MISMATCH);
+            int best = hd + s, tb = 0;
+            if (e > best) { best = e; tb = 1; }
+            if (f > best) { best = f; tb = 2; }
+            if (best <= 0) { H[AT(r, b)] = 0; tH[AT(r, b)] = 3; }
+            else {
+                H[AT(r, b)] = best; tH[AT(r, b)] = (uint8_t)tb;
+                if (best > best_s) { best_s = best; best_r = r; best_b = b; }
+            }
+        }
+    }
+    int r = best_r, b = best_b, state = 0, matches = 0, cols = 0;
+    int sr = best_r, sb = best_b; /* first aligned cell seen so far */
+    while (best_s > 0) {
+        if (state == 0) {
+            if (!VALID(r, b) || tH[AT(r, b)] == 3) break;
+            int tb = tH[AT(r, b)];
+            if (tb == 0) {
+                sr = r; sb = b; cols++;
+                if (q[r] <= 3 && q[r] == tc[(int64_t)r + lo + b]) matches++;
+                r--; /* diagonal: same band index, previous row */
+            } else state = tb;
+        } else if (state == 1) { /* E: came from the left (same row, target - 1) */
+            int tb = tE[AT(r, b)]; cols++; b--; if (tb == 0) state = 0;
+        } else { /* F: came from above (row - 1, same target => band index + 1) */
+            int tb = tF[AT(r, b)]; cols++; r--; b++; if (tb == 0) state = 0;
+        }
+    }
+#undef AT
+#undef VALID
+    out7[0] = best_s;
+    if (best_s > 0) {
+        out7[1] = sr; out7[2] = best_r + 1;
+        out7[3] = (int32_t)((int64_t)sr + lo + sb); out7[4] = (int32_t)((int64_t)best_r + lo + best_b + 1);
+    } else out7[1] = out7[2] = out7[3] = out7[4] = 0;
+    out7[5] = matches; out7[6] = cols;
+    free(H); free(E); free(F); free(tH); free(tE); free(tF);
+}
+
+static int cmp_hit(const void *a, const void *b) {
+    const kp_hit *x = a, *y = b;
+    if (x->gene != y->gene) return x->gene < y->gene ? -1 : 1;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    if (x->contig != y->contig) return x->contig < y->contig ? -1 : 1;
+    if (x->t_start != y->t_start) return x->t_start < y->t_start ? -1 : 1;
+    if (x->strand != y->strand) return x->strand > y->strand ? -1 : 1;
+    if (x->q_start != y->q_start) return x->q_start < y->q_start ? -1 : 1;
+    if (x->q_end != y->q_end) return x->q_end < y->q_end ? -1 : 1;
+    if (x->t_end != y->t_end) return x->t_end < y->t_end ? -1 : 1;
+    if (x->matches != y->matches) return x->matches > y->matches ? -1 : 1;
+    return x->block_len < y->block_len ? -1 : (x->block_len > y->block_len);
+}
+
+static int same_span(const kp_hit *x, const kp_hit *y) {
+    return x->gene == y->gene && x->contig == y->contig && x->strand == y->strand && x->q_start == y->q_start &&
+           x->q_end == y->q_end && x->t_start == y->t_start && x->t_end == y->t_end;
+}
+
+static void asm_init(kpo_asm *a, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                     const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns) {
+    a->words = words; a->padded_len = padded_len; a->ctg_start = ctg_start; a->ctg_len = ctg_len; a->n_ctg = n_ctg;
+    a->n_runs = n_runs; a->n_nruns = n_nruns;
+    asm_unpack(a);
+}
+
+/* Stage entry points (for stage-by-stage parity tests).  Each returns the count; when the buffer is too small the
+ * first `cap` items are written and the full count is still returned. */
+KPO_API int64_t kpo_anchors(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                            const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, uint64_t *out,
+                            int64_t cap) {
+    kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
+    uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
+    if (out) memcpy(out, keys, (size_t)(n < cap ? n : cap) * sizeof(uint64_t));
+    free(keys); free(a.codes);
+    return n;
+}
+
+KPO_API int64_t kpo_tasks(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                          const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, kpo_task *out,
+                          int64_t cap) {
+    kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
+    uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
+    kpo_task *tasks; int64_t nt = make_tasks(&a, keys, n, &tasks);
+    if (out) memcpy(out, tasks, (size_t)(nt < cap ? nt : cap) * sizeof(kpo_task));
+    free(tasks); free(keys); free(a.codes);
+    return nt;
+}
+
+/* raw DP result per task, before the score filter: [n][7] = score, q_start, q_end (query as aligned: reverse
+ * complement coordinates for strand -), t_start, t_end (assembly coordinates), matches, block_len */
+KPO_API int64_t kpo_sw(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                       const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, const kpo_task *tasks,
+                       int64_t n_tasks, int32_t *out7) {
+    kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
+    for (int64_t i = 0; i < n_tasks; i++) {
+        const kpo_task *t = &tasks[i];
+        int g = t->gs >> 1, qlen = db->off[g + 1] - db->off[g];
+        const uint8_t *q = ((t->gs & 1) ? db->rc : db->codes) + db->off[g];
+        int64_t cs = ctg_start[t->contig];
+        sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, out7 + 7 * i);
+    }
+    free(a.codes);
+    return n_tasks;
+}
+
+/* Full aligner for one assembly: hits in emission order.  Returns the number of hits (writes at most cap). */
+KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                          const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, kp_hit *out,
+                          int64_t cap, int64_t *stats /* optional [3]: anchors, tasks, dp cells */) {
+    kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
+    uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
+    kpo_task *tasks; int64_t nt = make_tasks(&a, keys, n, &tasks);
+    kp_hit *hits = malloc((size_t)(nt > 0 ? nt : 1) * sizeof(kp_hit));
+    int64_t nh = 0, cells = 0;
+    for (int64_t i = 0; i < nt; i++) {
+        const kpo_task *t = &tasks[i];
+        int g = t->gs >> 1, rev = t->gs & 1, qlen = db->off[g + 1] - db->off[g];
+        const uint8_t *q = (rev ? db->rc : db->codes) + db->off[g];
+        int64_t cs = ctg_start[t->contig];
+        int32_t r[7];
+        sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, r);
+        cells += (int64_t)qlen * t->width;
+        if (r[0] < KP_MIN_DP_SCORE) continue;
+        kp_hit *h = &hits[nh++];
+        memset(h, 0, sizeof *h);
+        h->gene = g; h->contig = t->contig; h->strand = rev ? -1 : 1;
+        h->q_start = rev ? qlen - r[2] : r[1];
+        h->q_end = rev ? qlen - r[1] : r[2];
+        h->t_start = (int32_t)(r[3] - cs); h->t_end = (int32_t)(r[4] - cs);
+        h->score = r[0]; h->matches = r[5]; h->block_len = r[6];
+    }
+    qsort(hits, (size_t)nh, sizeof(kp_hit), cmp_hit);
+    int64_t m = 0;
+    for (int64_t i = 0; i < nh; i++) { /* drop exact duplicates, then mark the first hit of each gene */
+        if (m > 0 && same_span(&hits[m - 1], &hits[i])) continue;
+        hits[m] = hits[i];
+        hits[m].mapq = (m == 0 || hits[m - 1].gene != hits[m].gene) ? 60 : 0;
+        m++;
+    }
+    if (out) memcpy(out, hits, (size_t)(m < cap ? m : cap) * sizeof(kp_hit));
+    if (stats) { stats[0] = n; stats[1] = nt; stats[2] = cells; }
+    free(hits); free(tasks); free(keys); free(a.codes);
+    return m;
+}
