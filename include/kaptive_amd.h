@@ -1,0 +1,102 @@
+/* kaptive_amd.h -- C ABI of libkaptive_amd.so: the MI355X (gfx950) implementation of Kaptive's typing hot path.
+ *
+ * The reference (klebgenomics/Kaptive) has no C ABI for this path: its native seam is the Python binding of the
+ * third-party rammappy wheel plus numba-compiled kernels.  Each entry point below names the reference interface it
+ * stands in for (paths relative to the reference checkout); INTEGRATION.md shows the ctypes binding a Kaptive
+ * maintainer would add.  Conventions: every call returns 0 on success or a negative KP_E* code and records a message
+ * retrievable with kp_last_error(); no exceptions cross the boundary; the caller owns every host buffer it passes and
+ * may free it as soon as the call returns unless stated otherwise; the library owns all device memory.  A context is
+ * bound to one GPU and one HIP stream; calls on one context must be serialised by the caller, distinct contexts are
+ * independent (one context per device / per host thread).
+ */
+#ifndef KAPTIVE_AMD_H
+#define KAPTIVE_AMD_H
+
+#include <stdint.h>
+
+#include "kp_spec.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KP_API __attribute__((visibility("default")))
+
+#define KP_OK 0
+#define KP_EINVAL (-1)    /* bad argument (null pointer, limits of kp_spec.h exceeded, inconsistent offsets) */
+#define KP_EHIP (-2)      /* a HIP runtime call failed; message carries hipGetErrorString */
+#define KP_ENOMEM (-3)    /* host or device allocation failed */
+#define KP_ESTATE (-4)    /* call out of order (no database loaded, no batch aligned, ...) */
+#define KP_EOVERFLOW (-5) /* an internal device buffer overflowed and the automatic retry also failed */
+
+typedef struct kp_ctx kp_ctx;     /* one GPU + stream + resident database */
+typedef struct kp_batch kp_batch; /* a set of packed assemblies resident in HBM, plus its results */
+
+/* ---- context -------------------------------------------------------------------------------------------------- */
+KP_API int kp_ctx_create(int device_id, kp_ctx **out);
+KP_API void kp_ctx_destroy(kp_ctx *ctx);
+/* Message of the last failed call on ctx (ctx may be NULL for a failed kp_ctx_create). Never NULL. */
+KP_API const char *kp_last_error(const kp_ctx *ctx);
+/* The hipStream_t all work of this context is enqueued on (for event timing by the caller). */
+KP_API void *kp_ctx_stream(kp_ctx *ctx);
+
+/* ---- database ---------------------------------------------------------------------------------------------------
+ * Replaces what Serotyper.__init__ prepares for the aligner -- the list of (name, gene bytes) handed to
+ * rammappy's map_batch (src/kaptive/serotyping/core.py:111-121,154) -- with a device-resident seed index over all
+ * genes (both strands) and 4-bit copies of the gene sequences.
+ *   gene_codes : one byte per base, 0..3 = ACGT, 4 = anything else; genes back to back
+ *   gene_off   : n_genes + 1 offsets into gene_codes
+ * Loading a database replaces any previous one. */
+KP_API int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, int32_t n_genes);
+/* Number of (k-mer, gene, strand, position) postings in the resident seed index. */
+KP_API int64_t kp_db_n_postings(const kp_ctx *ctx);
+
+/* ---- batches of packed assemblies -------------------------------------------------------------------------------
+ * Replaces GenomeAssembly.get_rammappy_index / rammappy.Index.build (src/kaptive/core/genome.py:177-191): instead of
+ * a minimizer index per assembly, the 2-bit packed contigs themselves are made resident (layout: kp_spec.h).
+ *   words          : packed bases of all assemblies back to back (assembly a = words[asm_word_off[a] .. asm_word_off[a+1]))
+ *   asm_word_off   : n_asm + 1 offsets in uint32 words; each assembly's length is a multiple of KP_ASM_ALIGN bases
+ *   ctg_start/len  : per contig, start (multiple of KP_CONTIG_ALIGN) and length in the assembly's own padded space
+ *   asm_first_ctg  : n_asm + 1 offsets into ctg_start/ctg_len
+ *   n_runs         : [start,end) pairs of N runs, sorted per assembly, in the assembly's padded space
+ *   asm_first_nrun : n_asm + 1 offsets into n_runs (in runs, not ints)
+ * kp_batch_create copies from host memory; kp_batch_create_device adopts `words` already in device memory (it must
+ * stay valid until kp_batch_destroy) and copies only the small tables. */
+KP_API int kp_batch_create(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
+                    const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                    const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out);
+KP_API int kp_batch_create_device(kp_ctx *ctx, int32_t n_asm, const uint32_t *d_words, const int64_t *asm_word_off,
+                           const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                           const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out);
+KP_API void kp_batch_destroy(kp_batch *batch);
+
+/* ---- alignment --------------------------------------------------------------------------------------------------
+ * Replaces Aligner(...).map_batch(gene_seqs) with best_n=50000, pri_ratio=0.0 (src/kaptive/serotyping/core.py:
+ * 148-154): every database gene against every contig of every assembly of the batch, all hits reported.
+ * kp_batch_align enqueues the kernels (seed scan -> anchor sort -> band tasks -> banded Smith-Waterman) and returns;
+ * kp_batch_wait blocks until they finish, then finalises the hit table (emission order of kp_spec.h).  */
+KP_API int kp_batch_align(kp_ctx *ctx, kp_batch *batch);
+KP_API int kp_batch_wait(kp_ctx *ctx, kp_batch *batch);
+/* hit_off[n_asm+1]: hits of assembly a are rows hit_off[a] .. hit_off[a+1] of the table returned by kp_batch_hits.
+ * These are the columns the reference reads off rammappy hit objects (src/kaptive/core/alignment.py:415-446). */
+KP_API int kp_batch_hit_offsets(kp_ctx *ctx, kp_batch *batch, int64_t *hit_off);
+KP_API int kp_batch_hits(kp_ctx *ctx, kp_batch *batch, kp_hit *out, int64_t cap);
+/* counters of the last kp_batch_align: [0] anchors, [1] band tasks, [2] DP cells, [3] hits, [4] overflow retries */
+KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
+
+/* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and
+ * the band tasks of one assembly as 7 x int32 rows (gs, contig, lo, width, n_anchors, qmin, qmax) in device order. */
+KP_API int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint64_t *out, int64_t cap);
+KP_API int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, int32_t *out7, int64_t cap);
+
+/* ---- protein alignment ------------------------------------------------------------------------------------------
+ * Replaces PairwiseAligner.__call__ / _batched_banded_gotoh (src/kaptive/core/pairwise.py:255-325, 395-584) in its
+ * unseeded mode with the defaults gap_open 11, gap_extend 1, k 20.  Sequences are raw bytes (amino-acid letters).
+ *   out8 : n rows of score, matches, mismatches, gaps, q_start, q_end, t_start, t_end  */
+KP_API int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                     const int32_t *t_off, const int32_t *t_len, int32_t n, int32_t *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAPTIVE_AMD_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of libkaptive_amd.so (include/kaptive_amd.h).  There is no fallback: if the library or a GPU is
+missing, every entry point raises."""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
+
+HIT_DTYPE = np.dtype(
+    [("gene", "<i4"), ("contig", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("t_start", "<i4"), ("t_end", "<i4"),
+     ("score", "<i4"), ("matches", "<i4"), ("block_len", "<i4"), ("strand", "i1"), ("mapq", "u1"), ("pad", "u1", 2)]
+)  # fmt: skip
+TASK_DTYPE = np.dtype(
+    [("gs", "<i4"), ("contig", "<i4"), ("lo", "<i4"), ("width", "<i4"), ("n_anchors", "<i4"), ("qmin", "<i4"),
+     ("qmax", "<i4")]
+)  # fmt: skip
+
+EXPORTS = (
+    "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_db_load", "kp_db_n_postings",
+    "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
+    "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_anchors", "kp_batch_tasks",
+    "kp_protein_align",
+)  # fmt: skip
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not LIB_PATH.exists():
+                    raise NativeError(
+                        f"{LIB_PATH} is missing: build it with `python -m kaptive_amd.build` (hipcc, gfx950). "
+                        "kaptive_amd has no CPU fallback."
+                    )
+                h = C.CDLL(str(LIB_PATH))
+                h.kp_last_error.restype = C.c_char_p
+                h.kp_ctx_stream.restype = C.c_void_p
+                for f in ("kp_db_n_postings", "kp_batch_anchors", "kp_batch_tasks"):
+                    getattr(h, f).restype = C.c_int64
+                h.kp_ctx_destroy.restype = None
+                h.kp_batch_destroy.restype = None
+                _lib = h
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Context:
+    """One GPU + stream + resident database (kp_ctx)."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._h = C.c_void_p()
+        rc = lib().kp_ctx_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise NativeError(f"kp_ctx_create failed ({rc}): {lib().kp_last_error(None).decode()}")
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().kp_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc < 0:
+            msg = lib().kp_last_error(self._h).decode()
+            raise (ValueError if rc == -1 else NativeError)(f"{what} failed ({rc}): {msg}")
+
+    @property
+    def stream(self) -> int:
+        return int(lib().kp_ctx_stream(self._h) or 0)
+
+    def load_genes(self, gene_codes: np.ndarray, gene_off: np.ndarray) -> None:
+        codes, off = _c(gene_codes, np.uint8), _c(gene_off, np.int32)
+        self._check(lib().kp_db_load(self._h, _p(codes), _p(off), C.c_int32(len(off) - 1)), "kp_db_load")
+
+    @property
+    def n_postings(self) -> int:
+        return int(lib().kp_db_n_postings(self._h))
+
+    def protein_align(self, q, q_off, q_len, t, t_off, t_len) -> np.ndarray:
+        n = len(q_off)
+        out = np.zeros((n, 8), np.int32)
+        if n:
+            q, t = _c(q, np.uint8), _c(t, np.uint8)
+            self._check(
+                lib().kp_protein_align(self._h, _p(q), _p(_c(q_off, np.int32)), _p(_c(q_len, np.int32)), _p(t),
+                                       _p(_c(t_off, np.int32)), _p(_c(t_len, np.int32)), C.c_int32(n), _p(out)),
+                "kp_protein_align",
+            )  # fmt: skip
+        return out
+
+    def batch(self, packed: list, device_words: int | None = None) -> "Batch":
+        return Batch(self, packed, device_words)
+
+
+class Batch:
+    """Packed assemblies resident on the device (kp_batch). ``packed`` is a list of PackedAssembly; with
+    ``device_words`` (a device pointer to the concatenated words) nothing but the small tables is copied."""
+
+    def __init__(self, ctx: Context, packed: list, device_words: int | None = None) -> None:
+        self.ctx = ctx
+        self.n_asm = len(packed)
+        word_off = np.zeros(self.n_asm + 1, np.int64)
+        first_ctg = np.zeros(self.n_asm + 1, np.int32)
+        first_run = np.zeros(self.n_asm + 1, np.int32)
+        for i, pa in enumerate(packed):
+            word_off[i + 1] = word_off[i] + pa.padded_len // 16
+            first_ctg[i + 1] = first_ctg[i] + len(pa.ctg_start)
+            first_run[i + 1] = first_run[i] + len(pa.n_runs)
+
+        def cat(xs, dt):
+            return np.ascontiguousarray(np.concatenate(xs), dtype=dt) if xs else np.empty(0, dt)
+
+        ctg_start = cat([pa.ctg_start for pa in packed], np.int32)
+        ctg_len = cat([pa.ctg_len for pa in packed], np.int32)
+        n_runs = cat([pa.n_runs.reshape(-1) for pa in packed], np.int32)
+        self._h = C.c_void_p()
+        if device_words is None:
+            words = cat([pa.words for pa in packed], np.uint32)
+            rc = lib().kp_batch_create(ctx._h, C.c_int32(self.n_asm), _p(words), _p(word_off), _p(ctg_start),
+                                       _p(ctg_len), _p(first_ctg), _p(n_runs), _p(first_run), C.byref(self._h))  # fmt: skip
+        else:
+            rc = lib().kp_batch_create_device(ctx._h, C.c_int32(self.n_asm), C.c_void_p(device_words), _p(word_off),
+                                              _p(ctg_start), _p(ctg_len), _p(first_ctg), _p(n_runs), _p(first_run),
+                                              C.byref(self._h))  # fmt: skip
+        ctx._check(rc, "kp_batch_create")
+        self.total_words = int(word_off[-1])
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().kp_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def align_async(self) -> None:
+        self.ctx._check(lib().kp_batch_align(self.ctx._h, self._h), "kp_batch_align")
+
+    def wait(self) -> None:
+        self.ctx._check(lib().kp_batch_wait(self.ctx._h, self._h), "kp_batch_wait")
+
+    def align(self) -> tuple[np.ndarray, np.ndarray]:
+        """Run the aligner; returns (hits [HIT_DTYPE], hit_off [n_asm + 1])."""
+        self.align_async()
+        self.wait()
+        return self.hits()
+
+    def hits(self) -> tuple[np.ndarray, np.ndarray]:
+        off = np.zeros(self.n_asm + 1, np.int64)
+        self.ctx._check(lib().kp_batch_hit_offsets(self.ctx._h, self._h, _p(off)), "kp_batch_hit_offsets")
+        out = np.zeros(int(off[-1]), HIT_DTYPE)
+        self.ctx._check(lib().kp_batch_hits(self.ctx._h, self._h, _p(out), C.c_int64(len(out))), "kp_batch_hits")
+        return out, off
+
+    def stats(self) -> dict[str, int]:
+        s = np.zeros(5, np.int64)
+        self.ctx._check(lib().kp_batch_stats(self.ctx._h, self._h, _p(s)), "kp_batch_stats")
+        return dict(zip(("anchors", "tasks", "dp_cells", "hits", "retries"), s.tolist()))
+
+    def anchors(self, asm_index: int) -> np.ndarray:
+        n = lib().kp_batch_anchors(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))
+        self.ctx._check(n, "kp_batch_anchors")
+        out = np.zeros(n, np.uint64)
+        lib().kp_batch_anchors(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
+        return out
+
+    def tasks(self, asm_index: int) -> np.ndarray:
+        n = lib().kp_batch_tasks(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))
+        self.ctx._check(n, "kp_batch_tasks")
+        out = np.zeros(n, TASK_DTYPE)
+        lib().kp_batch_tasks(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
+        return out
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    with _lock:
+        if device not in _default_ctx:
+            _default_ctx[device] = Context(device)
+        return _default_ctx[device]
+
+
+def protein_align(device, q, q_off, q_len, t, t_off, t_len) -> np.ndarray:
+    return default_context(device).protein_align(q, q_off, q_len, t, t_off, t_len)

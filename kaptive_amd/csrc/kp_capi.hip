@@ -1,0 +1,630 @@
+// kp_capi.hip -- the C ABI of libkaptive_amd.so (include/kaptive_amd.h): context, resident database, batches,
+// orchestration of the alignment kernels on the context's stream, and host-side finalisation of the hit table.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "kp_internal.h"
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_global_error = "";
+
+template <class T>
+struct DevBuf {  // growable device allocation
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct kp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    // resident database
+    bool has_db = false;
+    int32_t n_genes = 0;
+    int64_t n_postings = 0;
+    std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
+    DevBuf<uint2> d_slots;
+    DevBuf<uint64_t> d_postings;
+    DevBuf<uint32_t> d_nib;
+    DevBuf<int32_t> d_nib_off, d_gene_len;
+    KpSeedIndex index{};
+    KpGenes genes{};
+    // protein stage
+    DevBuf<int8_t> d_blosum;
+    DevBuf<uint8_t> d_pq, d_pt;
+    DevBuf<int32_t> d_pmeta, d_pout, d_pscratch;
+    // sort scratch
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+};
+
+struct kp_batch {
+    kp_ctx *ctx = nullptr;
+    int32_t n_asm = 0;
+    bool owns_words = false;
+    uint32_t *d_words = nullptr;
+    DevBuf<int64_t> d_asm_word_off;
+    DevBuf<int32_t> d_ctg_start, d_ctg_len, d_asm_first_ctg, d_n_runs, d_asm_first_nrun;
+    std::vector<int32_t> h_asm_first_ctg, h_ctg_start;
+    KpBatchView view{};
+    // work buffers
+    uint32_t anchor_cap = 0, task_cap = 0;
+    DevBuf<uint64_t> d_anchors_a, d_anchors_b;
+    DevBuf<int32_t> d_anchor_contig;
+    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, then [3] task counts
+    DevBuf<uint32_t> d_seg;     // [2 * n_asm]
+    DevBuf<KpTask> d_tasks;
+    DevBuf<KpSwResult> d_results;
+    // results
+    bool aligned = false, finalised = false;
+    std::vector<uint32_t> h_counts;
+    std::vector<KpTask> h_tasks[3];
+    std::vector<KpSwResult> h_results[3];
+    std::vector<kp_hit> hits;
+    std::vector<int64_t> hit_off;
+    int64_t stats[5] = {0, 0, 0, 0, 0};
+};
+
+int kp_fail(kp_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    else {
+        std::lock_guard<std::mutex> lk(g_err_mutex);
+        g_global_error = msg;
+    }
+    return code;
+}
+
+namespace {
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    const long long x = std::atoll(v);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
+// BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
+// (src/kaptive/core/pairwise.py:343-391)
+void fill_blosum(int8_t *m) {
+    static const int8_t b[25][25] = {
+        {4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0, -2, -1, -1, -1, -4},
+        {-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3, -1, -2, 0, -1, -4},
+        {-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3, 4, -3, 0, -1, -4},
+        {-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3, 4, -3, 1, -1, -4},
+        {0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1, -3, -1, -3, -1, -4},
+        {-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2, 0, -2, 4, -1, -4},
+        {-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2, 1, -3, 4, -1, -4},
+        {0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3, -1, -4, -2, -1, -4},
+        {-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3, 0, -3, 0, -1, -4},
+        {-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3, -3, 3, -3, -1, -4},
+        {-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1, -4, 3, -3, -1, -4},
+        {-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2, 0, -3, 1, -1, -4},
+        {-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1, -3, 2, -1, -1, -4},
+        {-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1, -3, 0, -3, -1, -4},
+        {-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2, -2, -3, -1, -1, -4},
+        {1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2, 0, -2, 0, -1, -4},
+        {0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0, -1, -1, -1, -1, -4},
+        {-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3, -4, -2, -2, -1, -4},
+        {-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1, -3, -1, -2, -1, -4},
+        {0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4, -3, 2, -2, -1, -4},
+        {-2, -1, 4, 4, -3, 0, 1, -1, 0, -3, -4, 0, -3, -3, -2, 0, -1, -4, -3, -3, 4, -3, 0, -1, -4},
+        {-1, -2, -3, -3, -1, -2, -3, -4, -3, 3, 3, -3, 2, 0, -3, -2, -1, -2, -1, 2, -3, 3, -3, -1, -4},
+        {-1, 0, 0, 1, -3, 4, 4, -2, 0, -3, -3, 1, -1, -3, -1, 0, -1, -2, -2, -2, 0, -3, 4, -1, -4},
+        {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -4},
+        {-4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4, 1},
+    };
+    static const char alphabet[] = "ARNDCQEGHILKMFPSTWYVBJZX*";
+    std::memset(m, KP_PROT_FILL, 256 * 256);
+    for (int x = 0; x < 25; ++x)
+        for (int y = 0; y < 25; ++y) m[(uint8_t)alphabet[x] * 256 + (uint8_t)alphabet[y]] = b[x][y];
+}
+
+struct HostPosting { uint32_t key, gs, pos; };
+
+bool hit_less(const kp_hit &x, const kp_hit &y) {  // emission order of kp_spec.h
+    if (x.gene != y.gene) return x.gene < y.gene;
+    if (x.score != y.score) return x.score > y.score;
+    if (x.contig != y.contig) return x.contig < y.contig;
+    if (x.t_start != y.t_start) return x.t_start < y.t_start;
+    if (x.strand != y.strand) return x.strand > y.strand;
+    if (x.q_start != y.q_start) return x.q_start < y.q_start;
+    if (x.q_end != y.q_end) return x.q_end < y.q_end;
+    if (x.t_end != y.t_end) return x.t_end < y.t_end;
+    if (x.matches != y.matches) return x.matches > y.matches;
+    return x.block_len < y.block_len;
+}
+
+bool same_span(const kp_hit &x, const kp_hit &y) {
+    return x.gene == y.gene && x.contig == y.contig && x.strand == y.strand && x.q_start == y.q_start &&
+           x.q_end == y.q_end && x.t_start == y.t_start && x.t_end == y.t_end;
+}
+
+template <class T>
+int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n) {
+    KP_HIP_CHECK(ctx, buf.reserve(n));
+    if (n) KP_HIP_CHECK(ctx, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return KP_OK;
+}
+
+int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_word_off, const int32_t *ctg_start,
+                 const int32_t *ctg_len, const int32_t *asm_first_ctg, const int32_t *n_runs,
+                 const int32_t *asm_first_nrun) {
+    for (int a = 0; a < n_asm; ++a) {
+        const int64_t words = asm_word_off[a + 1] - asm_word_off[a];
+        if (words < 0 || (words * 16) % KP_ASM_ALIGN != 0 || (uint64_t)words * 16 > KP_MAX_ASM_LEN)
+            return kp_fail(ctx, KP_EINVAL, "assembly length must be a multiple of KP_ASM_ALIGN and <= KP_MAX_ASM_LEN");
+        if (asm_first_ctg[a + 1] < asm_first_ctg[a] || asm_first_nrun[a + 1] < asm_first_nrun[a])
+            return kp_fail(ctx, KP_EINVAL, "offset tables must be non-decreasing");
+        for (int c = asm_first_ctg[a]; c < asm_first_ctg[a + 1]; ++c) {
+            if (ctg_start[c] % (int)KP_CONTIG_ALIGN != 0 || ctg_len[c] < 0 ||
+                (int64_t)ctg_start[c] + ctg_len[c] > words * 16 ||
+                (c > asm_first_ctg[a] && ctg_start[c] < ctg_start[c - 1] + ctg_len[c - 1]))
+                return kp_fail(ctx, KP_EINVAL, "contig table violates the packed layout (kp_spec.h)");
+        }
+    }
+    const size_t n_ctg = (size_t)asm_first_ctg[n_asm], n_run = (size_t)asm_first_nrun[n_asm];
+    int rc;
+    if ((rc = upload(ctx, b->d_asm_word_off, asm_word_off, (size_t)n_asm + 1))) return rc;
+    if ((rc = upload(ctx, b->d_ctg_start, ctg_start, n_ctg))) return rc;
+    if ((rc = upload(ctx, b->d_ctg_len, ctg_len, n_ctg))) return rc;
+    if ((rc = upload(ctx, b->d_asm_first_ctg, asm_first_ctg, (size_t)n_asm + 1))) return rc;
+    if ((rc = upload(ctx, b->d_n_runs, n_runs, 2 * n_run))) return rc;
+    if ((rc = upload(ctx, b->d_asm_first_nrun, asm_first_nrun, (size_t)n_asm + 1))) return rc;
+    b->h_asm_first_ctg.assign(asm_first_ctg, asm_first_ctg + n_asm + 1);
+    b->h_ctg_start.assign(ctg_start, ctg_start + n_ctg);
+    b->view.words = b->d_words;
+    b->view.asm_word_off = b->d_asm_word_off.p;
+    b->view.ctg_start = b->d_ctg_start.p;
+    b->view.ctg_len = b->d_ctg_len.p;
+    b->view.asm_first_ctg = b->d_asm_first_ctg.p;
+    b->view.n_runs = b->d_n_runs.p;
+    b->view.asm_first_nrun = b->d_asm_first_nrun.p;
+    b->view.n_asm = n_asm;
+    b->view.total_words = asm_word_off[n_asm];
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // host tables may be freed by the caller after return
+    return KP_OK;
+}
+
+int batch_new(kp_ctx *ctx, int32_t n_asm, const int64_t *asm_word_off, kp_batch **out) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    if (!out || n_asm < 0 || !asm_word_off) return kp_fail(ctx, KP_EINVAL, "bad batch arguments");
+    if (asm_word_off[0] != 0) return kp_fail(ctx, KP_EINVAL, "asm_word_off[0] must be 0");
+    *out = nullptr;
+    return KP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kp_ctx_create(int device_id, kp_ctx **out) {
+    if (!out) return kp_fail(nullptr, KP_EINVAL, "out is null");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return kp_fail(nullptr, KP_EHIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n_dev) return kp_fail(nullptr, KP_EINVAL, "device_id out of range");
+    kp_ctx *ctx = new (std::nothrow) kp_ctx();
+    if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
+    ctx->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        delete ctx;
+        return kp_fail(nullptr, KP_EHIP, std::string("device setup failed: ") + hipGetErrorString(e));
+    }
+    std::vector<int8_t> m(256 * 256);
+    fill_blosum(m.data());
+    if (upload(ctx, ctx->d_blosum, m.data(), m.size()) != KP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        std::string msg = ctx->error;
+        kp_ctx_destroy(ctx);
+        return kp_fail(nullptr, KP_EHIP, "substitution table upload failed: " + msg);
+    }
+    *out = ctx;
+    return KP_OK;
+}
+
+void kp_ctx_destroy(kp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_slots.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
+    ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
+    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
+    if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *kp_last_error(const kp_ctx *ctx) {
+    if (ctx) return ctx->error.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_global_error;
+    return copy.c_str();
+}
+
+void *kp_ctx_stream(kp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, int32_t n_genes) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    if (!gene_off || n_genes < 0 || (n_genes > 0 && !gene_codes)) return kp_fail(ctx, KP_EINVAL, "bad database arguments");
+    if (n_genes > KP_MAX_GENES) return kp_fail(ctx, KP_EINVAL, "too many genes (KP_MAX_GENES)");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ctx->has_db = false;
+    ctx->gene_len.resize((size_t)n_genes);
+    std::vector<int32_t> nib_off(2 * (size_t)n_genes);
+    size_t n_words = 0;
+    for (int g = 0; g < n_genes; ++g) {
+        const int len = gene_off[g + 1] - gene_off[g];
+        if (len < 0 || len > KP_MAX_GENE_LEN) return kp_fail(ctx, KP_EINVAL, "gene length outside [0, KP_MAX_GENE_LEN]");
+        ctx->gene_len[(size_t)g] = len;
+        nib_off[(size_t)g] = (int32_t)n_words;
+        n_words += (size_t)(len + 7) / 8;
+    }
+    for (int g = 0; g < n_genes; ++g) {
+        nib_off[(size_t)n_genes + g] = (int32_t)n_words;
+        n_words += (size_t)(ctx->gene_len[(size_t)g] + 7) / 8;
+    }
+    std::vector<uint32_t> nib(std::max<size_t>(n_words, 1), 0x44444444u);
+    std::vector<uint8_t> rc;
+    std::vector<HostPosting> post;
+    for (int g = 0; g < n_genes; ++g) {
+        const int len = ctx->gene_len[(size_t)g];
+        const uint8_t *fwd = gene_codes + gene_off[g];
+        rc.resize((size_t)len);
+        for (int i = 0; i < len; ++i) {
+            const uint8_t c = fwd[len - 1 - i];
+            rc[(size_t)i] = c > 3 ? 4 : (uint8_t)(3 - c);
+        }
+        for (int s = 0; s < 2; ++s) {
+            const uint8_t *c = s ? rc.data() : fwd;
+            uint32_t *dst = nib.data() + nib_off[(size_t)(s ? n_genes + g : g)];
+            for (int i = 0; i < len; ++i) {
+                const uint32_t code = c[i] > 3 ? 4u : c[i];
+                dst[i >> 3] = (dst[i >> 3] & ~(15u << (4 * (i & 7)))) | (code << (4 * (i & 7)));
+            }
+            for (int p = 0; p + KP_K <= len; ++p) {  // seed rule + N check, as in kp_spec.h
+                if (c[p] > 3 || c[p + 1] > 3 || c[p + 3] > 3 || ((c[p] ^ c[p + 1] ^ c[p + 3]) & 3u) != KP_SEED_RULE_VALUE)
+                    continue;
+                uint32_t v = 0;
+                bool ok = true;
+                for (int i = 0; i < KP_K; ++i) {
+                    if (c[p + i] > 3) { ok = false; break; }
+                    v |= (uint32_t)c[p + i] << (2 * i);
+                }
+                if (ok) post.push_back(HostPosting{v, (uint32_t)(2 * g + s), (uint32_t)p});
+            }
+        }
+    }
+    std::sort(post.begin(), post.end(), [](const HostPosting &a, const HostPosting &b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.gs != b.gs) return a.gs < b.gs;
+        return a.pos < b.pos;
+    });
+    size_t n_unique = 0;
+    for (size_t i = 0; i < post.size(); ++i) n_unique += (i == 0 || post[i].key != post[i - 1].key);
+    uint32_t log_slots = 10;
+    while (((size_t)1 << log_slots) < 2 * n_unique + 1) ++log_slots;
+    if (log_slots > 30) return kp_fail(ctx, KP_EINVAL, "seed index too large");
+    const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
+    std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
+    std::vector<uint64_t> flat;
+    flat.reserve(post.size() + n_unique + 1);
+    for (size_t i = 0; i < post.size();) {
+        size_t j = i;
+        while (j < post.size() && post[j].key == post[i].key) ++j;
+        uint32_t slot = (post[i].key * 2654435769u) >> shift;
+        while (slots[slot].x != 0xFFFFFFFFu) slot = (slot + 1) & mask;
+        slots[slot] = make_uint2(post[i].key, (uint32_t)flat.size());
+        flat.push_back((uint64_t)(j - i));
+        for (size_t x = i; x < j; ++x)
+            flat.push_back(((uint64_t)post[x].gs << 46) | ((uint64_t)(KP_DIAG_BIAS - post[x].pos) << 16) | post[x].pos);
+        i = j;
+    }
+    if (flat.size() > 0xFFFFFFFFull) return kp_fail(ctx, KP_EINVAL, "seed index too large");
+    if (flat.empty()) flat.push_back(0);
+    int rcode;
+    if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->index = KpSeedIndex{ctx->d_slots.p, ctx->d_postings.p, mask, shift};
+    ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
+    ctx->n_genes = n_genes;
+    ctx->n_postings = (int64_t)post.size();
+    ctx->has_db = true;
+    return KP_OK;
+}
+
+int64_t kp_db_n_postings(const kp_ctx *ctx) { return ctx && ctx->has_db ? ctx->n_postings : 0; }
+
+int kp_batch_create(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
+                    const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                    const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out) {
+    int rc = batch_new(ctx, n_asm, asm_word_off, out);
+    if (rc) return rc;
+    if (!asm_first_ctg || !asm_first_nrun) return kp_fail(ctx, KP_EINVAL, "null offset table");
+    if (asm_word_off[n_asm] > 0 && !words) return kp_fail(ctx, KP_EINVAL, "null words");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    kp_batch *b = new (std::nothrow) kp_batch();
+    if (!b) return kp_fail(ctx, KP_ENOMEM, "out of host memory");
+    b->ctx = ctx; b->n_asm = n_asm; b->owns_words = true;
+    const size_t nw = (size_t)asm_word_off[n_asm];
+    hipError_t e = hipMalloc((void **)&b->d_words, std::max<size_t>(nw, 4) * sizeof(uint32_t));
+    if (e != hipSuccess) { delete b; return kp_fail(ctx, KP_ENOMEM, std::string("hipMalloc(words): ") + hipGetErrorString(e)); }
+    if (nw) e = hipMemcpyAsync(b->d_words, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_EHIP, std::string("H2D words: ") + hipGetErrorString(e)); }
+    rc = batch_tables(ctx, b, n_asm, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun);
+    if (rc) { kp_batch_destroy(b); return rc; }
+    *out = b;
+    return KP_OK;
+}
+
+int kp_batch_create_device(kp_ctx *ctx, int32_t n_asm, const uint32_t *d_words, const int64_t *asm_word_off,
+                           const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                           const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out) {
+    int rc = batch_new(ctx, n_asm, asm_word_off, out);
+    if (rc) return rc;
+    if (!asm_first_ctg || !asm_first_nrun) return kp_fail(ctx, KP_EINVAL, "null offset table");
+    if (asm_word_off[n_asm] > 0 && !d_words) return kp_fail(ctx, KP_EINVAL, "null words");
+    if (((uintptr_t)d_words & 15u) != 0) return kp_fail(ctx, KP_EINVAL, "device words must be 16-byte aligned");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    kp_batch *b = new (std::nothrow) kp_batch();
+    if (!b) return kp_fail(ctx, KP_ENOMEM, "out of host memory");
+    b->ctx = ctx; b->n_asm = n_asm; b->owns_words = false;
+    b->d_words = const_cast<uint32_t *>(d_words);
+    rc = batch_tables(ctx, b, n_asm, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun);
+    if (rc) { kp_batch_destroy(b); return rc; }
+    *out = b;
+    return KP_OK;
+}
+
+void kp_batch_destroy(kp_batch *b) {
+    if (!b) return;
+    if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+    if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
+    b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
+    b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
+    b->d_anchor_contig.release(); b->d_counts.release(); b->d_seg.release(); b->d_tasks.release();
+    b->d_results.release();
+    delete b;
+}
+
+static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
+    const size_t n_asm = (size_t)b->n_asm;
+    if ((uint64_t)n_asm * b->anchor_cap > 0xFFFFFFF0ull)
+        return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
+    KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
+    KP_HIP_CHECK(ctx, b->d_anchors_b.reserve(n_asm * b->anchor_cap));
+    KP_HIP_CHECK(ctx, b->d_anchor_contig.reserve(n_asm * b->anchor_cap));
+    KP_HIP_CHECK(ctx, b->d_counts.reserve(n_asm + 3));
+    KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
+    KP_HIP_CHECK(ctx, b->d_tasks.reserve(3 * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, b->d_results.reserve(3 * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (n_asm + 3) * sizeof(uint32_t), ctx->stream));
+    uint32_t *d_task_count = b->d_counts.p + n_asm;
+    kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, ctx->stream);
+    int rc = kp_sort_anchors(ctx, b->d_anchors_a.p, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->n_asm,
+                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->stream);
+    if (rc) return rc;
+    kp_launch_chain(b->view, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
+                    d_task_count, b->task_cap, ctx->stream);
+    static const int widths[3] = {32, 64, 128};
+    for (int c = 0; c < 3; ++c)
+        kp_launch_sw(b->view, ctx->genes, b->d_tasks.p + (size_t)c * b->task_cap, d_task_count + c, b->task_cap,
+                     widths[c], b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
+    KP_HIP_CHECK(ctx, hipGetLastError());
+    return KP_OK;
+}
+
+int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
+    if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
+    if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "no database loaded");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (b->anchor_cap == 0) b->anchor_cap = env_u32("KAPTIVE_AMD_ANCHOR_CAP", 1u << 17);
+    if (b->task_cap == 0) {
+        const uint64_t want = (uint64_t)std::max(b->n_asm, 1) * env_u32("KAPTIVE_AMD_TASKS_PER_ASM", 4096);
+        b->task_cap = (uint32_t)std::min<uint64_t>(want, 1u << 28);
+    }
+    b->aligned = false; b->finalised = false;
+    b->stats[4] = 0;
+    int rc = enqueue_align(ctx, b);
+    if (rc) return rc;
+    b->aligned = true;
+    return KP_OK;
+}
+
+int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
+    if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
+    if (!b->aligned) return kp_fail(ctx, KP_ESTATE, "kp_batch_align has not been called");
+    if (b->finalised) return KP_OK;
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n_asm = (size_t)b->n_asm;
+    for (int attempt = 0;; ++attempt) {
+        b->h_counts.resize(n_asm + 3);
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (n_asm + 3) * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t max_anchor = 0, max_task = 0;
+        for (size_t a = 0; a < n_asm; ++a) max_anchor = std::max(max_anchor, b->h_counts[a]);
+        for (int c = 0; c < 3; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
+        if (max_anchor <= b->anchor_cap && max_task <= b->task_cap) break;
+        if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
+        // a region overflowed: counts kept counting, so they say how much room a clean rerun needs
+        if (max_anchor > b->anchor_cap) b->anchor_cap = (max_anchor + 1023u) & ~1023u;
+        if (max_task > b->task_cap) b->task_cap = (max_task + 1023u) & ~1023u;
+        b->stats[4] += 1;
+        int rc = enqueue_align(ctx, b);
+        if (rc) return rc;
+    }
+    int64_t n_anchor = 0, n_task = 0, n_cells = 0;
+    for (size_t a = 0; a < n_asm; ++a) n_anchor += b->h_counts[a];
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = b->h_counts[n_asm + c];
+        b->h_tasks[c].resize(n);
+        b->h_results[c].resize(n);
+        if (n) {
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_tasks[c].data(), b->d_tasks.p + (size_t)c * b->task_cap,
+                                             n * sizeof(KpTask), hipMemcpyDeviceToHost, ctx->stream));
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_results[c].data(), b->d_results.p + (size_t)c * b->task_cap,
+                                             n * sizeof(KpSwResult), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        n_task += (int64_t)n;
+    }
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // ---- finalise: score filter, strand flip, contig-local coordinates, emission order, duplicates, mapq -------------
+    std::vector<int64_t> per_asm(n_asm + 1, 0);
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < b->h_tasks[c].size(); ++i) {
+            n_cells += (int64_t)ctx->gene_len[(size_t)(b->h_tasks[c][i].gs >> 1)] * b->h_tasks[c][i].width;
+            if (b->h_results[c][i].score >= KP_MIN_DP_SCORE) per_asm[(size_t)b->h_tasks[c][i].asm_id + 1]++;
+        }
+    for (size_t a = 0; a < n_asm; ++a) per_asm[a + 1] += per_asm[a];
+    std::vector<kp_hit> raw((size_t)per_asm[n_asm]);
+    std::vector<int64_t> fill(per_asm.begin(), per_asm.end() - 1);
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < b->h_tasks[c].size(); ++i) {
+            const KpTask &t = b->h_tasks[c][i];
+            const KpSwResult &r = b->h_results[c][i];
+            if (r.score < KP_MIN_DP_SCORE) continue;
+            const int gene = t.gs >> 1, rev = t.gs & 1, qlen = ctx->gene_len[(size_t)gene];
+            const int32_t cs = b->h_ctg_start[(size_t)b->h_asm_first_ctg[(size_t)t.asm_id] + (size_t)t.contig];
+            kp_hit h;
+            std::memset(&h, 0, sizeof h);
+            h.gene = gene; h.contig = t.contig; h.strand = rev ? -1 : 1;
+            h.q_start = rev ? qlen - r.q_end : r.q_start;
+            h.q_end = rev ? qlen - r.q_start : r.q_end;
+            h.t_start = r.t_start - cs; h.t_end = r.t_end - cs;
+            h.score = r.score; h.matches = r.matches; h.block_len = r.block_len;
+            raw[(size_t)fill[(size_t)t.asm_id]++] = h;
+        }
+    b->hits.clear();
+    b->hits.reserve(raw.size());
+    b->hit_off.assign(n_asm + 1, 0);
+    for (size_t a = 0; a < n_asm; ++a) {
+        kp_hit *first = raw.data() + per_asm[a], *last = raw.data() + per_asm[a + 1];
+        std::sort(first, last, hit_less);
+        const size_t base = b->hits.size();
+        for (kp_hit *h = first; h != last; ++h) {
+            if (b->hits.size() > base && same_span(b->hits.back(), *h)) continue;
+            h->mapq = (b->hits.size() == base || b->hits.back().gene != h->gene) ? 60 : 0;
+            b->hits.push_back(*h);
+        }
+        b->hit_off[a + 1] = (int64_t)b->hits.size();
+    }
+    b->stats[0] = n_anchor; b->stats[1] = n_task; b->stats[2] = n_cells; b->stats[3] = (int64_t)b->hits.size();
+    b->finalised = true;
+    return KP_OK;
+}
+
+int kp_batch_hit_offsets(kp_ctx *ctx, kp_batch *b, int64_t *hit_off) {
+    if (!ctx || !b || !hit_off) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    std::memcpy(hit_off, b->hit_off.data(), b->hit_off.size() * sizeof(int64_t));
+    return KP_OK;
+}
+
+int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
+    if (!ctx || !b || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    if (cap < (int64_t)b->hits.size()) return kp_fail(ctx, KP_EINVAL, "hit buffer too small");
+    if (!b->hits.empty()) std::memcpy(out, b->hits.data(), b->hits.size() * sizeof(kp_hit));
+    return KP_OK;
+}
+
+int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
+    if (!ctx || !b || !stats5) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    std::memcpy(stats5, b->stats, sizeof b->stats);
+    return KP_OK;
+}
+
+int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int64_t cap) {
+    if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    const int64_t n = b->h_counts[(size_t)a];
+    const int64_t m = std::min(n, cap);
+    if (out && m > 0) {
+        if (hipMemcpy(out, b->d_anchors_b.p + (size_t)a * b->anchor_cap, (size_t)m * sizeof(uint64_t),
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return kp_fail(ctx, KP_EHIP, "D2H anchors failed");
+    }
+    return n;
+}
+
+int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
+    if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    int64_t n = 0;
+    for (int c = 0; c < 3; ++c)
+        for (const KpTask &t : b->h_tasks[c]) {
+            if (t.asm_id != a) continue;
+            if (out7 && n < cap) {
+                int32_t *o = out7 + 7 * n;
+                o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = t.qmin; o[6] = t.qmax;
+            }
+            ++n;
+        }
+    return n;
+}
+
+int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                     const int32_t *t_off, const int32_t *t_len, int32_t n, int32_t *out8) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    if (n < 0 || (n > 0 && (!q_off || !q_len || !t_off || !t_len || !out8))) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (n == 0) return KP_OK;
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t q_bytes = 0, t_bytes = 0;
+    int max_band = 0;
+    for (int i = 0; i < n; ++i) {
+        if (q_len[i] < 0 || t_len[i] < 0 || q_off[i] < 0 || t_off[i] < 0 || q_len[i] > 65535 || t_len[i] > 65535)
+            return kp_fail(ctx, KP_EINVAL, "protein lengths must be within [0, 65535]");
+        q_bytes = std::max(q_bytes, (size_t)q_off[i] + (size_t)q_len[i]);
+        t_bytes = std::max(t_bytes, (size_t)t_off[i] + (size_t)t_len[i]);
+        const int d = std::abs(q_len[i] - t_len[i]);
+        max_band = std::max(max_band, 2 * std::max(KP_PROT_K, d + 1) + 1);
+    }
+    if ((q_bytes && !q) || (t_bytes && !t)) return kp_fail(ctx, KP_EINVAL, "null sequence data");
+    const int n_blocks = std::min(n, 256 * 8);
+    const size_t scratch_per_block = (size_t)max_band * 12;
+    std::vector<int32_t> meta(4 * (size_t)n);
+    std::memcpy(meta.data(), q_off, (size_t)n * 4);
+    std::memcpy(meta.data() + n, q_len, (size_t)n * 4);
+    std::memcpy(meta.data() + 2 * (size_t)n, t_off, (size_t)n * 4);
+    std::memcpy(meta.data() + 3 * (size_t)n, t_len, (size_t)n * 4);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_pq, q, q_bytes))) return rc;
+    if ((rc = upload(ctx, ctx->d_pt, t, t_bytes))) return rc;
+    if ((rc = upload(ctx, ctx->d_pmeta, meta.data(), meta.size()))) return rc;
+    KP_HIP_CHECK(ctx, ctx->d_pout.reserve(8 * (size_t)n));
+    KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks));
+    kp_launch_protein(ctx->d_pq.p, ctx->d_pmeta.p, ctx->d_pmeta.p + n, ctx->d_pt.p, ctx->d_pmeta.p + 2 * (size_t)n,
+                      ctx->d_pmeta.p + 3 * (size_t)n, n, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
+                      scratch_per_block, n_blocks, ctx->stream);
+    KP_HIP_CHECK(ctx, hipGetLastError());
+    KP_HIP_CHECK(ctx, hipMemcpyAsync(out8, ctx->d_pout.p, 8 * (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return KP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// kp_chain.hip -- sorted anchors -> band tasks (the "chaining" step of the aligner, include/kp_spec.h).
+//
+// Stands in for the chaining stage inside rammappy's map_batch (reference call site
+// src/kaptive/serotyping/core.py:154).  Anchors of an assembly arrive sorted by (gene*2+strand, diagonal, query pos).
+// Pass 1 labels every anchor with its contig.  Pass 2 runs one thread per anchor; the threads that sit on a hard
+// break (first anchor, new gene/strand, new contig, diagonal jump > KP_DIAG_GAP) walk their run forward, cut it
+// whenever it would span more than KP_MAX_SPREAD diagonals, and append one task per surviving cluster to the list of
+// its band-width class.  Runs are short (tens of anchors), so the sequential walk is not a bottleneck.
+#include "kp_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void kp_anchor_contig_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
+                                                               const uint32_t *__restrict__ count, uint32_t cap,
+                                                               int32_t *__restrict__ contig) {
+    const int a = blockIdx.y;
+    uint32_t n = count[a];
+    if (n > cap) n = cap;
+    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+    const int32_t *starts = b.ctg_start + c0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t k = keys[(size_t)a * cap + i];
+        const int32_t t = (int32_t)KP_KEY_DIAG(k) - KP_DIAG_BIAS + (int32_t)KP_KEY_QPOS(k);
+        int lo = 0, hi = nc;  // last contig starting at or before t
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (starts[mid] <= t) lo = mid + 1; else hi = mid;
+        }
+        contig[(size_t)a * cap + i] = lo - 1;
+    }
+}
+
+__device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
+                                              uint32_t qmax, int cnt, KpTask *tasks, uint32_t *task_count,
+                                              uint32_t task_cap) {
+    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
+    const int need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
+    const int w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+    const int cls = w == 32 ? 0 : (w == 64 ? 1 : 2);
+    const uint32_t slot = atomicAdd(&task_count[cls], 1u);
+    if (slot >= task_cap) return;  // counted, not stored: the host sees count > cap and retries with more room
+    KpTask t;
+    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
+    t.lo = (int32_t)d0 - KP_DIAG_BIAS - KP_BAND_MARGIN - (w - need) / 2;
+    t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
+    tasks[(size_t)cls * task_cap + slot] = t;
+}
+
+__global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restrict__ keys,
+                                                       const int32_t *__restrict__ contig,
+                                                       const uint32_t *__restrict__ count, uint32_t cap,
+                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
+                                                       uint32_t task_cap) {
+    const int a = blockIdx.y;
+    uint32_t n = count[a];
+    if (n > cap) n = cap;
+    const uint64_t *k = keys + (size_t)a * cap;
+    const int32_t *c = contig + (size_t)a * cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t gs = KP_KEY_GS(k[i]);
+        const int ctg = c[i];
+        if (i > 0 && KP_KEY_GS(k[i - 1]) == gs && c[i - 1] == ctg &&
+            KP_KEY_DIAG(k[i]) - KP_KEY_DIAG(k[i - 1]) <= KP_DIAG_GAP)
+            continue;  // not the head of a run
+        uint32_t d0 = KP_KEY_DIAG(k[i]), dprev = d0, q = KP_KEY_QPOS(k[i]);
+        uint32_t qmin = q, qmax = q;
+        int cnt = 1;
+        for (uint32_t j = i + 1; j < n; ++j) {
+            const uint32_t d = KP_KEY_DIAG(k[j]);
+            if (KP_KEY_GS(k[j]) != gs || c[j] != ctg || d - dprev > KP_DIAG_GAP) break;
+            q = KP_KEY_QPOS(k[j]);
+            if (d - d0 > KP_MAX_SPREAD) {  // soft cut: close the cluster, open the next one at j
+                flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
+                d0 = d; qmin = qmax = q; cnt = 0;
+            }
+            dprev = d;
+            cnt++;
+            qmin = min(qmin, q);
+            qmax = max(qmax, q);
+        }
+        flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
+    }
+}
+
+__global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t cap, int n_asm,
+                                   uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_asm) return;
+    const uint32_t n = count[a] > cap ? cap : count[a];
+    seg_begin[a] = (uint32_t)a * cap;
+    seg_end[a] = (uint32_t)a * cap + n;
+}
+
+}  // namespace
+
+void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,
+                        hipStream_t stream) {
+    if (n_asm == 0) return;
+    hipLaunchKernelGGL(kp_segments_kernel, dim3((n_asm + 255) / 256), dim3(256), 0, stream, count, cap, n_asm, seg_begin,
+                       seg_end);
+}
+
+void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
+                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count, uint32_t task_cap,
+                     hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    const dim3 grid(32, b.n_asm), block(256);
+    hipLaunchKernelGGL(kp_anchor_contig_kernel, grid, block, 0, stream, b, sorted_anchors, anchor_count, cap,
+                       anchor_contig);
+    hipLaunchKernelGGL(kp_chain_kernel, grid, block, 0, stream, sorted_anchors, anchor_contig, anchor_count, cap, tasks,
+                       task_count, task_cap);
+}

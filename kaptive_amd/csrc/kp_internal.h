@@ -1,0 +1,87 @@
+// kp_internal.h -- shared declarations of the HIP implementation (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/kaptive_amd.h"
+
+// ---- device-side views -------------------------------------------------------------------------------------------
+// Seed index: open-addressing table keyed by the 30-bit k-mer; slot = {key, first posting}; postings[first] holds the
+// count in its low word, followed by `count` posting words.  A posting word is the anchor key of the seed for target
+// position 0:  (gs << 46) | ((KP_DIAG_BIAS - qpos) << 16) | qpos ; adding (tpos << 16) yields the anchor key.
+struct KpSeedIndex {
+    const uint2 *slots;        // [n_slots], key == 0xFFFFFFFF marks an empty slot
+    const uint64_t *postings;  // count word + postings, per distinct k-mer
+    uint32_t slot_mask;        // n_slots - 1 (power of two)
+    uint32_t slot_shift;       // 32 - log2(n_slots): slot = (kmer * 2654435769u) >> slot_shift
+};
+
+struct KpGenes {
+    const uint32_t *nib;      // 4-bit codes (0..3 ACGT, 4 = N), 8 per word, each gene starts on a word boundary;
+                              // forward sequences first, then the reverse complements (same layout)
+    const int32_t *word_off;  // [2 * n_genes] first word of gene g (forward) / n_genes + g (reverse complement)
+    const int32_t *len;       // [n_genes]
+    int32_t n_genes;
+};
+
+struct KpBatchView {
+    const uint32_t *words;          // packed bases of the whole batch
+    const int64_t *asm_word_off;    // [n_asm + 1]
+    const int32_t *ctg_start;       // per contig, in its assembly's padded space
+    const int32_t *ctg_len;
+    const int32_t *asm_first_ctg;   // [n_asm + 1]
+    const int32_t *n_runs;          // pairs
+    const int32_t *asm_first_nrun;  // [n_asm + 1]
+    int32_t n_asm;
+    int64_t total_words;
+};
+
+// A band task (one banded alignment).  `asm_id` and the derived fields are filled by the chaining kernel.
+struct KpTask {
+    int32_t asm_id;
+    int32_t gs;         // gene * 2 + (strand < 0)
+    int32_t contig;     // contig index within the assembly
+    int32_t lo;         // lowest diagonal of the band (tpos - qpos, assembly coordinates)
+    int32_t width;      // 32 / 64 / 128
+    int32_t n_anchors;
+    int32_t qmin, qmax;
+};
+
+// Raw result of one task (before the score filter), same meaning as the oracle's kpo_sw rows.
+struct KpSwResult {
+    int32_t score, q_start, q_end, t_start, t_end, matches, block_len;
+};
+
+#define KP_HIP_CHECK(ctx, expr)                                                                     \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return kp_fail((ctx), KP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct kp_ctx;
+int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
+
+// ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
+// kp_scan.hip: stream the packed contigs, emit anchor keys into per-assembly regions of `anchors`
+//   (region a = anchors[a * cap .. a * cap + min(count[a], cap)); count[a] keeps counting past cap = overflow).
+void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *anchor_count,
+                    uint32_t cap, hipStream_t stream);
+// kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
+void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
+                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[3]*/, uint32_t task_cap,
+                     hipStream_t stream);
+// kp_sw.hip: banded Smith-Waterman of every task of one width class.
+void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
+                  uint32_t task_cap, int width, KpSwResult *results, hipStream_t stream);
+// kp_prot.hip
+void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                       const int32_t *t_off, const int32_t *t_len, int32_t n, const int8_t *blosum, int32_t *out8,
+                       int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream);
+// kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
+int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
+                    int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,
+                    hipStream_t stream);

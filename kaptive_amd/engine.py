@@ -1,0 +1,75 @@
+"""Engine: a database resident on one GPU, plus the batched entry points built on the C ABI.
+
+This is the host-side replacement for what the reference does per genome inside ``Serotyper.__call__`` before its
+reduction starts: build an index, construct an ``Aligner`` and call ``map_batch`` (src/kaptive/serotyping/core.py:
+145-155).  Here the database is uploaded once, assemblies go to the device as packed batches, and hit tables come
+back as columns.
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from kaptive_amd import _native
+from kaptive_amd.core.alignment import Alignments
+from kaptive_amd.core.genome import GenomeAssembly
+from kaptive_amd.core.pairwise import PairwiseAlignments
+from kaptive_amd.core.seq import Sequences
+from kaptive_amd.db import Database
+from kaptive_amd.pack import pack_sequences_flat
+
+
+class Engine:
+    def __init__(self, db: Database, device: int = 0) -> None:
+        self.db = db
+        self.device = device
+        self.ctx = _native.Context(device)
+        codes, off = pack_sequences_flat(db.genes)
+        self.ctx.load_genes(codes, off)
+        self._gene_names = tuple(str(i) for i in range(len(db.genes)))
+
+    def close(self) -> None:
+        self.ctx.close()
+
+    # -- stages -------------------------------------------------------------------------------------------------
+    def align_packed(self, packed: list):
+        """Hit table for a list of PackedAssembly: (hits, hit_off, stats)."""
+        batch = self.ctx.batch(packed)
+        try:
+            hits, off = batch.align()
+            return hits, off, batch.stats()
+        finally:
+            batch.close()
+
+    def hits_to_alignments(self, genome: GenomeAssembly, hits: np.ndarray) -> Alignments:
+        if len(hits) == 0:
+            return Alignments.empty()
+        db = self.db
+        return Alignments.from_hit_table(
+            self._gene_names, genome.contigs.ids,
+            q_ids=hits["gene"], q_lengths=db.genes.lengths[hits["gene"]], q_starts=hits["q_start"],
+            q_ends=hits["q_end"], t_ids=hits["contig"], t_lengths=genome.contigs.lengths[hits["contig"]],
+            t_starts=hits["t_start"], t_ends=hits["t_end"], strands=hits["strand"], block_lens=hits["block_len"],
+            matches=hits["matches"], scores=hits["score"], mapqs=hits["mapq"],
+        )  # fmt: skip
+
+    def align(self, genomes: Sequence[GenomeAssembly]) -> list[Alignments]:
+        hits, off, _ = self.align_packed([g.packed() for g in genomes])
+        return [self.hits_to_alignments(g, hits[off[i] : off[i + 1]]) for i, g in enumerate(genomes)]
+
+    def protein_aligner(self, queries: Sequences, targets: Sequences) -> PairwiseAlignments:
+        if len(queries.offsets) != len(targets.offsets):
+            raise ValueError("Query and target batches must have the same number of sequences.")
+        if len(queries.offsets) == 0:
+            return PairwiseAlignments.empty()
+        return PairwiseAlignments.from_table(
+            self.ctx.protein_align(queries.seqs, queries.offsets, queries.lengths, targets.seqs, targets.offsets,
+                                   targets.lengths)
+        )  # fmt: skip
+
+    def type_many(self, typer, genomes: Sequence[GenomeAssembly]) -> list:
+        """One device submission for the alignment of all genomes, then the reduction per genome."""
+        alns = self.align(genomes)
+        return [typer.reduce(g, a) for g, a in zip(genomes, alns)]

