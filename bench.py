@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- assemblies typed per second (K + O databases back to back) on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--assemblies A]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" types every assembly of the rank's resident batch against the synthetic KpSC K-locus database and then
+against the O-locus database (2 database passes per assembly): seed scan -> anchor sort -> chaining -> banded
+Smith-Waterman on the GPU, then the per-locus reduction and the protein DP.  Packed assemblies are resident in HBM
+before the timed region.  Ranks hold disjoint assemblies (weak scaling, no collective on the data path; the only
+torch.distributed calls are the barrier and the max-over-ranks of the elapsed time).  Rank 0 prints one JSON line.
+
+Extra objects in the line:
+  roofline      seed-scan kernel (the only kernel that streams every base): algorithmic bytes = 4 * packed words per
+                launch, duration from HIP events on the kernel's stream (kp_batch_profile), peak = 8 TB/s HBM3E.
+  dp            banded Smith-Waterman kernels: DP cells per second (integer VALU work; no HBM or MFMA roofline applies).
+  cpu_baseline  the CPU oracle (oracle/kp_oracle.c + the numpy reduction) typing a bounded sample of the same
+                assemblies on one host core.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from multiprocessing import get_context
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def _make_one(job):
+    kind, seed, length = job
+    from kaptive_amd.synth import make_assembly
+
+    db = _DBS[kind]
+    g = make_assembly(db, seed=seed, length=length)
+    pa = g.packed()
+    return g.id, g.contigs.ids, g.contigs.seqs, g.contigs.lengths, pa
+
+
+_DBS: dict = {}
+
+
+def build_workload(n_asm: int, seed0: int, length: float, workers: int):
+    """Synthetic KpSC-shaped databases and assemblies (SURVEY.md section 8d, config 2 inputs), generated before any
+    GPU state exists so that worker processes can be forked safely."""
+    from kaptive_amd.core.genome import GenomeAssembly
+    from kaptive_amd.core.seq import Sequences
+    from kaptive_amd.synth import make_db
+
+    _DBS["k"] = make_db("kpsc_k", seed=100)
+    _DBS["o"] = make_db("kpsc_o", seed=101)
+    jobs = [("k", seed0 + i, length) for i in range(n_asm)]
+    if workers > 1 and n_asm > 4:
+        with get_context("fork").Pool(workers) as pool:
+            rows = pool.map(_make_one, jobs, chunksize=max(1, n_asm // (workers * 4)))
+    else:
+        rows = [_make_one(j) for j in jobs]
+    genomes, packed = [], []
+    for gid, ids, seqs, lengths, pa in rows:
+        off = np.zeros(len(lengths), np.int32)
+        if len(lengths) > 1:
+            np.cumsum(lengths[:-1], out=off[1:])
+        g = GenomeAssembly(gid, Sequences(ids, seqs, off, lengths))
+        g._packed.append(pa)
+        genomes.append(g)
+        packed.append(pa)
+    return _DBS["k"], _DBS["o"], genomes, packed
+
+
+def cpu_baseline(dbs, genomes, budget_s: float = 20.0) -> dict:
+    """Type a bounded sample with the CPU oracle (C aligner + C protein DP + numpy reduction), one core."""
+    from kaptive_amd.core.pairwise import PairwiseAlignments
+    from kaptive_amd.pack import pack_sequences_flat
+    from kaptive_amd.serotyping.core import Serotyper
+    from oracle import oracle as O
+    from tests.golden_util import hits_to_alignments
+
+    def oracle_proteins(q, t):
+        return PairwiseAlignments.from_table(O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths))
+
+    stages = []
+    for db in dbs:
+        odb = O.OracleDB(*pack_sequences_flat(db.genes))
+        stages.append((db, odb, Serotyper(db, aligner=lambda g: None, protein_aligner=oracle_proteins)))
+    n = 0
+    t0 = time.perf_counter()
+    for g in genomes:
+        for db, odb, typer in stages:
+            hits = odb.align(g.packed())
+            typer.reduce(g, hits_to_alignments(db, g, hits))
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "assemblies/s", "cores": 1, "kind": "port",
+        "sample": f"first {n} assemblies of the same batch, K then O, CPU oracle (oracle/kp_oracle.c aligner + protein DP, "
+                  f"numpy reduction), {dt:.1f} s wall on 1 of {os.cpu_count()} host cores",
+    }  # fmt: skip
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--assemblies", type=int, default=1000, help="assemblies per GPU (resident batch)")
+    ap.add_argument("--length", type=float, default=5.0e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    t_gen = time.perf_counter()
+    db_k, db_o, genomes, packed = build_workload(args.assemblies, 200 + rank * args.assemblies, args.length, workers)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
+
+    from kaptive_amd.engine import Engine
+    from kaptive_amd.serotyping.core import Serotyper
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (kaptive_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stages = []
+    for db in (db_k, db_o):
+        eng = Engine(db, device=local_rank)
+        typer = Serotyper(db, device=local_rank)
+        typer._engine = eng
+        stages.append((eng, typer, eng.ctx.batch(packed)))
+
+    def step():
+        results = []
+        for eng, typer, batch in stages:
+            hits, off = batch.align()
+            for i, g in enumerate(genomes):
+                results.append(typer.reduce(g, eng.hits_to_alignments(g, hits[off[i] : off[i + 1]])))
+        return results
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_total = args.assemblies * world * args.steps
+        prof = [b.profile() for _, _, b in stages]
+        stats = [b.stats() for _, _, b in stages]
+        scan_ms = float(np.mean([p["scan"] for p in prof]))
+        scan_bytes = prof[0]["bytes_scanned"]
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
+        sw_ms = sum(p["sw32"] + p["sw64"] + p["sw128"] for p in prof)
+        cells = sum(s["dp_cells"] for s in stats)
+        typed = sum(1 for r in res if r.typeable)
+        line = {
+            "metric": "assemblies typed/sec (K+O)",
+            "value": n_total / elapsed,
+            "unit": "assemblies/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.assemblies} synthetic {args.length / 1e6:g} Mbp KpSC assemblies per GPU, K-locus "
+                            "then O-locus synthetic DB back-to-back (2 DB passes per assembly), packed batch resident in HBM",
+                "assemblies_per_gpu": args.assemblies,
+                "db_k": f"{len(db_k.loci)} loci / {len(db_k.genes)} genes",
+                "db_o": f"{len(db_o.loci)} loci / {len(db_o.genes)} genes",
+                "parallelism": f"{world} x independent shard, no collective",
+                "typeable_in_last_step": typed,
+                "workload_generation_s": round(t_gen, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "kp_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": scan_bytes,
+                "ms_per_launch": scan_ms,
+            },
+            "dp": {
+                "kernel": "kp_sw_kernel<16|32|64>", "cells_per_db_pass": [s["dp_cells"] for s in stats],
+                "ms": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
+                "tasks": [s["tasks"] for s in stats], "anchors": [s["anchors"] for s in stats],
+            },
+            "kernel_ms": {k: [p[k] for p in prof] for k in ("scan", "sort", "chain", "sw32", "sw64", "sw128")},
+        }  # fmt: skip
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline((db_k, db_o), genomes)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

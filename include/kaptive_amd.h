@@ -84,6 +84,11 @@ KP_API int kp_batch_hits(kp_ctx *ctx, kp_batch *batch, kp_hit *out, int64_t cap)
 /* counters of the last kp_batch_align: [0] anchors, [1] band tasks, [2] DP cells, [3] hits, [4] overflow retries */
 KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 
+/* Per-kernel durations of one alignment pass over the batch, measured with HIP events on the context's stream (the
+ * pass is re-run for the measurement; results are unchanged): ms6 = scan, anchor sort, chaining, SW width 32, 64, 128.
+ * bytes_scanned receives the algorithmic bytes the scan kernel streams (4 * total words). */
+KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms6, int64_t *bytes_scanned);
+
 /* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and
  * the band tasks of one assembly as 7 x int32 rows (gs, contig, lo, width, n_anchors, qmin, qmax) in device order. */
 KP_API int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint64_t *out, int64_t cap);

@@ -23,7 +23,8 @@ TASK_DTYPE = np.dtype(
 EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_db_load", "kp_db_n_postings",
     "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
-    "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_anchors", "kp_batch_tasks",
+    "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
+    "kp_batch_tasks",
     "kp_protein_align",
 )  # fmt: skip
 
@@ -177,6 +178,15 @@ class Batch:
         s = np.zeros(5, np.int64)
         self.ctx._check(lib().kp_batch_stats(self.ctx._h, self._h, _p(s)), "kp_batch_stats")
         return dict(zip(("anchors", "tasks", "dp_cells", "hits", "retries"), s.tolist()))
+
+    def profile(self) -> dict[str, float]:
+        """Per-kernel milliseconds of one more alignment pass (HIP events on the context's stream)."""
+        ms = np.zeros(6, np.float32)
+        nbytes = C.c_int64(0)
+        self.ctx._check(lib().kp_batch_profile(self.ctx._h, self._h, _p(ms), C.byref(nbytes)), "kp_batch_profile")
+        d = dict(zip(("scan", "sort", "chain", "sw32", "sw64", "sw128"), ms.tolist()))
+        d["bytes_scanned"] = int(nbytes.value)
+        return d
 
     def anchors(self, asm_index: int) -> np.ndarray:
         n = lib().kp_batch_anchors(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))

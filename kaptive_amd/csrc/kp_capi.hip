@@ -409,7 +409,7 @@ void kp_batch_destroy(kp_batch *b) {
     delete b;
 }
 
-static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
+static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     const size_t n_asm = (size_t)b->n_asm;
     if ((uint64_t)n_asm * b->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
@@ -422,16 +422,22 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, b->d_results.reserve(3 * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (n_asm + 3) * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
+    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
     kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, ctx->stream);
+    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
     int rc = kp_sort_anchors(ctx, b->d_anchors_a.p, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->n_asm,
                              &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->stream);
     if (rc) return rc;
+    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     kp_launch_chain(b->view, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
+    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
     static const int widths[3] = {32, 64, 128};
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c) {
         kp_launch_sw(b->view, ctx->genes, b->d_tasks.p + (size_t)c * b->task_cap, d_task_count + c, b->task_cap,
                      widths[c], b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
+        if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
+    }
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -556,6 +562,22 @@ int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
     if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
     std::memcpy(stats5, b->stats, sizeof b->stats);
     return KP_OK;
+}
+
+int kp_batch_profile(kp_ctx *ctx, kp_batch *b, float *ms6, int64_t *bytes_scanned) {
+    if (!ctx || !b || b->ctx != ctx || !ms6) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed (buffer sizes are settled there)");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev[7];
+    for (auto &e : ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
+    int rc = enqueue_align(ctx, b, ev);
+    if (rc == KP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "profile pass failed");
+    if (rc == KP_OK)
+        for (int i = 0; i < 6; ++i)
+            if (hipEventElapsedTime(&ms6[i], ev[i], ev[i + 1]) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "event timing failed");
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (bytes_scanned) *bytes_scanned = 4 * b->view.total_words;
+    return rc;
 }
 
 int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int64_t cap) {
