@@ -60,8 +60,12 @@ def build_workload(n_asm: int, seed0: int, length: float, workers: int):
     _DBS["o"] = make_db("kpsc_o", seed=101)
     jobs = [("k", seed0 + i, length) for i in range(n_asm)]
     if workers > 1 and n_asm > 4:
-        with get_context("fork").Pool(workers) as pool:
+        pool = get_context("fork").Pool(workers)
+        try:
             rows = pool.map(_make_one, jobs, chunksize=max(1, n_asm // (workers * 4)))
+        finally:  # close + join, never terminate(): a SIGTERM to the workers wedges tools that hook signals (rocprofv3)
+            pool.close()
+            pool.join()
     else:
         rows = [_make_one(j) for j in jobs]
     genomes, packed = [], []
@@ -116,6 +120,7 @@ def main() -> None:
     ap.add_argument("--assemblies", type=int, default=1000, help="assemblies per GPU (resident batch)")
     ap.add_argument("--length", type=float, default=5.0e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +129,7 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    workers = args.workers or max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
     t_gen = time.perf_counter()
     db_k, db_o, genomes, packed = build_workload(args.assemblies, 200 + rank * args.assemblies, args.length, workers)
     t_gen = time.perf_counter() - t_gen
