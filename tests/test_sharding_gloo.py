@@ -1,0 +1,77 @@
+"""N>1 path on CPU: two processes (gloo) each type their shard with the host-side reduction on recorded hit tables and
+rank 0 gathers the TSV rows; the result must equal the single-process order."""
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import torch.multiprocessing as mp
+
+from kaptive_amd.shard import shard_bounds
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 8, 100):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _rows_for(names):
+    from kaptive_amd.core.pairwise import PairwiseAlignments
+    from kaptive_amd.serotyping.core import Serotyper
+    from kaptive_amd.serotyping.io import KaptiveRow
+    from oracle import oracle as O
+    from tests.golden_util import hits_to_alignments, load_case, load_db
+
+    def proteins(q, t):
+        return PairwiseAlignments.from_table(O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths))
+
+    rows = []
+    for name in names:
+        key, genome, hits, *_ = load_case(name)
+        db = load_db(key)
+        typer = Serotyper(db, aligner=lambda g, d=db, h=hits: hits_to_alignments(d, g, h), protein_aligner=proteins)
+        rows.append(bytes(KaptiveRow.from_result(typer(genome))))
+    return rows
+
+
+CASES = ["k_plain1", "k_split", "k_nolocus", "o_extra2", "k_is"]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+
+    from kaptive_amd.shard import gather_rows, shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = gather_rows(_rows_for(shard(CASES, rank, world)))
+    if rank == 0:
+        q.put(rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_typing_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rows = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rows == _rows_for(CASES)
