@@ -1,0 +1,334 @@
+// kp_reduce_core.h -- per-assembly pieces of the batched reduction, written once as plain functions.
+//
+// They restate, for one assembly at a time and on flat arrays, the reduction the reference runs in numpy/numba after
+// its aligner returns (src/kaptive/serotyping/core.py:157-396); kaptive_amd/serotyping/core.py::Serotyper.reduce is
+// the golden-pinned statement of the same steps and is what these functions are tested against.  The HIP kernels in
+// kp_reduce.hip call them (block-parallel where the work is quadratic, one lane where it is inherently sequential and
+// tiny); tests/native_harness compiles the same header with g++ so the logic is checked in the GPU-less container.
+// Nothing here is a product CPU path: the product only ever loads the HIP build.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/kp_spec.h"
+
+#if defined(__HIPCC__)
+#define KP_HD __host__ __device__ __forceinline__
+#else
+#define KP_HD inline
+#endif
+
+// ---- records ---------------------------------------------------------------------------------------------------------
+#define KP_F_EXPECTED 1u
+#define KP_F_INSIDE 2u
+#define KP_F_EXTRA 4u
+#define KP_F_PARTIAL 8u
+#define KP_F_SPURIOUS 16u
+#define KP_F_PRIMARY 32u
+
+#define KP_STATE_NORMAL 0
+#define KP_STATE_PARTIAL 1
+#define KP_STATE_TRUNCATED 2
+#define KP_STATE_NOVEL 3
+
+#define KP_MAX_LOCUS_GENES 256 /* missing-gene mask width */
+
+typedef struct KpKept {  // one culled-and-kept hit, emission order
+    int32_t gene, contig, q_start, q_end, t_start, t_end, score;
+    int32_t prot_off, prot_len;  // translated protein inside the batch protein buffer
+    int32_t cluster;             // spatial cluster id (piece candidate)
+    int32_t dp[8];               // protein DP: score, matches, mismatches, gaps, qs, qe, ts, te
+    float pident, coverage;
+    int8_t strand, state;
+    uint8_t flags, pad_;
+} KpKept;
+
+typedef struct KpPiece {
+    int32_t contig, start, end, strand;
+    double mean_pos;
+} KpPiece;
+
+typedef struct KpAsmSummary {
+    int32_t n_hits, n_kept, n_final, n_pieces;
+    int32_t best_locus, n_expected, n_missing, overflow;  // overflow: bit0 kept list, bit1 pieces, bit2 locus too large
+    uint64_t missing_mask[KP_MAX_LOCUS_GENES / 64];       // bit j: gene locus_off + j not found inside the locus
+} KpAsmSummary;
+
+typedef struct KpTypingDb {  // device-resident views of the Database arrays the reduction reads
+    const uint16_t *gene_locus;     // db.gene_locus_indices
+    const uint8_t *gene_extra;      // db.extra_genes
+    const uint16_t *gene_pos;       // db.gene_positions
+    const int8_t *gene_strand;      // db.gene_intervals.strands
+    const int32_t *gene_len;        // db.genes.lengths
+    const int32_t *locus_gene_off;  // db.locus_gene_offsets
+    const int32_t *locus_gene_len;  // db.locus_gene_lengths
+    const uint8_t *prot;            // db.translations (bytes, stop codons kept)
+    const int32_t *prot_off, *prot_len;
+    int32_t n_genes, n_loci;
+} KpTypingDb;
+
+typedef struct KpTypingParams {
+    double min_gene_coverage;  // Serotyper.min_gene_coverage
+    float id_threshold;        // np.float32(db.metadata.id_threshold): the reference compares float32 identities
+    int32_t max_locus_length;  // db.max_locus_length (clustering tolerance)
+    int32_t edge_tolerance;    // Serotyper.partial_edge_tolerance
+} KpTypingParams;
+
+// ---- hit finalisation -----------------------------------------------------------------------------------------------
+// task result -> hit record (strand flip, contig-local coordinates); mapq is filled after sorting
+KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int score, int q_start, int q_end,
+                         int t_start, int t_end, int matches, int block_len) {
+    kp_hit h;
+    const int rev = gs & 1;
+    h.gene = gs >> 1; h.contig = contig;
+    h.q_start = rev ? qlen - q_end : q_start;
+    h.q_end = rev ? qlen - q_start : q_end;
+    h.t_start = t_start - ctg_start; h.t_end = t_end - ctg_start;
+    h.score = score; h.matches = matches; h.block_len = block_len;
+    h.strand = rev ? -1 : 1; h.mapq = 0; h.pad_[0] = h.pad_[1] = 0;
+    return h;
+}
+
+// emission order of kp_spec.h as three ascending 64-bit keys
+KP_HD void kp_hit_keys(const kp_hit &h, uint64_t k[3]) {
+    k[0] = ((uint64_t)(uint32_t)h.gene << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)h.score) << 20) | (uint32_t)h.contig;
+    k[1] = ((uint64_t)(uint32_t)h.t_start << 32) | ((uint64_t)(h.strand < 0 ? 1u : 0u) << 31) |
+           ((uint64_t)(uint32_t)h.q_start << 16) | (uint32_t)h.q_end;
+    k[2] = ((uint64_t)(uint32_t)h.t_end << 32) | ((uint64_t)(0xFFFFu - (uint32_t)h.matches) << 16) | (uint32_t)h.block_len;
+}
+
+KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t ia, const uint64_t b[3], uint32_t ib) {
+    if (a[0] != b[0]) return a[0] < b[0];
+    if (a[1] != b[1]) return a[1] < b[1];
+    if (a[2] != b[2]) return a[2] < b[2];
+    return ia < ib;
+}
+
+KP_HD bool kp_same_span(const kp_hit &x, const kp_hit &y) {
+    return x.gene == y.gene && x.contig == y.contig && x.strand == y.strand && x.q_start == y.q_start &&
+           x.q_end == y.q_end && x.t_start == y.t_start && x.t_end == y.t_end;
+}
+
+// ---- scoring (core.py:164-201) ----------------------------------------------------------------------------------------
+// hits are in emission order (gene ascending, score descending).  Best hit of gene g = highest query coverage among hits
+// with coverage >= min_cov, ties by higher score then earlier emission, i.e. the first maximum when walking the run.
+KP_HD int kp_lower_bound_gene(const kp_hit *hits, int n, int gene) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (hits[mid].gene < gene) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+KP_HD bool kp_gene_best_cov(const kp_hit *hits, int n, int gene, int gene_len, double min_cov, double *cov_out) {
+    bool found = false;
+    double best = 0.0;
+    for (int i = kp_lower_bound_gene(hits, n, gene); i < n && hits[i].gene == gene; ++i) {
+        const double cov = gene_len > 0 ? (double)(hits[i].q_end - hits[i].q_start) / (double)gene_len : 0.0;
+        if (cov >= min_cov && (!found || cov > best)) { best = cov; found = true; }
+    }
+    *cov_out = best;
+    return found;
+}
+
+// locus l: sum of best coverages of its non-extra genes in gene order (float64, same order as np.add.at), and count
+KP_HD void kp_locus_score(const kp_hit *hits, int n, const KpTypingDb &db, int locus, double min_cov, double *score,
+                          int32_t *count) {
+    double s = 0.0;
+    int c = 0;
+    const int g0 = db.locus_gene_off[locus], g1 = g0 + db.locus_gene_len[locus];
+    for (int g = g0; g < g1; ++g) {
+        if (db.gene_extra[g]) continue;
+        double cov;
+        if (kp_gene_best_cov(hits, n, g, db.gene_len[g], min_cov, &cov)) { s += cov; ++c; }
+    }
+    *score = s;
+    *count = c;
+}
+
+// ---- overlap cull (alignment.py:643-686, interval.py:698-751) ------------------------------------------------------------
+// visit order: (score + 1e9 * priority) desc, matches desc, uint8-wrapped (-mapq) asc, emission index asc (stable lexsort)
+KP_HD uint64_t kp_cull_key(const kp_hit &h, bool priority, uint32_t idx) {
+    const uint32_t s = ((priority ? 1u : 0u) << 20) | (uint32_t)h.score;  // scores are < 2^20
+    const uint32_t negq = (uint32_t)(uint8_t)(0u - (uint32_t)h.mapq);
+    return ((uint64_t)(0x1FFFFFu - s) << 43) | ((uint64_t)(0xFFFFu - (uint32_t)h.matches) << 27) |
+           ((uint64_t)negq << 19) | (uint64_t)idx;  // idx < 2^19
+}
+
+// greedy pass over `order`; kept_flag[i] set for survivors.  kept_* are scratch of capacity cap; returns survivors
+// (or -1 when cap is too small).
+KP_HD int kp_cull_sequential(const kp_hit *hits, int n, const uint32_t *order, uint8_t *kept_flag, int32_t *kept_ctg,
+                             int32_t *kept_s, int32_t *kept_e, int cap) {
+    int nk = 0;
+    for (int p = 0; p < n; ++p) {
+        const kp_hit &h = hits[order[p]];
+        const int s = h.t_start, e = h.t_end, len = e - s;
+        kept_flag[order[p]] = 0;
+        if (len <= 0) continue;
+        bool clash = false;
+        for (int j = 0; j < nk && !clash; ++j) {
+            if (kept_ctg[j] != h.contig) continue;
+            const int ov = (e < kept_e[j] ? e : kept_e[j]) - (s > kept_s[j] ? s : kept_s[j]);
+            const int klen = kept_e[j] - kept_s[j];
+            // ov / min(len, klen) > 0.1 in float64 <=> 10 * ov > min(len, klen) for these integer ranges
+            if (ov > 0 && (int64_t)ov * 10 > (int64_t)(len < klen ? len : klen)) clash = true;
+        }
+        if (clash) continue;
+        if (nk >= cap) return -1;
+        kept_ctg[nk] = h.contig; kept_s[nk] = s; kept_e[nk] = e;
+        ++nk;
+        kept_flag[order[p]] = 1;
+    }
+    return nk;
+}
+
+// ---- clustering, pieces, inside, missing (core.py:219-301) ---------------------------------------------------------------
+// kept[] is in emission order.  scratch: perm[nk].
+KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int best_locus, int64_t tolerance,
+                                 int32_t *perm, KpPiece *pieces, int piece_cap, KpAsmSummary *sum) {
+    // stable order by (contig, t_start, t_end): insertion sort of indices (nk is small)
+    for (int i = 0; i < nk; ++i) {
+        int j = i;
+        while (j > 0) {
+            const KpKept &a = kept[perm[j - 1]], &b = kept[i];
+            const bool gt = a.contig != b.contig ? a.contig > b.contig
+                            : (a.t_start != b.t_start ? a.t_start > b.t_start : a.t_end > b.t_end);
+            if (!gt) break;
+            perm[j] = perm[j - 1];
+            --j;
+        }
+        perm[j] = i;
+    }
+    int cur = 0;
+    int64_t cur_e = 0;
+    int cur_c = -1;
+    for (int p = 0; p < nk; ++p) {  // single linkage with tolerance (interval.py:626-637)
+        KpKept &k = kept[perm[p]];
+        if (p == 0) { cur = 0; cur_e = k.t_end; cur_c = k.contig; }
+        else if (k.contig == cur_c && (int64_t)k.t_start <= cur_e + tolerance) { if (k.t_end > cur_e) cur_e = k.t_end; }
+        else { ++cur; cur_e = k.t_end; cur_c = k.contig; }
+        k.cluster = cur;
+    }
+    const int n_clusters = nk ? cur + 1 : 0;
+    // flags; the first kept hit of an expected gene is its top-scoring one (emission order = gene asc, score desc)
+    for (int i = 0; i < nk; ++i) {
+        KpKept &k = kept[i];
+        uint8_t f = 0;
+        if (db.gene_extra[k.gene]) f |= KP_F_EXTRA;
+        else if ((int)db.gene_locus[k.gene] == best_locus) f |= KP_F_EXPECTED;
+        if ((f & KP_F_EXPECTED) && (i == 0 || kept[i - 1].gene != k.gene)) f |= KP_F_PRIMARY;
+        k.flags = f;
+    }
+    // one piece per cluster (ascending id) that holds a primary hit
+    int np = 0;
+    bool piece_overflow = false;
+    for (int c = 0; c < n_clusters; ++c) {
+        int ctg = -1, smin = 0, emax = 0, nprim = 0, vote = 0;
+        int64_t pos_sum = 0;
+        for (int i = 0; i < nk; ++i) {
+            const KpKept &k = kept[i];
+            if (k.cluster != c) continue;
+            if (ctg < 0) ctg = k.contig;
+            if (!(k.flags & KP_F_PRIMARY)) continue;
+            if (nprim == 0 || k.t_start < smin) smin = k.t_start;
+            if (nprim == 0 || k.t_end > emax) emax = k.t_end;
+            pos_sum += db.gene_pos[k.gene];
+            vote += (int)k.strand * (int)db.gene_strand[k.gene];
+            ++nprim;
+        }
+        if (nprim == 0) continue;
+        if (np >= piece_cap) { piece_overflow = true; break; }
+        pieces[np].contig = ctg; pieces[np].start = smin; pieces[np].end = emax;
+        pieces[np].strand = vote < 0 ? -1 : 1;
+        pieces[np].mean_pos = (double)pos_sum / (double)nprim;
+        ++np;
+    }
+    for (int i = 0; i < nk; ++i) {  // closed-interval overlap with any piece on the same contig
+        KpKept &k = kept[i];
+        for (int p = 0; p < np; ++p)
+            if (k.contig == pieces[p].contig && k.t_start <= pieces[p].end && k.t_end >= pieces[p].start) {
+                k.flags |= KP_F_INSIDE;
+                break;
+            }
+    }
+    // expected genes of the best locus that were not found inside
+    const int g0 = db.locus_gene_off[best_locus], gl = db.locus_gene_len[best_locus];
+    for (int w = 0; w < KP_MAX_LOCUS_GENES / 64; ++w) sum->missing_mask[w] = 0;
+    int n_exp = 0, n_missing = 0;
+    for (int j = 0; j < gl; ++j) {
+        const int g = g0 + j;
+        if (db.gene_extra[g]) continue;  // an "Extra genes" record has no expected genes
+        ++n_exp;
+        bool found = false;
+        for (int i = 0; i < nk && !found; ++i)
+            found = kept[i].gene == g && (kept[i].flags & (KP_F_EXPECTED | KP_F_INSIDE)) == (KP_F_EXPECTED | KP_F_INSIDE);
+        if (!found) {
+            ++n_missing;
+            if (j < KP_MAX_LOCUS_GENES) sum->missing_mask[j >> 6] |= (uint64_t)1 << (j & 63);
+        }
+    }
+    sum->n_pieces = np;
+    sum->n_expected = n_exp;
+    sum->n_missing = n_missing;
+    if (piece_overflow) sum->overflow |= 2;
+    if (gl > KP_MAX_LOCUS_GENES) sum->overflow |= 4;
+}
+
+// ---- extraction + translation from the packed stream (seq.py:612-741; models.py:252-259) -----------------------------------
+// base code at assembly position t: 0..3, or 4 inside an N run
+KP_HD int kp_code_at(const uint32_t *asm_words, const int32_t *runs, int n_runs, int32_t t) {
+    if (n_runs > 0) {
+        int lo = 0, hi = n_runs;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (runs[2 * mid + 1] <= t) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n_runs && runs[2 * lo] <= t) return 4;
+    }
+    return (int)((asm_words[t >> 4] >> (2 * (t & 15))) & 3u);
+}
+
+// amino acid of codon `c` (0-based) of the hit's extracted strand; the table is NCBI 11 indexed a*25+b*5+c with N=4
+KP_HD uint8_t kp_codon_aa(const uint32_t *asm_words, const int32_t *runs, int n_runs, int32_t abs_start,
+                          int32_t abs_end, int strand, int frame, int c, const uint8_t *codon_table) {
+    int code[3];
+    for (int x = 0; x < 3; ++x) {
+        const int off = frame + 3 * c + x;  // offset in the extracted (strand-corrected) sequence
+        if (strand >= 0) code[x] = kp_code_at(asm_words, runs, n_runs, abs_start + off);
+        else {
+            const int v = kp_code_at(asm_words, runs, n_runs, abs_end - 1 - off);
+            code[x] = v > 3 ? 4 : 3 - v;
+        }
+    }
+    return codon_table[code[0] * 25 + code[1] * 5 + code[2]];
+}
+
+KP_HD void kp_fill_codon_table(uint8_t *t /*125*/) {  // seq.py:418-499, amino acids in TCAG order
+    const char *aa = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    const int tcag[4] = {3, 1, 0, 2};
+    for (int i = 0; i < 125; ++i) t[i] = 'X';
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            for (int c = 0; c < 4; ++c) t[tcag[a] * 25 + tcag[b] * 5 + tcag[c]] = (uint8_t)aa[a * 16 + b * 4 + c];
+}
+
+// ---- gene states (core.py:363-394; alignment.py:774-809) ------------------------------------------------------------------
+KP_HD void kp_gene_state(KpKept *k, int gene_len, int contig_len, const KpTypingParams &prm) {
+    const int total = k->dp[1] + k->dp[2] + k->dp[3];
+    const double pid = total > 0 ? ((double)k->dp[1] * 100.0) / (double)total : 0.0;
+    k->pident = (float)pid;
+    const double prot_cov = ((double)k->prot_len * 3.0) / (double)gene_len;
+    double c = prot_cov * 100.0;
+    c = c < 0.0 ? 0.0 : (c > 100.0 ? 100.0 : c);
+    k->coverage = (float)c;
+    const bool fwd = k->strand == 1;
+    const bool left = k->t_start <= prm.edge_tolerance && (fwd ? k->q_start > 0 : k->q_end < gene_len);
+    const bool right = k->t_end >= contig_len - prm.edge_tolerance && (fwd ? k->q_end < gene_len : k->q_start > 0);
+    int state = KP_STATE_NORMAL;
+    if (left || right) { state = KP_STATE_PARTIAL; k->flags |= KP_F_PARTIAL; }
+    else if (prot_cov < 0.90) state = KP_STATE_TRUNCATED;
+    if (!(k->flags & KP_F_INSIDE) && k->pident < prm.id_threshold) k->flags |= KP_F_SPURIOUS;
+    if (state == KP_STATE_NORMAL && k->pident < prm.id_threshold) state = KP_STATE_NOVEL;
+    k->state = (int8_t)state;
+}

@@ -64,6 +64,15 @@ class Serotyper:
         np.add.at(n_exp, db.gene_locus_indices[~db.extra_genes], 1.0)
         self._expected_genes_per_locus = np.maximum(n_exp, 1.0)
         self._gene_names = tuple(str(i) for i in range(len(db.genes)))
+        # per-gene text columns of GeneHits, encoded once (core.py:316-327 builds them per call)
+        self._gene_ids_s32 = np.array([x.encode("utf-8") for x in db.genes.ids], dtype="S32")
+        self._cluster_s10 = np.array(
+            [db.cluster_keys[c].encode("utf-8") for c in db.gene_cluster_ids], dtype="S10"
+        ).reshape(-1)
+        self._product_s64 = np.array(
+            [db.description_keys[d].encode("utf-8") for d in db.gene_description_ids], dtype="S64"
+        ).reshape(-1)
+        self._gene_ids_obj = np.array(db.genes.ids, dtype=object)
 
     # -- native stages --------------------------------------------------------------------------------------------
     @property
@@ -184,37 +193,10 @@ class Serotyper:
         missing = np.setdiff1d(expected_genes, g[is_expected & is_inside], assume_unique=True)
         completeness = 1.0 - (len(missing) / len(expected_genes)) if len(expected_genes) > 0 else 1.0
 
-        hits = GeneHits(
-            gene_indices=g,
-            q_starts=culled.q_starts,
-            q_ends=culled.q_ends,
-            t_indices=t_idx,
-            t_starts=culled.t_starts,
-            t_ends=culled.t_ends,
-            strands=culled.strands,
-            is_expected=is_expected,
-            is_inside=is_inside,
-            is_extra=is_extra,
-            expected_positions=db.gene_positions[g].astype(np.int32),
-            expected_strands=db.gene_intervals.strands[g],
-            gene_ids=np.array([db.genes.ids[i].encode("utf-8") for i in g], dtype="S32"),
-            cluster_names=np.array([db.cluster_keys[db.gene_cluster_ids[i]].encode("utf-8") for i in g], dtype="S10"),
-            product_descriptions=np.array(
-                [db.description_keys[db.gene_description_ids[i]].encode("utf-8") for i in g], dtype="S64"
-            ),
-            coverages=coverages,
+        hits = self.gene_hits_table(
+            g, culled.q_starts, culled.q_ends, t_idx, culled.t_starts, culled.t_ends, culled.strands, is_expected,
+            is_inside, is_extra, coverages,
         )
-
-        # locus sequence, coverage, length discrepancy -- core.py:332-349
-        locus_seqs = (
-            genome.contigs.extract(pieces.ctg_indices, pieces.starts, pieces.ends, pieces.strands)
-            if len(pieces)
-            else Sequences.empty()
-        )
-        assem_len = np.sum(pieces.ends - pieces.starts)
-        ref_len = db.loci.lengths[best]
-        pcov = float(min(100.0, (assem_len / ref_len) * 100.0)) if ref_len > 0 else 0.0
-        discrepancy = float(assem_len - ref_len) if len(pieces) == 1 else float("nan")
 
         # gene states -- core.py:352-379
         gene_seqs = genome.contigs.extract_intervals(
@@ -230,7 +212,7 @@ class Serotyper:
         prot_alns = self.align_proteins(prot_seqs, db.translations[g])
         idents = prot_alns.pidents.astype(np.float32)
 
-        # weak homologues outside the locus are dropped; weak NORMAL genes become NOVEL -- core.py:383-396
+        # weak homologues outside the locus are dropped; weak NORMAL genes become NOVEL -- core.py:383-394
         threshold = db.metadata.id_threshold
         spurious = ~hits.is_inside & (idents < threshold)
         if spurious.any():
@@ -238,9 +220,41 @@ class Serotyper:
             hits, gene_seqs, prot_seqs = hits[keep], gene_seqs[keep], prot_seqs[keep]
             states, idents = states[keep], idents[keep]
         states[(states == _NORMAL) & (idents < threshold)] = _NOVEL
+
+        locus_seqs = (
+            genome.contigs.extract(pieces.ctg_indices, pieces.starts, pieces.ends, pieces.strands)
+            if len(pieces)
+            else Sequences.empty()
+        )
+        return self.finish(
+            genome.id, best, locus_scores[best], completeness, hits, states, idents, pieces,
+            tuple(db.genes.ids[i] for i in missing), locus_seqs, gene_seqs, prot_seqs,
+        )
+
+    def gene_hits_table(self, g, q_starts, q_ends, t_idx, t_starts, t_ends, strands, is_expected, is_inside, is_extra,
+                        coverages) -> GeneHits:
+        """GeneHits with the database-derived columns filled in (core.py:303-329)."""
+        db = self._db
+        return GeneHits(
+            gene_indices=g, q_starts=q_starts, q_ends=q_ends, t_indices=t_idx, t_starts=t_starts, t_ends=t_ends,
+            strands=strands, is_expected=is_expected, is_inside=is_inside, is_extra=is_extra,
+            expected_positions=db.gene_positions[g].astype(np.int32),
+            expected_strands=db.gene_intervals.strands[g],
+            gene_ids=self._gene_ids_s32[g], cluster_names=self._cluster_s10[g],
+            product_descriptions=self._product_s64[g], coverages=coverages,
+        )  # fmt: skip
+
+    def finish(self, genome_id, best, best_score, completeness, hits, states, idents, pieces, missing_ids, locus_seqs,
+               gene_seqs, prot_seqs) -> SerotypingResult:
+        """Everything after the per-hit work: locus coverage, mean identity, phenotype, confidence, result object
+        (core.py:343-349, 395-486).  Shared by the single-genome reduction and the batched GPU reduction."""
+        db = self._db
+        assem_len = np.sum(pieces.ends - pieces.starts)
+        ref_len = db.loci.lengths[best]
+        pcov = float(min(100.0, (assem_len / ref_len) * 100.0)) if ref_len > 0 else 0.0
+        discrepancy = float(assem_len - ref_len) if len(pieces) == 1 else float("nan")
         normal_idents = idents[states == _NORMAL]
         pident = float(np.mean(normal_idents)) if normal_idents.size > 0 else 0.0
-
         phenotype = self._phenotype(best, hits, states)
 
         # confidence -- core.py:445-459
@@ -250,7 +264,6 @@ class Serotyper:
             and np.count_nonzero(unexpected) <= self.max_other_genes
             and (self.allow_below_threshold or not np.any(hits.is_inside & (states == _NOVEL)))
         )
-
         meta = db.metadata
         return SerotypingResult(
             kaptive_version=KAPTIVE_COMPAT_VERSION,
@@ -258,10 +271,10 @@ class Serotyper:
             database_version=meta.version,
             database_organism=meta.organism,
             database_taxon=meta.taxon,
-            genome=genome.id,
+            genome=genome_id,
             best_locus_idx=best,
             best_locus_name=db.loci.ids[best],
-            best_locus_score=locus_scores[best],
+            best_locus_score=best_score,
             best_locus_completeness=completeness,
             length_discrepancy=discrepancy,
             gene_hits=hits,
@@ -275,7 +288,7 @@ class Serotyper:
             protein_identities=idents,
             phenotype=phenotype,
             typeable=bool(typeable),
-            missing_expected_genes=tuple(db.genes.ids[i] for i in missing),
+            missing_expected_genes=missing_ids,
         )
 
     def _phenotype(self, best: int, hits: GeneHits, states: np.ndarray) -> str:
