@@ -94,6 +94,42 @@ KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms6, int64_t *b
 KP_API int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint64_t *out, int64_t cap);
 KP_API int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, int32_t *out7, int64_t cap);
 
+/* ---- batched typing: hit table -> per-assembly records -----------------------------------------------------------------
+ * Replaces, for a whole batch, the reduction Serotyper.__call__ runs per genome after the aligner returns
+ * (src/kaptive/serotyping/core.py:157-396): per-gene best coverage and locus scores, overlap cull, clustering, locus
+ * pieces, inside/expected flags, missing genes, gene extraction + translation, protein identity, gene states.  Three
+ * float steps stay with the caller in numpy because only numpy reproduces their bits (kaptive_amd/serotyping/batch.py):
+ * the completeness**3 penalty and argmax between kp_batch_score and kp_batch_reduce, the argsort of piece positions
+ * and the float32 mean identity afterwards.
+ *
+ * kp_db_load_typing: the Database columns the reduction reads (src/kaptive/db/core.py:82-98), host pointers; call it
+ *   after kp_db_load (the gene count and gene lengths come from there). */
+typedef struct kp_typing_tables {
+    const uint16_t *gene_locus;    /* Database.gene_locus_indices */
+    const uint8_t *gene_extra;     /* Database.extra_genes */
+    const uint16_t *gene_pos;      /* Database.gene_positions */
+    const int8_t *gene_strand;     /* Database.gene_intervals.strands */
+    const int32_t *locus_gene_off; /* Database.locus_gene_offsets */
+    const int32_t *locus_gene_len; /* Database.locus_gene_lengths */
+    int32_t n_loci;
+    const uint8_t *prot;           /* Database.translations.seqs (stop codons kept) */
+    const int32_t *prot_off, *prot_len;
+} kp_typing_tables;
+KP_API int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *tables);
+/* After kp_batch_align: finalises the hit tables on the device and returns locus_scores (float64, sum of best query
+ * coverages per locus, core.py:188-193) and locus_counts (genes counted, core.py:196-198), both [n_asm][n_loci]. */
+KP_API int kp_batch_score(kp_ctx *ctx, kp_batch *batch, double min_gene_coverage, double *locus_scores,
+                          int32_t *locus_counts);
+/* Enqueues the rest of the reduction for the caller's choice of best locus per assembly (core.py:206). */
+KP_API int kp_batch_reduce(kp_ctx *ctx, kp_batch *batch, const int32_t *best_locus, const kp_typing_params *params);
+/* Waits, then copies out one summary per assembly and its kept hits / pieces at kept[a * kept_stride],
+ * pieces[a * piece_stride]; strides must be at least the values kp_batch_typing_caps reports. */
+KP_API int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *batch, int32_t *kept_cap, int32_t *piece_cap);
+KP_API int kp_batch_typing(kp_ctx *ctx, kp_batch *batch, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
+                           kp_piece *pieces, int32_t piece_stride);
+/* Translated proteins of one assembly (kp_kept.prot_off/prot_len index into it); returns bytes copied. */
+KP_API int kp_batch_proteins(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint8_t *out, int64_t cap);
+
 /* ---- protein alignment ------------------------------------------------------------------------------------------
  * Replaces PairwiseAligner.__call__ / _batched_banded_gotoh (src/kaptive/core/pairwise.py:255-325, 395-584) in its
  * unseeded mode with the defaults gap_open 11, gap_extend 1, k 20.  Sequences are raw bytes (amino-acid letters).

@@ -96,4 +96,49 @@ typedef struct kp_hit {
     uint8_t pad_[2];
 } kp_hit;
 
+/* ---- records of the batched reduction (one assembly = one summary, its kept hits and its locus pieces) ------------------
+ * They carry what SerotypingResult needs (src/kaptive/serotyping/models.py:513-536) minus strings and sequences. */
+#define KP_F_EXPECTED 1u /* gene belongs to the best locus and is not an extra gene (core.py:226-228) */
+#define KP_F_INSIDE 2u   /* overlaps a locus piece (core.py:273-278) */
+#define KP_F_EXTRA 4u    /* gene of an "Extra genes" record */
+#define KP_F_PARTIAL 8u  /* clipped by a contig edge (alignment.py:774-809) */
+#define KP_F_SPURIOUS 16u /* outside the locus and below the identity threshold: dropped from the result (core.py:383) */
+#define KP_F_PRIMARY 32u /* top-scoring kept hit of an expected gene (core.py:236-245) */
+
+#define KP_STATE_NORMAL 0
+#define KP_STATE_PARTIAL 1
+#define KP_STATE_TRUNCATED 2
+#define KP_STATE_NOVEL 3
+
+#define KP_MAX_LOCUS_GENES 256 /* width of the missing-gene mask */
+
+typedef struct kp_kept { /* one hit that survived the overlap cull, emission order */
+    int32_t gene, contig, q_start, q_end, t_start, t_end, score;
+    int32_t prot_off, prot_len; /* translated protein inside the assembly's protein buffer */
+    int32_t cluster;            /* spatial cluster id */
+    int32_t dp[8];              /* protein DP: score, matches, mismatches, gaps, q_start, q_end, t_start, t_end */
+    float pident, coverage;     /* float32, as the reference stores them */
+    int8_t strand, state;
+    uint8_t flags, pad_;
+} kp_kept;
+
+typedef struct kp_piece {
+    int32_t contig, start, end, strand;
+    double mean_pos; /* mean expected position of the piece's primary hits; the host orders pieces by it */
+} kp_piece;
+
+typedef struct kp_asm_summary {
+    int32_t n_hits, n_kept, n_final, n_pieces;
+    int32_t best_locus, n_expected, n_missing;
+    int32_t overflow; /* bit0 kept list, bit1 pieces, bit2 locus wider than the mask, bit3 protein buffer */
+    uint64_t missing_mask[KP_MAX_LOCUS_GENES / 64]; /* bit j: gene locus_gene_off + j not found inside the locus */
+} kp_asm_summary;
+
+typedef struct kp_typing_params {
+    double min_gene_coverage; /* Serotyper.min_gene_coverage */
+    float id_threshold;       /* np.float32(metadata.id_threshold): identities are compared as float32 */
+    int32_t max_locus_length; /* Database.max_locus_length, the clustering tolerance */
+    int32_t edge_tolerance;   /* Serotyper.partial_edge_tolerance */
+} kp_typing_params;
+
 #endif /* KP_SPEC_H */

@@ -24,9 +24,20 @@ EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_db_load", "kp_db_n_postings",
     "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
-    "kp_batch_tasks",
-    "kp_protein_align",
+    "kp_batch_tasks", "kp_db_load_typing", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align",
 )  # fmt: skip
+
+
+class TypingTables(C.Structure):  # kp_typing_tables
+    _fields_ = [("gene_locus", C.c_void_p), ("gene_extra", C.c_void_p), ("gene_pos", C.c_void_p),
+                ("gene_strand", C.c_void_p), ("locus_gene_off", C.c_void_p), ("locus_gene_len", C.c_void_p),
+                ("n_loci", C.c_int32), ("prot", C.c_void_p), ("prot_off", C.c_void_p), ("prot_len", C.c_void_p)]  # fmt: skip
+
+
+class TypingParams(C.Structure):  # kp_typing_params
+    _fields_ = [("min_gene_coverage", C.c_double), ("id_threshold", C.c_float), ("max_locus_length", C.c_int32),
+                ("edge_tolerance", C.c_int32)]  # fmt: skip
 
 _lib = None
 _lock = threading.Lock()
@@ -94,6 +105,19 @@ class Context:
     def load_genes(self, gene_codes: np.ndarray, gene_off: np.ndarray) -> None:
         codes, off = _c(gene_codes, np.uint8), _c(gene_off, np.int32)
         self._check(lib().kp_db_load(self._h, _p(codes), _p(off), C.c_int32(len(off) - 1)), "kp_db_load")
+
+    def load_typing(self, db) -> None:
+        """Upload the Database columns the batched reduction reads (kp_db_load_typing)."""
+        prot = db.translations
+        keep = dict(
+            gene_locus=_c(db.gene_locus_indices, np.uint16), gene_extra=_c(db.extra_genes, np.uint8),
+            gene_pos=_c(db.gene_positions, np.uint16), gene_strand=_c(db.gene_intervals.strands, np.int8),
+            locus_gene_off=_c(db.locus_gene_offsets, np.int32), locus_gene_len=_c(db.locus_gene_lengths, np.int32),
+            prot=_c(prot.seqs, np.uint8), prot_off=_c(prot.offsets, np.int32), prot_len=_c(prot.lengths, np.int32),
+        )  # fmt: skip
+        t = TypingTables(n_loci=len(db.loci), **{k: _p(v).value for k, v in keep.items()})
+        self._check(lib().kp_db_load_typing(self._h, C.byref(t)), "kp_db_load_typing")
+        self.n_loci = len(db.loci)
 
     @property
     def n_postings(self) -> int:
@@ -178,6 +202,45 @@ class Batch:
         s = np.zeros(5, np.int64)
         self.ctx._check(lib().kp_batch_stats(self.ctx._h, self._h, _p(s)), "kp_batch_stats")
         return dict(zip(("anchors", "tasks", "dp_cells", "hits", "retries"), s.tolist()))
+
+    # -- batched reduction ------------------------------------------------------------------------------------------
+    def score(self, min_gene_coverage: float) -> tuple[np.ndarray, np.ndarray]:
+        """(locus_scores f64, locus_counts i32), both [n_asm, n_loci]; finalises the hit tables on the device."""
+        n_loci = self.ctx.n_loci
+        scores = np.zeros((self.n_asm, n_loci), np.float64)
+        counts = np.zeros((self.n_asm, n_loci), np.int32)
+        self.ctx._check(
+            lib().kp_batch_score(self.ctx._h, self._h, C.c_double(min_gene_coverage), _p(scores), _p(counts)),
+            "kp_batch_score",
+        )
+        return scores, counts
+
+    def reduce_async(self, best_locus: np.ndarray, params: "TypingParams") -> None:
+        best = _c(best_locus, np.int32)
+        self.ctx._check(lib().kp_batch_reduce(self.ctx._h, self._h, _p(best), C.byref(params)), "kp_batch_reduce")
+
+    def typing(self):
+        """(summaries [n_asm], kept [n_asm, kept_cap], pieces [n_asm, piece_cap]) as structured arrays."""
+        from kaptive_amd.serotyping.batch import KEPT_DTYPE, PIECE_DTYPE, SUMMARY_DTYPE
+
+        for _ in range(2):  # capacities may grow inside kp_batch_typing when a buffer overflowed
+            kc, pc = C.c_int32(0), C.c_int32(0)
+            self.ctx._check(lib().kp_batch_typing_caps(self.ctx._h, self._h, C.byref(kc), C.byref(pc)), "typing_caps")
+            sums = np.zeros(self.n_asm, SUMMARY_DTYPE)
+            kept = np.zeros((self.n_asm, kc.value), KEPT_DTYPE)
+            pieces = np.zeros((self.n_asm, pc.value), PIECE_DTYPE)
+            rc = lib().kp_batch_typing(self.ctx._h, self._h, _p(sums), _p(kept), kc, _p(pieces), pc)
+            if rc == -1 and b"strides too small" in lib().kp_last_error(self.ctx._h):
+                continue
+            self.ctx._check(rc, "kp_batch_typing")
+            return sums, kept, pieces
+        raise NativeError("kp_batch_typing: capacities kept changing")
+
+    def proteins(self, asm_index: int, nbytes: int) -> np.ndarray:
+        out = np.zeros(nbytes, np.uint8)
+        self.ctx._check(lib().kp_batch_proteins(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(nbytes)),
+                        "kp_batch_proteins")  # fmt: skip
+        return out
 
     def profile(self) -> dict[str, float]:
         """Per-kernel milliseconds of one more alignment pass (HIP events on the context's stream)."""

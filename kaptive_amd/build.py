@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libkaptive_amd.so"
-SOURCES = ("kp_capi.hip", "kp_scan.hip", "kp_sort.hip", "kp_chain.hip", "kp_sw.hip", "kp_prot.hip")
+SOURCES = ("kp_capi.hip", "kp_scan.hip", "kp_sort.hip", "kp_chain.hip", "kp_sw.hip", "kp_prot.hip", "kp_reduce.hip")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -35,7 +35,7 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    headers = [CSRC / "kp_internal.h", INCLUDE / "kaptive_amd.h", INCLUDE / "kp_spec.h"]
+    headers = [CSRC / "kp_internal.h", CSRC / "kp_reduce_core.h", INCLUDE / "kaptive_amd.h", INCLUDE / "kp_spec.h"]
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     hipcc = _hipcc()

@@ -8,6 +8,21 @@
 #include <new>
 
 #include "kp_internal.h"
+#include "kp_reduce_core.h"
+
+// kp_reduce.hip
+void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
+                            const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
+                            uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells, hipStream_t stream);
+void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
+                     const KpTypingDb &db, double min_cov, double *scores, int32_t *counts, hipStream_t stream);
+void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
+                      const KpTypingDb &db, const KpTypingParams &prm, const int32_t *best, uint64_t *keys,
+                      uint32_t *order, uint8_t *kept_flag, KpKept *kept, int kept_cap, KpPiece *pieces, int piece_cap,
+                      KpAsmSummary *summary, uint8_t *prot, int prot_cap, int32_t *pair_q_off, int32_t *pair_q_len,
+                      int32_t *pair_t_off, int32_t *pair_t_len, hipStream_t stream);
+void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTypingParams &prm, KpKept *kept, int kept_cap,
+                      KpAsmSummary *summary, const int32_t *dp8, hipStream_t stream);
 
 namespace {
 
@@ -53,6 +68,14 @@ struct kp_ctx {
     // sort scratch
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    // typing tables (kp_db_load_typing)
+    bool has_typing = false;
+    DevBuf<uint16_t> d_gene_locus, d_gene_pos;
+    DevBuf<uint8_t> d_gene_extra, d_prot_db;
+    DevBuf<int8_t> d_gene_strand;
+    DevBuf<int32_t> d_locus_off, d_locus_len, d_prot_db_off, d_prot_db_len;
+    KpTypingDb typing{};
+    int max_db_prot_len = 0;
 };
 
 struct kp_batch {
@@ -72,12 +95,30 @@ struct kp_batch {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
+    // device-side hit tables (per-assembly regions of hit_cap rows)
+    uint32_t hit_cap = 0;
+    DevBuf<kp_hit> d_hits_raw, d_hits, d_hits_packed;
+    DevBuf<uint32_t> d_hit_counts;  // [n_asm] raw, then [n_asm] final
+    DevBuf<uint64_t> d_keys;        // 3 per hit row
+    DevBuf<unsigned long long> d_cells;
+    DevBuf<int64_t> d_hit_off;
+    // reduction
+    int kept_cap = 0, piece_cap = 0, prot_cap = 0;
+    DevBuf<uint32_t> d_order;
+    DevBuf<uint8_t> d_flag, d_prot;
+    DevBuf<double> d_scores;
+    DevBuf<int32_t> d_lcounts, d_best, d_pairs, d_dp, d_dp_scratch;
+    DevBuf<KpKept> d_kept;
+    DevBuf<KpPiece> d_pieces;
+    DevBuf<KpAsmSummary> d_summary;
+    KpTypingParams prm{};
+    bool scored = false, reduced = false;
     // results
     bool aligned = false, finalised = false;
-    std::vector<uint32_t> h_counts;
+    std::vector<uint32_t> h_counts, h_hit_counts;
     std::vector<KpTask> h_tasks[3];
-    std::vector<KpSwResult> h_results[3];
     std::vector<kp_hit> hits;
+    bool hits_fetched = false;
     std::vector<int64_t> hit_off;
     int64_t stats[5] = {0, 0, 0, 0, 0};
 };
@@ -137,24 +178,6 @@ void fill_blosum(int8_t *m) {
 }
 
 struct HostPosting { uint32_t key, gs, pos; };
-
-bool hit_less(const kp_hit &x, const kp_hit &y) {  // emission order of kp_spec.h
-    if (x.gene != y.gene) return x.gene < y.gene;
-    if (x.score != y.score) return x.score > y.score;
-    if (x.contig != y.contig) return x.contig < y.contig;
-    if (x.t_start != y.t_start) return x.t_start < y.t_start;
-    if (x.strand != y.strand) return x.strand > y.strand;
-    if (x.q_start != y.q_start) return x.q_start < y.q_start;
-    if (x.q_end != y.q_end) return x.q_end < y.q_end;
-    if (x.t_end != y.t_end) return x.t_end < y.t_end;
-    if (x.matches != y.matches) return x.matches > y.matches;
-    return x.block_len < y.block_len;
-}
-
-bool same_span(const kp_hit &x, const kp_hit &y) {
-    return x.gene == y.gene && x.contig == y.contig && x.strand == y.strand && x.q_start == y.q_start &&
-           x.q_end == y.q_end && x.t_start == y.t_start && x.t_end == y.t_end;
-}
 
 template <class T>
 int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n) {
@@ -247,6 +270,9 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->d_slots.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
+    ctx->d_gene_locus.release(); ctx->d_gene_pos.release(); ctx->d_gene_extra.release(); ctx->d_prot_db.release();
+    ctx->d_gene_strand.release(); ctx->d_locus_off.release(); ctx->d_locus_len.release();
+    ctx->d_prot_db_off.release(); ctx->d_prot_db_len.release();
     if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -268,6 +294,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (n_genes > KP_MAX_GENES) return kp_fail(ctx, KP_EINVAL, "too many genes (KP_MAX_GENES)");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ctx->has_db = false;
+    ctx->has_typing = false;
     ctx->gene_len.resize((size_t)n_genes);
     std::vector<int32_t> nib_off(2 * (size_t)n_genes);
     size_t n_words = 0;
@@ -406,6 +433,10 @@ void kp_batch_destroy(kp_batch *b) {
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
     b->d_anchor_contig.release(); b->d_counts.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release();
+    b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
+    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_flag.release();
+    b->d_prot.release(); b->d_scores.release(); b->d_lcounts.release(); b->d_best.release(); b->d_pairs.release();
+    b->d_dp.release(); b->d_dp_scratch.release(); b->d_kept.release(); b->d_pieces.release(); b->d_summary.release();
     delete b;
 }
 
@@ -451,11 +482,46 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         const uint64_t want = (uint64_t)std::max(b->n_asm, 1) * env_u32("KAPTIVE_AMD_TASKS_PER_ASM", 4096);
         b->task_cap = (uint32_t)std::min<uint64_t>(want, 1u << 28);
     }
-    b->aligned = false; b->finalised = false;
+    b->aligned = false; b->finalised = false; b->scored = false; b->reduced = false; b->hits_fetched = false;
     b->stats[4] = 0;
     int rc = enqueue_align(ctx, b);
     if (rc) return rc;
     b->aligned = true;
+    return KP_OK;
+}
+
+// hit-table finalisation on the device: compaction of the band-task results into per-assembly lists, emission order,
+// duplicates, mapq.  Grows hit_cap and repeats if an assembly produced more hits than its region holds.
+static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b) {
+    const size_t n_asm = (size_t)b->n_asm;
+    if (b->hit_cap == 0) b->hit_cap = env_u32("KAPTIVE_AMD_HIT_CAP", 4096);
+    for (int attempt = 0;; ++attempt) {
+        KP_HIP_CHECK(ctx, b->d_hits_raw.reserve(n_asm * b->hit_cap));
+        KP_HIP_CHECK(ctx, b->d_hits.reserve(n_asm * b->hit_cap));
+        KP_HIP_CHECK(ctx, b->d_keys.reserve(n_asm * b->hit_cap * 3));
+        KP_HIP_CHECK(ctx, b->d_hit_counts.reserve(2 * n_asm));
+        KP_HIP_CHECK(ctx, b->d_cells.reserve(1));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), ctx->stream));
+        kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, b->d_tasks.p, b->d_results.p, b->d_counts.p + n_asm,
+                               b->task_cap, b->d_hits_raw.p, b->d_hit_counts.p, b->hit_cap, b->d_keys.p, b->d_hits.p,
+                               b->d_hit_counts.p + n_asm, b->d_cells.p, ctx->stream);
+        KP_HIP_CHECK(ctx, hipGetLastError());
+        b->h_hit_counts.resize(2 * n_asm);
+        unsigned long long cells = 0;
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_hit_counts.data(), b->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, b->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t max_raw = 0;
+        for (size_t a = 0; a < n_asm; ++a) max_raw = std::max(max_raw, b->h_hit_counts[a]);
+        if (max_raw <= b->hit_cap) { b->stats[2] = (int64_t)cells; break; }
+        if (attempt >= 2) return kp_fail(ctx, KP_EOVERFLOW, "hit buffers overflowed repeatedly");
+        b->hit_cap = (max_raw + 255u) & ~255u;
+        b->stats[4] += 1;
+    }
+    b->hit_off.assign(n_asm + 1, 0);
+    for (size_t a = 0; a < n_asm; ++a) b->hit_off[a + 1] = b->hit_off[a] + (int64_t)b->h_hit_counts[n_asm + a];
     return KP_OK;
 }
 
@@ -482,62 +548,14 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         int rc = enqueue_align(ctx, b);
         if (rc) return rc;
     }
-    int64_t n_anchor = 0, n_task = 0, n_cells = 0;
+    int64_t n_anchor = 0, n_task = 0;
     for (size_t a = 0; a < n_asm; ++a) n_anchor += b->h_counts[a];
-    for (int c = 0; c < 3; ++c) {
-        const size_t n = b->h_counts[n_asm + c];
-        b->h_tasks[c].resize(n);
-        b->h_results[c].resize(n);
-        if (n) {
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_tasks[c].data(), b->d_tasks.p + (size_t)c * b->task_cap,
-                                             n * sizeof(KpTask), hipMemcpyDeviceToHost, ctx->stream));
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_results[c].data(), b->d_results.p + (size_t)c * b->task_cap,
-                                             n * sizeof(KpSwResult), hipMemcpyDeviceToHost, ctx->stream));
-        }
-        n_task += (int64_t)n;
-    }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    // ---- finalise: score filter, strand flip, contig-local coordinates, emission order, duplicates, mapq -------------
-    std::vector<int64_t> per_asm(n_asm + 1, 0);
-    for (int c = 0; c < 3; ++c)
-        for (size_t i = 0; i < b->h_tasks[c].size(); ++i) {
-            n_cells += (int64_t)ctx->gene_len[(size_t)(b->h_tasks[c][i].gs >> 1)] * b->h_tasks[c][i].width;
-            if (b->h_results[c][i].score >= KP_MIN_DP_SCORE) per_asm[(size_t)b->h_tasks[c][i].asm_id + 1]++;
-        }
-    for (size_t a = 0; a < n_asm; ++a) per_asm[a + 1] += per_asm[a];
-    std::vector<kp_hit> raw((size_t)per_asm[n_asm]);
-    std::vector<int64_t> fill(per_asm.begin(), per_asm.end() - 1);
-    for (int c = 0; c < 3; ++c)
-        for (size_t i = 0; i < b->h_tasks[c].size(); ++i) {
-            const KpTask &t = b->h_tasks[c][i];
-            const KpSwResult &r = b->h_results[c][i];
-            if (r.score < KP_MIN_DP_SCORE) continue;
-            const int gene = t.gs >> 1, rev = t.gs & 1, qlen = ctx->gene_len[(size_t)gene];
-            const int32_t cs = b->h_ctg_start[(size_t)b->h_asm_first_ctg[(size_t)t.asm_id] + (size_t)t.contig];
-            kp_hit h;
-            std::memset(&h, 0, sizeof h);
-            h.gene = gene; h.contig = t.contig; h.strand = rev ? -1 : 1;
-            h.q_start = rev ? qlen - r.q_end : r.q_start;
-            h.q_end = rev ? qlen - r.q_start : r.q_end;
-            h.t_start = r.t_start - cs; h.t_end = r.t_end - cs;
-            h.score = r.score; h.matches = r.matches; h.block_len = r.block_len;
-            raw[(size_t)fill[(size_t)t.asm_id]++] = h;
-        }
-    b->hits.clear();
-    b->hits.reserve(raw.size());
-    b->hit_off.assign(n_asm + 1, 0);
-    for (size_t a = 0; a < n_asm; ++a) {
-        kp_hit *first = raw.data() + per_asm[a], *last = raw.data() + per_asm[a + 1];
-        std::sort(first, last, hit_less);
-        const size_t base = b->hits.size();
-        for (kp_hit *h = first; h != last; ++h) {
-            if (b->hits.size() > base && same_span(b->hits.back(), *h)) continue;
-            h->mapq = (b->hits.size() == base || b->hits.back().gene != h->gene) ? 60 : 0;
-            b->hits.push_back(*h);
-        }
-        b->hit_off[a + 1] = (int64_t)b->hits.size();
-    }
-    b->stats[0] = n_anchor; b->stats[1] = n_task; b->stats[2] = n_cells; b->stats[3] = (int64_t)b->hits.size();
+    for (int c = 0; c < 3; ++c) n_task += b->h_counts[n_asm + c];
+    for (auto &v : b->h_tasks) v.clear();
+    int rc = finalise_hits_on_device(ctx, b);
+    if (rc) return rc;
+    b->stats[0] = n_anchor; b->stats[1] = n_task; b->stats[3] = b->hit_off[n_asm];
+    b->hits_fetched = false;
     b->finalised = true;
     return KP_OK;
 }
@@ -552,8 +570,17 @@ int kp_batch_hit_offsets(kp_ctx *ctx, kp_batch *b, int64_t *hit_off) {
 int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
     if (!ctx || !b || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
-    if (cap < (int64_t)b->hits.size()) return kp_fail(ctx, KP_EINVAL, "hit buffer too small");
-    if (!b->hits.empty()) std::memcpy(out, b->hits.data(), b->hits.size() * sizeof(kp_hit));
+    const size_t n_asm = (size_t)b->n_asm;
+    const int64_t total = b->hit_off[n_asm];
+    if (cap < total) return kp_fail(ctx, KP_EINVAL, "hit buffer too small");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (size_t a = 0; a < n_asm; ++a) {  // regions are contiguous per assembly; copy each used prefix
+        const int64_t n = b->hit_off[a + 1] - b->hit_off[a];
+        if (n > 0)
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(out + b->hit_off[a], b->d_hits.p + a * (size_t)b->hit_cap,
+                                             (size_t)n * sizeof(kp_hit), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return KP_OK;
 }
 
@@ -596,6 +623,14 @@ int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int
 int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
     if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    for (int c = 0; c < 3; ++c) {  // fetched on first use: only the stage tests look at tasks
+        const size_t nt = b->h_counts[(size_t)b->n_asm + c];
+        if (b->h_tasks[c].size() == nt) continue;
+        b->h_tasks[c].resize(nt);
+        if (nt && hipMemcpy(b->h_tasks[c].data(), b->d_tasks.p + (size_t)c * b->task_cap, nt * sizeof(KpTask),
+                            hipMemcpyDeviceToHost) != hipSuccess)
+            return kp_fail(ctx, KP_EHIP, "D2H tasks failed");
+    }
     int64_t n = 0;
     for (int c = 0; c < 3; ++c)
         for (const KpTask &t : b->h_tasks[c]) {
@@ -607,6 +642,177 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64
             ++n;
         }
     return n;
+}
+
+// ---- batched typing ---------------------------------------------------------------------------------------------------
+int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *t) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "kp_db_load must come first");
+    if (!t || t->n_loci <= 0 || !t->gene_locus || !t->gene_extra || !t->gene_pos || !t->gene_strand || !t->locus_gene_off ||
+        !t->locus_gene_len || !t->prot_off || !t->prot_len)
+        return kp_fail(ctx, KP_EINVAL, "bad typing tables");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t G = (size_t)ctx->n_genes, L = (size_t)t->n_loci;
+    size_t prot_bytes = 0;
+    int max_len = 0;
+    for (size_t g = 0; g < G; ++g) {
+        if (t->gene_locus[g] >= L) return kp_fail(ctx, KP_EINVAL, "gene_locus out of range");
+        if (t->prot_len[g] < 0 || t->prot_off[g] < 0 || t->prot_len[g] > 65535) return kp_fail(ctx, KP_EINVAL, "bad protein table");
+        prot_bytes = std::max(prot_bytes, (size_t)t->prot_off[g] + (size_t)t->prot_len[g]);
+        max_len = std::max(max_len, t->prot_len[g]);
+    }
+    for (size_t l = 0; l < L; ++l)
+        if (t->locus_gene_off[l] < 0 || t->locus_gene_len[l] < 0 || (size_t)t->locus_gene_off[l] + (size_t)t->locus_gene_len[l] > G)
+            return kp_fail(ctx, KP_EINVAL, "locus gene range out of bounds");
+    if (prot_bytes && !t->prot) return kp_fail(ctx, KP_EINVAL, "null protein data");
+    int rc;
+    if ((rc = upload(ctx, ctx->d_gene_locus, t->gene_locus, G))) return rc;
+    if ((rc = upload(ctx, ctx->d_gene_extra, t->gene_extra, G))) return rc;
+    if ((rc = upload(ctx, ctx->d_gene_pos, t->gene_pos, G))) return rc;
+    if ((rc = upload(ctx, ctx->d_gene_strand, t->gene_strand, G))) return rc;
+    if ((rc = upload(ctx, ctx->d_locus_off, t->locus_gene_off, L))) return rc;
+    if ((rc = upload(ctx, ctx->d_locus_len, t->locus_gene_len, L))) return rc;
+    if ((rc = upload(ctx, ctx->d_prot_db, t->prot, prot_bytes))) return rc;
+    if ((rc = upload(ctx, ctx->d_prot_db_off, t->prot_off, G))) return rc;
+    if ((rc = upload(ctx, ctx->d_prot_db_len, t->prot_len, G))) return rc;
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->typing = KpTypingDb{ctx->d_gene_locus.p, ctx->d_gene_extra.p, ctx->d_gene_pos.p, ctx->d_gene_strand.p,
+                             ctx->d_gene_len.p, ctx->d_locus_off.p, ctx->d_locus_len.p, ctx->d_prot_db.p,
+                             ctx->d_prot_db_off.p, ctx->d_prot_db_len.p, ctx->n_genes, (int32_t)t->n_loci};
+    ctx->max_db_prot_len = max_len;
+    ctx->has_typing = true;
+    return KP_OK;
+}
+
+int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *locus_scores, int32_t *locus_counts) {
+    if (!ctx || !b || b->ctx != ctx || !locus_scores || !locus_counts) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!ctx->has_typing) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
+    int rc = kp_batch_wait(ctx, b);
+    if (rc) return rc;
+    const size_t n = (size_t)b->n_asm * (size_t)ctx->typing.n_loci;
+    KP_HIP_CHECK(ctx, b->d_scores.reserve(n));
+    KP_HIP_CHECK(ctx, b->d_lcounts.reserve(n));
+    kp_launch_score(b->view, b->d_hits.p, b->d_hit_counts.p + b->n_asm, b->hit_cap, ctx->typing, min_gene_coverage,
+                    b->d_scores.p, b->d_lcounts.p, ctx->stream);
+    KP_HIP_CHECK(ctx, hipGetLastError());
+    if (n) {
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, b->d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, b->d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    b->prm.min_gene_coverage = min_gene_coverage;
+    b->scored = true;
+    return KP_OK;
+}
+
+static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
+    const size_t n_asm = (size_t)b->n_asm;
+    if ((uint64_t)n_asm * (uint64_t)b->prot_cap > 0x7FFFFFFFull)
+        return kp_fail(ctx, KP_EOVERFLOW, "protein buffer would exceed 2^31 bytes; use smaller batches");
+    const size_t slots = n_asm * (size_t)b->kept_cap;
+    KP_HIP_CHECK(ctx, b->d_order.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, b->d_flag.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, b->d_kept.reserve(slots));
+    KP_HIP_CHECK(ctx, b->d_pieces.reserve(n_asm * (size_t)b->piece_cap));
+    KP_HIP_CHECK(ctx, b->d_summary.reserve(n_asm));
+    KP_HIP_CHECK(ctx, b->d_prot.reserve(n_asm * (size_t)b->prot_cap));
+    KP_HIP_CHECK(ctx, b->d_pairs.reserve(4 * slots));
+    KP_HIP_CHECK(ctx, b->d_dp.reserve(8 * slots));
+    int32_t *q_off = b->d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
+    kp_launch_reduce(b->view, b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, ctx->typing, b->prm, b->d_best.p,
+                     b->d_keys.p, b->d_order.p, b->d_flag.p, b->d_kept.p, b->kept_cap, b->d_pieces.p, b->piece_cap,
+                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, ctx->stream);
+    // protein DP of every kept hit against its database protein (empty slots have length 0 and cost nothing)
+    const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 8);
+    // widest band: 2 * max(20, |len difference| + 1) + 1.  A hit's target span is at most gene length + band drift
+    // (KP_MAX_BAND), so its translation is at most the database protein + KP_MAX_BAND / 3 residues long.
+    const size_t longest = (size_t)ctx->max_db_prot_len + KP_MAX_BAND / 3 + 2;
+    const size_t scratch_per_block = (2 * (longest + 2) + 1) * 12;
+    KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
+    kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, ctx->d_blosum.p, b->d_dp.p,
+                      b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->stream);
+    kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, ctx->stream);
+    KP_HIP_CHECK(ctx, hipGetLastError());
+    return KP_OK;
+}
+
+int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const kp_typing_params *prm) {
+    if (!ctx || !b || b->ctx != ctx || !prm || (b->n_asm > 0 && !best_locus)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->scored) return kp_fail(ctx, KP_ESTATE, "kp_batch_score has not been called");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int a = 0; a < b->n_asm; ++a)
+        if (best_locus[a] < 0 || best_locus[a] >= ctx->typing.n_loci) return kp_fail(ctx, KP_EINVAL, "best_locus out of range");
+    b->prm = *prm;
+    if (b->kept_cap == 0) b->kept_cap = (int)env_u32("KAPTIVE_AMD_KEPT_CAP", 256);
+    if (b->piece_cap == 0) b->piece_cap = (int)env_u32("KAPTIVE_AMD_PIECE_CAP", 32);
+    if (b->prot_cap == 0) b->prot_cap = (int)env_u32("KAPTIVE_AMD_PROT_CAP", 32768);
+    int rc = upload(ctx, b->d_best, best_locus, (size_t)b->n_asm);
+    if (rc) return rc;
+    rc = enqueue_reduce(ctx, b);
+    if (rc) return rc;
+    b->reduced = true;
+    return KP_OK;
+}
+
+int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
+                    kp_piece *pieces, int32_t piece_stride) {
+    if (!ctx || !b || b->ctx != ctx || (b->n_asm > 0 && (!summaries || !kept || !pieces)))
+        return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n_asm = (size_t)b->n_asm;
+    std::vector<KpAsmSummary> sums(n_asm);
+    for (int attempt = 0;; ++attempt) {
+        if (n_asm)
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(sums.data(), b->d_summary.p, n_asm * sizeof(KpAsmSummary),
+                                             hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        int flags = 0;
+        for (const auto &s : sums) flags |= s.overflow;
+        if (!(flags & (1 | 2 | 8))) break;
+        if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
+        if (attempt >= 3) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
+        if (flags & 1) {
+            if (b->kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
+            b->kept_cap = std::min(b->kept_cap * 4, 2048);
+        }
+        if (flags & 2) b->piece_cap *= 4;
+        if (flags & 8) b->prot_cap *= 4;
+        b->stats[4] += 1;
+        int rc = enqueue_reduce(ctx, b);
+        if (rc) return rc;
+    }
+    if (kept_stride < 1 || piece_stride < 1) return kp_fail(ctx, KP_EINVAL, "strides must be positive");
+    for (size_t a = 0; a < n_asm; ++a) {
+        if (sums[a].n_kept > kept_stride || sums[a].n_pieces > piece_stride)
+            return kp_fail(ctx, KP_EINVAL, "output strides too small (see kp_batch_typing_caps)");
+        summaries[a] = sums[a];
+        if (sums[a].n_kept)
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(kept + a * (size_t)kept_stride, b->d_kept.p + a * (size_t)b->kept_cap,
+                                             (size_t)sums[a].n_kept * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->stream));
+        if (sums[a].n_pieces)
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces + a * (size_t)piece_stride, b->d_pieces.p + a * (size_t)b->piece_cap,
+                                             (size_t)sums[a].n_pieces * sizeof(KpPiece), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return KP_OK;
+}
+
+int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *b, int32_t *kept_cap, int32_t *piece_cap) {
+    if (!ctx || !b || !kept_cap || !piece_cap) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    *kept_cap = b->kept_cap;
+    *piece_cap = b->piece_cap;
+    return KP_OK;
+}
+
+int kp_batch_proteins(kp_ctx *ctx, kp_batch *b, int32_t asm_index, uint8_t *out, int64_t cap) {
+    if (!ctx || !b || asm_index < 0 || asm_index >= b->n_asm || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    const int64_t n = std::min<int64_t>(cap, b->prot_cap);
+    if (n > 0 && hipMemcpy(out, b->d_prot.p + (size_t)asm_index * (size_t)b->prot_cap, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        return kp_fail(ctx, KP_EHIP, "D2H proteins failed");
+    return (int)n;
 }
 
 int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,

@@ -36,6 +36,10 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
     const int lane = threadIdx.x;
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
         const int len1 = q_len[p], len2 = t_len[p];
+        if (len1 == 0 || len2 == 0) {  // nothing to align (also the empty slots of the batched reduction)
+            if (lane < 8) out8[8 * (size_t)p + lane] = 0;
+            continue;
+        }
         const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
         int d = len1 - len2;
         if (d < 0) d = -d;

@@ -1,0 +1,286 @@
+// kp_reduce.hip -- the per-assembly reduction on the device: hit table finalisation, locus scoring, overlap cull,
+// clustering / pieces, gene extraction + translation from the packed stream, and gene states.
+//
+// These kernels replace, for a whole batch at once, the Python/numba steps the reference runs per genome after its
+// aligner returns (src/kaptive/serotyping/core.py:157-396; numba kernels src/kaptive/core/interval.py:595-751,
+// src/kaptive/core/seq.py:612-741).  The per-assembly logic is in kp_reduce_core.h (shared with the test harness);
+// this file decides who runs what: one 64-lane wave per assembly, lanes in parallel over hits for the quadratic parts
+// (rank sorts) and over the kept list / codons for the rest, lane 0 for the short sequential tails.  Assemblies are
+// independent, so a batch of N assemblies keeps N waves busy; no step needs more than one wave's worth of LDS.
+#include "kp_internal.h"
+#include "kp_reduce_core.h"
+
+namespace {
+
+constexpr int KEPT_LDS = 2048;  // upper bound of kept hits per assembly the cull scratch can hold
+
+// ---- 1. band-task results -> per-assembly raw hit lists ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, const int32_t *__restrict__ gene_len,
+                                                             const KpTask *__restrict__ tasks,
+                                                             const KpSwResult *__restrict__ results,
+                                                             const uint32_t *__restrict__ task_count, uint32_t task_cap,
+                                                             kp_hit *__restrict__ raw, uint32_t *__restrict__ n_raw,
+                                                             uint32_t hit_cap, unsigned long long *__restrict__ cells) {
+    const int cls = blockIdx.y;
+    uint32_t n = task_count[cls];
+    if (n > task_cap) n = task_cap;
+    unsigned long long my_cells = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const KpTask t = tasks[(size_t)cls * task_cap + i];
+        const KpSwResult r = results[(size_t)cls * task_cap + i];
+        const int qlen = gene_len[t.gs >> 1];
+        my_cells += (unsigned long long)qlen * (unsigned)t.width;
+        if (r.score < KP_MIN_DP_SCORE) continue;
+        const int32_t cs = b.ctg_start[b.asm_first_ctg[t.asm_id] + t.contig];
+        const uint32_t slot = atomicAdd(&n_raw[t.asm_id], 1u);
+        if (slot < hit_cap)
+            raw[(size_t)t.asm_id * hit_cap + slot] =
+                kp_make_hit(t.gs, t.contig, cs, qlen, r.score, r.q_start, r.q_end, r.t_start, r.t_end, r.matches, r.block_len);
+    }
+    if (my_cells) atomicAdd(cells, my_cells);
+}
+
+// ---- 2. emission order, duplicates, mapq (kp_spec.h) -------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kp_hit_sort_kernel(const kp_hit *__restrict__ raw, const uint32_t *__restrict__ n_raw,
+                                                         uint32_t hit_cap, uint64_t *__restrict__ keys,
+                                                         kp_hit *__restrict__ hits, uint32_t *__restrict__ n_hits) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    uint32_t n = n_raw[a];
+    if (n > hit_cap) n = hit_cap;
+    const kp_hit *src = raw + (size_t)a * hit_cap;
+    kp_hit *dst = hits + (size_t)a * hit_cap;
+    uint64_t *k = keys + (size_t)a * hit_cap * 3;
+    for (uint32_t i = lane; i < n; i += 64) kp_hit_keys(src[i], k + 3 * (size_t)i);
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) {  // rank sort: all lanes stream the same key j -> broadcast loads
+        const uint64_t mine[3] = {k[3 * (size_t)i], k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += kp_keys_less(k + 3 * (size_t)j, j, mine, i) ? 1u : 0u;
+        dst[rank] = src[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t m = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (m > 0 && kp_same_span(dst[m - 1], dst[i])) continue;
+            kp_hit h = dst[i];
+            h.mapq = (m == 0 || dst[m - 1].gene != h.gene) ? 60 : 0;
+            dst[m++] = h;
+        }
+        n_hits[a] = m;
+    }
+}
+
+// ---- 3. locus scores (core.py:164-198) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kp_score_kernel(const kp_hit *__restrict__ hits, const uint32_t *__restrict__ n_hits,
+                                                      uint32_t hit_cap, KpTypingDb db, double min_cov,
+                                                      double *__restrict__ scores, int32_t *__restrict__ counts) {
+    const int a = blockIdx.x;
+    const kp_hit *h = hits + (size_t)a * hit_cap;
+    const int n = (int)n_hits[a];
+    for (int l = threadIdx.x; l < db.n_loci; l += 64)
+        kp_locus_score(h, n, db, l, min_cov, &scores[(size_t)a * db.n_loci + l], &counts[(size_t)a * db.n_loci + l]);
+}
+
+// ---- 4. cull, clusters, pieces, translation ------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_hit *__restrict__ hits,
+                                                       const uint32_t *__restrict__ n_hits, uint32_t hit_cap,
+                                                       KpTypingDb db, KpTypingParams prm, const int32_t *__restrict__ best,
+                                                       uint64_t *__restrict__ keys, uint32_t *__restrict__ order,
+                                                       uint8_t *__restrict__ kept_flag, KpKept *__restrict__ kept,
+                                                       int kept_cap, KpPiece *__restrict__ pieces, int piece_cap,
+                                                       KpAsmSummary *__restrict__ summary, uint8_t *__restrict__ prot,
+                                                       int prot_cap, int32_t *__restrict__ pair_q_off,
+                                                       int32_t *__restrict__ pair_q_len, int32_t *__restrict__ pair_t_off,
+                                                       int32_t *__restrict__ pair_t_len) {
+    __shared__ int32_t s_ctg[KEPT_LDS], s_s[KEPT_LDS], s_e[KEPT_LDS], s_perm[KEPT_LDS];
+    __shared__ uint8_t s_codon[128];
+    __shared__ int s_fail;
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const int n = (int)n_hits[a];
+    const kp_hit *h = hits + (size_t)a * hit_cap;
+    uint64_t *k = keys + (size_t)a * hit_cap;
+    uint32_t *ord = order + (size_t)a * hit_cap;
+    uint8_t *flag = kept_flag + (size_t)a * hit_cap;
+    KpKept *out = kept + (size_t)a * kept_cap;
+    KpPiece *pc = pieces + (size_t)a * piece_cap;
+    KpAsmSummary *sum = summary + a;
+    const int best_locus = best[a];
+    if (lane == 0) {
+        kp_fill_codon_table(s_codon);
+        KpAsmSummary z;
+        z.n_hits = n; z.n_kept = 0; z.n_final = 0; z.n_pieces = 0; z.best_locus = best_locus;
+        z.n_expected = 0; z.n_missing = 0; z.overflow = 0;
+        for (int w = 0; w < KP_MAX_LOCUS_GENES / 64; ++w) z.missing_mask[w] = 0;
+        *sum = z;
+        s_fail = 0;
+    }
+    // visit order of the cull
+    for (int i = lane; i < n; i += 64) k[i] = kp_cull_key(h[i], (int)db.gene_locus[h[i].gene] == best_locus, (uint32_t)i);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const uint64_t mine = k[i];
+        uint32_t rank = 0;
+        for (int j = 0; j < n; ++j) rank += k[j] < mine ? 1u : 0u;
+        ord[rank] = (uint32_t)i;
+    }
+    __syncthreads();
+    // greedy cull, 64 candidates fetched at a time, each tested against the kept list by all lanes
+    int nk = 0;
+    const int cap = kept_cap < KEPT_LDS ? kept_cap : KEPT_LDS;
+    bool fail = false;
+    if (n < 2) {  // below two hits the reference returns the table unchanged (alignment.py:665-666)
+        if (n == 1 && lane == 0) { flag[0] = 1; s_ctg[0] = h[0].contig; s_s[0] = h[0].t_start; s_e[0] = h[0].t_end; }
+        nk = n;
+    } else {
+        for (int p0 = 0; p0 < n && !fail; p0 += 64) {
+            const int mine = p0 + lane < n ? (int)ord[p0 + lane] : -1;
+            int mc = 0, ms = 0, me = 0;
+            if (mine >= 0) { mc = h[mine].contig; ms = h[mine].t_start; me = h[mine].t_end; }
+            const int lim = n - p0 < 64 ? n - p0 : 64;
+            for (int l = 0; l < lim; ++l) {
+                const int id = __shfl(mine, l), c = __shfl(mc, l), s = __shfl(ms, l), e = __shfl(me, l);
+                const int len = e - s;
+                bool clash = false;
+                if (len > 0)
+                    for (int j = lane; j < nk; j += 64) {
+                        if (s_ctg[j] != c) continue;
+                        const int ov = min(e, s_e[j]) - max(s, s_s[j]);
+                        const int klen = s_e[j] - s_s[j];
+                        if (ov > 0 && (int64_t)ov * 10 > (int64_t)min(len, klen)) clash = true;
+                    }
+                const bool keep = len > 0 && !__any(clash);
+                if (keep && nk >= cap) { fail = true; break; }
+                if (lane == 0) {
+                    flag[id] = keep ? 1 : 0;
+                    if (keep) { s_ctg[nk] = c; s_s[nk] = s; s_e[nk] = e; }
+                }
+                if (keep) ++nk;
+                __syncthreads();  // kept list update visible to all lanes before the next candidate
+            }
+        }
+    }
+    if (fail) {
+        if (lane == 0) { sum->overflow |= 1; sum->n_kept = 0; }
+        for (int j = lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
+        return;
+    }
+    __syncthreads();
+    // kept list in emission order, clusters, pieces, inside flags, missing genes, protein slots: short sequential tail
+    if (lane == 0) {
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!flag[i]) continue;
+            KpKept o;
+            o.gene = h[i].gene; o.contig = h[i].contig; o.q_start = h[i].q_start; o.q_end = h[i].q_end;
+            o.t_start = h[i].t_start; o.t_end = h[i].t_end; o.score = h[i].score; o.strand = h[i].strand;
+            o.prot_off = 0; o.prot_len = 0; o.cluster = 0; o.pident = 0.f; o.coverage = 0.f; o.state = 0; o.flags = 0;
+            o.pad_ = 0;
+            for (int x = 0; x < 8; ++x) o.dp[x] = 0;
+            out[m++] = o;
+        }
+        sum->n_kept = nk;
+        kp_cluster_and_pieces(out, nk, db, best_locus, prm.max_locus_length, s_perm, pc, piece_cap, sum);
+        int used = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int frame = (3 - out[i].q_start % 3) % 3, len = out[i].t_end - out[i].t_start;
+            const int max_codons = len > frame ? (len - frame) / 3 : 0;
+            if (used + max_codons > prot_cap) { sum->overflow |= 8; s_fail = 1; break; }
+            out[i].prot_off = used;
+            out[i].prot_len = max_codons;  // upper bound; the translation below shortens it at the first stop
+            used += max_codons;
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        for (int j = lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
+        return;
+    }
+    // translation: all lanes work on one kept hit at a time, one codon per lane per round
+    const uint32_t *asm_words = b.words + b.asm_word_off[a];
+    const int c0 = b.asm_first_ctg[a];
+    const int r0 = b.asm_first_nrun[a], n_runs = b.asm_first_nrun[a + 1] - r0;
+    const int32_t *runs = b.n_runs + 2 * (size_t)r0;
+    uint8_t *pa = prot + (size_t)a * prot_cap;
+    for (int i = 0; i < nk; ++i) {
+        const KpKept o = out[i];
+        const int frame = (3 - o.q_start % 3) % 3, max_codons = o.prot_len;
+        const int32_t cs = b.ctg_start[c0 + o.contig];
+        const int32_t a0 = cs + o.t_start, a1 = cs + o.t_end;
+        int first_stop = max_codons;
+        for (int base = 0; base < max_codons && first_stop == max_codons; base += 64) {
+            const int c = base + lane;
+            uint8_t aa = 0;
+            if (c < max_codons) aa = kp_codon_aa(asm_words, runs, n_runs, a0, a1, o.strand, frame, c, s_codon);
+            const unsigned long long stops = __ballot(c < max_codons && aa == '*');
+            if (stops) first_stop = base + __builtin_ctzll(stops);
+            if (c < first_stop && c < max_codons) pa[o.prot_off + c] = aa;
+        }
+        if (lane == 0) {
+            out[i].prot_len = first_stop;
+            const size_t slot = (size_t)a * kept_cap + i;
+            pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + o.prot_off);  // offset into the batch protein buffer
+            pair_q_len[slot] = first_stop;
+            pair_t_off[slot] = db.prot_off[o.gene];
+            pair_t_len[slot] = db.prot_len[o.gene];
+        }
+    }
+    for (int j = nk + lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
+}
+
+// ---- 6. identities, coverages, states (core.py:363-394) ------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kp_state_kernel(KpBatchView b, KpTypingDb db, KpTypingParams prm,
+                                                      KpKept *__restrict__ kept, int kept_cap,
+                                                      KpAsmSummary *__restrict__ summary, const int32_t *__restrict__ dp8) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    KpAsmSummary *sum = summary + a;
+    const int nk = sum->n_kept;
+    KpKept *out = kept + (size_t)a * kept_cap;
+    const int c0 = b.asm_first_ctg[a];
+    int alive = 0;
+    for (int i = lane; i < nk; i += 64) {
+        KpKept o = out[i];
+        const int32_t *dp = dp8 + 8 * ((size_t)a * kept_cap + i);
+        for (int x = 0; x < 8; ++x) o.dp[x] = dp[x];
+        kp_gene_state(&o, db.gene_len[o.gene], b.ctg_len[c0 + o.contig], prm);
+        out[i] = o;
+        alive += (o.flags & KP_F_SPURIOUS) ? 0 : 1;
+    }
+    for (int o = 32; o >= 1; o >>= 1) alive += __shfl_xor(alive, o);
+    if (lane == 0) sum->n_final = alive;
+}
+
+}  // namespace
+
+void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
+                            const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
+                            uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells,
+                            hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, 3), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
+                       task_cap, raw, n_raw, hit_cap, cells);
+    hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(64), 0, stream, raw, n_raw, hit_cap, keys, hits, n_hits);
+}
+
+void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
+                     const KpTypingDb &db, double min_cov, double *scores, int32_t *counts, hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_score_kernel, dim3(b.n_asm), dim3(64), 0, stream, hits, n_hits, hit_cap, db, min_cov, scores, counts);
+}
+
+void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
+                      const KpTypingDb &db, const KpTypingParams &prm, const int32_t *best, uint64_t *keys,
+                      uint32_t *order, uint8_t *kept_flag, KpKept *kept, int kept_cap, KpPiece *pieces, int piece_cap,
+                      KpAsmSummary *summary, uint8_t *prot, int prot_cap, int32_t *pair_q_off, int32_t *pair_q_len,
+                      int32_t *pair_t_off, int32_t *pair_t_len, hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_reduce_kernel, dim3(b.n_asm), dim3(64), 0, stream, b, hits, n_hits, hit_cap, db, prm, best, keys,
+                       order, kept_flag, kept, kept_cap, pieces, piece_cap, summary, prot, prot_cap, pair_q_off, pair_q_len,
+                       pair_t_off, pair_t_len);
+}
+
+void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTypingParams &prm, KpKept *kept, int kept_cap,
+                      KpAsmSummary *summary, const int32_t *dp8, hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_state_kernel, dim3(b.n_asm), dim3(64), 0, stream, b, db, prm, kept, kept_cap, summary, dp8);
+}

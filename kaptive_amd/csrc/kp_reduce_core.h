@@ -18,41 +18,11 @@
 #define KP_HD inline
 #endif
 
-// ---- records ---------------------------------------------------------------------------------------------------------
-#define KP_F_EXPECTED 1u
-#define KP_F_INSIDE 2u
-#define KP_F_EXTRA 4u
-#define KP_F_PARTIAL 8u
-#define KP_F_SPURIOUS 16u
-#define KP_F_PRIMARY 32u
-
-#define KP_STATE_NORMAL 0
-#define KP_STATE_PARTIAL 1
-#define KP_STATE_TRUNCATED 2
-#define KP_STATE_NOVEL 3
-
-#define KP_MAX_LOCUS_GENES 256 /* missing-gene mask width */
-
-typedef struct KpKept {  // one culled-and-kept hit, emission order
-    int32_t gene, contig, q_start, q_end, t_start, t_end, score;
-    int32_t prot_off, prot_len;  // translated protein inside the batch protein buffer
-    int32_t cluster;             // spatial cluster id (piece candidate)
-    int32_t dp[8];               // protein DP: score, matches, mismatches, gaps, qs, qe, ts, te
-    float pident, coverage;
-    int8_t strand, state;
-    uint8_t flags, pad_;
-} KpKept;
-
-typedef struct KpPiece {
-    int32_t contig, start, end, strand;
-    double mean_pos;
-} KpPiece;
-
-typedef struct KpAsmSummary {
-    int32_t n_hits, n_kept, n_final, n_pieces;
-    int32_t best_locus, n_expected, n_missing, overflow;  // overflow: bit0 kept list, bit1 pieces, bit2 locus too large
-    uint64_t missing_mask[KP_MAX_LOCUS_GENES / 64];       // bit j: gene locus_off + j not found inside the locus
-} KpAsmSummary;
+// ---- records (public layouts live in include/kp_spec.h) -----------------------------------------------------------------
+typedef kp_kept KpKept;
+typedef kp_piece KpPiece;
+typedef kp_asm_summary KpAsmSummary;
+typedef kp_typing_params KpTypingParams;
 
 typedef struct KpTypingDb {  // device-resident views of the Database arrays the reduction reads
     const uint16_t *gene_locus;     // db.gene_locus_indices
@@ -66,13 +36,6 @@ typedef struct KpTypingDb {  // device-resident views of the Database arrays the
     const int32_t *prot_off, *prot_len;
     int32_t n_genes, n_loci;
 } KpTypingDb;
-
-typedef struct KpTypingParams {
-    double min_gene_coverage;  // Serotyper.min_gene_coverage
-    float id_threshold;        // np.float32(db.metadata.id_threshold): the reference compares float32 identities
-    int32_t max_locus_length;  // db.max_locus_length (clustering tolerance)
-    int32_t edge_tolerance;    // Serotyper.partial_edge_tolerance
-} KpTypingParams;
 
 // ---- hit finalisation -----------------------------------------------------------------------------------------------
 // task result -> hit record (strand flip, contig-local coordinates); mapq is filled after sorting

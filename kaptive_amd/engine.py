@@ -28,6 +28,7 @@ class Engine:
         self.ctx = _native.Context(device)
         codes, off = pack_sequences_flat(db.genes)
         self.ctx.load_genes(codes, off)
+        self.ctx.load_typing(db)
         self._gene_names = tuple(str(i) for i in range(len(db.genes)))
 
     def close(self) -> None:
@@ -69,7 +70,36 @@ class Engine:
                                    targets.lengths)
         )  # fmt: skip
 
+    def typing_params(self, typer) -> "_native.TypingParams":
+        db = self.db
+        return _native.TypingParams(
+            typer.min_gene_coverage, float(np.float32(db.metadata.id_threshold)), db.max_locus_length,
+            typer.partial_edge_tolerance,
+        )
+
+    def type_batch(self, typer, batch, ids: Sequence[str], genomes: Sequence[GenomeAssembly] | None = None) -> list:
+        """Whole typing of a resident batch: alignment, device reduction, the three numpy float steps, result objects.
+        ``genomes`` (optional) lets the results carry the extracted locus / gene / protein sequences."""
+        from kaptive_amd.serotyping import batch as B
+
+        batch.align_async()
+        scores, counts = batch.score(typer.min_gene_coverage)
+        best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
+        batch.reduce_async(best, self.typing_params(typer))
+        sums, kept, pieces = batch.typing()
+        out = []
+        for a in range(batch.n_asm):
+            s = sums[a]
+            out.append(
+                B.assemble(typer, ids[a], s, kept[a, : s["n_kept"]], pieces[a, : s["n_pieces"]], scores[a, best[a]],
+                           genome=None if genomes is None else genomes[a])
+            )  # fmt: skip
+        return out
+
     def type_many(self, typer, genomes: Sequence[GenomeAssembly]) -> list:
-        """One device submission for the alignment of all genomes, then the reduction per genome."""
-        alns = self.align(genomes)
-        return [typer.reduce(g, a) for g, a in zip(genomes, alns)]
+        """One device submission for all genomes: alignment and reduction both run on the GPU."""
+        batch = self.ctx.batch([g.packed() for g in genomes])
+        try:
+            return self.type_batch(typer, batch, [g.id for g in genomes], genomes)
+        finally:
+            batch.close()

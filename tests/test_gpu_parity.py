@@ -229,3 +229,76 @@ def test_type_many_equals_single_calls():
         assert np.array_equal(r.gene_hits.t_starts, single.gene_hits.t_starts)
         assert r.protein_identities.tobytes() == single.protein_identities.tobytes()
     typer.engine.close()
+
+
+# ---- batched device reduction ---------------------------------------------------------------------------------------------
+def _results_equal(a, b, what):
+    da, db_ = a.to_dict(), b.to_dict()
+    for k in ("best_locus_idx", "best_locus_name", "phenotype", "typeable", "missing_expected_genes", "problems"):
+        assert da[k] == db_[k], (what, k, da[k], db_[k])
+    for k in ("best_locus_score", "best_locus_completeness", "length_discrepancy", "percent_identity", "percent_coverage"):
+        assert np.float64(da[k]).tobytes() == np.float64(db_[k]).tobytes(), (what, k, da[k], db_[k])
+    for k, v in da["gene_hits"].items():
+        assert np.array_equal(np.asarray(v), np.asarray(db_["gene_hits"][k])), (what, k)
+    assert np.array_equal(da["gene_states"], db_["gene_states"]), what
+    assert da["protein_identities"].tobytes() == db_["protein_identities"].tobytes(), what
+    for k, v in da["locus_pieces"].items():
+        assert np.array_equal(v, db_["locus_pieces"][k]), (what, k)
+    for grp in ("locus_seqs", "gene_seqs", "translations"):
+        assert da[grp]["seqs"] == db_[grp]["seqs"] and tuple(da[grp]["ids"]) == tuple(db_[grp]["ids"]), (what, grp)
+
+
+@pytest.mark.parametrize("key", ["k", "o"])
+def test_batched_device_reduction_matches_golden_cases(key):
+    """type_many = alignment + reduction on the device for all cases of one database in one batch; every result must
+    equal the reference's golden record (fields and TSV bytes)."""
+    names = [n for n in case_names() if not n.startswith("random_hits") and load_case(n)[0] == key
+             and not n.startswith("k_divergent_")]  # fmt: skip
+    cases = [load_case(n) for n in names]
+    typer = Serotyper(load_db(key))
+    results = typer.type_many([c[1] for c in cases])
+    for name, case, res in zip(names, cases, results):
+        check_result_against_golden(res, case[3], case[4])
+    typer.engine.close()
+
+
+def test_batched_device_reduction_matches_host_reduction_on_synthetic_batch(small_db):
+    """Device reduction vs the golden-pinned host reduction on assemblies no fixture covers, including edge cases."""
+    typer = Serotyper(small_db)
+    genomes = _assemblies(small_db) + [make_assembly(small_db, seed=400 + i, length=120_000, median_contigs=8,
+                                                      min_contig=200, sub_rate=0.02 * i) for i in range(8)]  # fmt: skip
+    many = typer.type_many(genomes)
+    for g, r in zip(genomes, many):
+        _results_equal(r, typer(g), g.id)
+    typer.engine.close()
+
+
+def test_batched_reduction_confidence_switches():
+    for tag in ("loose", "strict"):
+        key, genome, hits, exp, scalars, kwargs = load_case(f"k_divergent_{tag}")
+        typer = Serotyper(load_db(key), **kwargs)
+        check_result_against_golden(typer.type_many([genome])[0], exp, scalars)
+        typer.engine.close()
+
+
+def test_batched_reduction_full_size():
+    db = make_db("kpsc_k", seed=100)
+    typer = Serotyper(db)
+    genomes = [make_assembly(db, seed=200 + i) for i in range(4)]
+    for g, r in zip(genomes, typer.type_many(genomes)):
+        _results_equal(r, typer(g), g.id)
+    typer.engine.close()
+
+
+def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
+    monkeypatch.setenv("KAPTIVE_AMD_KEPT_CAP", "4")
+    monkeypatch.setenv("KAPTIVE_AMD_PIECE_CAP", "1")
+    monkeypatch.setenv("KAPTIVE_AMD_PROT_CAP", "256")
+    monkeypatch.setenv("KAPTIVE_AMD_HIT_CAP", "16")
+    typer = Serotyper(small_db)
+    genomes = _assemblies(small_db)[:4]
+    many = typer.type_many(genomes)
+    monkeypatch.undo()
+    for g, r in zip(genomes, many):
+        _results_equal(r, typer(g), g.id)
+    typer.engine.close()
