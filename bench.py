@@ -6,7 +6,8 @@
 
 One "step" types every assembly of the rank's resident batch against the synthetic KpSC K-locus database and then
 against the O-locus database (2 database passes per assembly): seed scan -> anchor sort -> chaining -> banded
-Smith-Waterman on the GPU, then the per-locus reduction and the protein DP.  Packed assemblies are resident in HBM
+Smith-Waterman, then hit finalisation, locus scoring, overlap cull, pieces, translation, protein DP and gene states,
+all on the GPU; the host does three small numpy float steps and builds the result objects.  Packed assemblies are resident in HBM
 before the timed region.  Ranks hold disjoint assemblies (weak scaling, no collective on the data path; the only
 torch.distributed calls are the barrier and the max-over-ranks of the elapsed time).  Rank 0 prints one JSON line.
 
@@ -41,7 +42,7 @@ def _make_one(job):
     from kaptive_amd.synth import make_assembly
 
     db = _DBS[kind]
-    g = make_assembly(db, seed=seed, length=length)
+    g = make_assembly(db, seed=seed, length=length, also=(_DBS["o"],))
     pa = g.packed()
     return g.id, g.contigs.ids, g.contigs.seqs, g.contigs.lengths, pa
 
@@ -160,12 +161,12 @@ def main() -> None:
         typer._engine = eng
         stages.append((eng, typer, eng.ctx.batch(packed)))
 
+    ids = [g.id for g in genomes]
+
     def step():
         results = []
         for eng, typer, batch in stages:
-            hits, off = batch.align()
-            for i, g in enumerate(genomes):
-                results.append(typer.reduce(g, eng.hits_to_alignments(g, hits[off[i] : off[i + 1]])))
+            results += eng.type_batch(typer, batch, ids)
         return results
 
     for _ in range(args.warmup):

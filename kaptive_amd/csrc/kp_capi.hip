@@ -771,7 +771,7 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         for (const auto &s : sums) flags |= s.overflow;
         if (!(flags & (1 | 2 | 8))) break;
         if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
-        if (attempt >= 3) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
+        if (attempt >= 8) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
         if (flags & 1) {
             if (b->kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
             b->kept_cap = std::min(b->kept_cap * 4, 2048);

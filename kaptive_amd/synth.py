@@ -158,6 +158,7 @@ def make_assembly(
     sub_rate: float | None = None,
     second_locus: int | None = None,
     n_run: int = 0,
+    also: tuple = (),
 ) -> GenomeAssembly:
     """One synthetic assembly holding a mutated copy of one database locus.
     ``locus`` < 0 plants no locus at all."""
@@ -208,6 +209,25 @@ def make_assembly(
             genome[at : at + len(other)] = other[: max(0, total - at)]
         if force_split or rng.random() < p_break:
             cuts_inside.append(where + int(rng.integers(len(copy) // 5, 4 * len(copy) // 5)))
+    for k, other in enumerate(also):  # one locus of each further database (e.g. the O locus next to the K locus)
+        typed2 = np.flatnonzero(~_locus_is_extra(other))
+        lj = int(rng.choice(typed2))
+        o2, n2 = int(other.loci.offsets[lj]), int(other.loci.lengths[lj])
+        copy2 = mutate(rng, other.loci.seqs[o2 : o2 + n2], float(rng.uniform(0.0, 0.03)))
+        g0, g1 = int(other.locus_gene_offsets[lj]), int(other.locus_gene_offsets[lj] + other.locus_gene_lengths[lj])
+        for gi in range(g0, g1):
+            s, e = int(other.gene_intervals.starts[gi]), int(other.gene_intervals.ends[gi])
+            if other.gene_intervals.strands[gi] > 0:
+                _kill_internal_stops(copy2[s:e])
+            else:
+                orf = revcomp(copy2[s:e])
+                _kill_internal_stops(orf)
+                copy2[s:e] = revcomp(orf)
+        if rng.random() < 0.5:
+            copy2 = revcomp(copy2)
+        at = total - total // 12 + k * 60_000  # the last twelfth of the genome is never used by the main locus
+        if at + len(copy2) < total:
+            genome[at : at + len(copy2)] = copy2
     extra_rows = np.flatnonzero(db.extra_genes)
     for gi in extra_rows:  # unlinked modifier genes planted elsewhere
         if rng.random() < p_extra / max(len(extra_rows), 1) * 3:
