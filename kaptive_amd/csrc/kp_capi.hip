@@ -20,9 +20,10 @@ void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *
                       const KpTypingDb &db, const KpTypingParams &prm, const int32_t *best, uint64_t *keys,
                       uint32_t *order, uint8_t *kept_flag, KpKept *kept, int kept_cap, KpPiece *pieces, int piece_cap,
                       KpAsmSummary *summary, uint8_t *prot, int prot_cap, int32_t *pair_q_off, int32_t *pair_q_len,
-                      int32_t *pair_t_off, int32_t *pair_t_len, hipStream_t stream);
+                      int32_t *pair_t_off, int32_t *pair_t_len, int32_t *n_pairs, int32_t *pair_base,
+                      hipStream_t stream);
 void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTypingParams &prm, KpKept *kept, int kept_cap,
-                      KpAsmSummary *summary, const int32_t *dp8, hipStream_t stream);
+                      KpAsmSummary *summary, const int32_t *dp8, const int32_t *pair_base, hipStream_t stream);
 
 namespace {
 
@@ -716,22 +717,25 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, b->d_pieces.reserve(n_asm * (size_t)b->piece_cap));
     KP_HIP_CHECK(ctx, b->d_summary.reserve(n_asm));
     KP_HIP_CHECK(ctx, b->d_prot.reserve(n_asm * (size_t)b->prot_cap));
-    KP_HIP_CHECK(ctx, b->d_pairs.reserve(4 * slots));
+    KP_HIP_CHECK(ctx, b->d_pairs.reserve(4 * slots + n_asm + 1));
     KP_HIP_CHECK(ctx, b->d_dp.reserve(8 * slots));
     int32_t *q_off = b->d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
+    int32_t *pair_base = t_len + slots, *n_pairs = pair_base + n_asm;
+    KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), ctx->stream));
     kp_launch_reduce(b->view, b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, ctx->typing, b->prm, b->d_best.p,
                      b->d_keys.p, b->d_order.p, b->d_flag.p, b->d_kept.p, b->kept_cap, b->d_pieces.p, b->piece_cap,
-                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, ctx->stream);
-    // protein DP of every kept hit against its database protein (empty slots have length 0 and cost nothing)
+                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->stream);
+    // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
     const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 8);
     // widest band: 2 * max(20, |len difference| + 1) + 1.  A hit's target span is at most gene length + band drift
     // (KP_MAX_BAND), so its translation is at most the database protein + KP_MAX_BAND / 3 residues long.
     const size_t longest = (size_t)ctx->max_db_prot_len + KP_MAX_BAND / 3 + 2;
     const size_t scratch_per_block = (2 * (longest + 2) + 1) * 12;
     KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
-    kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, ctx->d_blosum.p, b->d_dp.p,
-                      b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->stream);
-    kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, ctx->stream);
+    kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
+                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->stream);
+    kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, pair_base,
+                     ctx->stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -783,6 +787,15 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         if (rc) return rc;
     }
     if (kept_stride < 1 || piece_stride < 1) return kp_fail(ctx, KP_EINVAL, "strides must be positive");
+    if (n_asm && kept_stride == b->kept_cap && piece_stride == b->piece_cap) {  // same layout: two bulk copies
+        std::memcpy(summaries, sums.data(), n_asm * sizeof(KpAsmSummary));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, b->d_kept.p, n_asm * (size_t)b->kept_cap * sizeof(KpKept),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, b->d_pieces.p, n_asm * (size_t)b->piece_cap * sizeof(KpPiece),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return KP_OK;
+    }
     for (size_t a = 0; a < n_asm; ++a) {
         if (sums[a].n_kept > kept_stride || sums[a].n_pieces > piece_stride)
             return kp_fail(ctx, KP_EINVAL, "output strides too small (see kp_batch_typing_caps)");
@@ -846,7 +859,7 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     KP_HIP_CHECK(ctx, ctx->d_pout.reserve(8 * (size_t)n));
     KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks));
     kp_launch_protein(ctx->d_pq.p, ctx->d_pmeta.p, ctx->d_pmeta.p + n, ctx->d_pt.p, ctx->d_pmeta.p + 2 * (size_t)n,
-                      ctx->d_pmeta.p + 3 * (size_t)n, n, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
+                      ctx->d_pmeta.p + 3 * (size_t)n, n, nullptr, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
                       scratch_per_block, n_blocks, ctx->stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
     KP_HIP_CHECK(ctx, hipMemcpyAsync(out8, ctx->d_pout.p, 8 * (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost,

@@ -79,8 +79,8 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
                   uint32_t task_cap, int width, KpSwResult *results, hipStream_t stream);
 // kp_prot.hip
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
-                       const int32_t *t_off, const int32_t *t_len, int32_t n, const int8_t *blosum, int32_t *out8,
-                       int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream);
+                       const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,
+                       int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream);
 // kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
 int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
                     int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,

@@ -92,10 +92,11 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
                                                        KpAsmSummary *__restrict__ summary, uint8_t *__restrict__ prot,
                                                        int prot_cap, int32_t *__restrict__ pair_q_off,
                                                        int32_t *__restrict__ pair_q_len, int32_t *__restrict__ pair_t_off,
-                                                       int32_t *__restrict__ pair_t_len) {
+                                                       int32_t *__restrict__ pair_t_len, int32_t *__restrict__ n_pairs,
+                                                       int32_t *__restrict__ pair_base) {
     __shared__ int32_t s_ctg[KEPT_LDS], s_s[KEPT_LDS], s_e[KEPT_LDS], s_perm[KEPT_LDS];
     __shared__ uint8_t s_codon[128];
-    __shared__ int s_fail;
+    __shared__ int s_fail, s_base;
     const int a = blockIdx.x, lane = threadIdx.x;
     const int n = (int)n_hits[a];
     const kp_hit *h = hits + (size_t)a * hit_cap;
@@ -161,8 +162,7 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         }
     }
     if (fail) {
-        if (lane == 0) { sum->overflow |= 1; sum->n_kept = 0; }
-        for (int j = lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
+        if (lane == 0) { sum->overflow |= 1; sum->n_kept = 0; pair_base[a] = 0; }
         return;
     }
     __syncthreads();
@@ -190,12 +190,14 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
             out[i].prot_len = max_codons;  // upper bound; the translation below shortens it at the first stop
             used += max_codons;
         }
+        if (s_fail) sum->n_kept = 0;
+        // this assembly's slots in the batch-wide list of protein pairs
+        s_base = s_fail ? 0 : atomicAdd(n_pairs, nk);
+        pair_base[a] = s_base;
     }
     __syncthreads();
-    if (s_fail) {
-        for (int j = lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
-        return;
-    }
+    if (s_fail) return;
+    const size_t base = (size_t)s_base;
     // translation: all lanes work on one kept hit at a time, one codon per lane per round
     const uint32_t *asm_words = b.words + b.asm_word_off[a];
     const int c0 = b.asm_first_ctg[a];
@@ -218,20 +220,20 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         }
         if (lane == 0) {
             out[i].prot_len = first_stop;
-            const size_t slot = (size_t)a * kept_cap + i;
+            const size_t slot = base + i;
             pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + o.prot_off);  // offset into the batch protein buffer
             pair_q_len[slot] = first_stop;
             pair_t_off[slot] = db.prot_off[o.gene];
             pair_t_len[slot] = db.prot_len[o.gene];
         }
     }
-    for (int j = nk + lane; j < kept_cap; j += 64) pair_q_len[(size_t)a * kept_cap + j] = pair_t_len[(size_t)a * kept_cap + j] = 0;
 }
 
 // ---- 6. identities, coverages, states (core.py:363-394) ------------------------------------------------------------------
 __global__ __launch_bounds__(64) void kp_state_kernel(KpBatchView b, KpTypingDb db, KpTypingParams prm,
                                                       KpKept *__restrict__ kept, int kept_cap,
-                                                      KpAsmSummary *__restrict__ summary, const int32_t *__restrict__ dp8) {
+                                                      KpAsmSummary *__restrict__ summary, const int32_t *__restrict__ dp8,
+                                                      const int32_t *__restrict__ pair_base) {
     const int a = blockIdx.x, lane = threadIdx.x;
     KpAsmSummary *sum = summary + a;
     const int nk = sum->n_kept;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(64) void kp_state_kernel(KpBatchView b, KpTypingDb 
     int alive = 0;
     for (int i = lane; i < nk; i += 64) {
         KpKept o = out[i];
-        const int32_t *dp = dp8 + 8 * ((size_t)a * kept_cap + i);
+        const int32_t *dp = dp8 + 8 * ((size_t)pair_base[a] + i);
         for (int x = 0; x < 8; ++x) o.dp[x] = dp[x];
         kp_gene_state(&o, db.gene_len[o.gene], b.ctg_len[c0 + o.contig], prm);
         out[i] = o;
@@ -272,15 +274,17 @@ void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *
                       const KpTypingDb &db, const KpTypingParams &prm, const int32_t *best, uint64_t *keys,
                       uint32_t *order, uint8_t *kept_flag, KpKept *kept, int kept_cap, KpPiece *pieces, int piece_cap,
                       KpAsmSummary *summary, uint8_t *prot, int prot_cap, int32_t *pair_q_off, int32_t *pair_q_len,
-                      int32_t *pair_t_off, int32_t *pair_t_len, hipStream_t stream) {
+                      int32_t *pair_t_off, int32_t *pair_t_len, int32_t *n_pairs, int32_t *pair_base,
+                      hipStream_t stream) {
     if (b.n_asm == 0) return;
     hipLaunchKernelGGL(kp_reduce_kernel, dim3(b.n_asm), dim3(64), 0, stream, b, hits, n_hits, hit_cap, db, prm, best, keys,
                        order, kept_flag, kept, kept_cap, pieces, piece_cap, summary, prot, prot_cap, pair_q_off, pair_q_len,
-                       pair_t_off, pair_t_len);
+                       pair_t_off, pair_t_len, n_pairs, pair_base);
 }
 
 void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTypingParams &prm, KpKept *kept, int kept_cap,
-                      KpAsmSummary *summary, const int32_t *dp8, hipStream_t stream) {
+                      KpAsmSummary *summary, const int32_t *dp8, const int32_t *pair_base, hipStream_t stream) {
     if (b.n_asm == 0) return;
-    hipLaunchKernelGGL(kp_state_kernel, dim3(b.n_asm), dim3(64), 0, stream, b, db, prm, kept, kept_cap, summary, dp8);
+    hipLaunchKernelGGL(kp_state_kernel, dim3(b.n_asm), dim3(64), 0, stream, b, db, prm, kept, kept_cap, summary, dp8,
+                       pair_base);
 }
