@@ -57,6 +57,7 @@ struct kp_ctx {
     int64_t n_postings = 0;
     std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
     DevBuf<uint2> d_slots;
+    DevBuf<uint32_t> d_filter;
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
@@ -96,6 +97,7 @@ struct kp_batch {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
+    DevBuf<uint32_t> d_task_order;  // [384] histogram + cursors, then [3 * task_cap] permutation
     // device-side hit tables (per-assembly regions of hit_cap rows)
     uint32_t hit_cap = 0;
     DevBuf<kp_hit> d_hits_raw, d_hits, d_hits_packed;
@@ -268,7 +270,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_slots.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
+    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
     ctx->d_gene_locus.release(); ctx->d_gene_pos.release(); ctx->d_gene_extra.release(); ctx->d_prot_db.release();
@@ -353,6 +355,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (log_slots > 30) return kp_fail(ctx, KP_EINVAL, "seed index too large");
     const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
     std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
+    std::vector<uint32_t> filter((size_t)1 << (KP_FILTER_LOG2 - 5), 0u);
     std::vector<uint64_t> flat;
     flat.reserve(post.size() + n_unique + 1);
     for (size_t i = 0; i < post.size();) {
@@ -361,6 +364,8 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         uint32_t slot = (post[i].key * 2654435769u) >> shift;
         while (slots[slot].x != 0xFFFFFFFFu) slot = (slot + 1) & mask;
         slots[slot] = make_uint2(post[i].key, (uint32_t)flat.size());
+        const uint32_t fb = (post[i].key * 2654435769u) >> (32 - KP_FILTER_LOG2);
+        filter[fb >> 5] |= 1u << (fb & 31);
         flat.push_back((uint64_t)(j - i));
         for (size_t x = i; x < j; ++x)
             flat.push_back(((uint64_t)post[x].gs << 46) | ((uint64_t)(KP_DIAG_BIAS - post[x].pos) << 16) | post[x].pos);
@@ -370,12 +375,13 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (flat.empty()) flat.push_back(0);
     int rcode;
     if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_filter, filter.data(), filter.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->index = KpSeedIndex{ctx->d_slots.p, ctx->d_postings.p, mask, shift};
+    ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_slots.p, ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
     ctx->n_genes = n_genes;
     ctx->n_postings = (int64_t)post.size();
@@ -433,7 +439,7 @@ void kp_batch_destroy(kp_batch *b) {
     b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
     b->d_anchor_contig.release(); b->d_counts.release(); b->d_seg.release(); b->d_tasks.release();
-    b->d_results.release();
+    b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
     b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_flag.release();
     b->d_prot.release(); b->d_scores.release(); b->d_lcounts.release(); b->d_best.release(); b->d_pairs.release();
@@ -452,7 +458,9 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
     KP_HIP_CHECK(ctx, b->d_tasks.reserve(3 * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, b->d_results.reserve(3 * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, b->d_task_order.reserve(384 + 3 * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (n_asm + 3) * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, 384 * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
     kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, ctx->stream);
@@ -463,11 +471,14 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     kp_launch_chain(b->view, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
+    kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + 384,
+                         ctx->stream);
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
     static const int widths[3] = {32, 64, 128};
     for (int c = 0; c < 3; ++c) {
         kp_launch_sw(b->view, ctx->genes, b->d_tasks.p + (size_t)c * b->task_cap, d_task_count + c, b->task_cap,
-                     widths[c], b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
+                     b->d_task_order.p + 384 + (size_t)c * b->task_cap, widths[c],
+                     b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
         if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
     }
     KP_HIP_CHECK(ctx, hipGetLastError());

@@ -91,7 +91,67 @@ __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t 
     seg_end[a] = (uint32_t)a * cap + n;
 }
 
+// ---- task order: counting sort of each width class by query length, longest first ------------------------------------------
+// Tasks of one wave run in lock step for as many steps as the longest of them needs, so neighbours in the processing
+// order should have similar lengths; starting with the long ones also keeps the tail of the launch short.
+__device__ __forceinline__ int length_bucket(int qlen) {
+    const int b = qlen >> 5;
+    return 63 - (b > 63 ? 63 : b);
+}
+
+__global__ __launch_bounds__(256) void kp_task_hist_kernel(KpGenes genes, const KpTask *__restrict__ tasks,
+                                                           const uint32_t *__restrict__ task_count, uint32_t task_cap,
+                                                           uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_h[64];
+    const int cls = blockIdx.y;
+    uint32_t n = task_count[cls];
+    if (n > task_cap) n = task_cap;
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&s_h[length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[cls * 64 + threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, const KpTask *__restrict__ tasks,
+                                                              const uint32_t *__restrict__ task_count, uint32_t task_cap,
+                                                              uint32_t *__restrict__ hist, uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_start[64], s_h[64], s_base[64];
+    const int cls = blockIdx.y;
+    uint32_t n = task_count[cls];
+    if (n > task_cap) n = task_cap;
+    if (threadIdx.x == 0) {  // bucket starts from the finished histogram (64 entries: not worth a scan)
+        uint32_t acc = 0;
+        for (int k = 0; k < 64; ++k) { s_start[k] = acc; acc += hist[cls * 64 + k]; }
+    }
+    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    // each block handles one contiguous chunk so that it can reserve its slots with one atomic per bucket
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+        atomicAdd(&s_h[length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[192 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
+        s_h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int k = length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1]);
+        order[(size_t)cls * task_cap + s_start[k] + s_base[k] + atomicAdd(&s_h[k], 1u)] = i;
+    }
+}
+
 }  // namespace
+
+void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
+                          uint32_t *hist, uint32_t *order, hipStream_t stream) {
+    const dim3 grid(128, 3), block(256);
+    hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist);
+    hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist, order);
+}
 
 void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,
                         hipStream_t stream) {

@@ -13,7 +13,9 @@
 // Seed index: open-addressing table keyed by the 30-bit k-mer; slot = {key, first posting}; postings[first] holds the
 // count in its low word, followed by `count` posting words.  A posting word is the anchor key of the seed for target
 // position 0:  (gs << 46) | ((KP_DIAG_BIAS - qpos) << 16) | qpos ; adding (tpos << 16) yields the anchor key.
+#define KP_FILTER_LOG2 24  // bits in the presence filter: bit ((kmer * 2654435769u) >> (32 - KP_FILTER_LOG2))
 struct KpSeedIndex {
+    const uint32_t *filter;    // [2^KP_FILTER_LOG2 / 32] presence filter over the indexed k-mers
     const uint2 *slots;        // [n_slots], key == 0xFFFFFFFF marks an empty slot
     const uint64_t *postings;  // count word + postings, per distinct k-mer
     uint32_t slot_mask;        // n_slots - 1 (power of two)
@@ -76,7 +78,10 @@ void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const
                      hipStream_t stream);
 // kp_sw.hip: banded Smith-Waterman of every task of one width class.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, int width, KpSwResult *results, hipStream_t stream);
+                  uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream);
+// kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
+void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
+                          uint32_t *hist /*[384] zeroed*/, uint32_t *order, hipStream_t stream);
 // kp_prot.hip
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,

@@ -8,11 +8,15 @@
 // instruction).  The 65th..80th base needed by k-mers that start near the end of the lane's span come from the next
 // lane's first word (DPP/shuffle), so every word is fetched from HBM exactly once.  The context-free seed rule
 // (c[p]^c[p+1]^c[p+3]==1) is evaluated for 16 positions at a time with word-wide bit operations; only the selected
-// quarter of positions goes on to hash and probe the k-mer table.  Hits are rare outside the typed locus, so the
-// per-hit work (assembly / contig / N-run lookup, posting expansion, atomics) is off the streaming path.
+// quarter of positions goes on: first a 2^KP_FILTER_LOG2-bit presence filter (2 MB, stays in each XCD's L2) that
+// rejects most of them, then the k-mer table (tens of MB, Infinity Cache) for the rest.  Hits are rare outside the
+// typed locus, so the per-hit work (assembly / contig / N-run lookup, posting expansion, atomics) is off the
+// streaming path.
 #include "kp_internal.h"
 
 namespace {
+
+constexpr int PROBES = 8;
 
 __device__ __forceinline__ int upper_bound_i64(const int64_t *a, int n, int64_t v) {  // first i with a[i] > v
     int lo = 0, hi = n;
@@ -81,18 +85,32 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
             uint32_t sel = x & ~(x >> 1) & 0x55555555u;  // value 01: low bit set, high bit clear
             const uint64_t both = ((uint64_t)hi << 32) | lo;
             while (sel) {
-                const int bit = __builtin_ctz(sel);
-                sel &= sel - 1;
-                const uint32_t kmer = (uint32_t)(both >> bit) & KP_KMER_MASK;
-                uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
-                for (;;) {
-                    const uint2 e = idx.slots[slot];
-                    if (e.x == kmer) {
-                        emit_seed(b, idx, e.y, (u << 2) + k, bit >> 1, anchors, anchor_count, cap);
-                        break;
+                // up to PROBES selected positions at a time: all their filter words are requested before any is
+                // looked at, so a lane keeps several independent L2 reads in flight
+                uint32_t kmer[PROBES], filt[PROBES];
+                int bit[PROBES];
+#pragma unroll
+                for (int j = 0; j < PROBES; ++j) {
+                    const bool have = sel != 0;
+                    bit[j] = have ? __builtin_ctz(sel) : 0;
+                    sel &= sel - 1;  // no-op once sel is 0
+                    kmer[j] = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
+                    const uint32_t h = (kmer[j] * 2654435769u) >> (32 - KP_FILTER_LOG2);
+                    filt[j] = have ? ((idx.filter[h >> 5] >> (h & 31)) & 1u) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < PROBES; ++j) {
+                    if (!filt[j]) continue;  // ~93 % of selected positions stop here (KpSC K database)
+                    uint32_t slot = (kmer[j] * 2654435769u) >> idx.slot_shift;
+                    for (;;) {
+                        const uint2 e = idx.slots[slot];
+                        if (e.x == kmer[j]) {
+                            emit_seed(b, idx, e.y, (u << 2) + k, bit[j] >> 1, anchors, anchor_count, cap);
+                            break;
+                        }
+                        if (e.x == 0xFFFFFFFFu) break;
+                        slot = (slot + 1) & idx.slot_mask;
                     }
-                    if (e.x == 0xFFFFFFFFu) break;
-                    slot = (slot + 1) & idx.slot_mask;
                 }
             }
         }

@@ -26,11 +26,13 @@ constexpr int NEG = KP_NEG_INF;
 constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
 
-__device__ __forceinline__ int dpp_from_lower(int v, int fill) {  // lane i <- lane i-1 ; lane 0 <- fill
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+// One-lane wave shifts.  The lane without a source (0 resp. 63) reads 0 (bound_ctrl); every group-edge lane overrides
+// what it receives anyway, so no "old" operand (and no extra v_mov) is needed.
+__device__ __forceinline__ int dpp_from_lower(int v) {  // lane i <- lane i-1
+    return __builtin_amdgcn_mov_dpp(v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
-__device__ __forceinline__ int dpp_from_upper(int v, int fill) {  // lane i <- lane i+1 ; lane 63 <- fill
-    return __builtin_amdgcn_update_dpp(fill, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+__device__ __forceinline__ int dpp_from_upper(int v) {  // lane i <- lane i+1
+    return __builtin_amdgcn_mov_dpp(v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
 }
 
 struct Cell {
@@ -52,6 +54,10 @@ __device__ __forceinline__ void dp_cell(Cell &c, bool live, int r, int band_idx,
                                         unsigned diag_lo, unsigned diag_hi, int left_h, int left_e, unsigned left_hlo,
                                         unsigned left_hhi, unsigned left_elo, unsigned left_ehi, int up_h, int up_f,
                                         unsigned up_hlo, unsigned up_hhi, unsigned up_flo, unsigned up_fhi, Best &best) {
+    if (!live) {  // outside the task (row out of range, target outside the contig): reads as boundary for its neighbours
+        c.h = 0; c.e = NEG; c.f = NEG;
+        return;
+    }
     // E: gap in the query, arrives from the left
     const int e_open = left_h - OE, e_ext = left_e - EX;
     const bool eo = e_open >= e_ext;
@@ -73,14 +79,11 @@ __device__ __forceinline__ void dp_cell(Cell &c, bool live, int r, int band_idx,
     if (e > bestv) { bestv = e; p_lo = e_lo; p_hi = e_hi; }
     if (f > bestv) { bestv = f; p_lo = f_lo; p_hi = f_hi; }
     const int h = bestv > 0 ? bestv : 0;
-    // cells outside the task (row out of range, target outside the contig) read as boundary for their neighbours
-    c.h = live ? h : 0;
-    c.e = live ? e : NEG;
-    c.f = live ? f : NEG;
+    c.h = h; c.e = e; c.f = f;
     c.hp_lo = p_lo; c.hp_hi = p_hi;
     c.ep_lo = e_lo; c.ep_hi = e_hi;
     c.fp_lo = f_lo; c.fp_hi = f_hi;
-    if (live && h > best.score) { best.score = h; best.end_r = r; best.p_lo = p_lo; best.p_hi = p_hi; }
+    if (h > best.score) { best.score = h; best.end_r = r; best.p_lo = p_lo; best.p_hi = p_hi; }
 }
 
 // target code at window position x (relative to the band's lowest diagonal) for one task
@@ -101,6 +104,7 @@ __device__ __forceinline__ unsigned target_code(const uint32_t *__restrict__ asm
 template <int P>
 __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
+                                                   const uint32_t *__restrict__ order,
                                                    KpSwResult *__restrict__ results) {
     constexpr int G = 64 / P;
     constexpr int TW = (CH + P + 1 + 7) / 8 + 1;  // words of staged target codes per group
@@ -113,8 +117,9 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
     if (n_tasks > task_cap) n_tasks = task_cap;
 
     for (uint32_t quad = blockIdx.x; (uint64_t)quad * G < n_tasks; quad += gridDim.x) {
-        const uint32_t ti = quad * G + g;
-        const bool have = ti < n_tasks;
+        const uint32_t slot = quad * G + g;
+        const bool have = slot < n_tasks;
+        const uint32_t ti = have ? order[slot] : 0u;  // tasks of similar length share a wave (kp_chain.hip)
         KpTask tk;
         tk.asm_id = 0; tk.gs = 0; tk.contig = 0; tk.lo = 0;
         if (have) tk = tasks[ti];
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
                 // ---- systolic sequence feeds ----------------------------------------------------------------------
                 const unsigned q_in = nibble(qword, k);        // q[m] enters at lane 0
                 const unsigned t_in = nibble(tword, k);        // target code x = m + P enters at lane P-1
-                const unsigned q_shift = (unsigned)dpp_from_lower((int)qb, 4);
-                const unsigned t_shift = (unsigned)dpp_from_upper((int)t1, 5);
+                const unsigned q_shift = (unsigned)dpp_from_lower((int)qb);
+                const unsigned t_shift = (unsigned)dpp_from_upper((int)t1);
                 if (m > 0) {
                     t0 = t1;
                     t1 = (l == P - 1) ? t_in : t_shift;
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
                 const bool row_ok = (unsigned)r < (unsigned)qlen;
 
                 // ---- cell A (band index 2l): left neighbour = lane l-1's B of the previous step --------------------
-                int lh = dpp_from_lower(B.h, 0), le = dpp_from_lower(B.e, NEG);
-                unsigned lhlo = (unsigned)dpp_from_lower((int)B.hp_lo, 0), lhhi = (unsigned)dpp_from_lower((int)B.hp_hi, 0);
-                unsigned lelo = (unsigned)dpp_from_lower((int)B.ep_lo, 0), lehi = (unsigned)dpp_from_lower((int)B.ep_hi, 0);
+                int lh = dpp_from_lower(B.h), le = dpp_from_lower(B.e);
+                unsigned lhlo = (unsigned)dpp_from_lower((int)B.hp_lo), lhhi = (unsigned)dpp_from_lower((int)B.hp_hi);
+                unsigned lelo = (unsigned)dpp_from_lower((int)B.ep_lo), lehi = (unsigned)dpp_from_lower((int)B.ep_hi);
                 if (l == 0) { lh = 0; le = NEG; }
                 const int a_dh = A.h; const unsigned a_dlo = A.hp_lo, a_dhi = A.hp_hi;
                 const int b_dh = B.h; const unsigned b_dlo = B.hp_lo, b_dhi = B.hp_hi;
@@ -193,9 +198,9 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
                         B.h, B.f, B.hp_lo, B.hp_hi, B.fp_lo, B.fp_hi, bestA);
 
                 // ---- cell B (band index 2l+1): upper neighbour = lane l+1's A of this step -------------------------
-                int uh = dpp_from_upper(A.h, 0), uf = dpp_from_upper(A.f, NEG);
-                unsigned uhlo = (unsigned)dpp_from_upper((int)A.hp_lo, 0), uhhi = (unsigned)dpp_from_upper((int)A.hp_hi, 0);
-                unsigned uflo = (unsigned)dpp_from_upper((int)A.fp_lo, 0), ufhi = (unsigned)dpp_from_upper((int)A.fp_hi, 0);
+                int uh = dpp_from_upper(A.h), uf = dpp_from_upper(A.f);
+                unsigned uhlo = (unsigned)dpp_from_upper((int)A.hp_lo), uhhi = (unsigned)dpp_from_upper((int)A.hp_hi);
+                unsigned uflo = (unsigned)dpp_from_upper((int)A.fp_lo), ufhi = (unsigned)dpp_from_upper((int)A.fp_hi);
                 if (l == P - 1) { uh = 0; uf = NEG; }
                 dp_cell(B, row_ok && t1 != 5u, r, 2 * l + 1, qb, t1, b_dh, b_dlo, b_dhi, A.h, A.e, A.hp_lo, A.hp_hi,
                         A.ep_lo, A.ep_hi, uh, uf, uhlo, uhhi, uflo, ufhi, bestB);
@@ -233,13 +238,13 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
 }  // namespace
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, int width, KpSwResult *results, hipStream_t stream) {
+                  uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream) {
     // persistent-style grid: enough single-wave blocks to fill 256 CUs several times over; each strides over quads
     const dim3 grid(256 * 16), block(64);
     if (width == 32)
-        hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, results);
+        hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else if (width == 64)
-        hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, results);
+        hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else
-        hipLaunchKernelGGL(kp_sw_kernel<64>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, results);
+        hipLaunchKernelGGL(kp_sw_kernel<64>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
 }
