@@ -93,7 +93,8 @@ struct kp_batch {
     uint32_t anchor_cap = 0, task_cap = 0;
     DevBuf<uint64_t> d_anchors_a, d_anchors_b;
     DevBuf<int32_t> d_anchor_contig;
-    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, then [3] task counts
+    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [3] task counts, [n_asm] largest sub-slice demand
+    DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
@@ -438,7 +439,7 @@ void kp_batch_destroy(kp_batch *b) {
     if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
     b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
-    b->d_anchor_contig.release(); b->d_counts.release(); b->d_seg.release(); b->d_tasks.release();
+    b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
     b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_flag.release();
@@ -454,22 +455,27 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_anchors_b.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_anchor_contig.reserve(n_asm * b->anchor_cap));
-    KP_HIP_CHECK(ctx, b->d_counts.reserve(n_asm + 3));
+    KP_HIP_CHECK(ctx, b->d_counts.reserve(2 * n_asm + 3));
+    KP_HIP_CHECK(ctx, b->d_sub_counts.reserve(n_asm * KP_ANCHOR_SUBS));
     KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
     KP_HIP_CHECK(ctx, b->d_tasks.reserve(3 * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, b->d_results.reserve(3 * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, b->d_task_order.reserve(384 + 3 * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (n_asm + 3) * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + 3) * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, 384 * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
+    const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-    kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, ctx->stream);
+    kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, ctx->stream);
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
-    int rc = kp_sort_anchors(ctx, b->d_anchors_a.p, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->n_asm,
+    kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
+                             b->d_counts.p + n_asm + 3, ctx->stream);
+    int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
                              &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->stream);
     if (rc) return rc;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
-    kp_launch_chain(b->view, b->d_anchors_b.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
+    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
     kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + 384,
                          ctx->stream);
@@ -490,6 +496,7 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
     if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "no database loaded");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (b->anchor_cap == 0) b->anchor_cap = env_u32("KAPTIVE_AMD_ANCHOR_CAP", 1u << 17);
+    b->anchor_cap = std::max<uint32_t>((b->anchor_cap + KP_ANCHOR_SUBS - 1) / KP_ANCHOR_SUBS, 16u) * KP_ANCHOR_SUBS;
     if (b->task_cap == 0) {
         const uint64_t want = (uint64_t)std::max(b->n_asm, 1) * env_u32("KAPTIVE_AMD_TASKS_PER_ASM", 4096);
         b->task_cap = (uint32_t)std::min<uint64_t>(want, 1u << 28);
@@ -544,17 +551,18 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
     for (int attempt = 0;; ++attempt) {
-        b->h_counts.resize(n_asm + 3);
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (n_asm + 3) * sizeof(uint32_t),
+        b->h_counts.resize(2 * n_asm + 3);
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + 3) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->stream));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        uint32_t max_anchor = 0, max_task = 0;
-        for (size_t a = 0; a < n_asm; ++a) max_anchor = std::max(max_anchor, b->h_counts[a]);
+        uint32_t max_slice = 0, max_task = 0;
+        for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + 3 + a]);
         for (int c = 0; c < 3; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
-        if (max_anchor <= b->anchor_cap && max_task <= b->task_cap) break;
+        const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
+        if (max_slice <= sub_cap && max_task <= b->task_cap) break;
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
         // a region overflowed: counts kept counting, so they say how much room a clean rerun needs
-        if (max_anchor > b->anchor_cap) b->anchor_cap = (max_anchor + 1023u) & ~1023u;
+        if (max_slice > sub_cap) b->anchor_cap = ((max_slice + 15u) & ~15u) * KP_ANCHOR_SUBS;
         if (max_task > b->task_cap) b->task_cap = (max_task + 1023u) & ~1023u;
         b->stats[4] += 1;
         int rc = enqueue_align(ctx, b);
@@ -625,7 +633,7 @@ int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int
     const int64_t n = b->h_counts[(size_t)a];
     const int64_t m = std::min(n, cap);
     if (out && m > 0) {
-        if (hipMemcpy(out, b->d_anchors_b.p + (size_t)a * b->anchor_cap, (size_t)m * sizeof(uint64_t),
+        if (hipMemcpy(out, b->d_anchors_a.p + (size_t)a * b->anchor_cap, (size_t)m * sizeof(uint64_t),
                       hipMemcpyDeviceToHost) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "D2H anchors failed");
     }

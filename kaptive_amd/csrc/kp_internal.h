@@ -68,10 +68,14 @@ struct kp_ctx;
 int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
-// kp_scan.hip: stream the packed contigs, emit anchor keys into per-assembly regions of `anchors`
-//   (region a = anchors[a * cap .. a * cap + min(count[a], cap)); count[a] keeps counting past cap = overflow).
-void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *anchor_count,
-                    uint32_t cap, hipStream_t stream);
+// kp_scan.hip: stream the packed contigs, emit anchor keys.  Each assembly's region of sub_cap * KP_ANCHOR_SUBS keys is
+//   cut into KP_ANCHOR_SUBS sub-slices with their own counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past
+//   sub_cap = overflow); kp_launch_anchor_compact then packs each assembly's slices into one run.
+#define KP_ANCHOR_SUBS 64
+void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *sub_count,
+                    uint32_t sub_cap, hipStream_t stream);
+void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
+                              uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[3]*/, uint32_t task_cap,

@@ -36,17 +36,36 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
     return lo;
 }
 
+// Per-lane cache of where its 64 bases live: the assembly is fixed for a lane's unit, the contig is remembered from
+// the previous hit (hits cluster inside the typed locus), so most hits validate without any search.
+struct LaneWhere {
+    int a;          // assembly index, -1 = not looked up yet
+    int64_t word0;  // first batch word of that assembly
+    int32_t c_lo, c_hi;  // padded-space bounds [c_lo, c_hi) of the cached contig (empty = none)
+};
+
 // A seed at batch word `word`, base `i` matched the table: validate it against contig bounds and N runs, then append
-// one anchor per posting to the assembly's region.
+// one anchor per posting to sub-slice `sub` of the assembly's region.  Appends of one assembly are spread over
+// KP_ANCHOR_SUBS counters because all hits of an assembly happen in one short burst (the typed locus) and would
+// otherwise serialise on a single atomic word.
 __device__ __noinline__ void emit_seed(const KpBatchView &b, const KpSeedIndex &idx, uint32_t first_posting,
-                                       int64_t word, int i, uint64_t *anchors, uint32_t *anchor_count, uint32_t cap) {
-    const int a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
-    if (a < 0 || a >= b.n_asm) return;
-    const int32_t t = (int32_t)((word - b.asm_word_off[a]) * 16 + i);
-    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
-    const int c = upper_bound_i32(b.ctg_start + c0, nc, t) - 1;
-    if (c < 0) return;
-    if (t + KP_K > b.ctg_start[c0 + c] + b.ctg_len[c0 + c]) return;  // k-mer runs past the contig (or sits in padding)
+                                       int64_t word, int i, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap,
+                                       uint32_t sub, LaneWhere &w) {
+    if (w.a < 0) {
+        w.a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
+        if (w.a < 0 || w.a >= b.n_asm) { w.a = -1; return; }
+        w.word0 = b.asm_word_off[w.a];
+    }
+    const int a = w.a;
+    const int32_t t = (int32_t)((word - w.word0) * 16 + i);
+    if (t < w.c_lo || t + KP_K > w.c_hi) {
+        const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+        const int c = upper_bound_i32(b.ctg_start + c0, nc, t) - 1;
+        if (c < 0) return;
+        w.c_lo = b.ctg_start[c0 + c];
+        w.c_hi = w.c_lo + b.ctg_len[c0 + c];
+        if (t + KP_K > w.c_hi) return;  // k-mer runs past the contig (or sits in padding)
+    }
     const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
     if (nr > 0) {  // first run whose end is > t; it overlaps the k-mer iff it starts before t + K
         int lo = 0, hi = nr;
@@ -57,15 +76,16 @@ __device__ __noinline__ void emit_seed(const KpBatchView &b, const KpSeedIndex &
         if (lo < nr && b.n_runs[2 * (r0 + lo)] < t + KP_K) return;
     }
     const uint32_t cnt = (uint32_t)idx.postings[first_posting];
-    const uint32_t base = atomicAdd(&anchor_count[a], cnt);
-    uint64_t *dst = anchors + (size_t)a * cap;
+    const size_t slice = (size_t)a * KP_ANCHOR_SUBS + sub;
+    const uint32_t base = atomicAdd(&sub_count[slice], cnt);
+    uint64_t *dst = anchors + slice * sub_cap;
     const uint64_t shift = (uint64_t)(uint32_t)t << 16;
     for (uint32_t j = 0; j < cnt; ++j)
-        if (base + j < cap) dst[base + j] = idx.postings[first_posting + 1 + j] + shift;
+        if (base + j < sub_cap) dst[base + j] = idx.postings[first_posting + 1 + j] + shift;
 }
 
 __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ anchors,
-                                                       uint32_t *__restrict__ anchor_count, uint32_t cap) {
+                                                       uint32_t *__restrict__ sub_count, uint32_t sub_cap) {
     const int64_t n_units = b.total_words >> 2;  // 16-byte units; every assembly is a whole number of them
     const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;  // whole waves iterate together (shuffle below)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -74,6 +94,8 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_iter_units; u += stride) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (u < n_units) v = vec[u];
+        LaneWhere where{-1, 0, 0, 0};
+        const uint32_t sub = (uint32_t)u & (KP_ANCHOR_SUBS - 1);
         uint32_t next = __shfl_down(v.x, 1);
         if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
         const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
                     for (;;) {
                         const uint2 e = idx.slots[slot];
                         if (e.x == kmer[j]) {
-                            emit_seed(b, idx, e.y, (u << 2) + k, bit[j] >> 1, anchors, anchor_count, cap);
+                            emit_seed(b, idx, e.y, (u << 2) + k, bit[j] >> 1, anchors, sub_count, sub_cap, sub, where);
                             break;
                         }
                         if (e.x == 0xFFFFFFFFu) break;
@@ -117,7 +139,44 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
     }
 }
 
+// sub-slices of each assembly -> one contiguous run per assembly (input of the sort); count[a] = anchors stored,
+// need[a] = the largest demand of any of its sub-slices (overflow if > sub_cap)
+__global__ __launch_bounds__(256) void kp_anchor_compact_kernel(const uint64_t *__restrict__ sliced,
+                                                                const uint32_t *__restrict__ sub_count, uint32_t sub_cap,
+                                                                uint64_t *__restrict__ out, uint32_t *__restrict__ count,
+                                                                uint32_t *__restrict__ need) {
+    __shared__ uint32_t s_off[KP_ANCHOR_SUBS + 1];
+    const int a = blockIdx.x;
+    const uint32_t *sc = sub_count + (size_t)a * KP_ANCHOR_SUBS;
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0, mx = 0;
+        for (int k = 0; k < KP_ANCHOR_SUBS; ++k) {
+            s_off[k] = acc;
+            acc += sc[k] < sub_cap ? sc[k] : sub_cap;
+            mx = sc[k] > mx ? sc[k] : mx;
+        }
+        s_off[KP_ANCHOR_SUBS] = acc;
+        count[a] = acc;
+        need[a] = mx;
+    }
+    __syncthreads();
+    const size_t cap = (size_t)sub_cap * KP_ANCHOR_SUBS;
+    for (int k = 0; k < KP_ANCHOR_SUBS; ++k) {
+        const uint32_t n = s_off[k + 1] - s_off[k];
+        const uint64_t *src = sliced + ((size_t)a * KP_ANCHOR_SUBS + k) * sub_cap;
+        uint64_t *dst = out + (size_t)a * cap + s_off[k];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
 }  // namespace
+
+void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
+                              uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_anchor_compact_kernel, dim3(b.n_asm), dim3(256), 0, stream, sliced, sub_count, sub_cap, out,
+                       count, need);
+}
 
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *anchor_count,
                     uint32_t cap, hipStream_t stream) {
