@@ -132,6 +132,8 @@ typedef struct kp_asm_summary {
     int32_t best_locus, n_expected, n_missing;
     int32_t overflow; /* bit0 kept list, bit1 pieces, bit2 locus wider than the mask, bit3 protein buffer */
     uint64_t missing_mask[KP_MAX_LOCUS_GENES / 64]; /* bit j: gene locus_gene_off + j not found inside the locus */
+    float ident_sum;   /* float32 sum of the identities of NORMAL genes, associated exactly as np.add.reduce does */
+    int32_t n_normal;  /* how many; mean identity = float32(float64(ident_sum) / n_normal) (core.py:395-396) */
 } kp_asm_summary;
 
 typedef struct kp_typing_params {

@@ -806,6 +806,18 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         if (rc) return rc;
     }
     if (kept_stride < 1 || piece_stride < 1) return kp_fail(ctx, KP_EINVAL, "strides must be positive");
+    // identity sums use numpy's float32 association; a few dozen adds per assembly, done here on the copied rows
+    auto ident_sums = [&]() {
+        std::vector<float> vals;
+        for (size_t a = 0; a < n_asm; ++a) {
+            vals.clear();
+            const KpKept *k = kept + a * (size_t)kept_stride;
+            for (int i = 0; i < summaries[a].n_kept; ++i)
+                if (!(k[i].flags & KP_F_SPURIOUS) && k[i].state == KP_STATE_NORMAL) vals.push_back(k[i].pident);
+            summaries[a].n_normal = (int32_t)vals.size();
+            summaries[a].ident_sum = kp_np_sum_f32(vals.data(), (int)vals.size());
+        }
+    };
     if (n_asm && kept_stride == b->kept_cap && piece_stride == b->piece_cap) {  // same layout: two bulk copies
         std::memcpy(summaries, sums.data(), n_asm * sizeof(KpAsmSummary));
         KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, b->d_kept.p, n_asm * (size_t)b->kept_cap * sizeof(KpKept),
@@ -813,6 +825,7 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, b->d_pieces.p, n_asm * (size_t)b->piece_cap * sizeof(KpPiece),
                                          hipMemcpyDeviceToHost, ctx->stream));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ident_sums();
         return KP_OK;
     }
     for (size_t a = 0; a < n_asm; ++a) {
@@ -827,6 +840,7 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
                                              (size_t)sums[a].n_pieces * sizeof(KpPiece), hipMemcpyDeviceToHost, ctx->stream));
     }
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ident_sums();
     return KP_OK;
 }
 

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         z.n_hits = n; z.n_kept = 0; z.n_final = 0; z.n_pieces = 0; z.best_locus = best_locus;
         z.n_expected = 0; z.n_missing = 0; z.overflow = 0;
         for (int w = 0; w < KP_MAX_LOCUS_GENES / 64; ++w) z.missing_mask[w] = 0;
+        z.ident_sum = 0.f; z.n_normal = 0;
         *sum = z;
         s_fail = 0;
     }

@@ -276,6 +276,33 @@ KP_HD void kp_fill_codon_table(uint8_t *t /*125*/) {  // seq.py:418-499, amino a
             for (int c = 0; c < 4; ++c) t[tcag[a] * 25 + tcag[b] * 5 + tcag[c]] = (uint8_t)aa[a * 16 + b * 4 + c];
 }
 
+// ---- float32 sum with numpy's association (np.add.reduce on a contiguous float32 array) -----------------------------------
+// np.mean(float32 array) = float32(float64(reduce) / n) where reduce is numpy's blocked pairwise summation over the
+// whole array (checked against np.add.reduce for every length class in tests/test_reduce_core_cpu.py): < 8 items sequential from 0, <= 128 items eight running sums combined as a tree, else split in two
+// (multiple of 8) halves.  Reproduced here so that the batched mean identity has the reference's bits (core.py:395-396).
+KP_HD float kp_np_pairwise_f32(const float *a, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return kp_np_pairwise_f32(a, n2) + kp_np_pairwise_f32(a + n2, n - n2);
+}
+
+KP_HD float kp_np_sum_f32(const float *a, int n) { return n <= 0 ? 0.f : kp_np_pairwise_f32(a, n); }
+
 // ---- gene states (core.py:363-394; alignment.py:774-809) ------------------------------------------------------------------
 KP_HD void kp_gene_state(KpKept *k, int gene_len, int contig_len, const KpTypingParams &prm) {
     const int total = k->dp[1] + k->dp[2] + k->dp[3];

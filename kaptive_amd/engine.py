@@ -77,29 +77,26 @@ class Engine:
             typer.partial_edge_tolerance,
         )
 
-    def type_batch(self, typer, batch, ids: Sequence[str], genomes: Sequence[GenomeAssembly] | None = None) -> list:
-        """Whole typing of a resident batch: alignment, device reduction, the three numpy float steps, result objects.
-        ``genomes`` (optional) lets the results carry the extracted locus / gene / protein sequences."""
+    def type_batch(self, typer, batch, ids: Sequence[str], genomes: Sequence[GenomeAssembly] | None = None,
+                   aligned: bool = False):
+        """Whole typing of a resident batch: alignment and reduction on the device, the numpy float steps, and the
+        per-assembly decisions as columns.  Returns a ``BatchTyping``; ``.results()`` / ``.rows()`` materialise objects
+        and TSV lines.  ``genomes`` (optional) lets the result objects carry the extracted sequences; ``aligned`` says
+        that ``batch.align_async()`` has already been enqueued."""
         from kaptive_amd.serotyping import batch as B
 
-        batch.align_async()
+        if not aligned:
+            batch.align_async()
         scores, counts = batch.score(typer.min_gene_coverage)
         best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
         batch.reduce_async(best, self.typing_params(typer))
         sums, kept, pieces = batch.typing()
-        out = []
-        for a in range(batch.n_asm):
-            s = sums[a]
-            out.append(
-                B.assemble(typer, ids[a], s, kept[a, : s["n_kept"]], pieces[a, : s["n_pieces"]], scores[a, best[a]],
-                           genome=None if genomes is None else genomes[a])
-            )  # fmt: skip
-        return out
+        return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes)
 
     def type_many(self, typer, genomes: Sequence[GenomeAssembly]) -> list:
         """One device submission for all genomes: alignment and reduction both run on the GPU."""
         batch = self.ctx.batch([g.packed() for g in genomes])
         try:
-            return self.type_batch(typer, batch, [g.id for g in genomes], genomes)
+            return self.type_batch(typer, batch, [g.id for g in genomes], genomes).results()
         finally:
             batch.close()

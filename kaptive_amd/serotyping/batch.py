@@ -31,9 +31,10 @@ KEPT_DTYPE = np.dtype(
 PIECE_DTYPE = np.dtype([("contig", "<i4"), ("start", "<i4"), ("end", "<i4"), ("strand", "<i4"), ("mean_pos", "<f8")])
 SUMMARY_DTYPE = np.dtype(
     [("n_hits", "<i4"), ("n_kept", "<i4"), ("n_final", "<i4"), ("n_pieces", "<i4"), ("best_locus", "<i4"),
-     ("n_expected", "<i4"), ("n_missing", "<i4"), ("overflow", "<i4"), ("missing_mask", "<u8", MAX_LOCUS_GENES // 64)]
+     ("n_expected", "<i4"), ("n_missing", "<i4"), ("overflow", "<i4"), ("missing_mask", "<u8", MAX_LOCUS_GENES // 64),
+     ("ident_sum", "<f4"), ("n_normal", "<i4")]
 )  # fmt: skip
-assert KEPT_DTYPE.itemsize == 84 and PIECE_DTYPE.itemsize == 24 and SUMMARY_DTYPE.itemsize == 64
+assert KEPT_DTYPE.itemsize == 84 and PIECE_DTYPE.itemsize == 24 and SUMMARY_DTYPE.itemsize == 72
 
 
 def choose_best_loci(locus_scores: np.ndarray, locus_counts: np.ndarray, expected_per_locus: np.ndarray):
@@ -88,3 +89,103 @@ def assemble(typer, genome_id: str, summary: np.void, kept: np.ndarray, pieces: 
         genome_id, best, best_score, completeness, hits, k["state"].copy(), k["pident"].copy(), locus_pieces, missing,
         locus_seqs, gene_seqs, prot_seqs,
     )  # fmt: skip
+
+
+class BatchTyping:
+    """Typing results of a whole batch as columns (one row per assembly), finished with array operations.
+
+    Everything ``Serotyper.finish`` decides per genome (core.py:343-349, 395-459; models.py:538-558) is computed here
+    for all assemblies at once; ``result(i)`` builds the full ``SerotypingResult`` of one assembly on demand and
+    ``rows()`` formats the TSV lines.  Scalars per assembly:
+
+    best_locus, best_score, completeness, percent_identity, percent_coverage, length_discrepancy, typeable, problems,
+    phenotype, n_pieces, n_hits (hits kept in the result).
+    """
+
+    def __init__(self, typer, ids, sums, kept, pieces, scores, best, genomes=None) -> None:
+        self.typer, self.ids, self.genomes = typer, list(ids), genomes
+        self.sums, self.kept, self.pieces = sums, kept, pieces
+        db = typer._db
+        n = len(sums)
+        self.best_locus = np.asarray(best, np.int32)
+        self.best_score = scores[np.arange(n), self.best_locus] if n else np.zeros(0)
+        n_kept, n_pieces = sums["n_kept"], sums["n_pieces"]
+        valid = np.arange(kept.shape[1])[None, :] < n_kept[:, None]
+        flags, state = kept["flags"], kept["state"]
+        alive = valid & ((flags & F_SPURIOUS) == 0)
+        inside, expected, extra = (flags & F_INSIDE) != 0, (flags & F_EXPECTED) != 0, (flags & F_EXTRA) != 0
+        self.alive = alive
+        self.n_hits = alive.sum(axis=1)
+        self.n_pieces = n_pieces
+        # completeness of the reconstructed locus (core.py:299-301)
+        n_exp, n_missing = sums["n_expected"], sums["n_missing"]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self.completeness = np.where(n_exp > 0, 1.0 - (n_missing / np.maximum(n_exp, 1)), 1.0)
+        # locus coverage and length discrepancy (core.py:343-349)
+        pvalid = np.arange(pieces.shape[1])[None, :] < n_pieces[:, None]
+        assem_len = np.where(pvalid, pieces["end"].astype(np.int64) - pieces["start"], 0).sum(axis=1)
+        ref_len = db.loci.lengths[self.best_locus].astype(np.int64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cov = np.minimum(100.0, (assem_len / ref_len) * 100.0)
+        self.percent_coverage = np.where(ref_len > 0, cov, 0.0)
+        self.length_discrepancy = np.where(n_pieces == 1, (assem_len - ref_len).astype(np.float64), np.nan)
+        # mean identity over NORMAL genes (core.py:395-396): the float32 sum arrives with numpy's own association
+        # (kp_np_sum_f32); np.mean then divides by the count in float64 and rounds to float32
+        counts = sums["n_normal"]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean32 = (sums["ident_sum"].astype(np.float64) / counts).astype(np.float32)
+        self.percent_identity = np.where(counts > 0, mean32, np.float32(0)).astype(np.float64)
+        # confidence (core.py:445-459)
+        unexpected = alive & inside & ~expected & ~extra & (state != 2)
+        novel_inside = (alive & inside & (state == 3)).any(axis=1)
+        self.typeable = (
+            (self.completeness >= typer.min_completeness)
+            & (unexpected.sum(axis=1) <= typer.max_other_genes)
+            & (typer.allow_below_threshold | ~novel_inside)
+        )
+        # problem flags (models.py:538-558)
+        p = (n_pieces > 1).astype(np.int32)
+        p |= 2 * (alive & inside & ~expected & ~extra).any(axis=1)
+        p |= 4 * ((self.completeness < 1.0) | (alive & ~inside & expected).any(axis=1))
+        p |= 8 * novel_inside
+        p |= 16 * (alive & inside & ((state == 2) | (state == 1))).any(axis=1)
+        self.problems = p
+        self.phenotype = self._phenotypes(db, alive, state)
+
+    def _phenotypes(self, db, alive, state) -> list:
+        """Phenotype rules for the whole batch (core.py:399-442); most databases have none."""
+        names = [db.serotypes[b] for b in self.best_locus]
+        rules = db.phenotypes
+        if len(rules) == 0 or len(names) == 0:
+            return names
+        applicable = rules.locus_masks[:, self.best_locus].any(axis=0)  # assemblies whose best locus has any rule
+        for a in np.flatnonzero(applicable):
+            k = self.kept[a][alive[a]]
+            hits = _HitsView(k["gene"])
+            names[a] = self.typer._phenotype(int(self.best_locus[a]), hits, k["state"])
+        return names
+
+    def __len__(self) -> int:
+        return len(self.sums)
+
+    def result(self, i: int) -> SerotypingResult:
+        s = self.sums[i]
+        return assemble(
+            self.typer, self.ids[i], s, self.kept[i, : s["n_kept"]], self.pieces[i, : s["n_pieces"]],
+            self.best_score[i], genome=None if self.genomes is None else self.genomes[i],
+        )  # fmt: skip
+
+    def results(self) -> list:
+        return [self.result(i) for i in range(len(self))]
+
+    def rows(self) -> list:
+        from kaptive_amd.serotyping.io import KaptiveRow
+
+        return [bytes(KaptiveRow.from_result(self.result(i))) for i in range(len(self))]
+
+
+class _HitsView:
+    """The one attribute ``Serotyper._phenotype`` reads off a GeneHits."""
+
+    def __init__(self, gene_indices) -> None:
+        self.gene_indices = gene_indices

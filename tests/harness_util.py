@@ -95,8 +95,17 @@ def reduce(hits, hdb, prm, best, pa, kept_cap=2048, piece_cap=64, prot_cap=1 << 
     return kept[:nk], pieces[: int(summary["n_pieces"][0])], summary[0], prot
 
 
-def states(kept, hdb, prm, ctg_len, dp8):
+def states(kept, hdb, prm, ctg_len, dp8, summary=None):
     cl = np.ascontiguousarray(ctg_len, np.int32)
     dp = np.ascontiguousarray(dp8, np.int32)
-    lib().kph_states(_p(kept), C.c_int(len(kept)), C.byref(hdb.struct), C.byref(prm), _p(cl), _p(dp))
+    s = np.zeros(1, SUMMARY_DTYPE) if summary is None else np.array([summary], SUMMARY_DTYPE)
+    lib().kph_states(_p(kept), C.c_int(len(kept)), C.byref(hdb.struct), C.byref(prm), _p(cl), _p(dp), _p(s))
+    if summary is not None:
+        summary["ident_sum"], summary["n_normal"] = s[0]["ident_sum"], s[0]["n_normal"]
     return kept
+
+
+def np_sum_f32(a: np.ndarray) -> np.float32:
+    a = np.ascontiguousarray(a, np.float32)
+    lib().kph_np_sum_f32.restype = C.c_float
+    return np.float32(lib().kph_np_sum_f32(_p(a), C.c_int(len(a))))

@@ -88,12 +88,18 @@ int kph_reduce(const kp_hit *hits, int n, const KpTypingDb *db, const KpTypingPa
 }
 
 void kph_states(KpKept *kept, int nk, const KpTypingDb *db, const KpTypingParams *prm, const int32_t *ctg_len,
-                const int32_t *dp8) {
+                const int32_t *dp8, KpAsmSummary *sum) {
+    std::vector<float> vals;
     for (int i = 0; i < nk; ++i) {
         std::memcpy(kept[i].dp, dp8 + 8 * (size_t)i, 8 * sizeof(int32_t));
         kp_gene_state(&kept[i], db->gene_len[kept[i].gene], ctg_len[kept[i].contig], *prm);
+        if (!(kept[i].flags & KP_F_SPURIOUS) && kept[i].state == KP_STATE_NORMAL) vals.push_back(kept[i].pident);
     }
+    sum->n_normal = (int32_t)vals.size();
+    sum->ident_sum = kp_np_sum_f32(vals.data(), (int)vals.size());
 }
+
+float kph_np_sum_f32(const float *a, int n) { return kp_np_sum_f32(a, n); }
 
 int kph_sizes(int *out) {
     out[0] = (int)sizeof(kp_hit); out[1] = (int)sizeof(KpKept); out[2] = (int)sizeof(KpPiece);

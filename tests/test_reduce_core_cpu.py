@@ -54,3 +54,67 @@ def test_core_reduction_matches_reference(name, oracle):
     bare = B.assemble(typer, genome.id, summary, kept, pieces, scores[best[0]], genome=None)
     row = bytes(KaptiveRow.from_result(bare)).replace(KAPTIVE_COMPAT_VERSION.encode(), scalars["kaptive_version"].encode())
     assert row == bytes(exp["kaptive_row"])
+
+
+def _batch_from_cases(names, oracle):
+    """Stack several golden cases of one database into the arrays the device returns for a batch."""
+    key0 = load_case(names[0])[0]
+    db = load_db(key0)
+    typer = Serotyper(db, aligner=lambda g: None)
+    hdb, prm = H.HarnessDb(db), H.params(db, typer)
+    rows, genomes, exps = [], [], []
+    for name in names:
+        key, genome, hits, exp, scalars, kwargs = load_case(name)
+        assert key == key0 and not kwargs
+        scores, counts = H.locus_scores(hits, hdb, typer.min_gene_coverage)
+        best, _, _ = B.choose_best_loci(scores[None, :], counts[None, :], typer._expected_genes_per_locus)
+        kept, pieces, summary, prot = H.reduce(hits, hdb, prm, best[0], genome.packed())
+        dp = oracle.protein_align(prot, kept["prot_off"], kept["prot_len"], db.translations.seqs,
+                                  db.translations.offsets[kept["gene"]], db.translations.lengths[kept["gene"]])
+        kept = H.states(kept, hdb, prm, genome.contigs.lengths, dp, summary)
+        rows.append((summary, kept, pieces, scores, best[0]))
+        genomes.append(genome)
+        exps.append((exp, scalars))
+    n, kc, pc = len(rows), max(len(r[1]) for r in rows) + 3, max(len(r[2]) for r in rows) + 2
+    sums = np.zeros(n, B.SUMMARY_DTYPE)
+    kept = np.zeros((n, kc), B.KEPT_DTYPE)
+    kept["pident"] = 55.5  # garbage beyond n_kept must not leak into any column
+    pieces = np.zeros((n, pc), B.PIECE_DTYPE)
+    scores = np.zeros((n, len(db.loci)))
+    best = np.zeros(n, np.int32)
+    for i, (s, k, p, sc, b) in enumerate(rows):
+        sums[i], scores[i], best[i] = s, sc, b
+        kept[i, : len(k)] = k
+        pieces[i, : len(p)] = p
+    return typer, genomes, exps, B.BatchTyping(typer, [g.id for g in genomes], sums, kept, pieces, scores, best, genomes)
+
+
+@pytest.mark.parametrize("key", ["k", "o"])
+def test_batch_columns_match_reference(key, oracle):
+    names = [n for n in case_names() if not n.startswith("k_divergent_") and load_case(n)[0] == key]
+    typer, genomes, exps, bt = _batch_from_cases(names, oracle)
+    from kaptive_amd.serotyping.models import SerotypingProblem
+
+    for i, (exp, scalars) in enumerate(exps):
+        res = bt.result(i)
+        check_result_against_golden(res, exp, scalars)
+        # the vectorised columns agree with the per-assembly objects bit for bit
+        assert bt.typeable[i] == res.typeable and bt.phenotype[i] == res.phenotype, names[i]
+        assert SerotypingProblem(int(bt.problems[i])) == res.problems, names[i]
+        for col, val in (("percent_identity", res.percent_identity), ("percent_coverage", res.percent_coverage),
+                         ("completeness", res.best_locus_completeness), ("length_discrepancy", res.length_discrepancy),
+                         ("best_score", res.best_locus_score)):  # fmt: skip
+            assert np.float64(getattr(bt, col)[i]).tobytes() == np.float64(val).tobytes(), (names[i], col)
+        assert bt.n_hits[i] == len(res.gene_hits) and bt.n_pieces[i] == len(res.locus_pieces)
+
+
+def test_float32_sum_has_numpys_association():
+    """kp_np_sum_f32 (used for the batched mean identity) must reproduce np.add.reduce / np.mean on float32 arrays of
+    every length class of numpy's pairwise summation (< 8, <= 128, split)."""
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 150)) + [255, 256, 257, 1000, 2047]:
+        vals = (rng.random(n) * 100).astype(np.float32)
+        got = H.np_sum_f32(vals)
+        assert got.tobytes() == np.float32(np.add.reduce(vals) if n else 0).tobytes(), n
+        if n:
+            assert np.float32(np.float64(got) / n).tobytes() == np.float32(np.mean(vals)).tobytes(), n
