@@ -10,6 +10,8 @@
 
 namespace {
 
+constexpr int WALK = 8;
+
 __global__ __launch_bounds__(256) void kp_anchor_contig_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
                                                                const uint32_t *__restrict__ count, uint32_t cap,
                                                                int32_t *__restrict__ contig) {
@@ -65,18 +67,31 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
         uint32_t d0 = KP_KEY_DIAG(k[i]), dprev = d0, q = KP_KEY_QPOS(k[i]);
         uint32_t qmin = q, qmax = q;
         int cnt = 1;
-        for (uint32_t j = i + 1; j < n; ++j) {
-            const uint32_t d = KP_KEY_DIAG(k[j]);
-            if (KP_KEY_GS(k[j]) != gs || c[j] != ctg || d - dprev > KP_DIAG_GAP) break;
-            q = KP_KEY_QPOS(k[j]);
-            if (d - d0 > KP_MAX_SPREAD) {  // soft cut: close the cluster, open the next one at j
-                flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
-                d0 = d; qmin = qmax = q; cnt = 0;
+        bool open = true;
+        for (uint32_t j0 = i + 1; j0 < n && open; j0 += WALK) {  // fetch WALK anchors at a time: the walk is latency-bound
+            uint64_t kk[WALK];
+            int32_t cc[WALK];
+#pragma unroll
+            for (int u = 0; u < WALK; ++u) {
+                const uint32_t j = j0 + u < n ? j0 + u : n - 1;
+                kk[u] = k[j];
+                cc[u] = c[j];
             }
-            dprev = d;
-            cnt++;
-            qmin = min(qmin, q);
-            qmax = max(qmax, q);
+#pragma unroll
+            for (int u = 0; u < WALK; ++u) {
+                if (!open || j0 + u >= n) { open = open && j0 + u < n; continue; }
+                const uint32_t d = KP_KEY_DIAG(kk[u]);
+                if (KP_KEY_GS(kk[u]) != gs || cc[u] != ctg || d - dprev > KP_DIAG_GAP) { open = false; continue; }
+                q = KP_KEY_QPOS(kk[u]);
+                if (d - d0 > KP_MAX_SPREAD) {  // soft cut: close the cluster, open the next one here
+                    flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
+                    d0 = d; qmin = qmax = q; cnt = 0;
+                }
+                dprev = d;
+                cnt++;
+                qmin = min(qmin, q);
+                qmax = max(qmax, q);
+            }
         }
         flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
     }

@@ -12,17 +12,17 @@
 // other parity (left: b-1, up: b+1) or their own previous value (diagonal).  Instead of storing traceback matrices,
 // every state carries the statistics of the path it came from (same tie rules).
 //
-// Two paths, same arithmetic:
-//   * register path (band <= 64 diagonals and both proteins <= 2048 residues -- every full-length gene): lane b owns
-//     diagonal b; state lives in registers; the two neighbour exchanges per step are DPP wave shifts; both sequences
-//     and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the time loop.
-//   * general path (wider bands: truncated or partial genes): band state in LDS, or in global scratch when wider than
-//     LDS_CELLS, one barrier per time step.
+// Two kernels, same arithmetic:
+//   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 2048 residues -- every full-length gene): lane b
+//     owns diagonal b; state lives in registers; the two neighbour exchanges per step are DPP wave shifts; both
+//     sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the time loop.
+//   * kp_protein_wide_kernel (wider bands: truncated or partial genes): band state in LDS (up to LDS_CELLS entries, else
+//     global scratch), one barrier per time step, and only the band entries whose cell exists at that step are visited.
 #include "kp_internal.h"
 
 namespace {
 
-constexpr int LDS_CELLS = 160;  // band cells held in LDS by the general path; wider bands use global scratch
+constexpr int LDS_CELLS = 1024;  // band cells held in LDS by the wide-band kernel; wider bands use global scratch
 constexpr int NF = 12;          // ints per band cell: M,D,I + 3 payload words each
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
@@ -116,12 +116,17 @@ __device__ __forceinline__ Result protein_pair_general(BandPtr st, int cap, cons
     const int t_last = 2 * len1 + 2 * k;
     for (int tm = 2; tm <= t_last; ++tm) {
         __syncthreads();
-        for (int b = (tm & 1) + 2 * lane; b < nb; b += 128) {
+        // band entries whose cell (i, j) lies inside the matrix at this time step; entries outside keep what they hold
+        // (the initial boundary, or a cell no later cell reads), so nothing else needs to be touched
+        int b_lo = max(0, max(tm - 2 * len1, 2 * k + 2 - tm));
+        const int b_hi = min(nb - 1, min(tm - 2, 2 * k + 2 * len2 - tm));
+        b_lo += (b_lo ^ tm) & 1;
+        for (int b = b_lo + 2 * lane; b <= b_hi; b += 128) {
             const int i2 = tm - b;  // = 2i
             const int i = i2 >> 1, j = i + b - k;
             int m = 0, dv = NEGP, iv = NEGP;
             Pay pm{0, 0, 0}, pd{0, 0, 0}, pi{0, 0, 0};
-            if (i2 >= 2 && i <= len1 && j >= 1 && j <= len2) {
+            {
                 int um = 0, ud = NEGP; Pay upm{0, 0, 0}, upd{0, 0, 0};
                 if (b + 1 < nb) {
                     um = F(0, b + 1); ud = F(1, b + 1);
@@ -168,14 +173,39 @@ __device__ __forceinline__ Result protein_pair_general(BandPtr st, int cap, cons
     return r;
 }
 
+__device__ __forceinline__ bool fits_registers(int len1, int len2, int nb) {
+    return nb <= 64 && len1 <= REG_MAX_LEN && len2 <= REG_MAX_LEN;
+}
+
+__device__ __forceinline__ void store_result(Result r, int lane, int32_t *__restrict__ o) {
+    // wave reduction: max score, then smallest i, then smallest j
+    int best = r.best, bi = r.bi, bj = r.bj;
+    Pay bp = r.bp;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int b2 = __shfl_xor(best, off), i2 = __shfl_xor(bi, off), j2 = __shfl_xor(bj, off);
+        const unsigned a2 = __shfl_xor(bp.a, off), g2 = __shfl_xor(bp.g, off), s2v = __shfl_xor(bp.s, off);
+        // lanes that never saw a positive cell carry best = 0 and must lose against any positive score
+        const bool take = b2 > best || (b2 == best && b2 > 0 && (i2 < bi || (i2 == bi && j2 < bj)));
+        if (take) { best = b2; bi = i2; bj = j2; bp = Pay{a2, g2, s2v}; }
+    }
+    if (lane == 0) {
+        if (best > 0) {
+            o[0] = best; o[1] = (int)(bp.a >> 16); o[2] = (int)(bp.a & 0xFFFFu); o[3] = (int)bp.g;
+            o[4] = (int)(bp.s >> 16); o[5] = bi; o[6] = (int)(bp.s & 0xFFFFu); o[7] = bj;
+        } else {
+            for (int x = 0; x < 8; ++x) o[x] = 0;
+        }
+    }
+}
+
+// pairs whose band fits one diagonal per lane (and the empty ones)
 __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                         const int32_t *__restrict__ q_len,
                                                         const uint8_t *__restrict__ t, const int32_t *__restrict__ t_off,
                                                         const int32_t *__restrict__ t_len, int32_t n_host,
                                                         const int32_t *__restrict__ n_dev,
-                                                        const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
-                                                        int32_t *__restrict__ scratch, size_t scratch_ints_per_block) {
-    __shared__ int s_band[LDS_CELLS * NF];
+                                                        const int8_t *__restrict__ blosum, int32_t *__restrict__ out8) {
     __shared__ uint16_t s_seq1[REG_MAX_LEN], s_seq2[REG_MAX_LEN];
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
@@ -198,44 +228,44 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
             if (lane < 8) out8[8 * (size_t)p + lane] = 0;
             continue;
         }
+        int d = len1 - len2;
+        if (d < 0) d = -d;
+        const int k = max(KP_PROT_K, d + 1);
+        if (!fits_registers(len1, len2, 2 * k + 1)) continue;  // kp_protein_wide_kernel's
         const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+        __syncthreads();
+        for (int x = lane; x < len1; x += 64) s_seq1[x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
+        for (int x = lane; x < len2; x += 64) s_seq2[x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
+        __syncthreads();
+        store_result(protein_pair_registers(s_seq1, s_seq2, s_mat, len1, len2, k, lane), lane, out8 + 8 * (size_t)p);
+    }
+}
+
+// the rest: wide bands (truncated / partial genes) and very long proteins
+__global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
+                                                             const int32_t *__restrict__ q_len,
+                                                             const uint8_t *__restrict__ t, const int32_t *__restrict__ t_off,
+                                                             const int32_t *__restrict__ t_len, int32_t n_host,
+                                                             const int32_t *__restrict__ n_dev,
+                                                             const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
+                                                             int32_t *__restrict__ scratch, size_t scratch_ints_per_block) {
+    __shared__ int s_band[LDS_CELLS * NF];
+    const int lane = threadIdx.x;
+    const int n = n_dev ? *n_dev : n_host;
+    for (int p = blockIdx.x; p < n; p += gridDim.x) {
+        const int len1 = q_len[p], len2 = t_len[p];
+        if (len1 == 0 || len2 == 0) continue;
         int d = len1 - len2;
         if (d < 0) d = -d;
         const int k = max(KP_PROT_K, d + 1);
         const int nb = 2 * k + 1;
+        if (fits_registers(len1, len2, nb)) continue;
+        const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
         Result r;
-        if (nb <= 64 && len1 <= REG_MAX_LEN && len2 <= REG_MAX_LEN) {
-            __syncthreads();
-            for (int x = lane; x < len1; x += 64) s_seq1[x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
-            for (int x = lane; x < len2; x += 64) s_seq2[x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
-            __syncthreads();
-            r = protein_pair_registers(s_seq1, s_seq2, s_mat, len1, len2, k, lane);
-        } else if (nb <= LDS_CELLS) {
-            r = protein_pair_general(s_band, LDS_CELLS, s1, s2, len1, len2, k, blosum, lane);
-        } else {
-            r = protein_pair_general(scratch + (size_t)blockIdx.x * scratch_ints_per_block, nb, s1, s2, len1, len2, k,
-                                     blosum, lane);
-        }
-        // wave reduction: max score, then smallest i, then smallest j
-        int best = r.best, bi = r.bi, bj = r.bj;
-        Pay bp = r.bp;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int b2 = __shfl_xor(best, o), i2 = __shfl_xor(bi, o), j2 = __shfl_xor(bj, o);
-            const unsigned a2 = __shfl_xor(bp.a, o), g2 = __shfl_xor(bp.g, o), s2v = __shfl_xor(bp.s, o);
-            // lanes that never saw a positive cell carry best = 0 and must lose against any positive score
-            const bool take = b2 > best || (b2 == best && b2 > 0 && (i2 < bi || (i2 == bi && j2 < bj)));
-            if (take) { best = b2; bi = i2; bj = j2; bp = Pay{a2, g2, s2v}; }
-        }
-        if (lane == 0) {
-            int32_t *o = out8 + 8 * (size_t)p;
-            if (best > 0) {
-                o[0] = best; o[1] = (int)(bp.a >> 16); o[2] = (int)(bp.a & 0xFFFFu); o[3] = (int)bp.g;
-                o[4] = (int)(bp.s >> 16); o[5] = bi; o[6] = (int)(bp.s & 0xFFFFu); o[7] = bj;
-            } else {
-                for (int x = 0; x < 8; ++x) o[x] = 0;
-            }
-        }
+        if (nb <= LDS_CELLS) r = protein_pair_general(s_band, LDS_CELLS, s1, s2, len1, len2, k, blosum, lane);
+        else r = protein_pair_general(scratch + (size_t)blockIdx.x * scratch_ints_per_block, nb, s1, s2, len1, len2, k,
+                                      blosum, lane);
+        store_result(r, lane, out8 + 8 * (size_t)p);
     }
 }
 
@@ -247,5 +277,7 @@ void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_
                        int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream) {
     if (n == 0) return;
     hipLaunchKernelGGL(kp_protein_kernel, dim3(n_blocks), dim3(64), 0, stream, q, q_off, q_len, t, t_off, t_len, n, n_dev,
-                       blosum, out8, scratch, scratch_ints_per_block);
+                       blosum, out8);
+    hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, stream, q, q_off, q_len, t, t_off, t_len, n,
+                       n_dev, blosum, out8, scratch, scratch_ints_per_block);
 }

@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int KEPT_LDS = 2048;  // upper bound of kept hits per assembly the cull scratch can hold
+constexpr int SORT_LDS = 4096;  // sort keys staged in LDS per assembly (more hits than this fall back to global reads)
 
 // ---- 1. band-task results -> per-assembly raw hit lists ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, const int32_t *__restrict__ gene_len,
@@ -50,12 +51,20 @@ __global__ __launch_bounds__(64) void kp_hit_sort_kernel(const kp_hit *__restric
     const kp_hit *src = raw + (size_t)a * hit_cap;
     kp_hit *dst = hits + (size_t)a * hit_cap;
     uint64_t *k = keys + (size_t)a * hit_cap * 3;
-    for (uint32_t i = lane; i < n; i += 64) kp_hit_keys(src[i], k + 3 * (size_t)i);
+    __shared__ uint64_t s_k0[SORT_LDS];  // leading key of every hit: almost every comparison is decided by it
+    for (uint32_t i = lane; i < n; i += 64) {
+        kp_hit_keys(src[i], k + 3 * (size_t)i);
+        if (i < SORT_LDS) s_k0[i] = k[3 * (size_t)i];
+    }
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {  // rank sort: all lanes stream the same key j -> broadcast loads
+    for (uint32_t i = lane; i < n; i += 64) {  // rank sort: all lanes read the same key j -> LDS broadcast
         const uint64_t mine[3] = {k[3 * (size_t)i], k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) rank += kp_keys_less(k + 3 * (size_t)j, j, mine, i) ? 1u : 0u;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
+            if (other < mine[0]) ++rank;
+            else if (other == mine[0]) rank += kp_keys_less(k + 3 * (size_t)j, j, mine, i) ? 1u : 0u;
+        }
         dst[rank] = src[i];
     }
     __syncthreads();
@@ -94,7 +103,12 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
                                                        int32_t *__restrict__ pair_q_len, int32_t *__restrict__ pair_t_off,
                                                        int32_t *__restrict__ pair_t_len, int32_t *__restrict__ n_pairs,
                                                        int32_t *__restrict__ pair_base) {
-    __shared__ int32_t s_ctg[KEPT_LDS], s_s[KEPT_LDS], s_e[KEPT_LDS], s_perm[KEPT_LDS];
+    // one 32 KB LDS block: first the cull keys (rank sort), afterwards the kept list of the greedy cull and the
+    // permutation scratch of the clustering
+    __shared__ uint64_t s_raw[SORT_LDS];
+    static_assert(SORT_LDS * sizeof(uint64_t) == 4 * KEPT_LDS * sizeof(int32_t), "LDS block is shared");
+    int32_t *s_ctg = reinterpret_cast<int32_t *>(s_raw), *s_s = s_ctg + KEPT_LDS, *s_e = s_s + KEPT_LDS,
+            *s_perm = s_e + KEPT_LDS;
     __shared__ uint8_t s_codon[128];
     __shared__ int s_fail, s_base;
     const int a = blockIdx.x, lane = threadIdx.x;
@@ -118,12 +132,17 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         s_fail = 0;
     }
     // visit order of the cull
-    for (int i = lane; i < n; i += 64) k[i] = kp_cull_key(h[i], (int)db.gene_locus[h[i].gene] == best_locus, (uint32_t)i);
+    for (int i = lane; i < n; i += 64) {
+        k[i] = kp_cull_key(h[i], (int)db.gene_locus[h[i].gene] == best_locus, (uint32_t)i);
+        if (i < SORT_LDS) s_raw[i] = k[i];
+    }
     __syncthreads();
     for (int i = lane; i < n; i += 64) {
         const uint64_t mine = k[i];
         uint32_t rank = 0;
-        for (int j = 0; j < n; ++j) rank += k[j] < mine ? 1u : 0u;
+        const int n_lds = n < SORT_LDS ? n : SORT_LDS;
+        for (int j = 0; j < n_lds; ++j) rank += s_raw[j] < mine ? 1u : 0u;
+        for (int j = n_lds; j < n; ++j) rank += k[j] < mine ? 1u : 0u;
         ord[rank] = (uint32_t)i;
     }
     __syncthreads();
