@@ -745,7 +745,7 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
                      b->d_keys.p, b->d_order.p, b->d_flag.p, b->d_kept.p, b->kept_cap, b->d_pieces.p, b->piece_cap,
                      b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->stream);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
-    const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 8);
+    const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 24);
     // widest band: 2 * max(20, |len difference| + 1) + 1.  A hit's target span is at most gene length + band drift
     // (KP_MAX_BAND), so its translation is at most the database protein + KP_MAX_BAND / 3 residues long.
     const size_t longest = (size_t)ctx->max_db_prot_len + KP_MAX_BAND / 3 + 2;

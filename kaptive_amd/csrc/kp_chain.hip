@@ -32,20 +32,34 @@ __global__ __launch_bounds__(256) void kp_anchor_contig_kernel(KpBatchView b, co
     }
 }
 
+// Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
+// produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
+constexpr int STAGE0 = 224, STAGE12 = 16;  // staged tasks per block for width class 0 / classes 1 and 2
+
+struct TaskStage {
+    KpTask t0[STAGE0], t1[STAGE12], t2[STAGE12];
+    uint32_t n[3], base[3];
+};
+
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
                                               uint32_t qmax, int cnt, KpTask *tasks, uint32_t *task_count,
-                                              uint32_t task_cap) {
+                                              uint32_t task_cap, TaskStage &st) {
     if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
     const int need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
     const int w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
     const int cls = w == 32 ? 0 : (w == 64 ? 1 : 2);
-    const uint32_t slot = atomicAdd(&task_count[cls], 1u);
-    if (slot >= task_cap) return;  // counted, not stored: the host sees count > cap and retries with more room
     KpTask t;
     t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - KP_BAND_MARGIN - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
-    tasks[(size_t)cls * task_cap + slot] = t;
+    const uint32_t s = atomicAdd(&st.n[cls], 1u);
+    const uint32_t room = cls == 0 ? STAGE0 : STAGE12;
+    if (s < room) {
+        (cls == 0 ? st.t0 : (cls == 1 ? st.t1 : st.t2))[s] = t;
+        return;
+    }
+    const uint32_t slot = atomicAdd(&task_count[cls], 1u);  // stage full: append directly
+    if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = t;  // beyond cap: counted, not stored (host retries)
 }
 
 __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restrict__ keys,
@@ -53,11 +67,14 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
                                                        const uint32_t *__restrict__ count, uint32_t cap,
                                                        KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
                                                        uint32_t task_cap) {
+    __shared__ TaskStage st;
     const int a = blockIdx.y;
     uint32_t n = count[a];
     if (n > cap) n = cap;
     const uint64_t *k = keys + (size_t)a * cap;
     const int32_t *c = contig + (size_t)a * cap;
+    if (threadIdx.x < 3) st.n[threadIdx.x] = 0;
+    __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t gs = KP_KEY_GS(k[i]);
         const int ctg = c[i];
@@ -84,7 +101,7 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
                 if (KP_KEY_GS(kk[u]) != gs || cc[u] != ctg || d - dprev > KP_DIAG_GAP) { open = false; continue; }
                 q = KP_KEY_QPOS(kk[u]);
                 if (d - d0 > KP_MAX_SPREAD) {  // soft cut: close the cluster, open the next one here
-                    flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
+                    flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap, st);
                     d0 = d; qmin = qmax = q; cnt = 0;
                 }
                 dprev = d;
@@ -93,7 +110,22 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
                 qmax = max(qmax, q);
             }
         }
-        flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap);
+        flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap, st);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t room = threadIdx.x == 0 ? STAGE0 : STAGE12;
+        const uint32_t m = st.n[threadIdx.x] < room ? st.n[threadIdx.x] : room;
+        st.n[threadIdx.x] = m;
+        st.base[threadIdx.x] = m ? atomicAdd(&task_count[threadIdx.x], m) : 0u;
+    }
+    __syncthreads();
+    for (int cls = 0; cls < 3; ++cls) {
+        const KpTask *src = cls == 0 ? st.t0 : (cls == 1 ? st.t1 : st.t2);
+        for (uint32_t i = threadIdx.x; i < st.n[cls]; i += blockDim.x) {
+            const uint32_t slot = st.base[cls] + i;
+            if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = src[i];
+        }
     }
 }
 

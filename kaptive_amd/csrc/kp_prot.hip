@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int LDS_CELLS = 1024;  // band cells held in LDS by the wide-band kernel; wider bands use global scratch
+constexpr int LDS_CELLS = 512;  // band cells held in LDS by the wide-band kernel; wider bands use global scratch
 constexpr int NF = 12;          // ints per band cell: M,D,I + 3 payload words each
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
@@ -33,11 +33,12 @@ struct Pay {  // path statistics: a = matches << 16 | mismatches, g = gaps, s = 
     unsigned a, g, s;
 };
 
-__device__ __forceinline__ int from_lower(int v, int fill) {  // lane b <- lane b-1
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+// one-lane wave shifts; the edge lane reads 0 (bound_ctrl) and is overridden by the caller where that matters
+__device__ __forceinline__ int from_lower(int v) {  // lane b <- lane b-1
+    return __builtin_amdgcn_mov_dpp(v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
-__device__ __forceinline__ int from_upper(int v, int fill) {  // lane b <- lane b+1
-    return __builtin_amdgcn_update_dpp(fill, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+__device__ __forceinline__ int from_upper(int v) {  // lane b <- lane b+1
+    return __builtin_amdgcn_mov_dpp(v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
 }
 
 struct Result {
@@ -56,12 +57,12 @@ __device__ __forceinline__ Result protein_pair_registers(const uint16_t *s_seq1,
     const int t_last = 2 * len1 + 2 * k;
     for (int tm = 2; tm <= t_last; ++tm) {
         // neighbours of the other parity: up = lane b+1 (row i-1), left = lane b-1 (row i)
-        int um = from_upper(m, 0), ud = from_upper(dv, NEGP);
-        Pay upm{(unsigned)from_upper((int)pm.a, 0), (unsigned)from_upper((int)pm.g, 0), (unsigned)from_upper((int)pm.s, 0)};
-        Pay upd{(unsigned)from_upper((int)pd.a, 0), (unsigned)from_upper((int)pd.g, 0), (unsigned)from_upper((int)pd.s, 0)};
-        int lm = from_lower(m, 0), li = from_lower(iv, NEGP);
-        Pay lpm{(unsigned)from_lower((int)pm.a, 0), (unsigned)from_lower((int)pm.g, 0), (unsigned)from_lower((int)pm.s, 0)};
-        Pay lpi{(unsigned)from_lower((int)pi.a, 0), (unsigned)from_lower((int)pi.g, 0), (unsigned)from_lower((int)pi.s, 0)};
+        int um = from_upper(m), ud = from_upper(dv);
+        Pay upm{(unsigned)from_upper((int)pm.a), (unsigned)from_upper((int)pm.g), (unsigned)from_upper((int)pm.s)};
+        Pay upd{(unsigned)from_upper((int)pd.a), (unsigned)from_upper((int)pd.g), (unsigned)from_upper((int)pd.s)};
+        int lm = from_lower(m), li = from_lower(iv);
+        Pay lpm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g), (unsigned)from_lower((int)pm.s)};
+        Pay lpi{(unsigned)from_lower((int)pi.a), (unsigned)from_lower((int)pi.g), (unsigned)from_lower((int)pi.s)};
         if (b + 1 >= nb) { um = 0; ud = NEGP; }
         if (b == 0) { lm = 0; li = NEGP; }
         const int i2 = tm - b, i = i2 >> 1, j = i + b - k;
