@@ -190,7 +190,7 @@ def main() -> None:
         scan_ms = float(np.mean([p["scan"] for p in prof]))
         scan_bytes = prof[0]["bytes_scanned"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
-        sw_ms = sum(p["sw32"] + p["sw64"] + p["sw128"] for p in prof)
+        sw_ms = sum(p["sw16"] + p["sw32"] + p["sw64"] + p["sw128"] for p in prof)
         cells = sum(s["dp_cells"] for s in stats)
         typed = int(sum(bt.typeable.sum() for bt in res))
         t_rows = time.perf_counter()
@@ -226,11 +226,11 @@ def main() -> None:
                 "ms_per_launch": scan_ms,
             },
             "dp": {
-                "kernel": "kp_sw_kernel<16|32|64>", "cells_per_db_pass": [s["dp_cells"] for s in stats],
+                "kernel": "kp_sw_kernel<8|16|32|64>", "cells_per_db_pass": [s["dp_cells"] for s in stats],
                 "ms": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
                 "tasks": [s["tasks"] for s in stats], "anchors": [s["anchors"] for s in stats],
             },
-            "kernel_ms": {k: [p[k] for p in prof] for k in ("scan", "sort", "chain", "sw32", "sw64", "sw128")},
+            "kernel_ms": {k: [p[k] for p in prof] for k in ("scan", "sort", "chain", "sw16", "sw32", "sw64", "sw128")},
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline((db_k, db_o), genomes)

@@ -85,9 +85,10 @@ KP_API int kp_batch_hits(kp_ctx *ctx, kp_batch *batch, kp_hit *out, int64_t cap)
 KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 
 /* Per-kernel durations of one alignment pass over the batch, measured with HIP events on the context's stream (the
- * pass is re-run for the measurement; results are unchanged): ms6 = scan, anchor sort, chaining, SW width 32, 64, 128.
- * bytes_scanned receives the algorithmic bytes the scan kernel streams (4 * total words). */
-KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms6, int64_t *bytes_scanned);
+ * pass is re-run for the measurement; results are unchanged): ms7 = scan, anchor compaction + sort, chaining + task
+ * ordering, SW width 16, 32, 64, 128.  bytes_scanned receives the algorithmic bytes the scan kernel streams (4 * total
+ * words). */
+KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms7, int64_t *bytes_scanned);
 
 /* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and
  * the band tasks of one assembly as 7 x int32 rows (gs, contig, lo, width, n_anchors, qmin, qmax) in device order. */

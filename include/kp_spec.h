@@ -49,10 +49,12 @@
  * Anchors of one assembly are sorted by key and cut into clusters: a new cluster starts when gs changes, the contig
  * changes, the diagonal jumps by more than KP_DIAG_GAP, or the cluster would span more than KP_MAX_SPREAD diagonals.
  * A cluster becomes a task when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases
- * (qmax - qmin + K).  Its band is the anchors' diagonal range widened by KP_BAND_MARGIN on both sides, rounded up to
- * 32, 64 or 128 diagonals and centred. */
+ * (qmax - qmin + K).  Its band is the anchors' diagonal range widened on both sides and centred: by
+ * KP_BAND_MARGIN_NARROW when that fits 16 diagonals (anchors on one or two adjacent diagonals: no indel seen), otherwise by
+ * KP_BAND_MARGIN, rounded up to 32, 64 or 128 diagonals. */
 #define KP_DIAG_GAP 32
 #define KP_BAND_MARGIN 15
+#define KP_BAND_MARGIN_NARROW 7 /* clusters whose anchors span at most 2 diagonals get a 16-diagonal band */
 #define KP_MAX_BAND 128
 #define KP_MAX_SPREAD (KP_MAX_BAND - 2 * KP_BAND_MARGIN - 1)
 #define KP_MIN_ANCHORS 3

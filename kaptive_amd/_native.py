@@ -244,10 +244,10 @@ class Batch:
 
     def profile(self) -> dict[str, float]:
         """Per-kernel milliseconds of one more alignment pass (HIP events on the context's stream)."""
-        ms = np.zeros(6, np.float32)
+        ms = np.zeros(7, np.float32)
         nbytes = C.c_int64(0)
         self.ctx._check(lib().kp_batch_profile(self.ctx._h, self._h, _p(ms), C.byref(nbytes)), "kp_batch_profile")
-        d = dict(zip(("scan", "sort", "chain", "sw32", "sw64", "sw128"), ms.tolist()))
+        d = dict(zip(("scan", "sort", "chain", "sw16", "sw32", "sw64", "sw128"), ms.tolist()))
         d["bytes_scanned"] = int(nbytes.value)
         return d
 

@@ -27,6 +27,8 @@ void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTyping
 
 namespace {
 
+constexpr size_t ORDER_HEAD = KP_N_CLASSES * 128;  // task-order histogram + cursors (kp_chain.hip)
+
 std::mutex g_err_mutex;
 std::string g_global_error = "";
 
@@ -93,12 +95,12 @@ struct kp_batch {
     uint32_t anchor_cap = 0, task_cap = 0;
     DevBuf<uint64_t> d_anchors_a, d_anchors_b;
     DevBuf<int32_t> d_anchor_contig;
-    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [3] task counts, [n_asm] largest sub-slice demand
+    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
-    DevBuf<uint32_t> d_task_order;  // [384] histogram + cursors, then [3 * task_cap] permutation
+    DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
     // device-side hit tables (per-assembly regions of hit_cap rows)
     uint32_t hit_cap = 0;
     DevBuf<kp_hit> d_hits_raw, d_hits, d_hits_packed;
@@ -120,7 +122,7 @@ struct kp_batch {
     // results
     bool aligned = false, finalised = false;
     std::vector<uint32_t> h_counts, h_hit_counts;
-    std::vector<KpTask> h_tasks[3];
+    std::vector<KpTask> h_tasks[KP_N_CLASSES];
     std::vector<kp_hit> hits;
     bool hits_fetched = false;
     std::vector<int64_t> hit_off;
@@ -455,35 +457,35 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_anchors_b.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_anchor_contig.reserve(n_asm * b->anchor_cap));
-    KP_HIP_CHECK(ctx, b->d_counts.reserve(2 * n_asm + 3));
+    KP_HIP_CHECK(ctx, b->d_counts.reserve(2 * n_asm + KP_N_CLASSES));
     KP_HIP_CHECK(ctx, b->d_sub_counts.reserve(n_asm * KP_ANCHOR_SUBS));
     KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
-    KP_HIP_CHECK(ctx, b->d_tasks.reserve(3 * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, b->d_results.reserve(3 * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, b->d_task_order.reserve(384 + 3 * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + 3) * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, b->d_tasks.reserve(KP_N_CLASSES * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, b->d_results.reserve(KP_N_CLASSES * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, b->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)b->task_cap));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, 384 * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
     const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
     kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, ctx->stream);
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
     kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
-                             b->d_counts.p + n_asm + 3, ctx->stream);
+                             b->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
     int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
                              &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->stream);
     if (rc) return rc;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
-    kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + 384,
+    kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + ORDER_HEAD,
                          ctx->stream);
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
-    static const int widths[3] = {32, 64, 128};
-    for (int c = 0; c < 3; ++c) {
+    static const int widths[KP_N_CLASSES] = {16, 32, 64, 128};
+    for (int c = 0; c < KP_N_CLASSES; ++c) {
         kp_launch_sw(b->view, ctx->genes, b->d_tasks.p + (size_t)c * b->task_cap, d_task_count + c, b->task_cap,
-                     b->d_task_order.p + 384 + (size_t)c * b->task_cap, widths[c],
+                     b->d_task_order.p + ORDER_HEAD + (size_t)c * b->task_cap, widths[c],
                      b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
         if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
     }
@@ -551,13 +553,13 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
     for (int attempt = 0;; ++attempt) {
-        b->h_counts.resize(2 * n_asm + 3);
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + 3) * sizeof(uint32_t),
+        b->h_counts.resize(2 * n_asm + KP_N_CLASSES);
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->stream));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t max_slice = 0, max_task = 0;
-        for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + 3 + a]);
-        for (int c = 0; c < 3; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
+        for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + KP_N_CLASSES + a]);
+        for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
         const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
         if (max_slice <= sub_cap && max_task <= b->task_cap) break;
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
@@ -570,7 +572,7 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     }
     int64_t n_anchor = 0, n_task = 0;
     for (size_t a = 0; a < n_asm; ++a) n_anchor += b->h_counts[a];
-    for (int c = 0; c < 3; ++c) n_task += b->h_counts[n_asm + c];
+    for (int c = 0; c < KP_N_CLASSES; ++c) n_task += b->h_counts[n_asm + c];
     for (auto &v : b->h_tasks) v.clear();
     int rc = finalise_hits_on_device(ctx, b);
     if (rc) return rc;
@@ -611,17 +613,17 @@ int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
     return KP_OK;
 }
 
-int kp_batch_profile(kp_ctx *ctx, kp_batch *b, float *ms6, int64_t *bytes_scanned) {
-    if (!ctx || !b || b->ctx != ctx || !ms6) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+int kp_batch_profile(kp_ctx *ctx, kp_batch *b, float *ms7, int64_t *bytes_scanned) {
+    if (!ctx || !b || b->ctx != ctx || !ms7) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed (buffer sizes are settled there)");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipEvent_t ev[7];
+    hipEvent_t ev[4 + KP_N_CLASSES];
     for (auto &e : ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
     int rc = enqueue_align(ctx, b, ev);
     if (rc == KP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "profile pass failed");
     if (rc == KP_OK)
-        for (int i = 0; i < 6; ++i)
-            if (hipEventElapsedTime(&ms6[i], ev[i], ev[i + 1]) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "event timing failed");
+        for (int i = 0; i < 3 + KP_N_CLASSES; ++i)
+            if (hipEventElapsedTime(&ms7[i], ev[i], ev[i + 1]) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "event timing failed");
     for (auto &e : ev) (void)hipEventDestroy(e);
     if (bytes_scanned) *bytes_scanned = 4 * b->view.total_words;
     return rc;
@@ -643,7 +645,7 @@ int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int
 int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
     if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
-    for (int c = 0; c < 3; ++c) {  // fetched on first use: only the stage tests look at tasks
+    for (int c = 0; c < KP_N_CLASSES; ++c) {  // fetched on first use: only the stage tests look at tasks
         const size_t nt = b->h_counts[(size_t)b->n_asm + c];
         if (b->h_tasks[c].size() == nt) continue;
         b->h_tasks[c].resize(nt);
@@ -652,7 +654,7 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64
             return kp_fail(ctx, KP_EHIP, "D2H tasks failed");
     }
     int64_t n = 0;
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < KP_N_CLASSES; ++c)
         for (const KpTask &t : b->h_tasks[c]) {
             if (t.asm_id != a) continue;
             if (out7 && n < cap) {

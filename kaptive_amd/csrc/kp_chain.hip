@@ -34,28 +34,33 @@ __global__ __launch_bounds__(256) void kp_anchor_contig_kernel(KpBatchView b, co
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
 // produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
-constexpr int STAGE0 = 224, STAGE12 = 16;  // staged tasks per block for width class 0 / classes 1 and 2
+constexpr int STAGE0 = 192, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
 
 struct TaskStage {
-    KpTask t0[STAGE0], t1[STAGE12], t2[STAGE12];
-    uint32_t n[3], base[3];
+    KpTask t0[STAGE0], rest[KP_N_CLASSES - 1][STAGE_REST];
+    uint32_t n[KP_N_CLASSES], base[KP_N_CLASSES];
+    __device__ KpTask *list(int cls) { return cls == 0 ? t0 : rest[cls - 1]; }
+    __device__ static uint32_t room(int cls) { return cls == 0 ? STAGE0 : STAGE_REST; }
 };
 
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
                                               uint32_t qmax, int cnt, KpTask *tasks, uint32_t *task_count,
                                               uint32_t task_cap, TaskStage &st) {
     if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
-    const int need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
-    const int w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
-    const int cls = w == 32 ? 0 : (w == 64 ? 1 : 2);
+    int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16, cls = 0;
+    if (need > 16) {
+        margin = KP_BAND_MARGIN;
+        need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
+        w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+        cls = w == 32 ? 1 : (w == 64 ? 2 : 3);
+    }
     KpTask t;
     t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
-    t.lo = (int32_t)d0 - KP_DIAG_BIAS - KP_BAND_MARGIN - (w - need) / 2;
+    t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
     const uint32_t s = atomicAdd(&st.n[cls], 1u);
-    const uint32_t room = cls == 0 ? STAGE0 : STAGE12;
-    if (s < room) {
-        (cls == 0 ? st.t0 : (cls == 1 ? st.t1 : st.t2))[s] = t;
+    if (s < TaskStage::room(cls)) {
+        st.list(cls)[s] = t;
         return;
     }
     const uint32_t slot = atomicAdd(&task_count[cls], 1u);  // stage full: append directly
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
     if (n > cap) n = cap;
     const uint64_t *k = keys + (size_t)a * cap;
     const int32_t *c = contig + (size_t)a * cap;
-    if (threadIdx.x < 3) st.n[threadIdx.x] = 0;
+    if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t gs = KP_KEY_GS(k[i]);
@@ -113,15 +118,15 @@ __global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restric
         flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap, st);
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
-        const uint32_t room = threadIdx.x == 0 ? STAGE0 : STAGE12;
+    if (threadIdx.x < KP_N_CLASSES) {
+        const uint32_t room = TaskStage::room(threadIdx.x);
         const uint32_t m = st.n[threadIdx.x] < room ? st.n[threadIdx.x] : room;
         st.n[threadIdx.x] = m;
         st.base[threadIdx.x] = m ? atomicAdd(&task_count[threadIdx.x], m) : 0u;
     }
     __syncthreads();
-    for (int cls = 0; cls < 3; ++cls) {
-        const KpTask *src = cls == 0 ? st.t0 : (cls == 1 ? st.t1 : st.t2);
+    for (int cls = 0; cls < KP_N_CLASSES; ++cls) {
+        const KpTask *src = st.list(cls);
         for (uint32_t i = threadIdx.x; i < st.n[cls]; i += blockDim.x) {
             const uint32_t slot = st.base[cls] + i;
             if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = src[i];
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, con
         atomicAdd(&s_h[length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1])], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {
-        s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[192 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
+        s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[KP_N_CLASSES * 64 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
         s_h[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, con
 
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist, uint32_t *order, hipStream_t stream) {
-    const dim3 grid(128, 3), block(256);
+    const dim3 grid(128, KP_N_CLASSES), block(256);
     hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist);
     hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist, order);
 }

@@ -42,13 +42,14 @@ struct KpBatchView {
     int64_t total_words;
 };
 
+#define KP_N_CLASSES 4  // band-width classes: 16, 32, 64, 128 diagonals
 // A band task (one banded alignment).  `asm_id` and the derived fields are filled by the chaining kernel.
 struct KpTask {
     int32_t asm_id;
     int32_t gs;         // gene * 2 + (strand < 0)
     int32_t contig;     // contig index within the assembly
     int32_t lo;         // lowest diagonal of the band (tpos - qpos, assembly coordinates)
-    int32_t width;      // 32 / 64 / 128
+    int32_t width;      // 16 / 32 / 64 / 128
     int32_t n_anchors;
     int32_t qmin, qmax;
 };
@@ -78,14 +79,14 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[3]*/, uint32_t task_cap,
+                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
                      hipStream_t stream);
 // kp_sw.hip: banded Smith-Waterman of every task of one width class.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
                   uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
-                          uint32_t *hist /*[384] zeroed*/, uint32_t *order, hipStream_t stream);
+                          uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);
 // kp_prot.hip
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,

@@ -279,7 +279,7 @@ void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells,
                             hipStream_t stream) {
     if (b.n_asm == 0) return;
-    hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, 3), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
+    hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
                        task_cap, raw, n_raw, hit_cap, cells);
     hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(64), 0, stream, raw, n_raw, hit_cap, keys, hits, n_hits);
 }

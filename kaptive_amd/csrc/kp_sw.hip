@@ -5,7 +5,7 @@
 //
 // Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
 //   * a task's band has W = 2P diagonals; P lanes own it, lane l holds diagonals 2l ("A") and 2l+1 ("B");
-//     a 64-lane wave therefore runs 64/P tasks side by side (P = 16/32/64 for W = 32/64/128).
+//     a 64-lane wave therefore runs 64/P tasks side by side (P = 8/16/32/64 for W = 16/32/64/128).
 //   * time is skewed by lane: at macro step m lane l works on query row r = m - l, first cell A then cell B.  With that
 //     skew A's left neighbour is lane l-1's B of the previous step, B's upper neighbour is lane l+1's A of the
 //     same step, and everything else is the lane's own previous row -- two one-lane wave shifts per macro step, both
@@ -241,7 +241,9 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
                   uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream) {
     // persistent-style grid: enough single-wave blocks to fill 256 CUs several times over; each strides over quads
     const dim3 grid(256 * 16), block(64);
-    if (width == 32)
+    if (width == 16)
+        hipLaunchKernelGGL(kp_sw_kernel<8>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+    else if (width == 32)
         hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else if (width == 64)
         hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);

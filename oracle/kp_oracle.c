@@ -376,7 +376,7 @@ typedef struct kpo_task {
     int32_t gs;      /* gene*2 + strand */
     int32_t contig;
     int32_t lo;      /* lowest diagonal of the band, true value (tpos - qpos, assembly coordinates) */
-    int32_t width;   /* 32, 64 or 128 */
+    int32_t width;   /* 16, 32, 64 or 128 */
     int32_t n_anchors;
     int32_t qmin, qmax;
 } kpo_task;
@@ -406,12 +406,16 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
             if (q2 > qmax) qmax = q2;
         }
         if (cnt >= KP_MIN_ANCHORS && (int)(qmax - qmin) + KP_K >= KP_MIN_SEED_SPAN) {
-            int need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
-            int w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+            int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
+            if (need > 16) {
+                margin = KP_BAND_MARGIN;
+                need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
+                w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+            }
             if (nt == cap) { cap *= 2; tasks = realloc(tasks, (size_t)cap * sizeof(kpo_task)); }
             kpo_task *t = &tasks[nt++];
             t->gs = (int32_t)gs; t->contig = ctg; t->width = w; t->n_anchors = cnt;
-            t->lo = (int32_t)((int64_t)d0 - KP_DIAG_BIAS - KP_BAND_MARGIN - (w - need) / 2);
+            t->lo = (int32_t)((int64_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2);
             t->qmin = (int32_t)qmin; t->qmax = (int32_t)qmax;
         }
         i = j;
