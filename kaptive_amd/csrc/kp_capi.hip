@@ -97,6 +97,9 @@ struct kp_batch {
     DevBuf<int32_t> d_anchor_contig;
     DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
+    DevBuf<uint64_t> d_cand;        // candidate positions of the scan; d_cand_count[0] = how many
+    DevBuf<unsigned long long> d_cand_count;
+    uint64_t cand_cap = 0;
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
@@ -441,7 +444,7 @@ void kp_batch_destroy(kp_batch *b) {
     if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
     b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
-    b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_seg.release(); b->d_tasks.release();
+    b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
     b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_flag.release();
@@ -465,12 +468,17 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     KP_HIP_CHECK(ctx, b->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
+    if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 12 % of those to pass the filter
+        b->cand_cap = std::max<uint64_t>(4096, (uint64_t)(b->view.total_words * 4 * 0.12));
+    KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap));
+    KP_HIP_CHECK(ctx, b->d_cand_count.reserve(1));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
     const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-    kp_launch_scan(b->view, ctx->index, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, ctx->stream);
-    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
+    kp_launch_scan(b->view, ctx->index, b->d_cand.p, b->d_cand_count.p, b->cand_cap, b->d_anchors_a.p, b->d_sub_counts.p,
+                   sub_cap, ctx->stream, ev ? ev[1] : nullptr);
     kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
                              b->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
     int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
@@ -557,13 +565,16 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->stream));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long n_cand = 0;
+        KP_HIP_CHECK(ctx, hipMemcpy(&n_cand, b->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost));
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
         const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
-        if (max_slice <= sub_cap && max_task <= b->task_cap) break;
+        if (max_slice <= sub_cap && max_task <= b->task_cap && n_cand <= b->cand_cap) break;
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
         // a region overflowed: counts kept counting, so they say how much room a clean rerun needs
+        if (n_cand > b->cand_cap) b->cand_cap = n_cand + n_cand / 8;
         if (max_slice > sub_cap) b->anchor_cap = ((max_slice + 15u) & ~15u) * KP_ANCHOR_SUBS;
         if (max_task > b->task_cap) b->task_cap = (max_task + 1023u) & ~1023u;
         b->stats[4] += 1;

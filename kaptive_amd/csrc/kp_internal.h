@@ -69,12 +69,15 @@ struct kp_ctx;
 int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
-// kp_scan.hip: stream the packed contigs, emit anchor keys.  Each assembly's region of sub_cap * KP_ANCHOR_SUBS keys is
-//   cut into KP_ANCHOR_SUBS sub-slices with their own counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past
-//   sub_cap = overflow); kp_launch_anchor_compact then packs each assembly's slices into one run.
+// kp_scan.hip: pass 1 streams the packed contigs and records candidate positions (selected k-mers that pass the presence
+//   filter) in `cand` (n_cand keeps counting past cand_cap = overflow); pass 2 turns candidates into anchor keys.  Each
+//   assembly's anchor region of sub_cap * KP_ANCHOR_SUBS keys is cut into KP_ANCHOR_SUBS sub-slices with their own
+//   counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past sub_cap = overflow); kp_launch_anchor_compact then
+//   packs each assembly's slices into one run.  `after_scan` (optional) is recorded between the two passes.
 #define KP_ANCHOR_SUBS 64
-void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *sub_count,
-                    uint32_t sub_cap, hipStream_t stream);
+void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
+                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, hipStream_t stream,
+                    hipEvent_t after_scan);
 void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).

@@ -8,10 +8,9 @@
 // instruction).  The 65th..80th base needed by k-mers that start near the end of the lane's span come from the next
 // lane's first word (DPP/shuffle), so every word is fetched from HBM exactly once.  The context-free seed rule
 // (c[p]^c[p+1]^c[p+3]==1) is evaluated for 16 positions at a time with word-wide bit operations; only the selected
-// quarter of positions goes on: first a 2^KP_FILTER_LOG2-bit presence filter (2 MB, stays in each XCD's L2) that
-// rejects most of them, then the k-mer table (tens of MB, Infinity Cache) for the rest.  Hits are rare outside the
-// typed locus, so the per-hit work (assembly / contig / N-run lookup, posting expansion, atomics) is off the
-// streaming path.
+// quarter of positions goes on to a 2^KP_FILTER_LOG2-bit presence filter (2 MB, stays in each XCD's L2).  What passes
+// the filter is only recorded (kp_scan_kernel); a second, perfectly balanced kernel (kp_expand_kernel) probes the
+// k-mer table (tens of MB, Infinity Cache), validates and expands the postings into anchors.
 #include <cstdlib>
 
 #include "kp_internal.h"
@@ -38,70 +37,41 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
     return lo;
 }
 
-// Per-lane cache of where its 64 bases live: the assembly is fixed for a lane's unit, the contig is remembered from
-// the previous hit (hits cluster inside the typed locus), so most hits validate without any search.
-struct LaneWhere {
-    int a;          // assembly index, -1 = not looked up yet
-    int64_t word0;  // first batch word of that assembly
-    int32_t c_lo, c_hi;  // padded-space bounds [c_lo, c_hi) of the cached contig (empty = none)
-};
+// ---- pass 1: stream + select + presence filter -> candidate positions --------------------------------------------------
+// Every base is read once.  A selected k-mer that passes the filter becomes a candidate: its batch-wide base position
+// is staged in the wave's own LDS slice (ballot + popcount, no atomics) and flushed to the global candidate list with
+// one atomic per flush, so the streaming kernel has no data-dependent slow path: what a candidate costs later
+// (table probe, contig / N validation, posting expansion) is done by kp_expand_kernel with one thread per candidate.
+// MODE 0 = product; 1 = no filter reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for the
+// ablation in tools/scan_ablate.py and write a checksum so that the work is not optimised away.
+constexpr int STAGE_PER_WAVE = 1024;  // one round of PROBES positions per lane adds at most 64 * PROBES = 512 entries
 
-// A seed at batch word `word`, base `i` matched the table: validate it against contig bounds and N runs, then append
-// one anchor per posting to sub-slice `sub` of the assembly's region.  Appends of one assembly are spread over
-// KP_ANCHOR_SUBS counters because all hits of an assembly happen in one short burst (the typed locus) and would
-// otherwise serialise on a single atomic word.
-__device__ __noinline__ void emit_seed(const KpBatchView &b, const KpSeedIndex &idx, uint32_t first_posting,
-                                       int64_t word, int i, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap,
-                                       uint32_t sub, LaneWhere &w) {
-    if (w.a < 0) {
-        w.a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
-        if (w.a < 0 || w.a >= b.n_asm) { w.a = -1; return; }
-        w.word0 = b.asm_word_off[w.a];
-    }
-    const int a = w.a;
-    const int32_t t = (int32_t)((word - w.word0) * 16 + i);
-    if (t < w.c_lo || t + KP_K > w.c_hi) {
-        const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
-        const int c = upper_bound_i32(b.ctg_start + c0, nc, t) - 1;
-        if (c < 0) return;
-        w.c_lo = b.ctg_start[c0 + c];
-        w.c_hi = w.c_lo + b.ctg_len[c0 + c];
-        if (t + KP_K > w.c_hi) return;  // k-mer runs past the contig (or sits in padding)
-    }
-    const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
-    if (nr > 0) {  // first run whose end is > t; it overlaps the k-mer iff it starts before t + K
-        int lo = 0, hi = nr;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (b.n_runs[2 * (r0 + mid) + 1] <= t) lo = mid + 1; else hi = mid;
-        }
-        if (lo < nr && b.n_runs[2 * (r0 + lo)] < t + KP_K) return;
-    }
-    const uint32_t cnt = (uint32_t)idx.postings[first_posting];
-    const size_t slice = (size_t)a * KP_ANCHOR_SUBS + sub;
-    const uint32_t base = atomicAdd(&sub_count[slice], cnt);
-    uint64_t *dst = anchors + slice * sub_cap;
-    const uint64_t shift = (uint64_t)(uint32_t)t << 16;
-    for (uint32_t j = 0; j < cnt; ++j)
-        if (base + j < sub_cap) dst[base + j] = idx.postings[first_posting + 1 + j] + shift;
-}
-
-// MODE 0 = product; 1 = no filter/table reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for
-// the ablation in bench.py --ablate-scan and write a checksum so that the work is not optimised away.
 template <int MODE>
-__global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ anchors,
-                                                       uint32_t *__restrict__ sub_count, uint32_t sub_cap) {
+__global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ cand,
+                                                       unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
+    __shared__ uint64_t s_stage[4][STAGE_PER_WAVE];
     uint32_t checksum = 0;
     const int64_t n_units = b.total_words >> 2;  // 16-byte units; every assembly is a whole number of them
     const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;  // whole waves iterate together (shuffle below)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *stage = s_stage[wave];
+    uint32_t staged = 0;  // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    auto flush = [&]() {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_cand, (unsigned long long)staged);
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < staged; i += 64)
+            if (base + i < cand_cap) cand[base + i] = stage[i];
+        staged = 0;
+    };
+
     for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_iter_units; u += stride) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (u < n_units) v = vec[u];
-        LaneWhere where{-1, 0, 0, 0};
-        const uint32_t sub = (uint32_t)u & (KP_ANCHOR_SUBS - 1);
         uint32_t next = __shfl_down(v.x, 1);
         if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
         const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
@@ -113,39 +83,88 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
             const uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, lo, 2) ^ __builtin_amdgcn_alignbit(hi, lo, 6);
             uint32_t sel = x & ~(x >> 1) & 0x55555555u;  // value 01: low bit set, high bit clear
             const uint64_t both = ((uint64_t)hi << 32) | lo;
-            while (sel) {
+            const uint64_t word_base = (uint64_t)((u << 2) + k) << 4;  // batch-wide position of the word's first base
+            while (__any(sel != 0)) {  // wave-uniform: lanes that ran out of selected positions idle along
                 // up to PROBES selected positions at a time: all their filter words are requested before any is
                 // looked at, so a lane keeps several independent L2 reads in flight
-                uint32_t kmer[PROBES], filt[PROBES];
+                uint32_t filt[PROBES];
                 int bit[PROBES];
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
                     const bool have = sel != 0;
                     bit[j] = have ? __builtin_ctz(sel) : 0;
                     sel &= sel - 1;  // no-op once sel is 0
-                    kmer[j] = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
-                    const uint32_t h = (kmer[j] * 2654435769u) >> (32 - KP_FILTER_LOG2);
+                    const uint32_t kmer = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
+                    const uint32_t h = (kmer * 2654435769u) >> (32 - KP_FILTER_LOG2);
                     if (MODE == 1) { checksum += have ? h : 0u; filt[j] = 0; continue; }
                     filt[j] = have ? ((idx.filter[h >> 5] >> (h & 31)) & 1u) : 0u;
                 }
+                if (MODE != 0) continue;
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
-                    if (!filt[j]) continue;  // ~93 % of selected positions stop here (KpSC K database)
-                    uint32_t slot = (kmer[j] * 2654435769u) >> idx.slot_shift;
-                    for (;;) {
-                        const uint2 e = idx.slots[slot];
-                        if (e.x == kmer[j]) {
-                            emit_seed(b, idx, e.y, (u << 2) + k, bit[j] >> 1, anchors, sub_count, sub_cap, sub, where);
-                            break;
-                        }
-                        if (e.x == 0xFFFFFFFFu) break;
-                        slot = (slot + 1) & idx.slot_mask;
-                    }
+                    const unsigned long long pass = __ballot(filt[j] != 0);
+                    if (!pass) continue;  // ~93 % of selected positions stop at the filter (KpSC K database)
+                    if (filt[j]) stage[staged + __builtin_popcountll(pass & below)] = word_base + (uint64_t)(bit[j] >> 1);
+                    staged += (uint32_t)__builtin_popcountll(pass);
                 }
+                if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
             }
         }
     }
-    if (MODE != 0 && checksum == 0x9E3779B1u) sub_count[0] = checksum;  // practically never; keeps the work alive
+    if (MODE == 0 && staged) flush();
+    if (MODE != 0 && checksum == 0x9E3779B1u) n_cand[0] = checksum;  // practically never; keeps the work alive
+}
+
+// ---- pass 2: candidates -> anchors -------------------------------------------------------------------------------------
+// One thread per candidate: re-read its k-mer, probe the table, validate against contig bounds and N runs, and append
+// one anchor per posting to its assembly.  Appends of one assembly are spread over KP_ANCHOR_SUBS counters because all
+// hits of an assembly come in one burst (the typed locus) and would otherwise serialise on a single atomic word.
+__global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedIndex idx, const uint64_t *__restrict__ cand,
+                                                         const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
+                                                         uint64_t *__restrict__ anchors, uint32_t *__restrict__ sub_count,
+                                                         uint32_t sub_cap) {
+    unsigned long long n = *n_cand;
+    if (n > cand_cap) n = cand_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t pos = cand[i];
+        const int64_t word = (int64_t)(pos >> 4);
+        const int bitpos = 2 * (int)(pos & 15);
+        const uint64_t both = ((uint64_t)(word + 1 < b.total_words ? b.words[word + 1] : 0u) << 32) | b.words[word];
+        const uint32_t kmer = (uint32_t)(both >> bitpos) & KP_KMER_MASK;
+        uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
+        uint32_t first_posting = 0xFFFFFFFFu;
+        for (;;) {
+            const uint2 e = idx.slots[slot];
+            if (e.x == kmer) { first_posting = e.y; break; }
+            if (e.x == 0xFFFFFFFFu) break;
+            slot = (slot + 1) & idx.slot_mask;
+        }
+        if (first_posting == 0xFFFFFFFFu) continue;  // filter false positive
+        const int a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
+        if (a < 0 || a >= b.n_asm) continue;
+        const int32_t t = (int32_t)(pos - ((uint64_t)b.asm_word_off[a] << 4));
+        const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+        const int c = upper_bound_i32(b.ctg_start + c0, nc, t) - 1;
+        if (c < 0) continue;
+        if (t + KP_K > b.ctg_start[c0 + c] + b.ctg_len[c0 + c]) continue;  // runs past the contig (or sits in padding)
+        const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
+        if (nr > 0) {  // first run whose end is > t; it overlaps the k-mer iff it starts before t + K
+            int lo = 0, hi = nr;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (b.n_runs[2 * (r0 + mid) + 1] <= t) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nr && b.n_runs[2 * (r0 + lo)] < t + KP_K) continue;
+        }
+        const uint32_t cnt = (uint32_t)idx.postings[first_posting];
+        const size_t slice = (size_t)a * KP_ANCHOR_SUBS + (threadIdx.x & (KP_ANCHOR_SUBS - 1));
+        const uint32_t base = atomicAdd(&sub_count[slice], cnt);
+        uint64_t *dst = anchors + slice * sub_cap;
+        const uint64_t shift = (uint64_t)(uint32_t)t << 16;
+        for (uint32_t j = 0; j < cnt; ++j)
+            if (base + j < sub_cap) dst[base + j] = idx.postings[first_posting + 1 + j] + shift;
+    }
 }
 
 // sub-slices of each assembly -> one contiguous run per assembly (input of the sort); count[a] = anchors stored,
@@ -187,17 +206,19 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
                        count, need);
 }
 
-void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *anchors, uint32_t *anchor_count,
-                    uint32_t cap, hipStream_t stream) {
+void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
+                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, hipStream_t stream,
+                    hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
     int64_t blocks = (n_units + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
     static const int mode = []() { const char *m = getenv("KAPTIVE_AMD_SCAN_ABLATE"); return m ? atoi(m) : 0; }();
-    if (mode == 1)
-        hipLaunchKernelGGL(kp_scan_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, b, idx, anchors, anchor_count, cap);
-    else if (mode == 2)
-        hipLaunchKernelGGL(kp_scan_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, b, idx, anchors, anchor_count, cap);
-    else
-        hipLaunchKernelGGL(kp_scan_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, b, idx, anchors, anchor_count, cap);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (mode == 1) hipLaunchKernelGGL(kp_scan_kernel<1>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    else if (mode == 2) hipLaunchKernelGGL(kp_scan_kernel<2>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    else hipLaunchKernelGGL(kp_scan_kernel<0>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    if (after_scan) (void)hipEventRecord(after_scan, stream);
+    hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap, anchors,
+                       sub_count, sub_cap);
 }
