@@ -3,8 +3,10 @@ missing, every entry point raises."""
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import threading
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -41,6 +43,18 @@ class TypingParams(C.Structure):  # kp_typing_params
 
 _lib = None
 _lock = threading.Lock()
+_live: "weakref.WeakSet" = weakref.WeakSet()  # contexts and batches still holding device memory
+
+
+@atexit.register
+def _close_all() -> None:
+    """Release device objects before the HIP runtime's own exit handlers run (batches first, then contexts)."""
+    objs = list(_live)
+    for o in sorted(objs, key=lambda x: isinstance(x, Context)):
+        try:
+            o.close()
+        except Exception:
+            pass
 
 
 class NativeError(RuntimeError):
@@ -85,9 +99,13 @@ class Context:
         if rc != 0:
             raise NativeError(f"kp_ctx_create failed ({rc}): {lib().kp_last_error(None).decode()}")
         self.device = device
+        self._batches: "weakref.WeakSet" = weakref.WeakSet()
+        _live.add(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for b in list(self._batches):  # a batch must not outlive its context
+                b.close()
             lib().kp_ctx_destroy(self._h)
             self._h = None
 
@@ -171,10 +189,13 @@ class Batch:
                                               C.byref(self._h))  # fmt: skip
         ctx._check(rc, "kp_batch_create")
         self.total_words = int(word_off[-1])
+        ctx._batches.add(self)
+        _live.add(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            lib().kp_batch_destroy(self._h)
+            if getattr(self.ctx, "_h", None):  # the context owns the device; without it there is nothing to free
+                lib().kp_batch_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -469,7 +469,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
     if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 12 % of those to pass the filter
-        b->cand_cap = std::max<uint64_t>(4096, (uint64_t)(b->view.total_words * 4 * 0.12));
+        b->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)(b->view.total_words * 4 * 0.12));
     KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap));
     KP_HIP_CHECK(ctx, b->d_cand_count.reserve(1));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
