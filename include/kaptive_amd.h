@@ -84,10 +84,10 @@ KP_API int kp_batch_hits(kp_ctx *ctx, kp_batch *batch, kp_hit *out, int64_t cap)
 /* counters of the last kp_batch_align: [0] anchors, [1] band tasks, [2] DP cells, [3] hits, [4] overflow retries */
 KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 
-/* Per-kernel durations of one alignment pass over the batch, measured with HIP events on the context's stream (the
- * pass is re-run for the measurement; results are unchanged): ms7 = scan, anchor compaction + sort, chaining + task
- * ordering, SW width 16, 32, 64, 128.  bytes_scanned receives the algorithmic bytes the scan kernel streams (4 * total
- * words). */
+/* Stage durations of the most recent alignment pass of this batch (valid after kp_batch_wait), from HIP events the
+ * library records on the context's stream around every pass: ms7 = seed scan (kp_scan_kernel), candidate expansion +
+ * anchor compaction + sort, chaining + task ordering, SW width 16, 32, 64, 128.  bytes_scanned receives the algorithmic
+ * bytes the scan kernel streams (4 * total words). */
 KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms7, int64_t *bytes_scanned);
 
 /* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and

@@ -264,7 +264,7 @@ class Batch:
         return out
 
     def profile(self) -> dict[str, float]:
-        """Per-kernel milliseconds of one more alignment pass (HIP events on the context's stream)."""
+        """Stage milliseconds of the most recent alignment pass (HIP events recorded on the context's stream)."""
         ms = np.zeros(7, np.float32)
         nbytes = C.c_int64(0)
         self.ctx._check(lib().kp_batch_profile(self.ctx._h, self._h, _p(ms), C.byref(nbytes)), "kp_batch_profile")

@@ -130,6 +130,8 @@ struct kp_batch {
     bool hits_fetched = false;
     std::vector<int64_t> hit_off;
     int64_t stats[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[4 + KP_N_CLASSES] = {};  // stage boundaries of the most recent alignment pass
+    bool have_events = false;
 };
 
 int kp_fail(kp_ctx *ctx, int code, const std::string &msg) {
@@ -442,6 +444,8 @@ void kp_batch_destroy(kp_batch *b) {
     if (!b) return;
     if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
     if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
+    if (b->have_events)
+        for (auto &e : b->ev) (void)hipEventDestroy(e);
     b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
     b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
@@ -453,8 +457,13 @@ void kp_batch_destroy(kp_batch *b) {
     delete b;
 }
 
-static int enqueue_align(kp_ctx *ctx, kp_batch *b, hipEvent_t *ev = nullptr) {
+static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     const size_t n_asm = (size_t)b->n_asm;
+    if (!b->have_events) {
+        for (auto &e : b->ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
+        b->have_events = true;
+    }
+    hipEvent_t *ev = b->ev;
     if ((uint64_t)n_asm * b->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
     KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
@@ -626,18 +635,13 @@ int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
 
 int kp_batch_profile(kp_ctx *ctx, kp_batch *b, float *ms7, int64_t *bytes_scanned) {
     if (!ctx || !b || b->ctx != ctx || !ms7) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed (buffer sizes are settled there)");
+    if (!b->finalised || !b->have_events) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipEvent_t ev[4 + KP_N_CLASSES];
-    for (auto &e : ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
-    int rc = enqueue_align(ctx, b, ev);
-    if (rc == KP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "profile pass failed");
-    if (rc == KP_OK)
-        for (int i = 0; i < 3 + KP_N_CLASSES; ++i)
-            if (hipEventElapsedTime(&ms7[i], ev[i], ev[i + 1]) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "event timing failed");
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 3 + KP_N_CLASSES; ++i)
+        if (hipEventElapsedTime(&ms7[i], b->ev[i], b->ev[i + 1]) != hipSuccess)
+            return kp_fail(ctx, KP_EHIP, "event timing failed");
     if (bytes_scanned) *bytes_scanned = 4 * b->view.total_words;
-    return rc;
+    return KP_OK;
 }
 
 int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int64_t cap) {
