@@ -51,6 +51,22 @@ KP_API int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gen
 /* Number of (k-mer, gene, strand, position) postings in the resident seed index. */
 KP_API int64_t kp_db_n_postings(const kp_ctx *ctx);
 
+/* ---- FASTA ingest (host only) --------------------------------------------------------------------------------------------
+ * Replaces rammappy.fasta.parse_fasta_bytes + Sequences.from_records + the per-contig copies handed to Index.build
+ * (src/kaptive/core/genome.py:35-46,188; src/kaptive/core/seq.py:281-325): one pass from (decompressed) FASTA text to
+ * the packed layout of kp_spec.h.  The result is owned by the library until kp_fasta_free. */
+typedef struct kp_packed_fasta {
+    int64_t padded_len;   /* bases, multiple of KP_ASM_ALIGN */
+    int32_t n_contigs, n_runs;
+    uint32_t *words;      /* padded_len / 16 */
+    int32_t *ctg_start, *ctg_len;
+    int32_t *n_run_pairs; /* 2 * n_runs */
+    char *names;          /* contig names back to back (first word of each header), not NUL-terminated */
+    int32_t *name_off;    /* n_contigs + 1 */
+} kp_packed_fasta;
+KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
+KP_API void kp_fasta_free(kp_packed_fasta *packed);
+
 /* ---- batches of packed assemblies -------------------------------------------------------------------------------
  * Replaces GenomeAssembly.get_rammappy_index / rammappy.Index.build (src/kaptive/core/genome.py:177-191): instead of
  * a minimizer index per assembly, the 2-bit packed contigs themselves are made resident (layout: kp_spec.h).

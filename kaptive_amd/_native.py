@@ -27,8 +27,39 @@ EXPORTS = (
     "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_free",
 )  # fmt: skip
+
+
+class PackedFasta(C.Structure):  # kp_packed_fasta
+    _fields_ = [("padded_len", C.c_int64), ("n_contigs", C.c_int32), ("n_runs", C.c_int32),
+                ("words", C.POINTER(C.c_uint32)), ("ctg_start", C.POINTER(C.c_int32)), ("ctg_len", C.POINTER(C.c_int32)),
+                ("n_run_pairs", C.POINTER(C.c_int32)), ("names", C.POINTER(C.c_char)), ("name_off", C.POINTER(C.c_int32))]  # fmt: skip
+
+
+def fasta_pack(data: bytes):
+    """FASTA text -> (PackedAssembly, contig names), parsed and packed by the native library (no GPU needed)."""
+    from kaptive_amd.pack import PackedAssembly
+
+    h = lib()
+    h.kp_fasta_free.restype = None
+    out = C.POINTER(PackedFasta)()
+    rc = h.kp_fasta_pack(data, C.c_int64(len(data)), C.byref(out))
+    if rc != 0:
+        raise ValueError(f"kp_fasta_pack failed ({rc}): sequence too long for the packed layout or bad arguments")
+    try:
+        p = out.contents
+        nc, nr = p.n_contigs, p.n_runs
+        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.empty(0, dt)  # noqa: E731
+        words = arr(p.words, p.padded_len // 16, np.uint32)
+        off = arr(p.name_off, nc + 1, np.int32)
+        blob = C.string_at(p.names, int(off[-1])) if nc else b""
+        names = tuple(blob[off[i] : off[i + 1]].decode("utf-8", "replace") for i in range(nc))
+        pa = PackedAssembly(words, int(p.padded_len), arr(p.ctg_start, nc, np.int32), arr(p.ctg_len, nc, np.int32),
+                            arr(p.n_run_pairs, 2 * nr, np.int32).reshape(-1, 2))  # fmt: skip
+        return pa, names
+    finally:
+        h.kp_fasta_free(out)
 
 
 class TypingTables(C.Structure):  # kp_typing_tables

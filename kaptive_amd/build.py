@@ -18,7 +18,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libkaptive_amd.so"
-SOURCES = ("kp_capi.hip", "kp_scan.hip", "kp_sort.hip", "kp_chain.hip", "kp_sw.hip", "kp_prot.hip", "kp_reduce.hip")
+SOURCES = ("kp_capi.hip", "kp_scan.hip", "kp_sort.hip", "kp_chain.hip", "kp_sw.hip", "kp_prot.hip", "kp_reduce.hip",
+           "kp_fasta.cpp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -43,7 +44,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     def compile_one(name: str) -> Path:
         src, obj = CSRC / name, objdir / (name + ".o")
         if force or _stale(obj, [src, *headers]):
-            cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+            flags = FLAGS if name.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -28,17 +28,20 @@ _WS[[9, 10, 11, 12, 13, 32]] = True
 
 def parse_fasta_bytes(data: bytes) -> list[tuple[str, bytes]]:
     """Split FASTA text into ``(name, sequence)`` pairs: name = first word of the header line, sequence = all
-    following lines up to the next ``>`` with whitespace removed. Text before the first header is ignored."""
+    following lines up to the next ``>`` at a line start, with whitespace removed. Text before the first header is
+    ignored."""
     buf = np.frombuffer(data, dtype=np.uint8)
     if len(buf) == 0:
         return []
     line_start = np.r_[0, np.flatnonzero(buf == 10) + 1]
     line_start = line_start[line_start < len(buf)]
     headers = line_start[buf[line_start] == 62]
+    newlines = np.flatnonzero(buf == 10)
     out: list[tuple[str, bytes]] = []
     bounds = np.r_[headers, len(buf)]
-    for h, nxt in zip(bounds[:-1], bounds[1:]):
-        eol = h + int(np.argmax(buf[h:nxt] == 10)) if (buf[h:nxt] == 10).any() else nxt
+    for h, nxt in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
+        k = int(np.searchsorted(newlines, h))
+        eol = int(newlines[k]) if k < len(newlines) and newlines[k] < nxt else nxt
         words = data[h + 1 : eol].split()
         body = buf[min(eol + 1, nxt) : nxt]
         out.append((words[0].decode("utf-8", "replace") if words else "", body[~_WS[body]].tobytes()))

@@ -1,0 +1,114 @@
+"""FASTA ingest (native and Python), GenBank round trip, JSONL wire format and the CLI parser (no GPU needed)."""
+
+import gzip
+import json
+
+import numpy as np
+import pytest
+
+from kaptive_amd import _native
+from kaptive_amd.cli import build_parser, result_to_json, run_convert
+from kaptive_amd.core.genome import GenomeAssembly, parse_fasta_bytes
+from kaptive_amd.db import Database
+from kaptive_amd.db.genbank import database_from_genbank, write_genbank
+from kaptive_amd.serotyping.io import KaptiveRow
+from kaptive_amd.serotyping.models import SerotypingResult
+from kaptive_amd.synth import make_assembly, make_db
+from tests.golden_util import load_db
+
+
+def _messy_fasta(genome) -> bytes:
+    lines = [b"; comment before the first record", b""]
+    for i, r in enumerate(genome.contigs):
+        lines.append(b">" + r.id.encode() + (b" len=%d extra words" % len(r.seq) if i % 2 else b""))
+        width = 60 if i % 3 else 71
+        lines += [r.seq[j : j + width] for j in range(0, len(r.seq), width)]
+        if i % 4 == 0:
+            lines.append(b"")
+    return (b"\r\n" if len(genome.contigs) % 2 else b"\n").join(lines) + b"\n"
+
+
+def test_fasta_parsers_and_native_pack_agree(tmp_path):
+    db = load_db("k")
+    genome = make_assembly(db, seed=19, n_run=40, length=90_000, median_contigs=5, min_contig=200)
+    text = _messy_fasta(genome)
+    recs = parse_fasta_bytes(text)
+    assert [n for n, _ in recs] == list(genome.contigs.ids)
+    assert [s for _, s in recs] == [r.seq for r in genome.contigs]
+    packed, names = _native.fasta_pack(text)
+    ref = genome.packed()
+    assert names == genome.contigs.ids and packed.padded_len == ref.padded_len
+    for f in ("words", "ctg_start", "ctg_len", "n_runs"):
+        assert np.array_equal(getattr(packed, f), getattr(ref, f)), f
+    # files: plain and gzip, id = file name without the fasta suffix
+    p = tmp_path / "sample_7.fna.gz"
+    p.write_bytes(gzip.compress(text))
+    loaded = GenomeAssembly.from_file(p)
+    assert loaded.id == "sample_7" and loaded.contigs.ids == genome.contigs.ids
+    assert np.array_equal(loaded.contigs.seqs, genome.contigs.seqs)
+    with pytest.raises(NotImplementedError):
+        GenomeAssembly.from_file(tmp_path / "reads.fastq")
+    # degenerate inputs
+    for blob in (b"", b"no header at all\n", b">only_name\n", b">a\n\n>b\nACGT\n"):
+        pa, nm = _native.fasta_pack(blob)
+        assert len(nm) == len(parse_fasta_bytes(blob)) and pa.padded_len % 64 == 0
+
+
+@pytest.mark.parametrize("kind", ["kpsc_k", "kpsc_o"])
+def test_genbank_round_trip(kind, tmp_path):
+    db = make_db(kind, seed=5, n_loci=6 if kind == "kpsc_k" else None)
+    path = write_genbank(db, tmp_path / f"{kind}.gbk", antigen_word="K" if kind == "kpsc_k" else "O")
+    back = database_from_genbank(path)
+    assert back.loci.ids == db.loci.ids and back.genes.ids == db.genes.ids and back.serotypes == db.serotypes
+    for f in ("locus_gene_offsets", "locus_gene_lengths", "extra_genes", "gene_locus_indices", "gene_cluster_ids",
+              "gene_description_ids", "gene_positions"):  # fmt: skip
+        assert np.array_equal(getattr(back, f), getattr(db, f)), f
+    assert np.array_equal(back.genes.seqs, db.genes.seqs) and np.array_equal(back.translations.seqs, db.translations.seqs)
+    assert back.cluster_keys == db.cluster_keys and back.metadata.id_threshold == db.metadata.id_threshold
+    assert np.array_equal(back.phenotypes.locus_masks, db.phenotypes.locus_masks)
+    assert np.array_equal(back.phenotypes.extra_masks, db.phenotypes.extra_masks)
+    # blob round trip of the compiled database
+    again = Database.load(back.save(tmp_path / "db.npz"))
+    assert again.genes.ids == db.genes.ids and np.array_equal(again.loci.seqs, db.loci.seqs)
+
+
+def test_jsonl_round_trip_and_convert(tmp_path, oracle):
+    from tests.test_sharding_gloo import _rows_for
+    from kaptive_amd.core.pairwise import PairwiseAlignments
+    from kaptive_amd.serotyping.core import Serotyper
+    from tests.golden_util import hits_to_alignments, load_case
+
+    key, genome, hits, exp, scalars, _ = load_case("o_extra2")
+    db = load_db(key)
+    typer = Serotyper(
+        db, aligner=lambda g: hits_to_alignments(db, g, hits),
+        protein_aligner=lambda q, t: PairwiseAlignments.from_table(
+            oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)),
+    )  # fmt: skip
+    res = typer(genome)
+    line = result_to_json(res)
+    back = SerotypingResult.from_dict(json.loads(line))
+    assert bytes(KaptiveRow.from_result(back)) == bytes(KaptiveRow.from_result(res))
+    assert back.problems == res.problems and back.translations.ids == res.translations.ids
+    # NaN length discrepancy survives (fragmented locus)
+    key2, genome2, hits2, *_ = load_case("k_split")
+    db2 = load_db(key2)
+    res2 = Serotyper(db2, aligner=lambda g: hits_to_alignments(db2, g, hits2), protein_aligner=typer._protein_aligner)(genome2)
+    jl = tmp_path / "r.jsonl"
+    jl.write_bytes(line + result_to_json(res2))
+    args = build_parser().parse_args(["convert", str(jl), "-t", str(tmp_path / "o.tsv")])
+    assert run_convert(args) == 0
+    rows = (tmp_path / "o.tsv").read_bytes().splitlines(keepends=True)
+    assert rows[0] == KaptiveRow.header() and rows[1] == bytes(KaptiveRow.from_result(res))
+    assert rows[2] == bytes(KaptiveRow.from_result(res2)) and b"\tn/a\t" in rows[2]
+
+
+def test_cli_parser_matches_reference_flags():
+    ap = build_parser()
+    a = ap.parse_args(["assembly", "db.npz", "a.fasta", "b.fna.gz", "-o", "out.tsv", "-j", "out.jsonl", "--max-other-genes",
+                       "2", "--min-completeness", "0.7", "--below-threshold", "-t", "4", "--partial-edge-tolerance", "9",
+                       "-l", "loci", "-g", "genes", "-p", "prot", "--pha4ge", "p.tsv", "-V"])  # fmt: skip
+    assert a.genomes == ["a.fasta", "b.fna.gz"] and a.max_other_genes == 2 and a.min_completeness == 0.7
+    assert a.below_threshold and a.threads == 4 and a.partial_edge_tolerance == 9 and a.out == "out.tsv"
+    b = ap.parse_args(["type", "db.npz", "x.fa"])
+    assert b.func is a.func and b.max_other_genes == 1 and b.min_completeness == 0.5 and not b.below_threshold

@@ -302,3 +302,29 @@ def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
     for g, r in zip(genomes, many):
         _results_equal(r, typer(g), g.id)
     typer.engine.close()
+
+
+def test_cli_types_fasta_files_like_the_reference(tmp_path):
+    """`python -m kaptive_amd assembly db.npz *.fasta -o out.tsv -j out.jsonl`: rows equal the reference's golden rows."""
+    from kaptive_amd import KAPTIVE_COMPAT_VERSION
+    from kaptive_amd.cli import main
+    from kaptive_amd.serotyping.io import KaptiveRow
+
+    names = ["k_plain1", "k_split", "k_nolocus", "k_is", "k_nrun"]
+    paths, want = [], []
+    for n in names:
+        key, genome, hits, exp, scalars, _ = load_case(n)
+        p = tmp_path / f"{genome.id}.fasta"
+        p.write_bytes(genome.contigs.to_fasta())
+        paths.append(str(p))
+        want.append(bytes(exp["kaptive_row"]).replace(scalars["kaptive_version"].encode(), KAPTIVE_COMPAT_VERSION.encode(), 1))
+    db_path = load_db("k").save(tmp_path / "db_k.npz")
+    out, js = tmp_path / "out.tsv", tmp_path / "out.jsonl"
+    rc = main(["assembly", str(db_path), *paths, "-o", str(out), "-j", str(js), "-g", str(tmp_path / "genes"),
+               "--batch-size", "2", "-t", "2"])  # fmt: skip
+    assert rc == 0
+    rows = out.read_bytes().splitlines(keepends=True)
+    assert rows[0] == KaptiveRow.header() and rows[1:] == want
+    assert len(js.read_bytes().splitlines()) == len(names)
+    assert (tmp_path / "genes" / "k_plain1_kaptive_results.ffn").stat().st_size > 1000
+    assert main(["assembly", str(tmp_path / "missing.npz"), paths[0], "-o", str(out)]) == 1
