@@ -51,7 +51,8 @@ struct DevBuf {  // growable device allocation
 
 struct kp_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
+    hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
     std::string error;
     // resident database
     bool has_db = false;
@@ -130,7 +131,7 @@ struct kp_batch {
     bool hits_fetched = false;
     std::vector<int64_t> hit_off;
     int64_t stats[5] = {0, 0, 0, 0, 0};
-    hipEvent_t ev[4 + KP_N_CLASSES] = {};  // stage boundaries of the most recent alignment pass
+    hipEvent_t ev[4 + KP_N_CLASSES] = {};  // stage boundaries of the most recent alignment pass; the last one marks its end
     bool have_events = false;
 };
 
@@ -191,9 +192,9 @@ void fill_blosum(int8_t *m) {
 struct HostPosting { uint32_t key, gs, pos; };
 
 template <class T>
-int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n) {
+int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n, hipStream_t stream = nullptr) {
     KP_HIP_CHECK(ctx, buf.reserve(n));
-    if (n) KP_HIP_CHECK(ctx, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (n) KP_HIP_CHECK(ctx, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, stream ? stream : ctx->stream));
     return KP_OK;
 }
 
@@ -259,7 +260,8 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     kp_ctx *ctx = new (std::nothrow) kp_ctx();
     if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
     ctx->device = device_id;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipStreamCreate(&ctx->post)) != hipSuccess) {
         delete ctx;
         return kp_fail(nullptr, KP_EHIP, std::string("device setup failed: ") + hipGetErrorString(e));
     }
@@ -278,6 +280,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->post) (void)hipStreamSynchronize(ctx->post);
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
@@ -286,6 +289,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->d_prot_db_off.release(); ctx->d_prot_db_len.release();
     if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->post) (void)hipStreamDestroy(ctx->post);
     delete ctx;
 }
 
@@ -442,7 +446,11 @@ int kp_batch_create_device(kp_ctx *ctx, int32_t n_asm, const uint32_t *d_words, 
 
 void kp_batch_destroy(kp_batch *b) {
     if (!b) return;
-    if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+        (void)hipStreamSynchronize(b->ctx->post);
+    }
     if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
     if (b->have_events)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
@@ -539,18 +547,18 @@ static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b) {
         KP_HIP_CHECK(ctx, b->d_keys.reserve(n_asm * b->hit_cap * 3));
         KP_HIP_CHECK(ctx, b->d_hit_counts.reserve(2 * n_asm));
         KP_HIP_CHECK(ctx, b->d_cells.reserve(1));
-        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->stream));
-        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->post));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
         kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, b->d_tasks.p, b->d_results.p, b->d_counts.p + n_asm,
                                b->task_cap, b->d_hits_raw.p, b->d_hit_counts.p, b->hit_cap, b->d_keys.p, b->d_hits.p,
-                               b->d_hit_counts.p + n_asm, b->d_cells.p, ctx->stream);
+                               b->d_hit_counts.p + n_asm, b->d_cells.p, ctx->post);
         KP_HIP_CHECK(ctx, hipGetLastError());
         b->h_hit_counts.resize(2 * n_asm);
         unsigned long long cells = 0;
         KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_hit_counts.data(), b->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t),
-                                         hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, b->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                         hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, b->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         uint32_t max_raw = 0;
         for (size_t a = 0; a < n_asm; ++a) max_raw = std::max(max_raw, b->h_hit_counts[a]);
         if (max_raw <= b->hit_cap) { b->stats[2] = (int64_t)cells; break; }
@@ -570,12 +578,14 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
     for (int attempt = 0;; ++attempt) {
+        // the post stream picks up where this batch's alignment pass ends; later passes on ctx->stream are not waited for
+        KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->post, b->ev[3 + KP_N_CLASSES], 0));
         b->h_counts.resize(2 * n_asm + KP_N_CLASSES);
         KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
-                                         hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                         hipMemcpyDeviceToHost, ctx->post));
         unsigned long long n_cand = 0;
-        KP_HIP_CHECK(ctx, hipMemcpy(&n_cand, b->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&n_cand, b->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
@@ -620,9 +630,9 @@ int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
         const int64_t n = b->hit_off[a + 1] - b->hit_off[a];
         if (n > 0)
             KP_HIP_CHECK(ctx, hipMemcpyAsync(out + b->hit_off[a], b->d_hits.p + a * (size_t)b->hit_cap,
-                                             (size_t)n * sizeof(kp_hit), hipMemcpyDeviceToHost, ctx->stream));
+                                             (size_t)n * sizeof(kp_hit), hipMemcpyDeviceToHost, ctx->post));
     }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
     return KP_OK;
 }
 
@@ -712,7 +722,7 @@ int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *t) {
     if ((rc = upload(ctx, ctx->d_prot_db, t->prot, prot_bytes))) return rc;
     if ((rc = upload(ctx, ctx->d_prot_db_off, t->prot_off, G))) return rc;
     if ((rc = upload(ctx, ctx->d_prot_db_len, t->prot_len, G))) return rc;
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
     ctx->typing = KpTypingDb{ctx->d_gene_locus.p, ctx->d_gene_extra.p, ctx->d_gene_pos.p, ctx->d_gene_strand.p,
                              ctx->d_gene_len.p, ctx->d_locus_off.p, ctx->d_locus_len.p, ctx->d_prot_db.p,
                              ctx->d_prot_db_off.p, ctx->d_prot_db_len.p, ctx->n_genes, (int32_t)t->n_loci};
@@ -730,13 +740,13 @@ int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *l
     KP_HIP_CHECK(ctx, b->d_scores.reserve(n));
     KP_HIP_CHECK(ctx, b->d_lcounts.reserve(n));
     kp_launch_score(b->view, b->d_hits.p, b->d_hit_counts.p + b->n_asm, b->hit_cap, ctx->typing, min_gene_coverage,
-                    b->d_scores.p, b->d_lcounts.p, ctx->stream);
+                    b->d_scores.p, b->d_lcounts.p, ctx->post);
     KP_HIP_CHECK(ctx, hipGetLastError());
     if (n) {
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, b->d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, b->d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, b->d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, b->d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->post));
     }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
     b->prm.min_gene_coverage = min_gene_coverage;
     b->scored = true;
     return KP_OK;
@@ -757,10 +767,10 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, b->d_dp.reserve(8 * slots));
     int32_t *q_off = b->d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
     int32_t *pair_base = t_len + slots, *n_pairs = pair_base + n_asm;
-    KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), ctx->post));
     kp_launch_reduce(b->view, b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, ctx->typing, b->prm, b->d_best.p,
                      b->d_keys.p, b->d_order.p, b->d_flag.p, b->d_kept.p, b->kept_cap, b->d_pieces.p, b->piece_cap,
-                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->stream);
+                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->post);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
     const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 24);
     // widest band: 2 * max(20, |len difference| + 1) + 1.  A hit's target span is at most gene length + band drift
@@ -769,9 +779,9 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
     const size_t scratch_per_block = (2 * (longest + 2) + 1) * 12;
     KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
     kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
-                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->stream);
+                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post);
     kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, pair_base,
-                     ctx->stream);
+                     ctx->post);
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -786,7 +796,8 @@ int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const k
     if (b->kept_cap == 0) b->kept_cap = (int)env_u32("KAPTIVE_AMD_KEPT_CAP", 256);
     if (b->piece_cap == 0) b->piece_cap = (int)env_u32("KAPTIVE_AMD_PIECE_CAP", 32);
     if (b->prot_cap == 0) b->prot_cap = (int)env_u32("KAPTIVE_AMD_PROT_CAP", 32768);
-    int rc = upload(ctx, b->d_best, best_locus, (size_t)b->n_asm);
+    int rc = upload(ctx, b->d_best, best_locus, (size_t)b->n_asm, ctx->post);
+    if (rc == KP_OK && hipStreamSynchronize(ctx->post) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "H2D best loci failed");
     if (rc) return rc;
     rc = enqueue_reduce(ctx, b);
     if (rc) return rc;
@@ -805,8 +816,8 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
     for (int attempt = 0;; ++attempt) {
         if (n_asm)
             KP_HIP_CHECK(ctx, hipMemcpyAsync(sums.data(), b->d_summary.p, n_asm * sizeof(KpAsmSummary),
-                                             hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                             hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         int flags = 0;
         for (const auto &s : sums) flags |= s.overflow;
         if (!(flags & (1 | 2 | 8))) break;
@@ -838,10 +849,10 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
     if (n_asm && kept_stride == b->kept_cap && piece_stride == b->piece_cap) {  // same layout: two bulk copies
         std::memcpy(summaries, sums.data(), n_asm * sizeof(KpAsmSummary));
         KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, b->d_kept.p, n_asm * (size_t)b->kept_cap * sizeof(KpKept),
-                                         hipMemcpyDeviceToHost, ctx->stream));
+                                         hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, b->d_pieces.p, n_asm * (size_t)b->piece_cap * sizeof(KpPiece),
-                                         hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                                         hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         ident_sums();
         return KP_OK;
     }
@@ -851,12 +862,12 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         summaries[a] = sums[a];
         if (sums[a].n_kept)
             KP_HIP_CHECK(ctx, hipMemcpyAsync(kept + a * (size_t)kept_stride, b->d_kept.p + a * (size_t)b->kept_cap,
-                                             (size_t)sums[a].n_kept * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->stream));
+                                             (size_t)sums[a].n_kept * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->post));
         if (sums[a].n_pieces)
             KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces + a * (size_t)piece_stride, b->d_pieces.p + a * (size_t)b->piece_cap,
-                                             (size_t)sums[a].n_pieces * sizeof(KpPiece), hipMemcpyDeviceToHost, ctx->stream));
+                                             (size_t)sums[a].n_pieces * sizeof(KpPiece), hipMemcpyDeviceToHost, ctx->post));
     }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
     ident_sums();
     return KP_OK;
 }

@@ -60,7 +60,19 @@ __global__ __launch_bounds__(64) void kp_hit_sort_kernel(const kp_hit *__restric
     for (uint32_t i = lane; i < n; i += 64) {  // rank sort: all lanes read the same key j -> LDS broadcast
         const uint64_t mine[3] = {k[3 * (size_t)i], k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t n_lds = n < SORT_LDS ? n : SORT_LDS;
+        uint32_t j = 0;
+        for (; j + 8 <= n_lds; j += 8) {  // eight broadcast reads in flight, then eight compares
+            uint64_t o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = s_k0[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (o[u] < mine[0]) ++rank;
+                else if (o[u] == mine[0]) rank += kp_keys_less(k + 3 * (size_t)(j + u), j + u, mine, i) ? 1u : 0u;
+            }
+        }
+        for (; j < n; ++j) {
             const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
             if (other < mine[0]) ++rank;
             else if (other == mine[0]) rank += kp_keys_less(k + 3 * (size_t)j, j, mine, i) ? 1u : 0u;
@@ -141,8 +153,16 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         const uint64_t mine = k[i];
         uint32_t rank = 0;
         const int n_lds = n < SORT_LDS ? n : SORT_LDS;
-        for (int j = 0; j < n_lds; ++j) rank += s_raw[j] < mine ? 1u : 0u;
-        for (int j = n_lds; j < n; ++j) rank += k[j] < mine ? 1u : 0u;
+        int j = 0;
+        for (; j + 8 <= n_lds; j += 8) {
+            uint64_t o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = s_raw[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += o[u] < mine ? 1u : 0u;
+        }
+        for (; j < n_lds; ++j) rank += s_raw[j] < mine ? 1u : 0u;
+        for (j = n_lds; j < n; ++j) rank += k[j] < mine ? 1u : 0u;
         ord[rank] = (uint32_t)i;
     }
     __syncthreads();

@@ -93,6 +93,27 @@ class Engine:
         sums, kept, pieces = batch.typing()
         return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes)
 
+    def type_batches(self, typer, batches: Sequence, ids: Sequence[Sequence[str]], aligned: bool = False) -> list:
+        """Several resident batches through the same context, software-pipelined: all alignment passes are enqueued up
+        front and every host-side step of batch i (reading scores back, choosing best loci, copying records,
+        array finishing) runs while the device works on batches i+1..: the stream never waits for the host."""
+        from kaptive_amd.serotyping import batch as B
+
+        if not aligned:
+            for b in batches:
+                b.align_async()
+        staged = []
+        for b in batches:  # score needs the host in the loop (numpy argmax); reductions are enqueued as scores arrive
+            scores, counts = b.score(typer.min_gene_coverage)
+            best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
+            b.reduce_async(best, self.typing_params(typer))
+            staged.append((scores, best))
+        out = []
+        for b, i, (scores, best) in zip(batches, ids, staged):
+            sums, kept, pieces = b.typing()
+            out.append(B.BatchTyping(typer, i, sums, kept, pieces, scores, best))
+        return out
+
     def type_many(self, typer, genomes: Sequence[GenomeAssembly]) -> list:
         """One device submission for all genomes: alignment and reduction both run on the GPU."""
         batch = self.ctx.batch([g.packed() for g in genomes])
