@@ -123,7 +123,7 @@ def main() -> None:
     ap.add_argument("--length", type=float, default=5.0e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
-    ap.add_argument("--sub-batches", type=int, default=4,
+    ap.add_argument("--sub-batches", type=int, default=1,
                     help="resident device batches per database; they are software-pipelined so that host-side steps of "
                          "one overlap device work of the next")
     args = ap.parse_args()
@@ -177,7 +177,9 @@ def main() -> None:
             for b in batches:
                 b.align_async()
         out = []
-        for eng, typer, batches in stages:
+        # host-side steps of the smaller database first: its alignment pass ends long before the big one's, so its
+        # score / reduce / finish run while the device is still aligning the other
+        for eng, typer, batches in sorted(stages, key=lambda st: len(st[0].db.genes)):
             out += eng.type_batches(typer, batches, sub_ids, aligned=True)
         return out
 
