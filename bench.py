@@ -82,6 +82,22 @@ def build_workload(n_asm: int, seed0: int, length: float, workers: int):
     return _DBS["k"], _DBS["o"], genomes, packed
 
 
+def pmc_traffic(args):
+    """HBM bytes per scan launch from the PMC counters. Counters cannot be read from inside the process, so this is
+    the figure of the committed offline collection (profiles/scan_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE passes of this same command, gfx950 correction applied as MI355X_MICROARCH.md prescribes); it is
+    reported only when the workload is the one that collection ran, otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_pmc.json")
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+    except OSError:
+        return None
+    if pmc["workload"] != {"assemblies": args.assemblies, "length": args.length}:
+        return None
+    return pmc["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(dbs, genomes, budget_s: float = 20.0) -> dict:
     """Type a bounded sample with the CPU oracle (C aligner + C protein DP + numpy reduction), one core."""
     from kaptive_amd.core.pairwise import PairwiseAlignments
@@ -245,7 +261,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "kernel": "kp_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": scan_bytes,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args), "bytes_per_launch": scan_bytes,
                 "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
             },
             "dp": {

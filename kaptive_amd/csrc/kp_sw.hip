@@ -4,89 +4,135 @@
 // fields consumed at src/kaptive/core/alignment.py:415-446).  Recurrence, tie rules and scores: include/kp_spec.h.
 //
 // Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
-//   * a task's band has W = 2P diagonals; P lanes own it, lane l holds diagonals 2l ("A") and 2l+1 ("B");
-//     a 64-lane wave therefore runs 64/P tasks side by side (P = 8/16/32/64 for W = 16/32/64/128).
-//   * time is skewed by lane: at macro step m lane l works on query row r = m - l, first cell A then cell B.  With that
-//     skew A's left neighbour is lane l-1's B of the previous step, B's upper neighbour is lane l+1's A of the
-//     same step, and everything else is the lane's own previous row -- two one-lane wave shifts per macro step, both
-//     done with DPP (v_mov_b32_dpp wave_shr:1 / wave_shl:1), all state stays in registers.
-//   * sequences are streamed systolically: the query code enters at lane 0 and moves up one lane per step, the
-//     target code enters at lane P-1 and moves down; each group stages its query chunk and target window as 4-bit
-//     codes in LDS (N = 4, outside-contig = 5), so N runs and contig ends need no special path.
+//   * a task's band has W = 4P diagonals; P lanes own it, lane l holds the four adjacent diagonals 4l .. 4l+3 (cells
+//     A..D); a 64-lane wave therefore runs 64/P tasks side by side (P = 4/8/16/32 for W = 16/32/64/128).
+//   * time is skewed by lane: at step m lane l works on query row r = m - l, cells A, B, C, D in that order.  With
+//     that skew A's left neighbour is lane l-1's D of the previous step, D's upper neighbour is lane l+1's A of the
+//     same step, and every other neighbour is one of the lane's own registers -- two one-lane shifts per step, both
+//     done with DPP (v_mov_b32_dpp row_shr:1 / row_shl:1, wave_* for the 32-lane class), all state stays in registers.
+//   * sequences are streamed systolically: the query enters at lane 0 as a per-row score profile (five 6-bit signed
+//     fields indexed by the target code, so a substitution score is one v_bfe_i32) and moves up one lane per step, the
+//     target code enters at lane P-1 and moves down; both are staged per chunk in LDS (N and outside-contig have their
+//     own codes, so N runs and contig ends need no special path).
+//   * the gap states are kept pre-charged (H - open - ext, E - ext, F - ext), so E and F of a neighbour are one max.
 //   * start coordinates, matches and column counts ride along with the scores ("carry-forward" of the traceback): every
 //     state value carries the payload of the predecessor it was derived from, chosen by exactly the tie rules the
 //     oracle's stored traceback uses, so no DP matrix is ever written to memory.
+//   * steps whose rows and target positions are all inside the task (the bulk) run a variant without boundary masks.
 //   * the best cell of a task is found with a wave-level max reduction over (score, first row, first column).
 #include "kp_internal.h"
 
 namespace {
 
-constexpr int CH = 1024;  // macro steps staged per chunk
+constexpr int CH = 128;  // steps staged per chunk
 constexpr int NEG = KP_NEG_INF;
 constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
+constexpr unsigned T_OUT = 30u;  // profile field offset standing for "outside the contig" (no such field)
+// score profile of a query row: field t (6 bits, signed, at bit 6t) = score against target code t (0..3 ACGT, 4 = N)
+constexpr unsigned PROF_N = 0x3FFFFFFFu;  // KP_SC_N in every field
+constexpr unsigned PROF_MISMATCH = 0x3Cu | (0x3Cu << 6) | (0x3Cu << 12) | (0x3Cu << 18) | (0x3Fu << 24);
+static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1, "profile constants encode these scores");
 
-// One-lane wave shifts.  The lane without a source (0 resp. 63) reads 0 (bound_ctrl); every group-edge lane overrides
-// what it receives anyway, so no "old" operand (and no extra v_mov) is needed.
-__device__ __forceinline__ int dpp_from_lower(int v) {  // lane i <- lane i-1
-    return __builtin_amdgcn_mov_dpp(v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+// One-lane shifts.  The lane without a source reads 0 (bound_ctrl); every group-edge lane overrides what it receives
+// anyway.  Groups of up to 16 lanes never straddle a DPP row, so the row shifts do; the 32-lane class needs wave shifts.
+template <bool ROW>
+__device__ __forceinline__ int from_lower(int v) {  // lane i <- lane i-1
+    return ROW ? __builtin_amdgcn_mov_dpp(v, 0x111 /*row_shr:1*/, 0xf, 0xf, true)
+               : __builtin_amdgcn_mov_dpp(v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
-__device__ __forceinline__ int dpp_from_upper(int v) {  // lane i <- lane i+1
-    return __builtin_amdgcn_mov_dpp(v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+template <bool ROW>
+__device__ __forceinline__ int from_upper(int v) {  // lane i <- lane i+1
+    return ROW ? __builtin_amdgcn_mov_dpp(v, 0x101 /*row_shl:1*/, 0xf, 0xf, true)
+               : __builtin_amdgcn_mov_dpp(v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
 }
-
-struct Cell {
-    int h, e, f;
-    unsigned hp_lo, hp_hi;  // payload of h: lo = matches << 16 | columns, hi = start_row << 8 | start_band_index
-    unsigned ep_lo, ep_hi;
-    unsigned fp_lo, fp_hi;
-};
-
-struct Best {
-    int score, end_r;
-    unsigned p_lo, p_hi;
-};
 
 __device__ __forceinline__ unsigned nibble(unsigned word, int i) { return (word >> (4 * i)) & 15u; }
-
-// one DP cell; `left`/`up` give (h, gap score, payloads) of the neighbours, `diag_h`/`diag_p` the diagonal one
-__device__ __forceinline__ void dp_cell(Cell &c, bool live, int r, int band_idx, unsigned qb, unsigned tb, int diag_h,
-                                        unsigned diag_lo, unsigned diag_hi, int left_h, int left_e, unsigned left_hlo,
-                                        unsigned left_hhi, unsigned left_elo, unsigned left_ehi, int up_h, int up_f,
-                                        unsigned up_hlo, unsigned up_hhi, unsigned up_flo, unsigned up_fhi, Best &best) {
-    if (!live) {  // outside the task (row out of range, target outside the contig): reads as boundary for its neighbours
-        c.h = 0; c.e = NEG; c.f = NEG;
-        return;
-    }
-    // E: gap in the query, arrives from the left
-    const int e_open = left_h - OE, e_ext = left_e - EX;
-    const bool eo = e_open >= e_ext;
-    const int e = eo ? e_open : e_ext;
-    const unsigned e_lo = (eo ? left_hlo : left_elo) + 1u, e_hi = eo ? left_hhi : left_ehi;
-    // F: gap in the target, arrives from above
-    const int f_open = up_h - OE, f_ext = up_f - EX;
-    const bool fo = f_open >= f_ext;
-    const int f = fo ? f_open : f_ext;
-    const unsigned f_lo = (fo ? up_hlo : up_flo) + 1u, f_hi = fo ? up_hhi : up_fhi;
-    // diagonal
-    const bool known = (qb | tb) < 4u;
-    const bool eq = known && (qb == tb);
-    const int s = known ? (eq ? KP_SC_MATCH : KP_SC_MISMATCH) : KP_SC_N;
-    const bool fresh = diag_h == 0;
-    unsigned p_lo = (fresh ? 0u : diag_lo) + (eq ? 0x10001u : 1u);
-    unsigned p_hi = fresh ? (((unsigned)r << 8) | (unsigned)band_idx) : diag_hi;
-    int bestv = diag_h + s;
-    if (e > bestv) { bestv = e; p_lo = e_lo; p_hi = e_hi; }
-    if (f > bestv) { bestv = f; p_lo = f_lo; p_hi = f_hi; }
-    const int h = bestv > 0 ? bestv : 0;
-    c.h = h; c.e = e; c.f = f;
-    c.hp_lo = p_lo; c.hp_hi = p_hi;
-    c.ep_lo = e_lo; c.ep_hi = e_hi;
-    c.fp_lo = f_lo; c.fp_hi = f_hi;
-    if (h > best.score) { best.score = h; best.end_r = r; best.p_lo = p_lo; best.p_hi = p_hi; }
+__device__ __forceinline__ unsigned row_profile(unsigned qcode) {
+    return qcode < 4u ? (PROF_MISMATCH ^ (0x3Eu << (6u * qcode))) : PROF_N;  // -4 ^ 0x3E = +2 in the matching field
 }
 
-// target code at window position x (relative to the band's lowest diagonal) for one task
+// payload words: lo = matches << 16 | columns, hi = start_row << 8 | start_band_index
+struct Cell {
+    int h, hmoe, emex, fmex;  // H, H - (open + ext), E - ext, F - ext
+    unsigned hlo, hhi, elo, ehi, flo, fhi;
+};
+struct Gap {  // what a neighbour offers: its pre-charged H and gap state with their payloads
+    int hmoe, gmex;
+    unsigned hlo, hhi, glo, ghi;
+};
+struct Best {
+    int score, r;
+    unsigned lo, hi;
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void dp_cell(Cell &c, Best &best, int r, unsigned start_key, unsigned prof, unsigned tsh,
+                                        bool row_ok, const Gap &left, const Gap &up) {
+    // E: gap in the query, arrives from the left; F: gap in the target, arrives from above (open wins ties)
+    const bool eo = left.hmoe >= left.gmex;
+    const int e = max(left.hmoe, left.gmex);
+    const unsigned e_lo = (eo ? left.hlo : left.glo) + 1u, e_hi = eo ? left.hhi : left.ghi;
+    const bool fo = up.hmoe >= up.gmex;
+    const int f = max(up.hmoe, up.gmex);
+    const unsigned f_lo = (fo ? up.hlo : up.glo) + 1u, f_hi = fo ? up.hhi : up.ghi;
+    // diagonal: the lane's own previous row
+    const int s = __builtin_amdgcn_sbfe((int)prof, tsh, 6u);
+    const bool fresh = c.h == 0;
+    unsigned p_lo = (fresh ? 0u : c.hlo) + ((unsigned)max(s, 0) * 0x8000u + 1u);  // +1 column, +1 match when s == 2
+    unsigned p_hi = fresh ? start_key : c.hhi;
+    int bestv = c.h + s;
+    if (e > bestv) { bestv = e; p_lo = e_lo; p_hi = e_hi; }
+    if (f > bestv) { bestv = f; p_lo = f_lo; p_hi = f_hi; }
+    int h = max(bestv, 0), emex = e - EX, fmex = f - EX;
+    if (MASKED) {  // outside the task (row out of range, target outside the contig): reads as boundary for its neighbours
+        const bool live = row_ok && tsh != T_OUT;
+        h = live ? h : 0; emex = live ? emex : NEG; fmex = live ? fmex : NEG;
+    }
+    c.h = h; c.hmoe = h - OE; c.emex = emex; c.fmex = fmex;
+    c.hlo = p_lo; c.hhi = p_hi; c.elo = e_lo; c.ehi = e_hi; c.flo = f_lo; c.fhi = f_hi;
+    if (h > best.score) { best.score = h; best.r = r; best.lo = p_lo; best.hi = p_hi; }
+}
+
+__device__ __forceinline__ Gap as_left(const Cell &c) { return Gap{c.hmoe, c.emex, c.hlo, c.hhi, c.elo, c.ehi}; }
+__device__ __forceinline__ Gap as_up(const Cell &c) { return Gap{c.hmoe, c.fmex, c.hlo, c.hhi, c.flo, c.fhi}; }
+
+struct State {
+    Cell A, B, C, D;
+    Best bA, bB, bC, bD;
+    unsigned qb, t0, t1, t2, t3;
+};
+
+template <int P, bool MASKED>
+__device__ __forceinline__ void dp_step(State &s, int m, int l, int qlen, unsigned prof_in, unsigned t_in) {
+    constexpr bool ROW = P <= 16;
+    const unsigned q_shift = (unsigned)from_lower<ROW>((int)s.qb);
+    s.qb = (l == 0) ? prof_in : q_shift;  // profile of row m enters at lane 0
+    const int r = m - l;
+    const bool row_ok = MASKED ? ((unsigned)r < (unsigned)qlen) : true;
+    const unsigned key = ((unsigned)r << 8) | (unsigned)(4 * l);
+
+    Gap left;  // lane l-1's D of the previous step
+    left.hmoe = from_lower<ROW>(s.D.hmoe); left.gmex = from_lower<ROW>(s.D.emex);
+    left.hlo = (unsigned)from_lower<ROW>((int)s.D.hlo); left.hhi = (unsigned)from_lower<ROW>((int)s.D.hhi);
+    left.glo = (unsigned)from_lower<ROW>((int)s.D.elo); left.ghi = (unsigned)from_lower<ROW>((int)s.D.ehi);
+    if (l == 0) { left.hmoe = -OE; left.gmex = NEG; }
+    dp_cell<MASKED>(s.A, s.bA, r, key, s.qb, s.t0, row_ok, left, as_up(s.B));
+    dp_cell<MASKED>(s.B, s.bB, r, key + 1u, s.qb, s.t1, row_ok, as_left(s.A), as_up(s.C));
+    dp_cell<MASKED>(s.C, s.bC, r, key + 2u, s.qb, s.t2, row_ok, as_left(s.B), as_up(s.D));
+    Gap up;  // lane l+1's A of this step
+    up.hmoe = from_upper<ROW>(s.A.hmoe); up.gmex = from_upper<ROW>(s.A.fmex);
+    up.hlo = (unsigned)from_upper<ROW>((int)s.A.hlo); up.hhi = (unsigned)from_upper<ROW>((int)s.A.hhi);
+    up.glo = (unsigned)from_upper<ROW>((int)s.A.flo); up.ghi = (unsigned)from_upper<ROW>((int)s.A.fhi);
+    if (l == P - 1) { up.hmoe = -OE; up.gmex = NEG; }
+    dp_cell<MASKED>(s.D, s.bD, r, key + 3u, s.qb, s.t3, row_ok, as_left(s.C), up);
+
+    const unsigned t_shift = (unsigned)from_upper<ROW>((int)s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
+    s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
+    s.t3 = (l == P - 1) ? t_in : t_shift;  // target code x = m + 1 + 3P enters at lane P-1
+}
+
+// target code at window position t (assembly coordinates) for one task
 __device__ __forceinline__ unsigned target_code(const uint32_t *__restrict__ asm_words, int32_t t, int32_t cstart,
                                                 int32_t cend, const int32_t *__restrict__ runs, int n_runs) {
     if (t < cstart || t >= cend) return 5u;
@@ -107,9 +153,10 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
                                                    const uint32_t *__restrict__ order,
                                                    KpSwResult *__restrict__ results) {
     constexpr int G = 64 / P;
-    constexpr int TW = (CH + P + 1 + 7) / 8 + 1;  // words of staged target codes per group
-    __shared__ uint32_t s_q[G][CH / 8];
-    __shared__ uint32_t s_t[G][TW];
+    constexpr int W = 4 * P;
+    constexpr int TW = CH + 3 * P + 4;  // staged target codes per chunk: window x in [m0, m0 + CH + 3P]
+    __shared__ uint32_t s_prof[G][CH];
+    __shared__ uint8_t s_t[G][TW];
 
     const int lane = threadIdx.x;
     const int g = lane / P, l = lane % P;
@@ -134,85 +181,62 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
         const int32_t *runs = b.n_runs + 2 * (size_t)r0;
         const int lo = tk.lo;
 
-        int steps = have ? qlen + P - 1 : 0;  // macro steps this group needs
-        int max_steps = steps;
+        const int steps = have ? qlen + P - 1 : 0;  // steps this group needs
+        int max_steps = steps, min_q = qlen;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, o));
+        for (int o = 32; o >= 1; o >>= 1) {
+            max_steps = max(max_steps, __shfl_xor(max_steps, o));
+            min_q = min(min_q, __shfl_xor(min_q, o));
+        }
+        // every cell of every task of the wave inside its contig: steps P-1 .. min_q-1 need no boundary masks
+        const bool all_inside = __all(have && lo >= cstart && lo + qlen + W <= cend);
 
-        Cell A, B;
-        A.h = B.h = 0; A.e = B.e = A.f = B.f = NEG;
-        A.hp_lo = A.hp_hi = A.ep_lo = A.ep_hi = A.fp_lo = A.fp_hi = 0;
-        B = A;
-        Best bestA{0, 0, 0, 0}, bestB{0, 0, 0, 0};
-        unsigned qb = 4, t0 = 5, t1 = 5, qword = 0, tword = 0;
+        State st;
+        st.A.h = 0; st.A.hmoe = -OE; st.A.emex = NEG; st.A.fmex = NEG;
+        st.A.hlo = st.A.hhi = st.A.elo = st.A.ehi = st.A.flo = st.A.fhi = 0;
+        st.B = st.A; st.C = st.A; st.D = st.A;
+        st.bA = Best{0, 0, 0, 0}; st.bB = st.bA; st.bC = st.bA; st.bD = st.bA;
+        st.qb = PROF_N; st.t0 = st.t1 = st.t2 = st.t3 = T_OUT;
 
         for (int m0 = 0; m0 < max_steps; m0 += CH) {
-            // ---- stage this chunk: query rows [m0, m0+CH) and target window x in [m0, m0+CH+P] --------------------
+            // ---- stage this chunk: profiles of query rows [m0, m0+CH), target codes of window x in [m0, m0+CH+3P] ----
             __syncthreads();
             for (int w = l; w < CH / 8; w += P) {
                 const int r = m0 + 8 * w;
-                s_q[g][w] = (have && r < qlen) ? qnib[r >> 3] : 0x44444444u;
-            }
-            for (int w = l; w < TW; w += P) {
-                unsigned word = 0;
-                if (have) {
+                const uint32_t word = (have && r < qlen) ? qnib[r >> 3] : 0x44444444u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        word |= target_code(asm_words, lo + m0 + 8 * w + i, cstart, cend, runs, n_runs) << (4 * i);
-                } else word = 0x55555555u;
-                s_t[g][w] = word;
+                for (int i = 0; i < 8; ++i) s_prof[g][8 * w + i] = row_profile(nibble(word, i));
+            }
+            for (int x = l; x < TW; x += P) {
+                const unsigned code = have ? target_code(asm_words, lo + m0 + x, cstart, cend, runs, n_runs) : 5u;
+                s_t[g][x] = (uint8_t)(code < 5u ? 6u * code : T_OUT);
             }
             __syncthreads();
-            if (m0 == 0) {  // initial window: lane l holds target codes x = l and l + 1
-                t0 = nibble(s_t[g][l >> 3], l & 7);
-                t1 = nibble(s_t[g][(l + 1) >> 3], (l + 1) & 7);
+            if (m0 == 0) {  // initial window: cell k of lane l sits on x = 3l + k
+                st.t0 = s_t[g][3 * l]; st.t1 = s_t[g][3 * l + 1]; st.t2 = s_t[g][3 * l + 2]; st.t3 = s_t[g][3 * l + 3];
             }
             const int m_end = min(m0 + CH, max_steps);
-            for (int m = m0; m < m_end; ++m) {
-                const int k = m & 7;
-                if (k == 0) {
-                    qword = s_q[g][(m - m0) >> 3];
-                    tword = s_t[g][(m - m0 + P) >> 3];
+            int m = m0;
+            while (m < m_end) {
+                if (all_inside && m >= P - 1 && m + 4 <= min_q && m + 4 <= m_end) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        dp_step<P, false>(st, m + u, l, qlen, s_prof[g][m - m0 + u], s_t[g][m - m0 + u + 3 * P + 1]);
+                    m += 4;
+                } else {
+                    dp_step<P, true>(st, m, l, qlen, s_prof[g][m - m0], s_t[g][m - m0 + 3 * P + 1]);
+                    m += 1;
                 }
-                // ---- systolic sequence feeds ----------------------------------------------------------------------
-                const unsigned q_in = nibble(qword, k);        // q[m] enters at lane 0
-                const unsigned t_in = nibble(tword, k);        // target code x = m + P enters at lane P-1
-                const unsigned q_shift = (unsigned)dpp_from_lower((int)qb);
-                const unsigned t_shift = (unsigned)dpp_from_upper((int)t1);
-                if (m > 0) {
-                    t0 = t1;
-                    t1 = (l == P - 1) ? t_in : t_shift;
-                }
-                qb = (l == 0) ? q_in : q_shift;
-                const int r = m - l;
-                const bool row_ok = (unsigned)r < (unsigned)qlen;
-
-                // ---- cell A (band index 2l): left neighbour = lane l-1's B of the previous step --------------------
-                int lh = dpp_from_lower(B.h), le = dpp_from_lower(B.e);
-                unsigned lhlo = (unsigned)dpp_from_lower((int)B.hp_lo), lhhi = (unsigned)dpp_from_lower((int)B.hp_hi);
-                unsigned lelo = (unsigned)dpp_from_lower((int)B.ep_lo), lehi = (unsigned)dpp_from_lower((int)B.ep_hi);
-                if (l == 0) { lh = 0; le = NEG; }
-                const int a_dh = A.h; const unsigned a_dlo = A.hp_lo, a_dhi = A.hp_hi;
-                const int b_dh = B.h; const unsigned b_dlo = B.hp_lo, b_dhi = B.hp_hi;
-                dp_cell(A, row_ok && t0 != 5u, r, 2 * l, qb, t0, a_dh, a_dlo, a_dhi, lh, le, lhlo, lhhi, lelo, lehi,
-                        B.h, B.f, B.hp_lo, B.hp_hi, B.fp_lo, B.fp_hi, bestA);
-
-                // ---- cell B (band index 2l+1): upper neighbour = lane l+1's A of this step -------------------------
-                int uh = dpp_from_upper(A.h), uf = dpp_from_upper(A.f);
-                unsigned uhlo = (unsigned)dpp_from_upper((int)A.hp_lo), uhhi = (unsigned)dpp_from_upper((int)A.hp_hi);
-                unsigned uflo = (unsigned)dpp_from_upper((int)A.fp_lo), ufhi = (unsigned)dpp_from_upper((int)A.fp_hi);
-                if (l == P - 1) { uh = 0; uf = NEG; }
-                dp_cell(B, row_ok && t1 != 5u, r, 2 * l + 1, qb, t1, b_dh, b_dlo, b_dhi, A.h, A.e, A.hp_lo, A.hp_hi,
-                        A.ep_lo, A.ep_hi, uh, uf, uhlo, uhhi, uflo, ufhi, bestB);
             }
         }
 
         // ---- best cell of the task: max score, then first row, then first column ---------------------------------
-        int sc = bestA.score, er = bestA.end_r, eb = 2 * l;
-        unsigned plo = bestA.p_lo, phi = bestA.p_hi;
-        if (bestB.score > sc || (bestB.score == sc && bestB.end_r < er)) {
-            sc = bestB.score; er = bestB.end_r; eb = 2 * l + 1; plo = bestB.p_lo; phi = bestB.p_hi;
-        }
+        // (a lane visits its cells in column order and only replaces on a strictly higher score)
+        int sc = st.bA.score, er = st.bA.r, eb = 4 * l;
+        unsigned plo = st.bA.lo, phi = st.bA.hi;
+        if (st.bB.score > sc || (st.bB.score == sc && st.bB.r < er)) { sc = st.bB.score; er = st.bB.r; eb = 4 * l + 1; plo = st.bB.lo; phi = st.bB.hi; }
+        if (st.bC.score > sc || (st.bC.score == sc && st.bC.r < er)) { sc = st.bC.score; er = st.bC.r; eb = 4 * l + 2; plo = st.bC.lo; phi = st.bC.hi; }
+        if (st.bD.score > sc || (st.bD.score == sc && st.bD.r < er)) { sc = st.bD.score; er = st.bD.r; eb = 4 * l + 3; plo = st.bD.lo; phi = st.bD.hi; }
 #pragma unroll
         for (int o = 1; o < P; o <<= 1) {
             const int sc2 = __shfl_xor(sc, o), er2 = __shfl_xor(er, o), eb2 = __shfl_xor(eb, o);
@@ -242,11 +266,11 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
     // persistent-style grid: enough single-wave blocks to fill 256 CUs several times over; each strides over quads
     const dim3 grid(256 * 16), block(64);
     if (width == 16)
-        hipLaunchKernelGGL(kp_sw_kernel<8>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+        hipLaunchKernelGGL(kp_sw_kernel<4>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else if (width == 32)
-        hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+        hipLaunchKernelGGL(kp_sw_kernel<8>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else if (width == 64)
-        hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+        hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else
-        hipLaunchKernelGGL(kp_sw_kernel<64>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+        hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
 }
