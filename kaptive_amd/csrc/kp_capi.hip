@@ -60,7 +60,7 @@ struct kp_ctx {
     int64_t n_postings = 0;
     std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
     DevBuf<uint2> d_slots;
-    DevBuf<uint32_t> d_filter;
+    DevBuf<uint64_t> d_filter;
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
@@ -367,7 +367,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (log_slots > 30) return kp_fail(ctx, KP_EINVAL, "seed index too large");
     const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
     std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
-    std::vector<uint32_t> filter((size_t)1 << (KP_FILTER_LOG2 - 5), 0u);
+    std::vector<uint64_t> filter((size_t)1 << (KP_FILTER_LOG2 - 6), 0ull);
     std::vector<uint64_t> flat;
     flat.reserve(post.size() + n_unique + 1);
     for (size_t i = 0; i < post.size();) {
@@ -376,8 +376,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         uint32_t slot = (post[i].key * 2654435769u) >> shift;
         while (slots[slot].x != 0xFFFFFFFFu) slot = (slot + 1) & mask;
         slots[slot] = make_uint2(post[i].key, (uint32_t)flat.size());
-        const uint32_t fb = (post[i].key * 2654435769u) >> (32 - KP_FILTER_LOG2);
-        filter[fb >> 5] |= 1u << (fb & 31);
+        filter[kp_filter_block(post[i].key)] |= kp_filter_mask(post[i].key);
         flat.push_back((uint64_t)(j - i));
         for (size_t x = i; x < j; ++x)
             flat.push_back(((uint64_t)post[x].gs << 46) | ((uint64_t)(KP_DIAG_BIAS - post[x].pos) << 16) | post[x].pos);
@@ -485,8 +484,8 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, b->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)b->task_cap));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
-    if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 12 % of those to pass the filter
-        b->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)(b->view.total_words * 4 * 0.12));
+    if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 3 % of those to pass the filter
+        b->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)(b->view.total_words * 4 * 0.03));
     KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap));
     KP_HIP_CHECK(ctx, b->d_cand_count.reserve(1));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));

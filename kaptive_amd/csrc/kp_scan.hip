@@ -8,7 +8,7 @@
 // instruction).  The 65th..80th base needed by k-mers that start near the end of the lane's span come from the next
 // lane's first word (DPP/shuffle), so every word is fetched from HBM exactly once.  The context-free seed rule
 // (c[p]^c[p+1]^c[p+3]==1) is evaluated for 16 positions at a time with word-wide bit operations; only the selected
-// quarter of positions goes on to a 2^KP_FILTER_LOG2-bit presence filter (2 MB, stays in each XCD's L2).  What passes
+// quarter of positions goes on to the blocked-Bloom presence filter (2 MB, stays in each XCD's L2; kp_internal.h).  What passes
 // the filter is only recorded (kp_scan_kernel); a second, perfectly balanced kernel (kp_expand_kernel) probes the
 // k-mer table (tens of MB, Infinity Cache), validates and expands the postings into anchors.
 #include <cstdlib>
@@ -95,15 +95,16 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
                     bit[j] = have ? __builtin_ctz(sel) : 0;
                     sel &= sel - 1;  // no-op once sel is 0
                     const uint32_t kmer = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
-                    const uint32_t h = (kmer * 2654435769u) >> (32 - KP_FILTER_LOG2);
-                    if (MODE == 1) { checksum += have ? h : 0u; filt[j] = 0; continue; }
-                    filt[j] = have ? ((idx.filter[h >> 5] >> (h & 31)) & 1u) : 0u;
+                    const uint32_t blk = kp_filter_block(kmer);
+                    const uint64_t need = kp_filter_mask(kmer);
+                    if (MODE == 1) { checksum += have ? blk + (uint32_t)need : 0u; filt[j] = 0; continue; }
+                    filt[j] = (have && (idx.filter[blk] & need) == need) ? 1u : 0u;
                 }
                 if (MODE != 0) continue;
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
                     const unsigned long long pass = __ballot(filt[j] != 0);
-                    if (!pass) continue;  // ~93 % of selected positions stop at the filter (KpSC K database)
+                    if (!pass) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
                     if (filt[j]) stage[staged + __builtin_popcountll(pass & below)] = word_base + (uint64_t)(bit[j] >> 1);
                     staged += (uint32_t)__builtin_popcountll(pass);
                 }

@@ -153,16 +153,37 @@ class BatchTyping:
         self.phenotype = self._phenotypes(db, alive, state)
 
     def _phenotypes(self, db, alive, state) -> list:
-        """Phenotype rules for the whole batch (core.py:399-442); most databases have none."""
+        """Phenotype rules for the whole batch (core.py:399-442), as matrix products over (assembly, rule, cluster)
+        with the reference's int8 arithmetic; only assemblies with a valid suffix rule take the per-assembly path."""
         names = [db.serotypes[b] for b in self.best_locus]
         rules = db.phenotypes
         if len(rules) == 0 or len(names) == 0:
             return names
-        applicable = rules.locus_masks[:, self.best_locus].any(axis=0)  # assemblies whose best locus has any rule
-        for a in np.flatnonzero(applicable):
-            k = self.kept[a][alive[a]]
-            hits = _HitsView(k["gene"])
-            names[a] = self.typer._phenotype(int(self.best_locus[a]), hits, k["state"])
+        n, n_clu = len(names), len(db.cluster_keys)
+        applies = rules.locus_masks[:, self.best_locus].T  # [n, rules]
+        if not applies.any():
+            return names
+        # clusters with a working (NORMAL / PARTIAL) copy among the kept hits
+        rows, cols = np.nonzero(alive & ((state == 0) | (state == 1)))
+        active = np.zeros((n, n_clu), dtype=bool)
+        active[rows, db.gene_cluster_ids[self.kept["gene"][rows, cols]]] = True
+        extras_ok = (active.astype(np.int8) @ rules.extra_masks.T) == rules.extra_counts[None, :]
+        expected = self.typer._expected_clusters_per_locus()[self.best_locus]  # int8 [n, clusters]
+        applicable = rules.inactive_masks[None, :, :] & expected[:, None, :]  # int8 [n, rules, clusters]
+        knocked_out = (applicable * (~active).astype(np.int8)[:, None, :]).sum(axis=2, dtype=np.int8)
+        inactive_ok = ~(rules.inactive_masks.sum(axis=1) > 0)[None, :] | ((applicable.sum(axis=2) > 0) & (knocked_out > 0))
+        valid = applies & extras_ok & inactive_ok
+        if not valid.any():
+            return names
+        # replacing rules: the highest priority wins, the first of equals (np.argmax over the ascending subset)
+        prio = np.where(valid & ~rules.as_suffix[None, :], rules.priorities.astype(np.int16)[None, :], np.int16(-32768))
+        top = prio.argmax(axis=1)
+        for a in np.flatnonzero(prio.max(axis=1) > -32768):
+            names[a] = rules.ids[top[a]].decode("utf-8")
+        for a in np.flatnonzero((valid & rules.as_suffix[None, :]).any(axis=1)):
+            appending = np.flatnonzero(valid[a] & rules.as_suffix)
+            ranked = appending[np.argsort(-rules.priorities[appending])]
+            names[a] += "".join(rules.ids[i].decode("utf-8") for i in ranked)
         return names
 
     def __len__(self) -> int:

@@ -291,6 +291,17 @@ class Serotyper:
             missing_expected_genes=missing_ids,
         )
 
+    def _expected_clusters_per_locus(self) -> np.ndarray:
+        """int8 [n_loci, n_clusters]: 1 where the locus has a gene of the cluster (rows of `expected` in _phenotype)."""
+        cached = getattr(self, "_expected_clusters", None)
+        if cached is None:
+            db = self._db
+            cached = np.zeros((len(db.loci), len(db.cluster_keys)), dtype=np.int8)
+            for li, (o, ln) in enumerate(zip(db.locus_gene_offsets.tolist(), db.locus_gene_lengths.tolist())):
+                cached[li, db.gene_cluster_ids[o : o + ln]] = 1
+            self._expected_clusters = cached
+        return cached
+
     def _phenotype(self, best: int, hits: GeneHits, states: np.ndarray) -> str:
         """Apply the database's phenotype rules to the best locus' serotype -- core.py:399-442."""
         db = self._db
