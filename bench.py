@@ -192,11 +192,14 @@ def main() -> None:
         for _, _, batches in stages:  # K and O contexts have their own streams: both start right away
             for b in batches:
                 b.align_async()
+        # host-side steps of the smaller database first: its alignment pass ends long before the big one's.  Reductions
+        # of every database are enqueued before any result is collected, so the column-wise finishing of one database
+        # (host) runs while the device reduces the next
+        order = sorted(stages, key=lambda st: len(st[0].db.genes))
+        staged = [eng.reduce_batches(typer, batches, aligned=True) for eng, typer, batches in order]
         out = []
-        # host-side steps of the smaller database first: its alignment pass ends long before the big one's, so its
-        # score / reduce / finish run while the device is still aligning the other
-        for eng, typer, batches in sorted(stages, key=lambda st: len(st[0].db.genes)):
-            out += eng.type_batches(typer, batches, sub_ids, aligned=True)
+        for (eng, typer, batches), st in zip(order, staged):
+            out += eng.collect_batches(typer, batches, sub_ids, st)
         return out
 
     for _ in range(args.warmup):

@@ -53,6 +53,8 @@ struct kp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
     hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
+    hipStream_t aux = nullptr;     // forked off `post` for kernels that only fill a few CUs (wide-band proteins)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string error;
     // resident database
     bool has_db = false;
@@ -98,7 +100,7 @@ struct kp_batch {
     DevBuf<int32_t> d_anchor_contig;
     DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
-    DevBuf<uint64_t> d_cand;        // candidate positions of the scan; d_cand_count[0] = how many
+    DevBuf<uint64_t> d_cand;        // candidates of the scan: [cand_cap] positions, then [cand_cap] u32 k-mers; d_cand_count[0] = how many
     DevBuf<unsigned long long> d_cand_count;
     uint64_t cand_cap = 0;
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
@@ -261,7 +263,9 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
     ctx->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreate(&ctx->post)) != hipSuccess) {
+        (e = hipStreamCreate(&ctx->post)) != hipSuccess || (e = hipStreamCreate(&ctx->aux)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) {
         delete ctx;
         return kp_fail(nullptr, KP_EHIP, std::string("device setup failed: ") + hipGetErrorString(e));
     }
@@ -281,6 +285,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->post) (void)hipStreamSynchronize(ctx->post);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
@@ -290,6 +295,9 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->post) (void)hipStreamDestroy(ctx->post);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -486,7 +494,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
     if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 3 % of those to pass the filter
         b->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)(b->view.total_words * 4 * 0.03));
-    KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap));
+    KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap + (b->cand_cap + 1) / 2));  // u64 positions, then u32 k-mers
     KP_HIP_CHECK(ctx, b->d_cand_count.reserve(1));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
@@ -778,7 +786,8 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
     const size_t scratch_per_block = (2 * (longest + 2) + 1) * 12;
     KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
     kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
-                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post);
+                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post, ctx->aux, ctx->ev_fork,
+                      ctx->ev_join);
     kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, pair_base,
                      ctx->post);
     KP_HIP_CHECK(ctx, hipGetLastError());
@@ -920,7 +929,7 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks));
     kp_launch_protein(ctx->d_pq.p, ctx->d_pmeta.p, ctx->d_pmeta.p + n, ctx->d_pt.p, ctx->d_pmeta.p + 2 * (size_t)n,
                       ctx->d_pmeta.p + 3 * (size_t)n, n, nullptr, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
-                      scratch_per_block, n_blocks, ctx->stream);
+                      scratch_per_block, n_blocks, ctx->stream, nullptr, nullptr, nullptr);
     KP_HIP_CHECK(ctx, hipGetLastError());
     KP_HIP_CHECK(ctx, hipMemcpyAsync(out8, ctx->d_pout.p, 8 * (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost,
                                      ctx->stream));

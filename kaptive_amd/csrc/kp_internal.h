@@ -80,7 +80,8 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
 // kp_scan.hip: pass 1 streams the packed contigs and records candidate positions (selected k-mers that pass the presence
-//   filter) in `cand` (n_cand keeps counting past cand_cap = overflow); pass 2 turns candidates into anchor keys.  Each
+//   filter) in `cand` (room for cand_cap u64 positions followed by cand_cap u32 k-mers; n_cand keeps counting past
+//   cand_cap = overflow); pass 2 turns candidates into anchor keys.  Each
 //   assembly's anchor region of sub_cap * KP_ANCHOR_SUBS keys is cut into KP_ANCHOR_SUBS sub-slices with their own
 //   counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past sub_cap = overflow); kp_launch_anchor_compact then
 //   packs each assembly's slices into one run.  `after_scan` (optional) is recorded between the two passes.
@@ -103,7 +104,8 @@ void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint3
 // kp_prot.hip
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,
-                       int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream);
+                       int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream,
+                       hipStream_t aux, hipEvent_t fork, hipEvent_t join);  // aux != null: wide-band kernel runs beside the other
 // kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
 int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
                     int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,

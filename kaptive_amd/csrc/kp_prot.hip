@@ -275,10 +275,23 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
 // n pairs; when n_dev is not null the pair count is read from device memory (n is then only an upper bound)
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,
-                       int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream) {
+                       int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream,
+                       hipStream_t aux, hipEvent_t fork, hipEvent_t join) {
     if (n == 0) return;
+    // The wide-band kernel is a handful of long-running waves (its duration is one pair's time-step chain), the
+    // register kernel fills the chip: with a second stream they run side by side, joined before `stream` goes on.
+    hipStream_t wide = stream;
+    if (aux) {
+        (void)hipEventRecord(fork, stream);
+        (void)hipStreamWaitEvent(aux, fork, 0);
+        wide = aux;
+    }
+    hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, wide, q, q_off, q_len, t, t_off, t_len, n,
+                       n_dev, blosum, out8, scratch, scratch_ints_per_block);
     hipLaunchKernelGGL(kp_protein_kernel, dim3(n_blocks), dim3(64), 0, stream, q, q_off, q_len, t, t_off, t_len, n, n_dev,
                        blosum, out8);
-    hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, stream, q, q_off, q_len, t, t_off, t_len, n,
-                       n_dev, blosum, out8, scratch, scratch_ints_per_block);
+    if (aux) {
+        (void)hipEventRecord(join, aux);
+        (void)hipStreamWaitEvent(stream, join, 0);
+    }
 }

@@ -19,6 +19,13 @@ namespace {
 
 constexpr int PROBES = 8;
 
+// LDS written by some lanes of a wave, read by others of the same wave (no block barrier: waves loop independently)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int upper_bound_i64(const int64_t *a, int n, int64_t v) {  // first i with a[i] > v
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -44,12 +51,14 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 // (table probe, contig / N validation, posting expansion) is done by kp_expand_kernel with one thread per candidate.
 // MODE 0 = product; 1 = no filter reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for the
 // ablation in tools/scan_ablate.py and write a checksum so that the work is not optimised away.
-constexpr int STAGE_PER_WAVE = 1024;  // one round of PROBES positions per lane adds at most 64 * PROBES = 512 entries
+constexpr int STAGE_PER_WAVE = 768;  // one round of PROBES positions per lane adds at most 64 * PROBES = 512 entries
 
 template <int MODE>
 __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ cand,
+                                                       uint32_t *__restrict__ cand_kmer,
                                                        unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
     __shared__ uint64_t s_stage[4][STAGE_PER_WAVE];
+    __shared__ uint32_t s_stage_kmer[4][STAGE_PER_WAVE];
     uint32_t checksum = 0;
     const int64_t n_units = b.total_words >> 2;  // 16-byte units; every assembly is a whole number of them
     const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;  // whole waves iterate together (shuffle below)
@@ -57,6 +66,7 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
     const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t *stage = s_stage[wave];
+    uint32_t *stage_kmer = s_stage_kmer[wave];
     uint32_t staged = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
         if (lane == 0) base = atomicAdd(n_cand, (unsigned long long)staged);
         base = __shfl(base, 0);
         for (uint32_t i = lane; i < staged; i += 64)
-            if (base + i < cand_cap) cand[base + i] = stage[i];
+            if (base + i < cand_cap) { cand[base + i] = stage[i]; cand_kmer[base + i] = stage_kmer[i]; }
         staged = 0;
     };
 
@@ -87,14 +97,14 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
             while (__any(sel != 0)) {  // wave-uniform: lanes that ran out of selected positions idle along
                 // up to PROBES selected positions at a time: all their filter words are requested before any is
                 // looked at, so a lane keeps several independent L2 reads in flight
-                uint32_t filt[PROBES];
+                uint32_t filt[PROBES], kmers[PROBES];
                 int bit[PROBES];
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
                     const bool have = sel != 0;
                     bit[j] = have ? __builtin_ctz(sel) : 0;
                     sel &= sel - 1;  // no-op once sel is 0
-                    const uint32_t kmer = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
+                    const uint32_t kmer = kmers[j] = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
                     const uint32_t blk = kp_filter_block(kmer);
                     const uint64_t need = kp_filter_mask(kmer);
                     if (MODE == 1) { checksum += have ? blk + (uint32_t)need : 0u; filt[j] = 0; continue; }
@@ -105,7 +115,11 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
                 for (int j = 0; j < PROBES; ++j) {
                     const unsigned long long pass = __ballot(filt[j] != 0);
                     if (!pass) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
-                    if (filt[j]) stage[staged + __builtin_popcountll(pass & below)] = word_base + (uint64_t)(bit[j] >> 1);
+                    if (filt[j]) {
+                        const uint32_t at = staged + (uint32_t)__builtin_popcountll(pass & below);
+                        stage[at] = word_base + (uint64_t)(bit[j] >> 1);
+                        stage_kmer[at] = kmers[j];  // the expansion pass does not have to touch the bases again
+                    }
                     staged += (uint32_t)__builtin_popcountll(pass);
                 }
                 if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
@@ -117,54 +131,102 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
 }
 
 // ---- pass 2: candidates -> anchors -------------------------------------------------------------------------------------
-// One thread per candidate: re-read its k-mer, probe the table, validate against contig bounds and N runs, and append
-// one anchor per posting to its assembly.  Appends of one assembly are spread over KP_ANCHOR_SUBS counters because all
-// hits of an assembly come in one burst (the typed locus) and would otherwise serialise on a single atomic word.
+// One thread per candidate: re-read its k-mer, probe the table, validate against contig bounds and N runs, reserve room
+// for its postings in its assembly's anchor region.  The postings themselves are then copied by the whole wave as one
+// flat list (prefix sums of the counts, every lane finds the owner of its output item by binary search): a shared gene
+// family has ~160 postings per seed, a per-thread copy loop would run the wave at the pace of its longest list.  Appends of one assembly are spread over
+// KP_ANCHOR_SUBS counters because all hits of an assembly come in one burst (the typed locus) and would otherwise
+// serialise on a single atomic word.
 __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedIndex idx, const uint64_t *__restrict__ cand,
+                                                         const uint32_t *__restrict__ cand_kmer,
                                                          const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                          uint64_t *__restrict__ anchors, uint32_t *__restrict__ sub_count,
                                                          uint32_t sub_cap) {
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t pos = cand[i];
-        const int64_t word = (int64_t)(pos >> 4);
-        const int bitpos = 2 * (int)(pos & 15);
-        const uint64_t both = ((uint64_t)(word + 1 < b.total_words ? b.words[word + 1] : 0u) << 32) | b.words[word];
-        const uint32_t kmer = (uint32_t)(both >> bitpos) & KP_KMER_MASK;
-        uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
-        uint32_t first_posting = 0xFFFFFFFFu;
-        for (;;) {
-            const uint2 e = idx.slots[slot];
-            if (e.x == kmer) { first_posting = e.y; break; }
-            if (e.x == 0xFFFFFFFFu) break;
-            slot = (slot + 1) & idx.slot_mask;
-        }
-        if (first_posting == 0xFFFFFFFFu) continue;  // filter false positive
-        const int a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
-        if (a < 0 || a >= b.n_asm) continue;
-        const int32_t t = (int32_t)(pos - ((uint64_t)b.asm_word_off[a] << 4));
-        const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
-        const int c = upper_bound_i32(b.ctg_start + c0, nc, t) - 1;
-        if (c < 0) continue;
-        if (t + KP_K > b.ctg_start[c0 + c] + b.ctg_len[c0 + c]) continue;  // runs past the contig (or sits in padding)
-        const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
-        if (nr > 0) {  // first run whose end is > t; it overlaps the k-mer iff it starts before t + K
-            int lo = 0, hi = nr;
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (b.n_runs[2 * (r0 + mid) + 1] <= t) lo = mid + 1; else hi = mid;
+    struct WaveStage {  // survivors of the wave's current 64 candidates, in lane order
+        uint32_t start[64], room[64];
+        const uint64_t *src[64];
+        uint64_t *dst[64];
+        uint64_t shift[64];
+    };
+    __shared__ WaveStage s_stage[4];
+    WaveStage &sw = s_stage[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    // whole waves iterate together: the copy phase below needs every lane of the wave
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const uint64_t i = i0 + lane;
+        uint32_t first_posting = 0xFFFFFFFFu, cnt = 0, base = 0, t = 0;
+        size_t slice = 0;
+        if (i < n) {
+            const uint64_t pos = cand[i];
+            const int64_t word = (int64_t)(pos >> 4);
+            const uint32_t kmer = cand_kmer[i];
+            uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
+            for (;;) {
+                const uint2 e = idx.slots[slot];
+                if (e.x == kmer) { first_posting = e.y; break; }
+                if (e.x == 0xFFFFFFFFu) break;
+                slot = (slot + 1) & idx.slot_mask;
             }
-            if (lo < nr && b.n_runs[2 * (r0 + lo)] < t + KP_K) continue;
+            if (first_posting != 0xFFFFFFFFu) {  // else: filter false positive
+                bool ok = false;
+                const int a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
+                if (a >= 0 && a < b.n_asm) {
+                    t = (uint32_t)(pos - ((uint64_t)b.asm_word_off[a] << 4));
+                    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+                    const int c = upper_bound_i32(b.ctg_start + c0, nc, (int32_t)t) - 1;
+                    // the k-mer must not run past its contig (or sit in padding) ...
+                    ok = c >= 0 && (int32_t)t + KP_K <= b.ctg_start[c0 + c] + b.ctg_len[c0 + c];
+                    const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
+                    if (ok && nr > 0) {  // ... nor overlap an N run: first run whose end is > t starts before t + K
+                        int lo = 0, hi = nr;
+                        while (lo < hi) {
+                            int mid = (lo + hi) >> 1;
+                            if (b.n_runs[2 * (r0 + mid) + 1] <= (int32_t)t) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo < nr && b.n_runs[2 * (r0 + lo)] < (int32_t)t + KP_K) ok = false;
+                    }
+                    if (ok) {
+                        cnt = (uint32_t)idx.postings[first_posting];
+                        slice = (size_t)a * KP_ANCHOR_SUBS + (threadIdx.x & (KP_ANCHOR_SUBS - 1));
+                        base = atomicAdd(&sub_count[slice], cnt);
+                    }
+                }
+                if (!ok) cnt = 0;
+            }
         }
-        const uint32_t cnt = (uint32_t)idx.postings[first_posting];
-        const size_t slice = (size_t)a * KP_ANCHOR_SUBS + (threadIdx.x & (KP_ANCHOR_SUBS - 1));
-        const uint32_t base = atomicAdd(&sub_count[slice], cnt);
-        uint64_t *dst = anchors + slice * sub_cap;
-        const uint64_t shift = (uint64_t)(uint32_t)t << 16;
-        for (uint32_t j = 0; j < cnt; ++j)
-            if (base + j < sub_cap) dst[base + j] = idx.postings[first_posting + 1 + j] + shift;
+        // ---- load-balanced copy: output item k of the wave belongs to the survivor whose prefix range holds k ----------
+        const unsigned long long live = __ballot(cnt != 0);
+        if (!live) continue;
+        uint32_t incl = cnt;  // inclusive prefix sum of cnt over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        const int rank = __builtin_popcountll(live & ((1ull << lane) - 1ull));
+        const int n_live = __builtin_popcountll(live);
+        if (cnt) {
+            sw.start[rank] = incl - cnt;
+            sw.src[rank] = idx.postings + first_posting + 1;
+            sw.dst[rank] = anchors + slice * sub_cap + base;
+            sw.room[rank] = base < sub_cap ? sub_cap - base : 0u;
+            sw.shift[rank] = (uint64_t)t << 16;
+        }
+        wave_lds_sync();
+        for (uint32_t k = lane; k < total; k += 64) {
+            int lo = 0, hi = n_live;  // last survivor with start <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sw.start[mid] <= k) lo = mid; else hi = mid;
+            }
+            const uint32_t j = k - sw.start[lo];
+            if (j < sw.room[lo]) sw.dst[lo][j] = sw.src[lo][j] + sw.shift[lo];
+        }
+        wave_lds_sync();
     }
 }
 
@@ -216,10 +278,11 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
     if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
     static const int mode = []() { const char *m = getenv("KAPTIVE_AMD_SCAN_ABLATE"); return m ? atoi(m) : 0; }();
     const dim3 grid((unsigned)blocks), block(256);
-    if (mode == 1) hipLaunchKernelGGL(kp_scan_kernel<1>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-    else if (mode == 2) hipLaunchKernelGGL(kp_scan_kernel<2>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-    else hipLaunchKernelGGL(kp_scan_kernel<0>, grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    uint32_t *cand_kmer = reinterpret_cast<uint32_t *>(cand + cand_cap);  // second half of the candidate buffer
+    if (mode == 1) hipLaunchKernelGGL(kp_scan_kernel<1>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+    else if (mode == 2) hipLaunchKernelGGL(kp_scan_kernel<2>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+    else hipLaunchKernelGGL(kp_scan_kernel<0>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
     if (after_scan) (void)hipEventRecord(after_scan, stream);
-    hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap, anchors,
-                       sub_count, sub_cap);
+    hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap,
+                       anchors, sub_count, sub_cap);
 }

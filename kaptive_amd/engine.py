@@ -97,6 +97,11 @@ class Engine:
         """Several resident batches through the same context, software-pipelined: all alignment passes are enqueued up
         front and every host-side step of batch i (reading scores back, choosing best loci, copying records,
         array finishing) runs while the device works on batches i+1..: the stream never waits for the host."""
+        return self.collect_batches(typer, batches, ids, self.reduce_batches(typer, batches, aligned))
+
+    def reduce_batches(self, typer, batches: Sequence, aligned: bool = False) -> list:
+        """First half of ``type_batches``: scores back, best loci chosen (numpy), reductions enqueued.  Returns what
+        ``collect_batches`` needs; callers driving several databases put the other database's host work in between."""
         from kaptive_amd.serotyping import batch as B
 
         if not aligned:
@@ -108,6 +113,12 @@ class Engine:
             best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
             b.reduce_async(best, self.typing_params(typer))
             staged.append((scores, best))
+        return staged
+
+    def collect_batches(self, typer, batches: Sequence, ids: Sequence[Sequence[str]], staged: list) -> list:
+        """Second half: fetch the reduction records and finish them column-wise (``BatchTyping``)."""
+        from kaptive_amd.serotyping import batch as B
+
         out = []
         for b, i, (scores, best) in zip(batches, ids, staged):
             sums, kept, pieces = b.typing()
