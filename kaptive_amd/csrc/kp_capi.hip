@@ -62,7 +62,7 @@ struct kp_ctx {
     int64_t n_postings = 0;
     std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
     DevBuf<uint2> d_slots;
-    DevBuf<uint64_t> d_filter;
+    DevBuf<uint64_t> d_filter, d_lds_filter;
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
@@ -147,6 +147,15 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg) {
 }
 
 namespace {
+
+// Streams of the short, low-occupancy kernels that follow an alignment pass get the highest priority the device offers:
+// when another batch's alignment pass fills the chip, their waves are scheduled as soon as any slot frees up.
+hipError_t create_priority_stream(hipStream_t *stream) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(stream, hipStreamDefault, greatest);
+}
 
 uint32_t env_u32(const char *name, uint32_t dflt) {
     const char *v = std::getenv(name);
@@ -263,7 +272,7 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
     ctx->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreate(&ctx->post)) != hipSuccess || (e = hipStreamCreate(&ctx->aux)) != hipSuccess ||
+        (e = create_priority_stream(&ctx->post)) != hipSuccess || (e = create_priority_stream(&ctx->aux)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) {
         delete ctx;
@@ -286,7 +295,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->post) (void)hipStreamSynchronize(ctx->post);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
-    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
+    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
     ctx->d_gene_locus.release(); ctx->d_gene_pos.release(); ctx->d_gene_extra.release(); ctx->d_prot_db.release();
@@ -376,6 +385,11 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
     std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
     std::vector<uint64_t> filter((size_t)1 << (KP_FILTER_LOG2 - 6), 0ull);
+    // LDS tier of the filter for databases with few k-mers: >= 10 bits per k-mer must fit KP_LDS_FILTER_BLOCKS blocks
+    uint32_t lds_blocks = 0;
+    if (n_unique > 0 && n_unique * 10 <= (size_t)KP_LDS_FILTER_BLOCKS * 64)
+        lds_blocks = (uint32_t)std::min<size_t>(KP_LDS_FILTER_BLOCKS, std::max<size_t>(256, (n_unique * 16 + 63) / 64));
+    std::vector<uint64_t> lds_filter(std::max<uint32_t>(lds_blocks, 1), 0ull);
     std::vector<uint64_t> flat;
     flat.reserve(post.size() + n_unique + 1);
     for (size_t i = 0; i < post.size();) {
@@ -385,6 +399,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         while (slots[slot].x != 0xFFFFFFFFu) slot = (slot + 1) & mask;
         slots[slot] = make_uint2(post[i].key, (uint32_t)flat.size());
         filter[kp_filter_block(post[i].key)] |= kp_filter_mask(post[i].key);
+        if (lds_blocks) lds_filter[kp_lds_filter_block(post[i].key, lds_blocks)] |= kp_filter_mask(post[i].key);
         flat.push_back((uint64_t)(j - i));
         for (size_t x = i; x < j; ++x)
             flat.push_back(((uint64_t)post[x].gs << 46) | ((uint64_t)(KP_DIAG_BIAS - post[x].pos) << 16) | post[x].pos);
@@ -395,12 +410,14 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     int rcode;
     if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_filter, filter.data(), filter.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_lds_filter, lds_filter.data(), lds_filter.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_slots.p, ctx->d_postings.p, mask, shift};
+    ctx->index = KpSeedIndex{ctx->d_filter.p, lds_blocks ? ctx->d_lds_filter.p : nullptr, lds_blocks, ctx->d_slots.p,
+                             ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
     ctx->n_genes = n_genes;
     ctx->n_postings = (int64_t)post.size();

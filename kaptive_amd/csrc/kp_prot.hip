@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int LDS_CELLS = 512;  // band cells held in LDS by the wide-band kernel; wider bands use global scratch
+constexpr int LDS_CELLS = 1024;  // band cells held in LDS by the wide-band kernel (48 KB); wider bands use global scratch
 constexpr int NF = 12;          // ints per band cell: M,D,I + 3 payload words each
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;

@@ -51,14 +51,34 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 // (table probe, contig / N validation, posting expansion) is done by kp_expand_kernel with one thread per candidate.
 // MODE 0 = product; 1 = no filter reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for the
 // ablation in tools/scan_ablate.py and write a checksum so that the work is not optimised away.
-constexpr int STAGE_PER_WAVE = 768;  // one round of PROBES positions per lane adds at most 64 * PROBES = 512 entries
+//
+// Two filter tiers.  A database with few k-mers (O loci: tens of thousands) gets a filter small enough for LDS
+// (idx.lds_filter, <= KP_LDS_FILTER_BLOCKS 64-bit blocks): LDSF = true copies it into the block's LDS once and probes it
+// there, so the kernel is no longer limited by how many L1 misses a CU keeps in flight; blocks are 16 waves wide (one
+// per CU: the filter takes most of its LDS) with a small candidate stage per wave.  Otherwise the 2 MB filter is probed
+// in L2 (LDSF = false, 4-wave blocks, several per CU).
+template <bool LDSF> struct ScanShape {
+    static constexpr int WAVES = LDSF ? 16 : 4;
+    // a round of PROBES positions per lane adds at most 64 * PROBES = 512 entries (flush after the round); the LDS tier
+    // flushes inside the round, whenever fewer than 64 free entries are left
+    static constexpr int STAGE = LDSF ? 192 : 768;
+    static constexpr int FILTER_BLOCKS = LDSF ? KP_LDS_FILTER_BLOCKS : 1;
+};
 
-template <int MODE>
-__global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ cand,
-                                                       uint32_t *__restrict__ cand_kmer,
-                                                       unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
-    __shared__ uint64_t s_stage[4][STAGE_PER_WAVE];
-    __shared__ uint32_t s_stage_kmer[4][STAGE_PER_WAVE];
+template <int MODE, bool LDSF>
+__global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx,
+                                                                              uint64_t *__restrict__ cand,
+                                                                              uint32_t *__restrict__ cand_kmer,
+                                                                              unsigned long long *__restrict__ n_cand,
+                                                                              uint64_t cand_cap) {
+    constexpr int WAVES = ScanShape<LDSF>::WAVES, STAGE_PER_WAVE = ScanShape<LDSF>::STAGE;
+    __shared__ uint64_t s_stage[WAVES][STAGE_PER_WAVE];
+    __shared__ uint32_t s_stage_kmer[WAVES][STAGE_PER_WAVE];
+    __shared__ uint64_t s_filter[ScanShape<LDSF>::FILTER_BLOCKS];
+    if (LDSF) {
+        for (uint32_t i = threadIdx.x; i < idx.lds_filter_blocks; i += blockDim.x) s_filter[i] = idx.lds_filter[i];
+        __syncthreads();
+    }
     uint32_t checksum = 0;
     const int64_t n_units = b.total_words >> 2;  // 16-byte units; every assembly is a whole number of them
     const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;  // whole waves iterate together (shuffle below)
@@ -105,10 +125,11 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
                     bit[j] = have ? __builtin_ctz(sel) : 0;
                     sel &= sel - 1;  // no-op once sel is 0
                     const uint32_t kmer = kmers[j] = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
-                    const uint32_t blk = kp_filter_block(kmer);
+                    const uint32_t blk = LDSF ? kp_lds_filter_block(kmer, idx.lds_filter_blocks) : kp_filter_block(kmer);
                     const uint64_t need = kp_filter_mask(kmer);
                     if (MODE == 1) { checksum += have ? blk + (uint32_t)need : 0u; filt[j] = 0; continue; }
-                    filt[j] = (have && (idx.filter[blk] & need) == need) ? 1u : 0u;
+                    const uint64_t got = LDSF ? s_filter[blk] : (have ? idx.filter[blk] : 0ull);
+                    filt[j] = (have && (got & need) == need) ? 1u : 0u;
                 }
                 if (MODE != 0) continue;
 #pragma unroll
@@ -121,8 +142,9 @@ __global__ __launch_bounds__(256) void kp_scan_kernel(KpBatchView b, KpSeedIndex
                         stage_kmer[at] = kmers[j];  // the expansion pass does not have to touch the bases again
                     }
                     staged += (uint32_t)__builtin_popcountll(pass);
+                    if (LDSF && staged > STAGE_PER_WAVE - 64) flush();
                 }
-                if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
+                if (!LDSF && staged > STAGE_PER_WAVE - 64 * PROBES) flush();
             }
         }
     }
@@ -274,14 +296,24 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
                     hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
-    int64_t blocks = (n_units + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
-    static const int mode = []() { const char *m = getenv("KAPTIVE_AMD_SCAN_ABLATE"); return m ? atoi(m) : 0; }();
-    const dim3 grid((unsigned)blocks), block(256);
+    const char *env_mode = getenv("KAPTIVE_AMD_SCAN_ABLATE"), *env_lds = getenv("KAPTIVE_AMD_NO_LDS_FILTER");
+    const int mode = env_mode ? atoi(env_mode) : 0;
+    const bool no_lds = env_lds && atoi(env_lds);  // tests compare the two filter tiers
     uint32_t *cand_kmer = reinterpret_cast<uint32_t *>(cand + cand_cap);  // second half of the candidate buffer
-    if (mode == 1) hipLaunchKernelGGL(kp_scan_kernel<1>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
-    else if (mode == 2) hipLaunchKernelGGL(kp_scan_kernel<2>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
-    else hipLaunchKernelGGL(kp_scan_kernel<0>, grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+    if (idx.lds_filter_blocks && !no_lds && mode == 0) {
+        // one 16-wave block per CU (the filter fills most of its LDS); a few blocks per CU in the grid even out the tail
+        int64_t blocks = (n_units + 1023) / 1024;
+        if (blocks > 256 * 4) blocks = 256 * 4;
+        hipLaunchKernelGGL((kp_scan_kernel<0, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, b, idx, cand, cand_kmer,
+                           n_cand, cand_cap);
+    } else {
+        int64_t blocks = (n_units + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
+        const dim3 grid((unsigned)blocks), block(256);
+        if (mode == 1) hipLaunchKernelGGL((kp_scan_kernel<1, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+        else if (mode == 2) hipLaunchKernelGGL((kp_scan_kernel<2, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+        else hipLaunchKernelGGL((kp_scan_kernel<0, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+    }
     if (after_scan) (void)hipEventRecord(after_scan, stream);
     hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap,
                        anchors, sub_count, sub_cap);

@@ -20,6 +20,8 @@
 //     oracle's stored traceback uses, so no DP matrix is ever written to memory.
 //   * steps whose rows and target positions are all inside the task (the bulk) run a variant without boundary masks.
 //   * the best cell of a task is found with a wave-level max reduction over (score, first row, first column).
+#include <cstdlib>
+
 #include "kp_internal.h"
 
 namespace {
@@ -263,8 +265,11 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
                   uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream) {
-    // persistent-style grid: enough single-wave blocks to fill 256 CUs several times over; each strides over quads
-    const dim3 grid(256 * 16), block(64);
+    // many short-lived single-wave blocks (each strides over a quad or two): CU slots turn over every few hundred
+    // microseconds, so the tail is even and the high-priority streams of other batches' reductions get their turn
+    // (measured: 24.0 ms with 256 blocks per CU against 28-32 ms with 16 persistent ones, K pass of the bench)
+    const char *env = getenv("KAPTIVE_AMD_SW_BLOCKS_PER_CU");
+    const dim3 grid(256 * (env ? atoi(env) : 256)), block(64);
     if (width == 16)
         hipLaunchKernelGGL(kp_sw_kernel<4>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
     else if (width == 32)

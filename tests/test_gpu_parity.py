@@ -136,6 +136,24 @@ def test_anchor_task_hit_stages_match_oracle(ctx, small_setup, small_db):
     batch.close()
 
 
+def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
+    """A small database is scanned with its presence filter in LDS; KAPTIVE_AMD_NO_LDS_FILTER=1 sends the same batch
+    through the L2 tier.  The filter only prunes, so anchors and hits must be identical."""
+    asms = _assemblies(small_db)
+    packed = [a.packed() for a in asms]
+    lds = ctx.batch(packed)
+    hits_lds, off_lds = lds.align()
+    monkeypatch.setenv("KAPTIVE_AMD_NO_LDS_FILTER", "1")
+    l2 = ctx.batch(packed)
+    hits_l2, off_l2 = l2.align()
+    assert np.array_equal(off_lds, off_l2)
+    _same_records(hits_lds, hits_l2, "LDS vs L2 filter tier")
+    for i in range(len(packed)):
+        assert np.array_equal(lds.anchors(i), l2.anchors(i))
+    lds.close()
+    l2.close()
+
+
 def test_sw_raw_results_match_oracle(ctx, small_setup, small_db):
     """Every band task's DP result (also the ones below the score cut-off) equals the oracle's traceback."""
     odb = small_setup
