@@ -102,8 +102,9 @@ KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 
 /* Stage durations of the most recent alignment pass of this batch (valid after kp_batch_wait), from HIP events the
  * library records on the context's stream around every pass: ms7 = seed scan (kp_scan_kernel), candidate expansion +
- * anchor compaction + sort, chaining + task ordering, SW width 16, 32, 64, 128.  bytes_scanned receives the algorithmic
- * bytes the scan kernel streams (4 * total words). */
+ * anchor compaction + sort, chaining + task ordering, banded SW (all band widths run in one launch: its duration is in
+ * ms7[3], ms7[4..6] are 0 and kept for layout stability).  bytes_scanned receives the algorithmic bytes the scan kernel
+ * streams (4 * total words). */
 KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms7, int64_t *bytes_scanned);
 
 /* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and

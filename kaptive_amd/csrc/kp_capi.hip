@@ -531,13 +531,12 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + ORDER_HEAD,
                          ctx->stream);
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
-    static const int widths[KP_N_CLASSES] = {16, 32, 64, 128};
-    for (int c = 0; c < KP_N_CLASSES; ++c) {
-        kp_launch_sw(b->view, ctx->genes, b->d_tasks.p + (size_t)c * b->task_cap, d_task_count + c, b->task_cap,
-                     b->d_task_order.p + ORDER_HEAD + (size_t)c * b->task_cap, widths[c],
-                     b->d_results.p + (size_t)c * b->task_cap, ctx->stream);
+    // all four band classes in one launch (kp_sw.hip); the per-class event slots stay in the layout: the whole launch is
+    // booked on the first one, the others read 0
+    kp_launch_sw(b->view, ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p + ORDER_HEAD,
+                 b->d_results.p, ctx->stream);
+    for (int c = 0; c < KP_N_CLASSES; ++c)
         if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
-    }
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }

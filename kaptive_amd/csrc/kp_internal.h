@@ -103,9 +103,10 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
                      hipStream_t stream);
-// kp_sw.hip: banded Smith-Waterman of every task of one width class.
+// kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order and results at
+// c * task_cap and its count at task_count[c]; one launch covers all four.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream);
+                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, hipStream_t stream);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);

@@ -149,23 +149,26 @@ __device__ __forceinline__ unsigned target_code(const uint32_t *__restrict__ asm
     return (asm_words[t >> 4] >> (2 * (t & 15))) & 3u;
 }
 
+constexpr int PROF_WORDS = 16 * CH;                  // LDS of one block: profiles of 64/P groups x CH rows (P >= 4)
+constexpr int TCODE_BYTES = 16 * (CH + 3 * 4 + 4);   // ... and their target codes (largest for P = 4)
+
+// all tasks of one band class, seen from block `block` of `n_blocks` that work on the class
 template <int P>
-__global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
-                                                   const uint32_t *__restrict__ task_count, uint32_t task_cap,
-                                                   const uint32_t *__restrict__ order,
-                                                   KpSwResult *__restrict__ results) {
+__device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &genes, const KpTask *__restrict__ tasks,
+                                         uint32_t n_tasks, const uint32_t *__restrict__ order,
+                                         KpSwResult *__restrict__ results, uint32_t block, uint32_t n_blocks,
+                                         uint32_t *s_prof_raw, uint8_t *s_t_raw) {
     constexpr int G = 64 / P;
     constexpr int W = 4 * P;
     constexpr int TW = CH + 3 * P + 4;  // staged target codes per chunk: window x in [m0, m0 + CH + 3P]
-    __shared__ uint32_t s_prof[G][CH];
-    __shared__ uint8_t s_t[G][TW];
+    static_assert(G * CH <= PROF_WORDS && G * TW <= TCODE_BYTES, "LDS carve-up");
+    uint32_t(*s_prof)[CH] = reinterpret_cast<uint32_t(*)[CH]>(s_prof_raw);
+    uint8_t(*s_t)[TW] = reinterpret_cast<uint8_t(*)[TW]>(s_t_raw);
 
     const int lane = threadIdx.x;
     const int g = lane / P, l = lane % P;
-    uint32_t n_tasks = *task_count;
-    if (n_tasks > task_cap) n_tasks = task_cap;
 
-    for (uint32_t quad = blockIdx.x; (uint64_t)quad * G < n_tasks; quad += gridDim.x) {
+    for (uint32_t quad = block; (uint64_t)quad * G < n_tasks; quad += n_blocks) {
         const uint32_t slot = quad * G + g;
         const bool have = slot < n_tasks;
         const uint32_t ti = have ? order[slot] : 0u;  // tasks of similar length share a wave (kp_chain.hip)
@@ -261,21 +264,37 @@ __global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes,
     }
 }
 
+// One launch for all four band classes.  The wide classes hold few tasks but each of their waves runs a long step chain
+// (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of the grid and
+// run underneath the 16-diagonal class that fills the chip.
+constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
+
+__global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
+                                                   const uint32_t *__restrict__ task_count, uint32_t task_cap,
+                                                   const uint32_t *__restrict__ order,
+                                                   KpSwResult *__restrict__ results) {
+    __shared__ uint32_t s_prof[PROF_WORDS];
+    __shared__ uint8_t s_t[TCODE_BYTES];
+    // class c (0..3 = 16/32/64/128 diagonals): tasks, order and results at c * task_cap, count at task_count[c]
+    const uint32_t blk = blockIdx.x;
+    const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : 0;
+    const size_t off = (size_t)c * task_cap;
+    uint32_t n = task_count[c];
+    if (n > task_cap) n = task_cap;
+    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, results + off, blk, WIDE_BLOCKS, s_prof, s_t);
+    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, results + off, blk - WIDE_BLOCKS, WIDE_BLOCKS, s_prof, s_t);
+    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, results + off, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, s_prof, s_t);
+    else sw_class<4>(b, genes, tasks + off, n, order + off, results + off, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, s_prof, s_t);
+}
+
 }  // namespace
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, const uint32_t *order, int width, KpSwResult *results, hipStream_t stream) {
+                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, hipStream_t stream) {
     // many short-lived single-wave blocks (each strides over a quad or two): CU slots turn over every few hundred
     // microseconds, so the tail is even and the high-priority streams of other batches' reductions get their turn
     // (measured: 24.0 ms with 256 blocks per CU against 28-32 ms with 16 persistent ones, K pass of the bench)
     const char *env = getenv("KAPTIVE_AMD_SW_BLOCKS_PER_CU");
-    const dim3 grid(256 * (env ? atoi(env) : 256)), block(64);
-    if (width == 16)
-        hipLaunchKernelGGL(kp_sw_kernel<4>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
-    else if (width == 32)
-        hipLaunchKernelGGL(kp_sw_kernel<8>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
-    else if (width == 64)
-        hipLaunchKernelGGL(kp_sw_kernel<16>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
-    else
-        hipLaunchKernelGGL(kp_sw_kernel<32>, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
+    const dim3 grid(3 * WIDE_BLOCKS + 256 * (env ? atoi(env) : 256)), block(64);
+    hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
 }
