@@ -26,38 +26,68 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
     uint32_t n = task_count[cls];
     if (n > task_cap) n = task_cap;
     unsigned long long my_cells = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const KpTask t = tasks[(size_t)cls * task_cap + i];
-        const KpSwResult r = results[(size_t)cls * task_cap + i];
-        const int qlen = gene_len[t.gs >> 1];
-        my_cells += (unsigned long long)qlen * (unsigned)t.width;
-        if (r.score < KP_MIN_DP_SCORE) continue;
-        const int32_t cs = b.ctg_start[b.asm_first_ctg[t.asm_id] + t.contig];
-        const uint32_t slot = atomicAdd(&n_raw[t.asm_id], 1u);
-        if (slot < hit_cap)
+    const int lane = threadIdx.x & 63;
+    // whole waves iterate together: appends are aggregated per assembly within the wave (tasks of an assembly are
+    // neighbours in the list, a per-thread atomic would hit one counter 64 times in a row)
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        KpTask t;
+        t.asm_id = -1;
+        KpSwResult r;
+        r.score = 0;
+        int qlen = 0;
+        if (i < n) {
+            t = tasks[(size_t)cls * task_cap + i];
+            r = results[(size_t)cls * task_cap + i];
+            qlen = gene_len[t.gs >> 1];
+            my_cells += (unsigned long long)qlen * (unsigned)t.width;
+        }
+        const bool hit = i < n && r.score >= KP_MIN_DP_SCORE;
+        uint32_t slot = 0;
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int asm_l = __shfl(t.asm_id, leader);
+            const unsigned long long same = __ballot(hit && t.asm_id == asm_l) & todo;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&n_raw[asm_l], (uint32_t)__builtin_popcountll(same));
+            base = __shfl(base, leader);
+            if ((same >> lane) & 1ull) slot = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (hit && slot < hit_cap) {
+            const int32_t cs = b.ctg_start[b.asm_first_ctg[t.asm_id] + t.contig];
             raw[(size_t)t.asm_id * hit_cap + slot] =
                 kp_make_hit(t.gs, t.contig, cs, qlen, r.score, r.q_start, r.q_end, r.t_start, r.t_end, r.matches, r.block_len);
+        }
     }
     if (my_cells) atomicAdd(cells, my_cells);
 }
 
 // ---- 2. emission order, duplicates, mapq (kp_spec.h) -------------------------------------------------------------------
-__global__ __launch_bounds__(64) void kp_hit_sort_kernel(const kp_hit *__restrict__ raw, const uint32_t *__restrict__ n_raw,
-                                                         uint32_t hit_cap, uint64_t *__restrict__ keys,
-                                                         kp_hit *__restrict__ hits, uint32_t *__restrict__ n_hits) {
-    const int a = blockIdx.x, lane = threadIdx.x;
+// One block per assembly: rank sort (leading keys in LDS, every thread counts the hits that precede its own), then the
+// duplicate / mapq pass on neighbours of the sorted list (kp_same_span is an equivalence, so "equal to the last kept
+// hit" is "equal to the predecessor") with a block prefix sum for the compaction.  `raw` is scratch once the ranks are
+// known: the compacted list is built there and copied back.
+constexpr int SORT_THREADS = 256;
+
+__global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__restrict__ raw, const uint32_t *__restrict__ n_raw,
+                                                                   uint32_t hit_cap, uint64_t *__restrict__ keys,
+                                                                   kp_hit *__restrict__ hits, uint32_t *__restrict__ n_hits) {
+    const int a = blockIdx.x, tid = threadIdx.x;
     uint32_t n = n_raw[a];
     if (n > hit_cap) n = hit_cap;
-    const kp_hit *src = raw + (size_t)a * hit_cap;
+    kp_hit *src = raw + (size_t)a * hit_cap;
     kp_hit *dst = hits + (size_t)a * hit_cap;
     uint64_t *k = keys + (size_t)a * hit_cap * 3;
     __shared__ uint64_t s_k0[SORT_LDS];  // leading key of every hit: almost every comparison is decided by it
-    for (uint32_t i = lane; i < n; i += 64) {
+    __shared__ uint32_t s_scan[SORT_THREADS];
+    for (uint32_t i = tid; i < n; i += SORT_THREADS) {
         kp_hit_keys(src[i], k + 3 * (size_t)i);
         if (i < SORT_LDS) s_k0[i] = k[3 * (size_t)i];
     }
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) {  // rank sort: all lanes read the same key j -> LDS broadcast
+    for (uint32_t i = tid; i < n; i += SORT_THREADS) {  // rank sort: all lanes read the same key j -> LDS broadcast
         const uint64_t mine[3] = {k[3 * (size_t)i], k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
         uint32_t rank = 0;
         const uint32_t n_lds = n < SORT_LDS ? n : SORT_LDS;
@@ -80,16 +110,30 @@ __global__ __launch_bounds__(64) void kp_hit_sort_kernel(const kp_hit *__restric
         dst[rank] = src[i];
     }
     __syncthreads();
-    if (lane == 0) {
-        uint32_t m = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            if (m > 0 && kp_same_span(dst[m - 1], dst[i])) continue;
-            kp_hit h = dst[i];
-            h.mapq = (m == 0 || dst[m - 1].gene != h.gene) ? 60 : 0;
-            dst[m++] = h;
-        }
-        n_hits[a] = m;
+    // thread t owns the sorted positions [lo, hi); keep = not a duplicate of its predecessor
+    const uint32_t per = (n + SORT_THREADS - 1) / SORT_THREADS;
+    const uint32_t lo = min(n, (uint32_t)tid * per), hi = min(n, lo + per);
+    uint32_t kept = 0;
+    for (uint32_t i = lo; i < hi; ++i) kept += (i > 0 && kp_same_span(dst[i - 1], dst[i])) ? 0u : 1u;
+    s_scan[tid] = kept;
+    __syncthreads();
+    for (int o = 1; o < SORT_THREADS; o <<= 1) {  // inclusive scan
+        const uint32_t v = tid >= o ? s_scan[tid - o] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
     }
+    uint32_t m = s_scan[tid] - kept;  // first output slot of this thread
+    for (uint32_t i = lo; i < hi; ++i) {
+        if (i > 0 && kp_same_span(dst[i - 1], dst[i])) continue;
+        kp_hit h = dst[i];
+        h.mapq = (i == 0 || dst[i - 1].gene != h.gene) ? 60 : 0;  // a dropped predecessor has its keeper's gene
+        src[m++] = h;
+    }
+    const uint32_t total = s_scan[SORT_THREADS - 1];
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += SORT_THREADS) dst[i] = src[i];
+    if (tid == 0) n_hits[a] = total;
 }
 
 // ---- 3. locus scores (core.py:164-198) ---------------------------------------------------------------------------------
@@ -301,7 +345,8 @@ void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const
     if (b.n_asm == 0) return;
     hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
                        task_cap, raw, n_raw, hit_cap, cells);
-    hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(64), 0, stream, raw, n_raw, hit_cap, keys, hits, n_hits);
+    hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(SORT_THREADS), 0, stream, raw, n_raw, hit_cap, keys, hits,
+                       n_hits);
 }
 
 void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
