@@ -16,14 +16,12 @@
 //   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 2048 residues -- every full-length gene): lane b
 //     owns diagonal b; state lives in registers; the two neighbour exchanges per step are DPP wave shifts; both
 //     sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the time loop.
-//   * kp_protein_wide_kernel (wider bands: truncated or partial genes): band state in LDS (up to LDS_CELLS entries, else
-//     global scratch), one barrier per time step, and only the band entries whose cell exists at that step are visited.
+//   * kp_protein_wide_kernel (wider bands: truncated or partial genes, or very long proteins): strips of 64 rows, lane =
+//     row, cells of a row visited left to right one step behind the row above (see protein_pair_strips).
 #include "kp_internal.h"
 
 namespace {
 
-constexpr int LDS_CELLS = 1024;  // band cells held in LDS by the wide-band kernel (48 KB); wider bands use global scratch
-constexpr int NF = 12;          // ints per band cell: M,D,I + 3 payload words each
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
 constexpr int GE = KP_PROT_GAP_EXT;
@@ -101,76 +99,111 @@ __device__ __forceinline__ Result protein_pair_registers(const uint16_t *s_seq1,
     return r;
 }
 
-// ---- general path ---------------------------------------------------------------------------------------------------------
-template <class BandPtr>
-__device__ __forceinline__ Result protein_pair_general(BandPtr st, int cap, const uint8_t *__restrict__ s1,
-                                                       const uint8_t *__restrict__ s2, int len1, int len2, int k,
-                                                       const int8_t *__restrict__ blosum, int lane) {
-    const int nb = 2 * k + 1;
-#define F(field, b) st[(field) * cap + (b)]
-    __syncthreads();
-    for (int b = lane; b < nb; b += 64) {
-        F(0, b) = 0; F(1, b) = NEGP; F(2, b) = NEGP;
-        for (int f = 3; f < NF; ++f) F(f, b) = 0;
-    }
+// ---- row-strip path -------------------------------------------------------------------------------------------------------
+// Any band, any length.  The matrix is cut into strips of 64 rows; lane l owns row i0 + l of the strip and walks it left
+// to right, one step behind lane l-1 (cell (i, j) at step t = j - j_lo + l).  With that skew the upper neighbour
+// (i-1, j) is what lane l-1 produced in the previous step (one DPP shift of its M / D and their payloads), the diagonal
+// one is the upper neighbour fetched a step earlier, and the left one is the lane's own previous cell.  Only columns that
+// can be inside the band for some row of the strip are visited (j_lo .. j_hi); cells outside the band or the matrix
+// produce the boundary values (M = 0, D = I = -inf), exactly what the reference's band array returns for them.  The last
+// row of a strip is handed to the next strip's lane 0 through a row buffer (M, D and payloads per column: LDS ring for
+// windows up to RB_CAP - 64 columns, global scratch beyond).
+constexpr int RB_CAP = 1024;   // columns of the LDS row buffer (ring, indexed by j & (RB_CAP - 1))
+constexpr int RB_FIELDS = 8;   // M, D, payload of M (3), payload of D (3)
+constexpr int S2_CAP = 2048;   // residues of the second sequence staged per strip window
+
+struct RowBuf {
+    int *base;
+    int stride;  // ints between fields
+    int mask;    // column index mask (ring) or -1 (flat)
+    __device__ __forceinline__ int &at(int field, int j) const { return base[field * stride + (j & mask)]; }
+};
+
+__device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq2, const uint8_t *s_idx, const int8_t *s_mat,
+                                                      const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
+                                                      int len1, int len2, int k, int lane) {
     Result r{0, 0, 0, Pay{0, 0, 0}};
-    const int t_last = 2 * len1 + 2 * k;
-    for (int tm = 2; tm <= t_last; ++tm) {
+    int pj_lo = 1, pj_hi = 0;  // columns the previous strip left in the row buffer (none yet)
+    for (int i0 = 1; i0 <= len1; i0 += 64) {
+        const int i = i0 + lane;
+        const int j_lo = max(1, i0 - k), j_hi = min(len2, i0 + 63 + k);
+        const int width = j_hi - j_lo + 1;
+        const bool last_strip = i0 + 64 > len1;
         __syncthreads();
-        // band entries whose cell (i, j) lies inside the matrix at this time step; entries outside keep what they hold
-        // (the initial boundary, or a cell no later cell reads), so nothing else needs to be touched
-        int b_lo = max(0, max(tm - 2 * len1, 2 * k + 2 - tm));
-        const int b_hi = min(nb - 1, min(tm - 2, 2 * k + 2 * len2 - tm));
-        b_lo += (b_lo ^ tm) & 1;
-        for (int b = b_lo + 2 * lane; b <= b_hi; b += 128) {
-            const int i2 = tm - b;  // = 2i
-            const int i = i2 >> 1, j = i + b - k;
-            int m = 0, dv = NEGP, iv = NEGP;
-            Pay pm{0, 0, 0}, pd{0, 0, 0}, pi{0, 0, 0};
-            {
-                int um = 0, ud = NEGP; Pay upm{0, 0, 0}, upd{0, 0, 0};
-                if (b + 1 < nb) {
-                    um = F(0, b + 1); ud = F(1, b + 1);
-                    upm = Pay{(unsigned)F(3, b + 1), (unsigned)F(4, b + 1), (unsigned)F(5, b + 1)};
-                    upd = Pay{(unsigned)F(6, b + 1), (unsigned)F(7, b + 1), (unsigned)F(8, b + 1)};
-                }
-                if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};  // path would start there
-                const int d_open = um - GO, d_ext = ud - GE;
-                if (d_open >= d_ext) { dv = d_open; pd = upm; } else { dv = d_ext; pd = upd; }
-                pd.g += 1;
-                int lm = 0, li = NEGP; Pay lpm{0, 0, 0}, lpi{0, 0, 0};
-                if (b >= 1) {
-                    lm = F(0, b - 1); li = F(2, b - 1);
-                    lpm = Pay{(unsigned)F(3, b - 1), (unsigned)F(4, b - 1), (unsigned)F(5, b - 1)};
-                    lpi = Pay{(unsigned)F(9, b - 1), (unsigned)F(10, b - 1), (unsigned)F(11, b - 1)};
-                }
-                if (lm == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
-                const int i_open = lm - GO, i_ext = li - GE;
-                if (i_open >= i_ext) { iv = i_open; pi = lpm; } else { iv = i_ext; pi = lpi; }
-                pi.g += 1;
-                const int dm = F(0, b);
-                Pay dp{(unsigned)F(3, b), (unsigned)F(4, b), (unsigned)F(5, b)};
-                if (dm == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
-                const uint8_t c1 = s1[i - 1], c2 = s2[j - 1];
-                int bv = dm + (int)blosum[(int)c1 * 256 + c2];
-                pm = dp;
-                pm.a += (c1 == c2) ? 0x10000u : 1u;
-                if (dv > bv) { bv = dv; pm = pd; }
-                if (iv > bv) { bv = iv; pm = pi; }
-                if (bv > 0) {
-                    m = bv;
-                    if (m > r.best || (m == r.best && (i < r.bi || (i == r.bi && j < r.bj)))) {
-                        r.best = m; r.bi = i; r.bj = j; r.bp = pm;
-                    }
+        for (int x = lane; x < min(width, S2_CAP); x += 64) {
+            const uint8_t c = s2[j_lo - 1 + x];
+            s_seq2[x] = (uint16_t)(((unsigned)c << 8) | s_idx[c]);
+        }
+        __syncthreads();
+        unsigned c1 = 0;
+        if (i <= len1) { const uint8_t c = s1[i - 1]; c1 = ((unsigned)c << 8) | s_idx[c]; }
+        int m = 0, dv = NEGP, iv = NEGP;  // this lane's previous cell (i, j-1); D of it is what the lane below reads
+        Pay pm{0, 0, 0}, pd{0, 0, 0}, pi{0, 0, 0};
+        int dm = 0;  // M of (i-1, j-1) and its payload: the upper neighbour of the previous step
+        Pay dpm{0, 0, 0};
+        if (lane == 0 && j_lo - 1 >= pj_lo && j_lo - 1 <= pj_hi) {  // only row i0 can have an in-band cell left of the window
+            dm = rb.at(0, j_lo - 1);
+            dpm = Pay{(unsigned)rb.at(2, j_lo - 1), (unsigned)rb.at(3, j_lo - 1), (unsigned)rb.at(4, j_lo - 1)};
+        }
+        const int n_steps = width + 63;
+        for (int t = 0; t < n_steps; ++t) {
+            const int x = t - lane, j = j_lo + x;
+            // upper neighbour (i-1, j): lane l-1's cell of the previous step; row i0 reads the previous strip's last row
+            int um = from_lower(m), ud = from_lower(dv);
+            Pay upm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g), (unsigned)from_lower((int)pm.s)};
+            Pay upd{(unsigned)from_lower((int)pd.a), (unsigned)from_lower((int)pd.g), (unsigned)from_lower((int)pd.s)};
+            if (lane == 0) {
+                um = 0; ud = NEGP; upm = Pay{0, 0, 0}; upd = Pay{0, 0, 0};
+                if (j >= pj_lo && j <= pj_hi) {
+                    um = rb.at(0, j); ud = rb.at(1, j);
+                    upm = Pay{(unsigned)rb.at(2, j), (unsigned)rb.at(3, j), (unsigned)rb.at(4, j)};
+                    upd = Pay{(unsigned)rb.at(5, j), (unsigned)rb.at(6, j), (unsigned)rb.at(7, j)};
                 }
             }
-            F(0, b) = m; F(1, b) = dv; F(2, b) = iv;
-            F(3, b) = (int)pm.a; F(4, b) = (int)pm.g; F(5, b) = (int)pm.s;
-            F(6, b) = (int)pd.a; F(7, b) = (int)pd.g; F(8, b) = (int)pd.s;
-            F(9, b) = (int)pi.a; F(10, b) = (int)pi.g; F(11, b) = (int)pi.s;
+            const int raw_um = um;
+            const Pay raw_upm = upm;
+            int db = i - j;
+            if (db < 0) db = -db;
+            const bool in = x >= 0 && x < width && i <= len1 && db <= k;
+            int nm = 0, ndv = NEGP, niv = NEGP;
+            Pay npm{0, 0, 0}, npd{0, 0, 0}, npi{0, 0, 0};
+            if (in) {
+                if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};  // path would start there
+                const int d_open = um - GO, d_ext = ud - GE;
+                if (d_open >= d_ext) { ndv = d_open; npd = upm; } else { ndv = d_ext; npd = upd; }
+                npd.g += 1;
+                Pay lpm = pm;
+                if (m == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
+                const int i_open = m - GO, i_ext = iv - GE;
+                if (i_open >= i_ext) { niv = i_open; npi = lpm; } else { niv = i_ext; npi = pi; }
+                npi.g += 1;
+                Pay dp = dpm;
+                if (dm == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
+                unsigned c2;
+                if (x < S2_CAP) c2 = s_seq2[x];
+                else { const uint8_t c = s2[j - 1]; c2 = ((unsigned)c << 8) | s_idx[c]; }
+                const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
+                const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[x1 * 32 + x2];
+                int bv = dm + sc;
+                npm = dp;
+                npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
+                if (ndv > bv) { bv = ndv; npm = npd; }
+                if (niv > bv) { bv = niv; npm = npi; }
+                if (bv > 0) {
+                    nm = bv;
+                    if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
+                }
+            }
+            dm = raw_um; dpm = raw_upm;  // (i-1, j) is the diagonal neighbour of the next column
+            m = nm; dv = ndv; iv = niv; pm = npm; pd = npd; pi = npi;
+            if (lane == 63 && !last_strip && x >= 0 && x < width) {  // hand the strip's last row to the next strip
+                rb.at(0, j) = m; rb.at(1, j) = dv;
+                rb.at(2, j) = (int)pm.a; rb.at(3, j) = (int)pm.g; rb.at(4, j) = (int)pm.s;
+                rb.at(5, j) = (int)pd.a; rb.at(6, j) = (int)pd.g; rb.at(7, j) = (int)pd.s;
+            }
         }
+        pj_lo = j_lo; pj_hi = j_hi;
     }
-#undef F
     return r;
 }
 
@@ -200,6 +233,22 @@ __device__ __forceinline__ void store_result(Result r, int lane, int32_t *__rest
     }
 }
 
+// compact substitution table in LDS: s_idx = index of each byte in ARNDCQEGHILKMFPSTWYVBJZX* (32 for everything else),
+// s_mat = the 32 x 32 corner of the reference's 256 x 256 lookup those indices address
+__device__ __forceinline__ void stage_blosum(const int8_t *__restrict__ blosum, int8_t *s_mat, uint8_t *s_idx, int lane) {
+    for (int c = lane; c < 256; c += 64) s_idx[c] = 32;
+    __syncthreads();
+    if (lane < 25) s_idx[(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[lane]] = (uint8_t)lane;
+    __syncthreads();
+    for (int x = lane; x < 32 * 32; x += 64) {
+        const int a = x >> 5, c = x & 31;
+        s_mat[x] = (a < 25 && c < 25) ? blosum[(int)(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[a] * 256 +
+                                               (int)(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[c]]
+                                      : (int8_t)KP_PROT_FILL;
+    }
+    __syncthreads();
+}
+
 // pairs whose band fits one diagonal per lane (and the empty ones)
 __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                         const int32_t *__restrict__ q_len,
@@ -211,17 +260,7 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
     const int lane = threadIdx.x;
-    // compact substitution table: index of each byte in ARNDCQEGHILKMFPSTWYVBJZX*, 32 for everything else
-    for (int c = lane; c < 256; c += 64) s_idx[c] = 32;
-    __syncthreads();
-    if (lane < 25) s_idx[(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[lane]] = (uint8_t)lane;
-    __syncthreads();
-    for (int x = lane; x < 32 * 32; x += 64) {
-        const int a = x >> 5, c = x & 31;
-        s_mat[x] = (a < 25 && c < 25) ? blosum[(int)(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[a] * 256 +
-                                               (int)(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[c]]
-                                      : (int8_t)KP_PROT_FILL;
-    }
+    stage_blosum(blosum, s_mat, s_idx, lane);
     const int n = n_dev ? *n_dev : n_host;
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
         const int len1 = q_len[p], len2 = t_len[p];
@@ -250,8 +289,12 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
                                                              const int32_t *__restrict__ n_dev,
                                                              const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
                                                              int32_t *__restrict__ scratch, size_t scratch_ints_per_block) {
-    __shared__ int s_band[LDS_CELLS * NF];
+    __shared__ int s_rb[RB_FIELDS * RB_CAP];
+    __shared__ uint16_t s_seq2[S2_CAP];
+    __shared__ int8_t s_mat[32 * 32];
+    __shared__ uint8_t s_idx[256];
     const int lane = threadIdx.x;
+    stage_blosum(blosum, s_mat, s_idx, lane);
     const int n = n_dev ? *n_dev : n_host;
     for (int p = blockIdx.x; p < n; p += gridDim.x) {
         const int len1 = q_len[p], len2 = t_len[p];
@@ -259,13 +302,12 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
         int d = len1 - len2;
         if (d < 0) d = -d;
         const int k = max(KP_PROT_K, d + 1);
-        const int nb = 2 * k + 1;
-        if (fits_registers(len1, len2, nb)) continue;
-        const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
-        Result r;
-        if (nb <= LDS_CELLS) r = protein_pair_general(s_band, LDS_CELLS, s1, s2, len1, len2, k, blosum, lane);
-        else r = protein_pair_general(scratch + (size_t)blockIdx.x * scratch_ints_per_block, nb, s1, s2, len1, len2, k,
-                                      blosum, lane);
+        if (fits_registers(len1, len2, 2 * k + 1)) continue;
+        // the ring holds the previous strip's window while the current one overwrites it 64 columns further on
+        const bool ring = min(len2, 127 + 2 * k) + 64 <= RB_CAP;
+        const RowBuf rb = ring ? RowBuf{s_rb, RB_CAP, RB_CAP - 1}
+                               : RowBuf{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1, -1};
+        const Result r = protein_pair_strips(rb, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
         store_result(r, lane, out8 + 8 * (size_t)p);
     }
 }

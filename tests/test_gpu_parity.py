@@ -68,6 +68,32 @@ def test_protein_dp_random_vs_oracle(ctx, oracle):
     assert len(bad) == 0, (bad[:5], want[bad[:3]], got[bad[:3]], q.lengths[bad[:3]], t.lengths[bad[:3]])
 
 
+def test_protein_dp_long_and_wide_vs_oracle(ctx, oracle):
+    """Shapes of the row-strip kernel the random test does not reach: windows wider than the LDS row buffer (flat scratch
+    path), windows wider than the staged target residues, proteins longer than the register kernel takes with a narrow
+    band (many strips, ring buffer), a band far wider than either protein."""
+    rng = np.random.default_rng(17)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+    qs, ts = [], []
+    for len_t, len_q, sub in ((1500, 300, 0.1), (3000, 100, 0.05), (2500, 2480, 0.2), (2300, 2300, 0.3), (1000, 20, 0.0),
+                              (4200, 3900, 0.15), (64, 1200, 0.1), (65, 129, 0.0), (2049, 2049, 0.02), (1100, 990, 0.4)):
+        t = aa[rng.integers(0, 20, size=len_t)]
+        start = int(rng.integers(0, max(1, len_t - len_q))) if len_q < len_t else 0
+        q = np.resize(t[start:], len_q).copy() if len_q > len_t else t[start : start + len_q].copy()
+        hit = rng.random(len(q)) < sub
+        q[hit] = aa[rng.integers(0, 20, size=int(hit.sum()))]
+        for s in np.flatnonzero(rng.random(len(q)) < 0.004)[::-1]:
+            q = np.delete(q, slice(s, s + 2)) if rng.random() < 0.5 else np.insert(q, s, aa[rng.integers(0, 20, size=3)])
+        qs.append(q.tobytes())
+        ts.append(t.tobytes() + b"*")
+    q, t = Sequences.from_bytes(qs), Sequences.from_bytes(ts)
+    want = oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    got = ctx.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert len(bad) == 0, (bad[:5], want[bad[:3]], got[bad[:3]], q.lengths[bad[:3]], t.lengths[bad[:3]])
+    assert (want[:, 0] > 0).sum() >= 8
+
+
 # ---- aligner stages --------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def small_db():
