@@ -51,6 +51,7 @@ struct DevBuf {  // growable device allocation
 
 struct kp_ctx {
     int device = 0;
+    int key_bits = 64;             // bits of an anchor key that can be set for this database (bounds the radix sort)
     hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
     hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
     hipStream_t aux = nullptr;     // forked off `post` for kernels that only fill a few CUs (wide-band proteins)
@@ -420,6 +421,8 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
                              ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
     ctx->n_genes = n_genes;
+    ctx->key_bits = 46;  // anchor keys: gene/strand index above bit 46 (kp_spec.h)
+    while (ctx->key_bits < 64 && (2ull * (uint64_t)n_genes) >> (ctx->key_bits - 46)) ++ctx->key_bits;
     ctx->n_postings = (int64_t)post.size();
     ctx->has_db = true;
     return KP_OK;
@@ -523,7 +526,8 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
                              b->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
     int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
-                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->stream);
+                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->key_bits,
+                             ctx->stream);
     if (rc) return rc;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
     kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,

@@ -118,4 +118,4 @@ void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_
 // kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
 int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
                     int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,
-                    hipStream_t stream);
+                    int end_bit, hipStream_t stream);
