@@ -800,10 +800,9 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
                      b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->post);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
     const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 24);
-    // widest band: 2 * max(20, |len difference| + 1) + 1.  A hit's target span is at most gene length + band drift
-    // (KP_MAX_BAND), so its translation is at most the database protein + KP_MAX_BAND / 3 residues long.
-    const size_t longest = (size_t)ctx->max_db_prot_len + KP_MAX_BAND / 3 + 2;
-    const size_t scratch_per_block = (2 * (longest + 2) + 1) * 12;
+    // row buffer of the strip kernel when a pair's window does not fit its LDS ring: KP_PROT_ROWBUF_FIELDS ints per
+    // column of the database protein (kp_prot.hip)
+    const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)ctx->max_db_prot_len + 1);
     KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
     kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
                       b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post, ctx->aux, ctx->ev_fork,
@@ -924,18 +923,17 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     if (n == 0) return KP_OK;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t q_bytes = 0, t_bytes = 0;
-    int max_band = 0;
+    int max_t_len = 0;
     for (int i = 0; i < n; ++i) {
         if (q_len[i] < 0 || t_len[i] < 0 || q_off[i] < 0 || t_off[i] < 0 || q_len[i] > 65535 || t_len[i] > 65535)
             return kp_fail(ctx, KP_EINVAL, "protein lengths must be within [0, 65535]");
         q_bytes = std::max(q_bytes, (size_t)q_off[i] + (size_t)q_len[i]);
         t_bytes = std::max(t_bytes, (size_t)t_off[i] + (size_t)t_len[i]);
-        const int d = std::abs(q_len[i] - t_len[i]);
-        max_band = std::max(max_band, 2 * std::max(KP_PROT_K, d + 1) + 1);
+        max_t_len = std::max(max_t_len, t_len[i]);
     }
     if ((q_bytes && !q) || (t_bytes && !t)) return kp_fail(ctx, KP_EINVAL, "null sequence data");
-    const int n_blocks = std::min(n, 256 * 8);
-    const size_t scratch_per_block = (size_t)max_band * 12;
+    const int n_blocks = std::max(1, std::min((n + 3) / 4, 256 * 16));
+    const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)max_t_len + 1);  // see kp_prot.hip
     std::vector<int32_t> meta(4 * (size_t)n);
     std::memcpy(meta.data(), q_off, (size_t)n * 4);
     std::memcpy(meta.data() + n, q_len, (size_t)n * 4);

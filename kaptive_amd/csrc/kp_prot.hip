@@ -13,9 +13,10 @@
 // every state carries the statistics of the path it came from (same tie rules).
 //
 // Two kernels, same arithmetic:
-//   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 2048 residues -- every full-length gene): lane b
-//     owns diagonal b; state lives in registers; the two neighbour exchanges per step are DPP wave shifts; both
-//     sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the time loop.
+//   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 1024 residues -- every full-length gene): 16 lanes
+//     per pair, four adjacent diagonals per lane, four pairs per wave; state lives in registers; the two neighbour
+//     exchanges per step are DPP row shifts; sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the
+//     step loop.
 //   * kp_protein_wide_kernel (wider bands: truncated or partial genes, or very long proteins): strips of 64 rows, lane =
 //     row, cells of a row visited left to right one step behind the row above (see protein_pair_strips).
 #include "kp_internal.h"
@@ -25,7 +26,7 @@ namespace {
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
 constexpr int GE = KP_PROT_GAP_EXT;
-constexpr int REG_MAX_LEN = 2048;
+constexpr int REG_MAX_LEN = 1024;  // residues per sequence the register kernel stages (four pairs per block)
 
 struct Pay {  // path statistics: a = matches << 16 | mismatches, g = gaps, s = start_i << 16 | start_j
     unsigned a, g, s;
@@ -45,56 +46,95 @@ struct Result {
 };
 
 // ---- register path ------------------------------------------------------------------------------------------------------
+// Band of up to 64 diagonals on 16 lanes: lane l owns the four adjacent diagonals b = 4l .. 4l+3 (cells c = 0..3) and
+// works on row i = m - l + 1 at step m, so a wave aligns four pairs side by side.  With that skew the first cell's left
+// neighbour is lane l-1's last cell of the previous step, the last cell's upper neighbour is lane l+1's first cell of
+// the same step, everything else is one of the lane's own registers (DPP row shifts; a group of 16 lanes is a DPP row).
 // s_seq1/s_seq2: residues as (raw byte << 8 | BLOSUM index 0..24, 32 = outside the alphabet); s_mat: 32x32 scores.
-__device__ __forceinline__ Result protein_pair_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
-                                                         const int8_t *s_mat, int len1, int len2, int k, int lane) {
-    const int nb = 2 * k + 1, b = lane;
-    int m = 0, dv = NEGP, iv = NEGP;
-    Pay pm{0, 0, 0}, pd{0, 0, 0}, pi{0, 0, 0};
+constexpr int QP = 16;  // lanes per pair
+
+__device__ __forceinline__ int row_lower(int v) {  // lane b <- lane b-1 within the group's DPP row
+    return __builtin_amdgcn_mov_dpp(v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int row_upper(int v) {  // lane b <- lane b+1
+    return __builtin_amdgcn_mov_dpp(v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ Pay row_lower(Pay p) {
+    return Pay{(unsigned)row_lower((int)p.a), (unsigned)row_lower((int)p.g), (unsigned)row_lower((int)p.s)};
+}
+__device__ __forceinline__ Pay row_upper(Pay p) {
+    return Pay{(unsigned)row_upper((int)p.a), (unsigned)row_upper((int)p.g), (unsigned)row_upper((int)p.s)};
+}
+
+struct PCell {
+    int m, dv, iv;
+    Pay pm, pd, pi;
+};
+
+// one cell (i, j); `left` = (i, j-1): its M, I and their payloads; `up` = (i-1, j): its M, D and their payloads; the
+// diagonal neighbour (i-1, j-1) is the cell's own previous value.  Same statements as the reference's kernel, see top.
+__device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, int j, unsigned c1, unsigned c2,
+                                          const int8_t *s_mat, int lm, int li, Pay lpm, Pay lpi, int um, int ud, Pay upm,
+                                          Pay upd) {
+    int nm = 0, ndv = NEGP, niv = NEGP;
+    Pay npm{0, 0, 0}, npd{0, 0, 0}, npi{0, 0, 0};
+    if (in) {
+        if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};
+        const int d_open = um - GO, d_ext = ud - GE;
+        if (d_open >= d_ext) { ndv = d_open; npd = upm; } else { ndv = d_ext; npd = upd; }
+        npd.g += 1;
+        if (lm == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
+        const int i_open = lm - GO, i_ext = li - GE;
+        if (i_open >= i_ext) { niv = i_open; npi = lpm; } else { niv = i_ext; npi = lpi; }
+        npi.g += 1;
+        Pay dp = c.pm;
+        if (c.m == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
+        const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
+        const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[x1 * 32 + x2];  // 32 marks a byte outside the alphabet
+        int bv = c.m + sc;
+        npm = dp;
+        npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
+        if (ndv > bv) { bv = ndv; npm = npd; }
+        if (niv > bv) { bv = niv; npm = npi; }
+        if (bv > 0) {
+            nm = bv;
+            if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
+        }
+    }
+    // cells outside the matrix or the band take boundary values, exactly as the reference's band array holds them
+    c.m = nm; c.dv = ndv; c.iv = niv; c.pm = npm; c.pd = npd; c.pi = npi;
+}
+
+__device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
+                                                         const int8_t *s_mat, int len1, int len2, int k, int l,
+                                                         int max_steps) {
+    const int nb = 2 * k + 1;
+    PCell A{0, NEGP, NEGP, Pay{0, 0, 0}, Pay{0, 0, 0}, Pay{0, 0, 0}};
+    PCell B = A, C = A, D = A;
     Result r{0, 0, 0, Pay{0, 0, 0}};
-    const int t_last = 2 * len1 + 2 * k;
-    for (int tm = 2; tm <= t_last; ++tm) {
-        // neighbours of the other parity: up = lane b+1 (row i-1), left = lane b-1 (row i)
-        int um = from_upper(m), ud = from_upper(dv);
-        Pay upm{(unsigned)from_upper((int)pm.a), (unsigned)from_upper((int)pm.g), (unsigned)from_upper((int)pm.s)};
-        Pay upd{(unsigned)from_upper((int)pd.a), (unsigned)from_upper((int)pd.g), (unsigned)from_upper((int)pd.s)};
-        int lm = from_lower(m), li = from_lower(iv);
-        Pay lpm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g), (unsigned)from_lower((int)pm.s)};
-        Pay lpi{(unsigned)from_lower((int)pi.a), (unsigned)from_lower((int)pi.g), (unsigned)from_lower((int)pi.s)};
-        if (b + 1 >= nb) { um = 0; ud = NEGP; }
-        if (b == 0) { lm = 0; li = NEGP; }
-        const int i2 = tm - b, i = i2 >> 1, j = i + b - k;
-        const bool mine = ((i2 & 1) == 0) && b < nb;  // this lane's parity
-        const bool in = mine && i2 >= 2 && i <= len1 && j >= 1 && j <= len2;
-        int nm = 0, ndv = NEGP, niv = NEGP;
-        Pay npm{0, 0, 0}, npd{0, 0, 0}, npi{0, 0, 0};
-        if (in) {
-            if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};
-            const int d_open = um - GO, d_ext = ud - GE;
-            if (d_open >= d_ext) { ndv = d_open; npd = upm; } else { ndv = d_ext; npd = upd; }
-            npd.g += 1;
-            if (lm == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
-            const int i_open = lm - GO, i_ext = li - GE;
-            if (i_open >= i_ext) { niv = i_open; npi = lpm; } else { niv = i_ext; npi = lpi; }
-            npi.g += 1;
-            Pay dp = pm;
-            if (m == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
-            const unsigned c1 = s_seq1[i - 1], c2 = s_seq2[j - 1];
-            const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
-            const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[x1 * 32 + x2];  // 32 marks a byte outside the alphabet
-            int bv = m + sc;
-            npm = dp;
-            npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
-            if (ndv > bv) { bv = ndv; npm = npd; }
-            if (niv > bv) { bv = niv; npm = npi; }
-            if (bv > 0) {
-                nm = bv;
-                if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // rows only grow within a lane
-            }
-        }
-        if (mine) {  // cells outside the matrix take boundary values, exactly as the band array of the general path
-            m = nm; dv = ndv; iv = niv; pm = npm; pd = npd; pi = npi;
-        }
+    for (int m = 0; m < max_steps; ++m) {  // max_steps is wave-uniform (the longest pair of the quad)
+        const int i = m - l + 1, j0 = i + 4 * l - k;  // column of cell A
+        const bool row_ok = i >= 1 && i <= len1;
+        const unsigned c1 = row_ok ? s_seq1[i - 1] : 0u;
+        unsigned c2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) c2[c] = (j0 + c >= 1 && j0 + c <= len2) ? s_seq2[j0 + c - 1] : 0u;
+        // A: left neighbour = lane l-1's D of the previous step
+        int lm = row_lower(D.m), li = row_lower(D.iv);
+        Pay lpm = row_lower(D.pm), lpi = row_lower(D.pi);
+        if (l == 0) { lm = 0; li = NEGP; }
+        prot_cell(A, r, row_ok && j0 >= 1 && j0 <= len2 && 4 * l < nb, i, j0, c1, c2[0], s_mat, lm, li, lpm, lpi, B.m, B.dv,
+                  B.pm, B.pd);
+        prot_cell(B, r, row_ok && j0 + 1 >= 1 && j0 + 1 <= len2 && 4 * l + 1 < nb, i, j0 + 1, c1, c2[1], s_mat, A.m, A.iv, A.pm,
+                  A.pi, C.m, C.dv, C.pm, C.pd);
+        prot_cell(C, r, row_ok && j0 + 2 >= 1 && j0 + 2 <= len2 && 4 * l + 2 < nb, i, j0 + 2, c1, c2[2], s_mat, B.m, B.iv, B.pm,
+                  B.pi, D.m, D.dv, D.pm, D.pd);
+        // D: upper neighbour = lane l+1's A of this step
+        int um = row_upper(A.m), ud = row_upper(A.dv);
+        Pay upm = row_upper(A.pm), upd = row_upper(A.pd);
+        if (l == QP - 1) { um = 0; ud = NEGP; }
+        prot_cell(D, r, row_ok && j0 + 3 >= 1 && j0 + 3 <= len2 && 4 * l + 3 < nb, i, j0 + 3, c1, c2[3], s_mat, C.m, C.iv, C.pm,
+                  C.pi, um, ud, upm, upd);
     }
     return r;
 }
@@ -109,7 +149,7 @@ __device__ __forceinline__ Result protein_pair_registers(const uint16_t *s_seq1,
 // row of a strip is handed to the next strip's lane 0 through a row buffer (M, D and payloads per column: LDS ring for
 // windows up to RB_CAP - 64 columns, global scratch beyond).
 constexpr int RB_CAP = 1024;   // columns of the LDS row buffer (ring, indexed by j & (RB_CAP - 1))
-constexpr int RB_FIELDS = 8;   // M, D, payload of M (3), payload of D (3)
+constexpr int RB_FIELDS = KP_PROT_ROWBUF_FIELDS;  // M, D, payload of M (3), payload of D (3)
 constexpr int S2_CAP = 2048;   // residues of the second sequence staged per strip window
 
 struct RowBuf {
@@ -211,19 +251,21 @@ __device__ __forceinline__ bool fits_registers(int len1, int len2, int nb) {
     return nb <= 64 && len1 <= REG_MAX_LEN && len2 <= REG_MAX_LEN;
 }
 
-__device__ __forceinline__ void store_result(Result r, int lane, int32_t *__restrict__ o) {
-    // wave reduction: max score, then smallest i, then smallest j
+// reduction over the `width` lanes that hold one pair (64 = the whole wave): max score, then smallest i, then smallest j
+__device__ __forceinline__ void store_result(Result r, int lane_in_group, int32_t *__restrict__ o, int width = 64,
+                                             bool active = true) {
     int best = r.best, bi = r.bi, bj = r.bj;
     Pay bp = r.bp;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
+        if (off >= width) break;
         const int b2 = __shfl_xor(best, off), i2 = __shfl_xor(bi, off), j2 = __shfl_xor(bj, off);
         const unsigned a2 = __shfl_xor(bp.a, off), g2 = __shfl_xor(bp.g, off), s2v = __shfl_xor(bp.s, off);
         // lanes that never saw a positive cell carry best = 0 and must lose against any positive score
         const bool take = b2 > best || (b2 == best && b2 > 0 && (i2 < bi || (i2 == bi && j2 < bj)));
         if (take) { best = b2; bi = i2; bj = j2; bp = Pay{a2, g2, s2v}; }
     }
-    if (lane == 0) {
+    if (lane_in_group == 0 && active) {
         if (best > 0) {
             o[0] = best; o[1] = (int)(bp.a >> 16); o[2] = (int)(bp.a & 0xFFFFu); o[3] = (int)bp.g;
             o[4] = (int)(bp.s >> 16); o[5] = bi; o[6] = (int)(bp.s & 0xFFFFu); o[7] = bj;
@@ -249,35 +291,40 @@ __device__ __forceinline__ void stage_blosum(const int8_t *__restrict__ blosum, 
     __syncthreads();
 }
 
-// pairs whose band fits one diagonal per lane (and the empty ones)
+// pairs whose band fits 64 diagonals (and the empty ones): four pairs per wave
 __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                         const int32_t *__restrict__ q_len,
                                                         const uint8_t *__restrict__ t, const int32_t *__restrict__ t_off,
                                                         const int32_t *__restrict__ t_len, int32_t n_host,
                                                         const int32_t *__restrict__ n_dev,
                                                         const int8_t *__restrict__ blosum, int32_t *__restrict__ out8) {
-    __shared__ uint16_t s_seq1[REG_MAX_LEN], s_seq2[REG_MAX_LEN];
+    __shared__ uint16_t s_seq1[4][REG_MAX_LEN], s_seq2[4][REG_MAX_LEN];
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, g = lane / QP, l = lane % QP;
     stage_blosum(blosum, s_mat, s_idx, lane);
     const int n = n_dev ? *n_dev : n_host;
-    for (int p = blockIdx.x; p < n; p += gridDim.x) {
-        const int len1 = q_len[p], len2 = t_len[p];
-        if (len1 == 0 || len2 == 0) {  // nothing to align
-            if (lane < 8) out8[8 * (size_t)p + lane] = 0;
-            continue;
-        }
+    for (int p0 = 4 * blockIdx.x; p0 < n; p0 += 4 * gridDim.x) {
+        const int p = p0 + g;
+        int len1 = 0, len2 = 0;
+        if (p < n) { len1 = q_len[p]; len2 = t_len[p]; }
+        const bool empty = p < n && (len1 == 0 || len2 == 0);  // nothing to align: all zeros
         int d = len1 - len2;
         if (d < 0) d = -d;
         const int k = max(KP_PROT_K, d + 1);
-        if (!fits_registers(len1, len2, 2 * k + 1)) continue;  // kp_protein_wide_kernel's
-        const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+        const bool mine = p < n && !empty && fits_registers(len1, len2, 2 * k + 1);  // else kp_protein_wide_kernel's
         __syncthreads();
-        for (int x = lane; x < len1; x += 64) s_seq1[x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
-        for (int x = lane; x < len2; x += 64) s_seq2[x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
+        if (mine) {
+            const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+            for (int x = l; x < len1; x += QP) s_seq1[g][x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
+            for (int x = l; x < len2; x += QP) s_seq2[g][x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
+        }
         __syncthreads();
-        store_result(protein_pair_registers(s_seq1, s_seq2, s_mat, len1, len2, k, lane), lane, out8 + 8 * (size_t)p);
+        int steps = mine ? len1 + QP - 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
+        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, mine ? len1 : 0, mine ? len2 : 0, k, l, steps);
+        store_result(r, l, out8 + 8 * (size_t)(p < n ? p : 0), QP, mine || empty);
     }
 }
 

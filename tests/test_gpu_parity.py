@@ -76,7 +76,7 @@ def test_protein_dp_long_and_wide_vs_oracle(ctx, oracle):
     aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
     qs, ts = [], []
     for len_t, len_q, sub in ((1500, 300, 0.1), (3000, 100, 0.05), (2500, 2480, 0.2), (2300, 2300, 0.3), (1000, 20, 0.0),
-                              (4200, 3900, 0.15), (64, 1200, 0.1), (65, 129, 0.0), (2049, 2049, 0.02), (1100, 990, 0.4)):
+                              (4200, 3900, 0.15), (5000, 4500, 0.1), (64, 1200, 0.1), (65, 129, 0.0), (2049, 2049, 0.02), (1100, 990, 0.4)):
         t = aa[rng.integers(0, 20, size=len_t)]
         start = int(rng.integers(0, max(1, len_t - len_q))) if len_q < len_t else 0
         q = np.resize(t[start:], len_q).copy() if len_q > len_t else t[start : start + len_q].copy()
