@@ -140,8 +140,9 @@ KP_API int kp_batch_score(kp_ctx *ctx, kp_batch *batch, double min_gene_coverage
                           int32_t *locus_counts);
 /* Enqueues the rest of the reduction for the caller's choice of best locus per assembly (core.py:206). */
 KP_API int kp_batch_reduce(kp_ctx *ctx, kp_batch *batch, const int32_t *best_locus, const kp_typing_params *params);
-/* Waits, then copies out one summary per assembly and its kept hits / pieces at kept[a * kept_stride],
- * pieces[a * piece_stride]; strides must be at least the values kp_batch_typing_caps reports. */
+/* kp_batch_typing_caps waits for the reduction and reports the largest number of kept hits / pieces any assembly of the
+ * batch has (at least 1): the smallest strides kp_batch_typing accepts.  kp_batch_typing copies out one summary per
+ * assembly and its kept hits / pieces at kept[a * kept_stride], pieces[a * piece_stride]. */
 KP_API int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *batch, int32_t *kept_cap, int32_t *piece_cap);
 KP_API int kp_batch_typing(kp_ctx *ctx, kp_batch *batch, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
                            kp_piece *pieces, int32_t piece_stride);

@@ -118,6 +118,7 @@ struct kp_batch {
     // reduction
     int kept_cap = 0, piece_cap = 0, prot_cap = 0;
     DevBuf<uint32_t> d_order;
+    DevBuf<uint32_t> d_pack;  // kept / piece rows cut to the strides the caller asked for (kp_batch_typing)
     DevBuf<uint8_t> d_flag, d_prot;
     DevBuf<double> d_scores;
     DevBuf<int32_t> d_lcounts, d_best, d_pairs, d_dp, d_dp_scratch;
@@ -126,6 +127,9 @@ struct kp_batch {
     DevBuf<KpAsmSummary> d_summary;
     KpTypingParams prm{};
     bool scored = false, reduced = false;
+    bool sums_valid = false;  // h_sums / max_kept / max_pieces belong to the most recent reduction
+    std::vector<KpAsmSummary> h_sums;
+    int32_t max_kept = 1, max_pieces = 1;
     // results
     bool aligned = false, finalised = false;
     std::vector<uint32_t> h_counts, h_hit_counts;
@@ -486,7 +490,7 @@ void kp_batch_destroy(kp_batch *b) {
     b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
-    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_flag.release();
+    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_pack.release(); b->d_flag.release();
     b->d_prot.release(); b->d_scores.release(); b->d_lcounts.release(); b->d_best.release(); b->d_pairs.release();
     b->d_dp.release(); b->d_dp_scratch.release(); b->d_kept.release(); b->d_pieces.release(); b->d_summary.release();
     delete b;
@@ -829,24 +833,22 @@ int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const k
     rc = enqueue_reduce(ctx, b);
     if (rc) return rc;
     b->reduced = true;
+    b->sums_valid = false;
     return KP_OK;
 }
 
-int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
-                    kp_piece *pieces, int32_t piece_stride) {
-    if (!ctx || !b || b->ctx != ctx || (b->n_asm > 0 && (!summaries || !kept || !pieces)))
-        return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
-    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+// waits for the reduction, re-runs it with larger buffers while any assembly overflowed one, and keeps the summaries
+static int fetch_summaries(kp_ctx *ctx, kp_batch *b) {
+    if (b->sums_valid) return KP_OK;
     const size_t n_asm = (size_t)b->n_asm;
-    std::vector<KpAsmSummary> sums(n_asm);
+    b->h_sums.resize(n_asm);
     for (int attempt = 0;; ++attempt) {
         if (n_asm)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(sums.data(), b->d_summary.p, n_asm * sizeof(KpAsmSummary),
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_sums.data(), b->d_summary.p, n_asm * sizeof(KpAsmSummary),
                                              hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         int flags = 0;
-        for (const auto &s : sums) flags |= s.overflow;
+        for (const auto &s : b->h_sums) flags |= s.overflow;
         if (!(flags & (1 | 2 | 8))) break;
         if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
         if (attempt >= 8) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
@@ -860,50 +862,64 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
         int rc = enqueue_reduce(ctx, b);
         if (rc) return rc;
     }
-    if (kept_stride < 1 || piece_stride < 1) return kp_fail(ctx, KP_EINVAL, "strides must be positive");
-    // identity sums use numpy's float32 association; a few dozen adds per assembly, done here on the copied rows
-    auto ident_sums = [&]() {
-        std::vector<float> vals;
-        for (size_t a = 0; a < n_asm; ++a) {
-            vals.clear();
-            const KpKept *k = kept + a * (size_t)kept_stride;
-            for (int i = 0; i < summaries[a].n_kept; ++i)
-                if (!(k[i].flags & KP_F_SPURIOUS) && k[i].state == KP_STATE_NORMAL) vals.push_back(k[i].pident);
-            summaries[a].n_normal = (int32_t)vals.size();
-            summaries[a].ident_sum = kp_np_sum_f32(vals.data(), (int)vals.size());
-        }
-    };
-    if (n_asm && kept_stride == b->kept_cap && piece_stride == b->piece_cap) {  // same layout: two bulk copies
-        std::memcpy(summaries, sums.data(), n_asm * sizeof(KpAsmSummary));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, b->d_kept.p, n_asm * (size_t)b->kept_cap * sizeof(KpKept),
-                                         hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, b->d_pieces.p, n_asm * (size_t)b->piece_cap * sizeof(KpPiece),
-                                         hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
-        ident_sums();
-        return KP_OK;
+    b->max_kept = 1; b->max_pieces = 1;
+    for (const auto &s : b->h_sums) {
+        b->max_kept = std::max(b->max_kept, s.n_kept);
+        b->max_pieces = std::max(b->max_pieces, s.n_pieces);
     }
-    for (size_t a = 0; a < n_asm; ++a) {
-        if (sums[a].n_kept > kept_stride || sums[a].n_pieces > piece_stride)
-            return kp_fail(ctx, KP_EINVAL, "output strides too small (see kp_batch_typing_caps)");
-        summaries[a] = sums[a];
-        if (sums[a].n_kept)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(kept + a * (size_t)kept_stride, b->d_kept.p + a * (size_t)b->kept_cap,
-                                             (size_t)sums[a].n_kept * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->post));
-        if (sums[a].n_pieces)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces + a * (size_t)piece_stride, b->d_pieces.p + a * (size_t)b->piece_cap,
-                                             (size_t)sums[a].n_pieces * sizeof(KpPiece), hipMemcpyDeviceToHost, ctx->post));
-    }
+    b->sums_valid = true;
+    return KP_OK;
+}
+
+int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
+                    kp_piece *pieces, int32_t piece_stride) {
+    if (!ctx || !b || b->ctx != ctx || (b->n_asm > 0 && (!summaries || !kept || !pieces)))
+        return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n_asm = (size_t)b->n_asm;
+    int rc = fetch_summaries(ctx, b);
+    if (rc) return rc;
+    if (n_asm == 0) return KP_OK;
+    if (kept_stride < b->max_kept || piece_stride < b->max_pieces)
+        return kp_fail(ctx, KP_EINVAL, "output strides too small (see kp_batch_typing_caps)");
+    std::memcpy(summaries, b->h_sums.data(), n_asm * sizeof(KpAsmSummary));
+    // rows of the device buffers are kept_cap / piece_cap records long; only the first `stride` records of each are
+    // wanted (a batch keeps a few dozen hits per assembly, the buffers leave room for hundreds): packed on the device,
+    // then one linear copy each
+    const size_t kw = (size_t)std::min(kept_stride, b->kept_cap) * sizeof(KpKept) / 4;
+    const size_t pw = (size_t)std::min(piece_stride, b->piece_cap) * sizeof(KpPiece) / 4;
+    KP_HIP_CHECK(ctx, b->d_pack.reserve(n_asm * ((size_t)kept_stride * sizeof(KpKept) + (size_t)piece_stride * sizeof(KpPiece)) / 4));
+    uint32_t *pk = b->d_pack.p, *pp = pk + n_asm * (size_t)kept_stride * sizeof(KpKept) / 4;
+    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(b->d_kept.p), (size_t)b->kept_cap * sizeof(KpKept) / 4, pk,
+                        (size_t)kept_stride * sizeof(KpKept) / 4, kw, (int)n_asm, ctx->post);
+    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(b->d_pieces.p), (size_t)b->piece_cap * sizeof(KpPiece) / 4, pp,
+                        (size_t)piece_stride * sizeof(KpPiece) / 4, pw, (int)n_asm, ctx->post);
+    KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, pk, n_asm * (size_t)kept_stride * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->post));
+    KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, pp, n_asm * (size_t)piece_stride * sizeof(KpPiece), hipMemcpyDeviceToHost,
+                                     ctx->post));
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
-    ident_sums();
+    // identity sums use numpy's float32 association; a few dozen adds per assembly, done here on the copied rows
+    std::vector<float> vals;
+    for (size_t a = 0; a < n_asm; ++a) {
+        vals.clear();
+        const KpKept *k = kept + a * (size_t)kept_stride;
+        for (int i = 0; i < summaries[a].n_kept; ++i)
+            if (!(k[i].flags & KP_F_SPURIOUS) && k[i].state == KP_STATE_NORMAL) vals.push_back(k[i].pident);
+        summaries[a].n_normal = (int32_t)vals.size();
+        summaries[a].ident_sum = kp_np_sum_f32(vals.data(), (int)vals.size());
+    }
     return KP_OK;
 }
 
 int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *b, int32_t *kept_cap, int32_t *piece_cap) {
-    if (!ctx || !b || !kept_cap || !piece_cap) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (!ctx || !b || b->ctx != ctx || !kept_cap || !piece_cap) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
-    *kept_cap = b->kept_cap;
-    *piece_cap = b->piece_cap;
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = fetch_summaries(ctx, b);
+    if (rc) return rc;
+    *kept_cap = b->max_kept;
+    *piece_cap = b->max_pieces;
     return KP_OK;
 }
 

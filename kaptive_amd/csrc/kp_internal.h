@@ -111,6 +111,8 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);
 // kp_prot.hip
+void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, size_t dst_pitch, size_t width, int rows,
+                         hipStream_t stream);  // kp_reduce.hip: row-wise copy between pitched word matrices
 #define KP_PROT_ROWBUF_FIELDS 8  // ints per column of the strip kernel's row buffer (scratch: fields x (longest target + 1))
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,

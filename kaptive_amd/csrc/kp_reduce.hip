@@ -336,7 +336,22 @@ __global__ __launch_bounds__(64) void kp_state_kernel(KpBatchView b, KpTypingDb 
     if (lane == 0) sum->n_final = alive;
 }
 
+// rows of `width` words from a matrix with row pitch src_pitch into one with row pitch dst_pitch (words beyond `width`
+// of a destination row are zeroed)
+__global__ __launch_bounds__(256) void kp_pack_rows_kernel(const uint32_t *__restrict__ src, size_t src_pitch,
+                                                           uint32_t *__restrict__ dst, size_t dst_pitch, size_t width) {
+    const uint32_t *s = src + blockIdx.x * src_pitch;
+    uint32_t *d = dst + blockIdx.x * dst_pitch;
+    for (size_t i = threadIdx.x; i < dst_pitch; i += blockDim.x) d[i] = i < width ? s[i] : 0u;
+}
+
 }  // namespace
+
+void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, size_t dst_pitch, size_t width, int rows,
+                         hipStream_t stream) {
+    if (rows == 0 || dst_pitch == 0) return;
+    hipLaunchKernelGGL(kp_pack_rows_kernel, dim3(rows), dim3(256), 0, stream, src, src_pitch, dst, dst_pitch, width);
+}
 
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
