@@ -152,13 +152,19 @@ constexpr int RB_CAP = 1024;   // columns of the LDS row buffer (ring, indexed b
 constexpr int RB_FIELDS = KP_PROT_ROWBUF_FIELDS;  // M, D, payload of M (3), payload of D (3)
 constexpr int S2_CAP = 2048;   // residues of the second sequence staged per strip window
 
-struct RowBuf {
+// two row buffers, two instantiations: the compiler must see which address space `base` is in (LDS reads instead of
+// flat ones on the per-step path of lane 0)
+struct RingRowBuf {  // LDS, RB_CAP columns, indexed by j & (RB_CAP - 1)
     int *base;
-    int stride;  // ints between fields
-    int mask;    // column index mask (ring) or -1 (flat)
-    __device__ __forceinline__ int &at(int field, int j) const { return base[field * stride + (j & mask)]; }
+    __device__ __forceinline__ int &at(int field, int j) const { return base[field * RB_CAP + (j & (RB_CAP - 1))]; }
+};
+struct FlatRowBuf {  // global scratch, one slot per column
+    int *base;
+    int stride;  // ints between fields (len2 + 1)
+    __device__ __forceinline__ int &at(int field, int j) const { return base[field * stride + j]; }
 };
 
+template <class RowBuf>
 __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq2, const uint8_t *s_idx, const int8_t *s_mat,
                                                       const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
                                                       int len1, int len2, int k, int lane) {
@@ -352,9 +358,12 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
         if (fits_registers(len1, len2, 2 * k + 1)) continue;
         // the ring holds the previous strip's window while the current one overwrites it 64 columns further on
         const bool ring = min(len2, 127 + 2 * k) + 64 <= RB_CAP;
-        const RowBuf rb = ring ? RowBuf{s_rb, RB_CAP, RB_CAP - 1}
-                               : RowBuf{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1, -1};
-        const Result r = protein_pair_strips(rb, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
+        Result r;
+        if (ring)
+            r = protein_pair_strips(RingRowBuf{s_rb}, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
+        else
+            r = protein_pair_strips(FlatRowBuf{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1}, s_seq2,
+                                    s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
         store_result(r, lane, out8 + 8 * (size_t)p);
     }
 }
