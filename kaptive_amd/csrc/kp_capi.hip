@@ -804,10 +804,10 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
                      b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->post);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
     const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 24);
-    // row buffer of the strip kernel when a pair's window does not fit its LDS ring: KP_PROT_ROWBUF_FIELDS ints per
-    // column of the database protein (kp_prot.hip)
+    // row buffer of the strip kernel: KP_PROT_ROWBUF_FIELDS ints per column of the database protein, one region per
+    // block, and 64 ints for its work counter (kp_prot.hip)
     const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)ctx->max_db_prot_len + 1);
-    KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks));
+    KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks + 64));
     kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
                       b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post, ctx->aux, ctx->ev_fork,
                       ctx->ev_join);
@@ -948,7 +948,7 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
         max_t_len = std::max(max_t_len, t_len[i]);
     }
     if ((q_bytes && !q) || (t_bytes && !t)) return kp_fail(ctx, KP_EINVAL, "null sequence data");
-    const int n_blocks = std::max(1, std::min((n + 3) / 4, 256 * 16));
+    const int n_blocks = std::max(1, std::min(n, 256 * 16));
     const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)max_t_len + 1);  // see kp_prot.hip
     std::vector<int32_t> meta(4 * (size_t)n);
     std::memcpy(meta.data(), q_off, (size_t)n * 4);
@@ -960,7 +960,7 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     if ((rc = upload(ctx, ctx->d_pt, t, t_bytes))) return rc;
     if ((rc = upload(ctx, ctx->d_pmeta, meta.data(), meta.size()))) return rc;
     KP_HIP_CHECK(ctx, ctx->d_pout.reserve(8 * (size_t)n));
-    KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks));
+    KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks + 64));
     kp_launch_protein(ctx->d_pq.p, ctx->d_pmeta.p, ctx->d_pmeta.p + n, ctx->d_pt.p, ctx->d_pmeta.p + 2 * (size_t)n,
                       ctx->d_pmeta.p + 3 * (size_t)n, n, nullptr, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
                       scratch_per_block, n_blocks, ctx->stream, nullptr, nullptr, nullptr);

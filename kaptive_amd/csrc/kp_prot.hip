@@ -18,7 +18,10 @@
 //     exchanges per step are DPP row shifts; sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the
 //     step loop.
 //   * kp_protein_wide_kernel (wider bands: truncated or partial genes, or very long proteins): strips of 64 rows, lane =
-//     row, cells of a row visited left to right one step behind the row above (see protein_pair_strips).
+//     row, cells of a row visited left to right one step behind the row above (see protein_pair_strips); pairs are
+//     taken off a shared counter.
+#include <algorithm>
+
 #include "kp_internal.h"
 
 namespace {
@@ -145,27 +148,36 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
 // (i-1, j) is what lane l-1 produced in the previous step (one DPP shift of its M / D and their payloads), the diagonal
 // one is the upper neighbour fetched a step earlier, and the left one is the lane's own previous cell.  Only columns that
 // can be inside the band for some row of the strip are visited (j_lo .. j_hi); cells outside the band or the matrix
-// produce the boundary values (M = 0, D = I = -inf), exactly what the reference's band array returns for them.  The last
-// row of a strip is handed to the next strip's lane 0 through a row buffer (M, D and payloads per column: LDS ring for
-// windows up to RB_CAP - 64 columns, global scratch beyond).
-constexpr int RB_CAP = 1024;   // columns of the LDS row buffer (ring, indexed by j & (RB_CAP - 1))
+// produce the boundary values (M = 0, D = I = -inf), exactly what the reference's band array returns for them.
+// The last row of a strip is handed to the next strip's lane 0 through a row buffer in global scratch (M, D and their
+// payloads per column, one region per block), 64 columns at a time in both directions: lane 63 collects its cells in a
+// small LDS array that the whole wave flushes one column per lane; the next strip's lanes fetch one column each into
+// registers a chunk ahead and publish it to LDS when its turn comes, so the per-step accesses are LDS only, global
+// latency is paid once per 64 steps, and the kernel needs 10 KB of LDS (it shares the CUs with kp_protein_kernel).
 constexpr int RB_FIELDS = KP_PROT_ROWBUF_FIELDS;  // M, D, payload of M (3), payload of D (3)
+constexpr int RB_CHUNK = 64;   // columns published per refill (one per lane)
 constexpr int S2_CAP = 2048;   // residues of the second sequence staged per strip window
 
-// two row buffers, two instantiations: the compiler must see which address space `base` is in (LDS reads instead of
-// flat ones on the per-step path of lane 0)
-struct RingRowBuf {  // LDS, RB_CAP columns, indexed by j & (RB_CAP - 1)
-    int *base;
-    __device__ __forceinline__ int &at(int field, int j) const { return base[field * RB_CAP + (j & (RB_CAP - 1))]; }
-};
-struct FlatRowBuf {  // global scratch, one slot per column
-    int *base;
+struct RowBuf {
+    int *base;   // global scratch of this block
     int stride;  // ints between fields (len2 + 1)
     __device__ __forceinline__ int &at(int field, int j) const { return base[field * stride + j]; }
 };
 
-template <class RowBuf>
-__device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq2, const uint8_t *s_idx, const int8_t *s_mat,
+// column j of the previous strip's last row as lane 0 must see it: stored values inside [pj_lo, pj_hi], boundary outside
+__device__ __forceinline__ void row_buf_column(const RowBuf &rb, int j, int pj_lo, int pj_hi, int (&v)[RB_FIELDS]) {
+    v[0] = 0; v[1] = NEGP;
+#pragma unroll
+    for (int f = 2; f < RB_FIELDS; ++f) v[f] = 0;
+    if (j >= pj_lo && j <= pj_hi) {
+#pragma unroll
+        for (int f = 0; f < RB_FIELDS; ++f) v[f] = rb.at(f, j);
+    }
+}
+
+__device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[RB_CHUNK], int (*s_out)[RB_CHUNK],
+                                                      uint16_t *s_seq2,
+                                                      const uint8_t *s_idx, const int8_t *s_mat,
                                                       const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
                                                       int len1, int len2, int k, int lane) {
     Result r{0, 0, 0, Pay{0, 0, 0}};
@@ -175,6 +187,7 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq
         const int j_lo = max(1, i0 - k), j_hi = min(len2, i0 + 63 + k);
         const int width = j_hi - j_lo + 1;
         const bool last_strip = i0 + 64 > len1;
+        __threadfence();  // the previous strip's row-buffer stores (lane 63) are visible to every lane's loads
         __syncthreads();
         for (int x = lane; x < min(width, S2_CAP); x += 64) {
             const uint8_t c = s2[j_lo - 1 + x];
@@ -191,20 +204,28 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq
             dm = rb.at(0, j_lo - 1);
             dpm = Pay{(unsigned)rb.at(2, j_lo - 1), (unsigned)rb.at(3, j_lo - 1), (unsigned)rb.at(4, j_lo - 1)};
         }
+        int ahead[RB_FIELDS];  // this lane's column of the chunk that is published next
+        row_buf_column(rb, j_lo + lane, pj_lo, pj_hi, ahead);
         const int n_steps = width + 63;
         for (int t = 0; t < n_steps; ++t) {
+            if ((t & (RB_CHUNK - 1)) == 0) {  // wave-uniform: publish columns j_lo + t .. + 63, start fetching the next 64
+#pragma unroll
+                for (int f = 0; f < RB_FIELDS; ++f) s_chunk[f][lane] = ahead[f];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                row_buf_column(rb, j_lo + t + RB_CHUNK + lane, pj_lo, pj_hi, ahead);
+            }
             const int x = t - lane, j = j_lo + x;
             // upper neighbour (i-1, j): lane l-1's cell of the previous step; row i0 reads the previous strip's last row
             int um = from_lower(m), ud = from_lower(dv);
             Pay upm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g), (unsigned)from_lower((int)pm.s)};
             Pay upd{(unsigned)from_lower((int)pd.a), (unsigned)from_lower((int)pd.g), (unsigned)from_lower((int)pd.s)};
             if (lane == 0) {
-                um = 0; ud = NEGP; upm = Pay{0, 0, 0}; upd = Pay{0, 0, 0};
-                if (j >= pj_lo && j <= pj_hi) {
-                    um = rb.at(0, j); ud = rb.at(1, j);
-                    upm = Pay{(unsigned)rb.at(2, j), (unsigned)rb.at(3, j), (unsigned)rb.at(4, j)};
-                    upd = Pay{(unsigned)rb.at(5, j), (unsigned)rb.at(6, j), (unsigned)rb.at(7, j)};
-                }
+                const int c = t & (RB_CHUNK - 1);
+                um = s_chunk[0][c]; ud = s_chunk[1][c];
+                upm = Pay{(unsigned)s_chunk[2][c], (unsigned)s_chunk[3][c], (unsigned)s_chunk[4][c]};
+                upd = Pay{(unsigned)s_chunk[5][c], (unsigned)s_chunk[6][c], (unsigned)s_chunk[7][c]};
             }
             const int raw_um = um;
             const Pay raw_upm = upm;
@@ -242,10 +263,25 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, uint16_t *s_seq
             }
             dm = raw_um; dpm = raw_upm;  // (i-1, j) is the diagonal neighbour of the next column
             m = nm; dv = ndv; iv = niv; pm = npm; pd = npd; pi = npi;
-            if (lane == 63 && !last_strip && x >= 0 && x < width) {  // hand the strip's last row to the next strip
-                rb.at(0, j) = m; rb.at(1, j) = dv;
-                rb.at(2, j) = (int)pm.a; rb.at(3, j) = (int)pm.g; rb.at(4, j) = (int)pm.s;
-                rb.at(5, j) = (int)pd.a; rb.at(6, j) = (int)pd.g; rb.at(7, j) = (int)pd.s;
+            // hand the strip's last row to the next strip: lane 63 collects its cells in LDS, every 64 columns (and at the
+            // end of the row) the whole wave writes them to the row buffer, one column per lane
+            const int xo = t - 63;  // lane 63's column index: wave-uniform
+            if (!last_strip && xo >= 0 && xo < width) {
+                const int slot = xo & (RB_CHUNK - 1);
+                if (lane == 63) {
+                    s_out[0][slot] = m; s_out[1][slot] = dv;
+                    s_out[2][slot] = (int)pm.a; s_out[3][slot] = (int)pm.g; s_out[4][slot] = (int)pm.s;
+                    s_out[5][slot] = (int)pd.a; s_out[6][slot] = (int)pd.g; s_out[7][slot] = (int)pd.s;
+                }
+                if (slot == RB_CHUNK - 1 || xo == width - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane <= slot) {
+#pragma unroll
+                        for (int f = 0; f < RB_FIELDS; ++f) rb.at(f, j_lo + xo - slot + lane) = s_out[f][lane];
+                    }
+                }
             }
         }
         pj_lo = j_lo; pj_hi = j_hi;
@@ -334,37 +370,44 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
     }
 }
 
-// the rest: wide bands (truncated / partial genes) and very long proteins
+// the rest: wide bands (truncated / partial genes) and very long proteins.  A pair here is one long dependent chain of
+// steps for a single wave, so the launch lasts as long as its slowest block: the blocks take the pairs off a shared
+// counter instead of striding over them, and skip what kp_protein_kernel handles.
+constexpr int QUEUE_GRAB = 1;
+
 __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                              const int32_t *__restrict__ q_len,
                                                              const uint8_t *__restrict__ t, const int32_t *__restrict__ t_off,
                                                              const int32_t *__restrict__ t_len, int32_t n_host,
                                                              const int32_t *__restrict__ n_dev,
                                                              const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
-                                                             int32_t *__restrict__ scratch, size_t scratch_ints_per_block) {
-    __shared__ int s_rb[RB_FIELDS * RB_CAP];
+                                                             int32_t *__restrict__ scratch, size_t scratch_ints_per_block,
+                                                             int32_t *__restrict__ queue) {
+    __shared__ int s_chunk[RB_FIELDS][RB_CHUNK], s_out[RB_FIELDS][RB_CHUNK];
     __shared__ uint16_t s_seq2[S2_CAP];
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
     const int lane = threadIdx.x;
-    stage_blosum(blosum, s_mat, s_idx, lane);
     const int n = n_dev ? *n_dev : n_host;
-    for (int p = blockIdx.x; p < n; p += gridDim.x) {
-        const int len1 = q_len[p], len2 = t_len[p];
-        if (len1 == 0 || len2 == 0) continue;
-        int d = len1 - len2;
-        if (d < 0) d = -d;
-        const int k = max(KP_PROT_K, d + 1);
-        if (fits_registers(len1, len2, 2 * k + 1)) continue;
-        // the ring holds the previous strip's window while the current one overwrites it 64 columns further on
-        const bool ring = min(len2, 127 + 2 * k) + 64 <= RB_CAP;
-        Result r;
-        if (ring)
-            r = protein_pair_strips(RingRowBuf{s_rb}, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
-        else
-            r = protein_pair_strips(FlatRowBuf{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1}, s_seq2,
-                                    s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2, k, lane);
-        store_result(r, lane, out8 + 8 * (size_t)p);
+    bool staged = false;
+    for (;;) {
+        int p0 = 0;
+        if (lane == 0) p0 = atomicAdd(queue, QUEUE_GRAB);
+        p0 = __shfl(p0, 0);
+        if (p0 >= n) break;
+        for (int p = p0; p < min(n, p0 + QUEUE_GRAB); ++p) {
+            const int len1 = q_len[p], len2 = t_len[p];
+            if (len1 == 0 || len2 == 0) continue;
+            int d = len1 - len2;
+            if (d < 0) d = -d;
+            const int k = max(KP_PROT_K, d + 1);
+            if (fits_registers(len1, len2, 2 * k + 1)) continue;
+            if (!staged) { stage_blosum(blosum, s_mat, s_idx, lane); staged = true; }  // many blocks find nothing to do
+            const RowBuf rb{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1};
+            const Result r = protein_pair_strips(rb, s_chunk, s_out, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2,
+                                                 k, lane);
+            store_result(r, lane, out8 + 8 * (size_t)p);
+        }
     }
 }
 
@@ -384,10 +427,12 @@ void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_
         (void)hipStreamWaitEvent(aux, fork, 0);
         wide = aux;
     }
-    hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, wide, q, q_off, q_len, t, t_off, t_len, n,
-                       n_dev, blosum, out8, scratch, scratch_ints_per_block);
-    hipLaunchKernelGGL(kp_protein_kernel, dim3(n_blocks), dim3(64), 0, stream, q, q_off, q_len, t, t_off, t_len, n, n_dev,
-                       blosum, out8);
+    int32_t *queue = scratch + (size_t)n_blocks * scratch_ints_per_block;  // callers leave 64 ints behind the regions
+    (void)hipMemsetAsync(queue, 0, sizeof(int32_t), wide);
+    hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, wide, q, q_off, q_len, t, t_off, t_len, n, n_dev,
+                       blosum, out8, scratch, scratch_ints_per_block, queue);
+    hipLaunchKernelGGL(kp_protein_kernel, dim3(std::min(n_blocks, (n + 3) / 4)), dim3(64), 0, stream, q, q_off, q_len, t,
+                       t_off, t_len, n, n_dev, blosum, out8);
     if (aux) {
         (void)hipEventRecord(join, aux);
         (void)hipStreamWaitEvent(stream, join, 0);

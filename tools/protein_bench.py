@@ -35,7 +35,10 @@ def main():
     for name, n, lt, lq in (("full-length 20000", 20000, (200, 600), (200, 600)),
                             ("truncated 1000", 1000, (200, 600), (20, 150)),
                             ("truncated 4000", 4000, (200, 600), (20, 150)),
-                            ("one truncated", 1, (599, 600), (50, 51))):
+                            ("one truncated", 1, (599, 600), (50, 51)),
+                            ("64 x (600, 450)", 64, (599, 600), (450, 451)),
+                            ("64 x (600, 50)", 64, (599, 600), (50, 51)),
+                            ("2000 x (600, 450)", 2000, (599, 600), (450, 451))):
         q, t = pairs(rng, n, lt, lq)
         for _ in range(2):
             t0 = time.perf_counter()
