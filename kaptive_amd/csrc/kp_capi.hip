@@ -98,7 +98,6 @@ struct kp_batch {
     // work buffers
     uint32_t anchor_cap = 0, task_cap = 0;
     DevBuf<uint64_t> d_anchors_a, d_anchors_b;
-    DevBuf<int32_t> d_anchor_contig;
     DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
     DevBuf<uint64_t> d_cand;        // candidates of the scan: [cand_cap] positions, then [cand_cap] u32 k-mers; d_cand_count[0] = how many
@@ -487,7 +486,7 @@ void kp_batch_destroy(kp_batch *b) {
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
     b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
-    b->d_anchor_contig.release(); b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
+    b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
     b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_pack.release(); b->d_flag.release();
@@ -507,7 +506,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
     KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_anchors_b.reserve(n_asm * b->anchor_cap));
-    KP_HIP_CHECK(ctx, b->d_anchor_contig.reserve(n_asm * b->anchor_cap));
     KP_HIP_CHECK(ctx, b->d_counts.reserve(2 * n_asm + KP_N_CLASSES));
     KP_HIP_CHECK(ctx, b->d_sub_counts.reserve(n_asm * KP_ANCHOR_SUBS));
     KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
@@ -534,7 +532,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
                              ctx->stream);
     if (rc) return rc;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
-    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_anchor_contig.p, b->d_tasks.p,
+    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
     kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + ORDER_HEAD,
                          ctx->stream);

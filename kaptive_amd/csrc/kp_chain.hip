@@ -2,39 +2,25 @@
 //
 // Stands in for the chaining stage inside rammappy's map_batch (reference call site
 // src/kaptive/serotyping/core.py:154).  Anchors of an assembly arrive sorted by (gene*2+strand, diagonal, query pos).
-// Pass 1 labels every anchor with its contig.  Pass 2 runs one thread per anchor; the threads that sit on a hard
-// break (first anchor, new gene/strand, new contig, diagonal jump > KP_DIAG_GAP) walk their run forward, cut it
-// whenever it would span more than KP_MAX_SPREAD diagonals, and append one task per surviving cluster to the list of
-// its band-width class.  Runs are short (tens of anchors), so the sequential walk is not a bottleneck.
+// A run is a maximal stretch without a hard break (new gene/strand, new contig, diagonal jump > KP_DIAG_GAP); a run is
+// cut greedily into clusters whenever it would span more than KP_MAX_SPREAD diagonals; every cluster with enough
+// anchors becomes one task in the list of its band-width class.
+//
+// One wave per slice of an assembly's anchor list, 64 anchors per round: every lane takes one anchor (contig by binary
+// search, hard-break flag against its predecessor), the breaks are a ballot, and the pieces between breaks are merged
+// into the cluster the wave carries in uniform registers (first / last diagonal by readlane -- diagonals ascend within
+// a run --, query extent by a wave reduction).  Only a piece that would stretch the cluster past KP_MAX_SPREAD is walked
+// anchor by anchor.  A slice that starts inside a run leaves that run to the wave before it, which keeps going past its
+// own end until the run is over.
 #include "kp_internal.h"
 
 namespace {
 
-constexpr int WALK = 8;
-
-__global__ __launch_bounds__(256) void kp_anchor_contig_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
-                                                               const uint32_t *__restrict__ count, uint32_t cap,
-                                                               int32_t *__restrict__ contig) {
-    const int a = blockIdx.y;
-    uint32_t n = count[a];
-    if (n > cap) n = cap;
-    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
-    const int32_t *starts = b.ctg_start + c0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t k = keys[(size_t)a * cap + i];
-        const int32_t t = (int32_t)KP_KEY_DIAG(k) - KP_DIAG_BIAS + (int32_t)KP_KEY_QPOS(k);
-        int lo = 0, hi = nc;  // last contig starting at or before t
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (starts[mid] <= t) lo = mid + 1; else hi = mid;
-        }
-        contig[(size_t)a * cap + i] = lo - 1;
-    }
-}
+constexpr int CHAIN_SLICES = 8;  // waves per assembly
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
 // produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
-constexpr int STAGE0 = 192, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
+constexpr int STAGE0 = 256, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
 
 struct TaskStage {
     KpTask t0[STAGE0], rest[KP_N_CLASSES - 1][STAGE_REST];
@@ -43,6 +29,7 @@ struct TaskStage {
     __device__ static uint32_t room(int cls) { return cls == 0 ? STAGE0 : STAGE_REST; }
 };
 
+// called by one lane
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
                                               uint32_t qmax, int cnt, KpTask *tasks, uint32_t *task_count,
                                               uint32_t task_cap, TaskStage &st) {
@@ -58,7 +45,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
-    const uint32_t s = atomicAdd(&st.n[cls], 1u);
+    const uint32_t s = st.n[cls]++;
     if (s < TaskStage::room(cls)) {
         st.list(cls)[s] = t;
         return;
@@ -67,67 +54,126 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = t;  // beyond cap: counted, not stored (host retries)
 }
 
-__global__ __launch_bounds__(256) void kp_chain_kernel(const uint64_t *__restrict__ keys,
-                                                       const int32_t *__restrict__ contig,
-                                                       const uint32_t *__restrict__ count, uint32_t cap,
-                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
-                                                       uint32_t task_cap) {
+struct Cluster {  // wave-uniform
+    bool open;
+    uint32_t gs, d0, dprev, qmin, qmax;
+    int ctg, cnt;
+};
+
+__global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ count, uint32_t cap,
+                                                      KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
+                                                      uint32_t task_cap) {
     __shared__ TaskStage st;
-    const int a = blockIdx.y;
+    const int a = blockIdx.y, lane = threadIdx.x;
     uint32_t n = count[a];
     if (n > cap) n = cap;
+    const uint32_t per = (((n + CHAIN_SLICES - 1) / CHAIN_SLICES) + 63u) & ~63u;  // whole rounds of 64 anchors
+    const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
+    if (lo >= n) return;
     const uint64_t *k = keys + (size_t)a * cap;
-    const int32_t *c = contig + (size_t)a * cap;
-    if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t gs = KP_KEY_GS(k[i]);
-        const int ctg = c[i];
-        if (i > 0 && KP_KEY_GS(k[i - 1]) == gs && c[i - 1] == ctg &&
-            KP_KEY_DIAG(k[i]) - KP_KEY_DIAG(k[i - 1]) <= KP_DIAG_GAP)
-            continue;  // not the head of a run
-        uint32_t d0 = KP_KEY_DIAG(k[i]), dprev = d0, q = KP_KEY_QPOS(k[i]);
-        uint32_t qmin = q, qmax = q;
-        int cnt = 1;
-        bool open = true;
-        for (uint32_t j0 = i + 1; j0 < n && open; j0 += WALK) {  // fetch WALK anchors at a time: the walk is latency-bound
-            uint64_t kk[WALK];
-            int32_t cc[WALK];
-#pragma unroll
-            for (int u = 0; u < WALK; ++u) {
-                const uint32_t j = j0 + u < n ? j0 + u : n - 1;
-                kk[u] = k[j];
-                cc[u] = c[j];
-            }
-#pragma unroll
-            for (int u = 0; u < WALK; ++u) {
-                if (!open || j0 + u >= n) { open = open && j0 + u < n; continue; }
-                const uint32_t d = KP_KEY_DIAG(kk[u]);
-                if (KP_KEY_GS(kk[u]) != gs || cc[u] != ctg || d - dprev > KP_DIAG_GAP) { open = false; continue; }
-                q = KP_KEY_QPOS(kk[u]);
-                if (d - d0 > KP_MAX_SPREAD) {  // soft cut: close the cluster, open the next one here
-                    flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap, st);
-                    d0 = d; qmin = qmax = q; cnt = 0;
-                }
-                dprev = d;
-                cnt++;
-                qmin = min(qmin, q);
-                qmax = max(qmax, q);
-            }
+    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+    const int32_t *starts = b.ctg_start + c0;
+    auto contig_of = [&](uint64_t key) {  // last contig starting at or before the anchor's target position
+        const int32_t t = (int32_t)KP_KEY_DIAG(key) - KP_DIAG_BIAS + (int32_t)KP_KEY_QPOS(key);
+        int l = 0, h = nc;
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (starts[mid] <= t) l = mid + 1; else h = mid;
         }
-        flush_cluster(a, gs, ctg, d0, dprev, qmin, qmax, cnt, tasks, task_count, task_cap, st);
-    }
+        return l - 1;
+    };
+    if (lane < KP_N_CLASSES) st.n[lane] = 0;
     __syncthreads();
-    if (threadIdx.x < KP_N_CLASSES) {
-        const uint32_t room = TaskStage::room(threadIdx.x);
-        const uint32_t m = st.n[threadIdx.x] < room ? st.n[threadIdx.x] : room;
-        st.n[threadIdx.x] = m;
-        st.base[threadIdx.x] = m ? atomicAdd(&task_count[threadIdx.x], m) : 0u;
+
+    uint64_t prev_key = 0;  // the anchor before the round's first one
+    int prev_ctg = -1;
+    bool have_prev = lo > 0;
+    if (have_prev) { prev_key = k[lo - 1]; prev_ctg = contig_of(prev_key); }
+    Cluster cur;
+    cur.open = false; cur.gs = cur.d0 = cur.dprev = cur.qmin = cur.qmax = 0; cur.ctg = 0; cur.cnt = 0;
+    auto flush = [&]() {
+        if (cur.open && lane == 0)
+            flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, cur.cnt, tasks, task_count, task_cap, st);
+        cur.open = false;
+    };
+
+    for (uint32_t w = lo; w < n; w += 64) {
+        const bool overrun = w >= hi;  // past the slice: only to finish the run that is still open
+        if (overrun && !cur.open) break;
+        const uint32_t i = w + lane;
+        const bool valid = i < n;
+        const uint64_t key = valid ? k[i] : 0ull;
+        const uint32_t gs = KP_KEY_GS(key), d = KP_KEY_DIAG(key), q = KP_KEY_QPOS(key);
+        const int ctg = valid ? contig_of(key) : -1;
+        uint64_t pk = ((uint64_t)__shfl_up((uint32_t)(key >> 32), 1) << 32) | __shfl_up((uint32_t)key, 1);
+        int pc = __shfl_up(ctg, 1);
+        bool has_pred = true;
+        if (lane == 0) { pk = prev_key; pc = prev_ctg; has_pred = have_prev; }
+        const bool head = valid && (!has_pred || KP_KEY_GS(pk) != gs || pc != ctg || d - KP_KEY_DIAG(pk) > KP_DIAG_GAP);
+        const unsigned long long heads = __ballot(head);
+        const int n_valid = (int)min(64u, n - w);
+        int pos = 0;
+        while (pos < n_valid) {
+            const bool starts_run = (heads >> pos) & 1ull;
+            if (starts_run && overrun) break;  // the run the slice left open ends here; the next slice owns what follows
+            const unsigned long long later = pos < 63 ? heads & (~0ull << (pos + 1)) : 0ull;
+            const int end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
+            if (starts_run) {
+                flush();
+                cur.open = true;
+                cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
+                cur.d0 = cur.dprev = __shfl(d, pos);
+                cur.qmin = cur.qmax = __shfl(q, pos);
+                cur.cnt = 1;
+                pos += 1;
+                if (pos >= end) continue;
+            }
+            if (!cur.open) { pos = end; continue; }  // tail of a run that began before this slice: the previous wave's
+            const uint32_t d_last = __shfl(d, end - 1);
+            if (d_last - cur.d0 <= KP_MAX_SPREAD) {  // the whole piece joins the cluster
+                const bool mine = lane >= pos && lane < end;
+                uint32_t mn = mine ? q : 0xFFFFFFFFu, mx = mine ? q : 0u;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                    mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+                }
+                cur.qmin = min(cur.qmin, mn); cur.qmax = max(cur.qmax, mx);
+                cur.dprev = d_last;
+                cur.cnt += end - pos;
+            } else {  // a soft cut falls inside the piece: anchor by anchor, exactly the greedy rule
+                for (int u = pos; u < end; ++u) {
+                    const uint32_t du = __shfl(d, u), qu = __shfl(q, u);
+                    if (du - cur.d0 > KP_MAX_SPREAD) {
+                        flush();
+                        cur.open = true;
+                        cur.d0 = du; cur.qmin = cur.qmax = qu; cur.cnt = 0;
+                    }
+                    cur.dprev = du;
+                    cur.cnt++;
+                    cur.qmin = min(cur.qmin, qu); cur.qmax = max(cur.qmax, qu);
+                }
+            }
+            pos = end;
+        }
+        if (overrun && pos < n_valid) break;  // stopped at the head that ends the overrun
+        prev_key = __shfl(key, n_valid - 1);
+        prev_ctg = __shfl(ctg, n_valid - 1);
+        have_prev = true;
+    }
+    flush();
+    __syncthreads();
+    if (lane < KP_N_CLASSES) {
+        const uint32_t room = TaskStage::room(lane);
+        const uint32_t m = st.n[lane] < room ? st.n[lane] : room;
+        st.n[lane] = m;
+        st.base[lane] = m ? atomicAdd(&task_count[lane], m) : 0u;
     }
     __syncthreads();
     for (int cls = 0; cls < KP_N_CLASSES; ++cls) {
         const KpTask *src = st.list(cls);
-        for (uint32_t i = threadIdx.x; i < st.n[cls]; i += blockDim.x) {
+        for (uint32_t i = lane; i < st.n[cls]; i += 64) {
             const uint32_t slot = st.base[cls] + i;
             if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = src[i];
         }
@@ -213,12 +259,8 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count, uint32_t task_cap,
-                     hipStream_t stream) {
+                     KpTask *tasks, uint32_t *task_count, uint32_t task_cap, hipStream_t stream) {
     if (b.n_asm == 0) return;
-    const dim3 grid(32, b.n_asm), block(256);
-    hipLaunchKernelGGL(kp_anchor_contig_kernel, grid, block, 0, stream, b, sorted_anchors, anchor_count, cap,
-                       anchor_contig);
-    hipLaunchKernelGGL(kp_chain_kernel, grid, block, 0, stream, sorted_anchors, anchor_contig, anchor_count, cap, tasks,
-                       task_count, task_cap);
+    hipLaunchKernelGGL(kp_chain_kernel, dim3(CHAIN_SLICES, b.n_asm), dim3(64), 0, stream, b, sorted_anchors, anchor_count,
+                       cap, tasks, task_count, task_cap);
 }

@@ -101,8 +101,7 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     int32_t *anchor_contig, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
-                     hipStream_t stream);
+                     KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap, hipStream_t stream);
 // kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order and results at
 // c * task_cap and its count at task_count[c]; one launch covers all four.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
