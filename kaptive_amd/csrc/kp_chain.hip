@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int CHAIN_SLICES = 8;  // waves per assembly
+constexpr int CHAIN_SLICES = 16;  // waves per assembly
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
 // produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
@@ -98,12 +98,43 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
         cur.open = false;
     };
 
+    // [from, to) of the round joins the open cluster (same run: no hard break inside)
+    auto merge = [&](int from, int to, uint32_t d, uint32_t q) {
+        const uint32_t d_last = __shfl(d, to - 1);
+        if (d_last - cur.d0 <= KP_MAX_SPREAD) {  // the whole piece joins the cluster
+            const bool mine = threadIdx.x >= (unsigned)from && threadIdx.x < (unsigned)to;
+            uint32_t mn = mine ? q : 0xFFFFFFFFu, mx = mine ? q : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+            }
+            cur.qmin = min(cur.qmin, mn); cur.qmax = max(cur.qmax, mx);
+            cur.dprev = d_last;
+            cur.cnt += to - from;
+        } else {  // a soft cut falls inside the piece: anchor by anchor, exactly the greedy rule
+            for (int u = from; u < to; ++u) {
+                const uint32_t du = __shfl(d, u), qu = __shfl(q, u);
+                if (du - cur.d0 > KP_MAX_SPREAD) {
+                    flush();
+                    cur.open = true;
+                    cur.d0 = du; cur.qmin = cur.qmax = qu; cur.cnt = 0;
+                }
+                cur.dprev = du;
+                cur.cnt++;
+                cur.qmin = min(cur.qmin, qu); cur.qmax = max(cur.qmax, qu);
+            }
+        }
+    };
+
+    uint64_t next_key = lo + lane < n ? k[lo + lane] : 0ull;  // the following round's anchors are fetched a round ahead
     for (uint32_t w = lo; w < n; w += 64) {
         const bool overrun = w >= hi;  // past the slice: only to finish the run that is still open
         if (overrun && !cur.open) break;
         const uint32_t i = w + lane;
         const bool valid = i < n;
-        const uint64_t key = valid ? k[i] : 0ull;
+        const uint64_t key = next_key;
+        next_key = i + 64 < n ? k[i + 64] : 0ull;
         const uint32_t gs = KP_KEY_GS(key), d = KP_KEY_DIAG(key), q = KP_KEY_QPOS(key);
         const int ctg = valid ? contig_of(key) : -1;
         uint64_t pk = ((uint64_t)__shfl_up((uint32_t)(key >> 32), 1) << 32) | __shfl_up((uint32_t)key, 1);
@@ -113,54 +144,32 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
         const bool head = valid && (!has_pred || KP_KEY_GS(pk) != gs || pc != ctg || d - KP_KEY_DIAG(pk) > KP_DIAG_GAP);
         const unsigned long long heads = __ballot(head);
         const int n_valid = (int)min(64u, n - w);
-        int pos = 0;
-        while (pos < n_valid) {
-            const bool starts_run = (heads >> pos) & 1ull;
-            if (starts_run && overrun) break;  // the run the slice left open ends here; the next slice owns what follows
-            const unsigned long long later = pos < 63 ? heads & (~0ull << (pos + 1)) : 0ull;
-            const int end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
-            if (starts_run) {
-                flush();
-                cur.open = true;
-                cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
-                cur.d0 = cur.dprev = __shfl(d, pos);
-                cur.qmin = cur.qmax = __shfl(q, pos);
-                cur.cnt = 1;
-                pos += 1;
-                if (pos >= end) continue;
-            }
-            if (!cur.open) { pos = end; continue; }  // tail of a run that began before this slice: the previous wave's
-            const uint32_t d_last = __shfl(d, end - 1);
-            if (d_last - cur.d0 <= KP_MAX_SPREAD) {  // the whole piece joins the cluster
-                const bool mine = lane >= pos && lane < end;
-                uint32_t mn = mine ? q : 0xFFFFFFFFu, mx = mine ? q : 0u;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    mn = min(mn, (uint32_t)__shfl_xor(mn, o));
-                    mx = max(mx, (uint32_t)__shfl_xor(mx, o));
-                }
-                cur.qmin = min(cur.qmin, mn); cur.qmax = max(cur.qmax, mx);
-                cur.dprev = d_last;
-                cur.cnt += end - pos;
-            } else {  // a soft cut falls inside the piece: anchor by anchor, exactly the greedy rule
-                for (int u = pos; u < end; ++u) {
-                    const uint32_t du = __shfl(d, u), qu = __shfl(q, u);
-                    if (du - cur.d0 > KP_MAX_SPREAD) {
-                        flush();
-                        cur.open = true;
-                        cur.d0 = du; cur.qmin = cur.qmax = qu; cur.cnt = 0;
-                    }
-                    cur.dprev = du;
-                    cur.cnt++;
-                    cur.qmin = min(cur.qmin, qu); cur.qmax = max(cur.qmax, qu);
-                }
-            }
-            pos = end;
-        }
-        if (overrun && pos < n_valid) break;  // stopped at the head that ends the overrun
         prev_key = __shfl(key, n_valid - 1);
         prev_ctg = __shfl(ctg, n_valid - 1);
         have_prev = true;
+        const int first = heads ? (int)__builtin_ctzll(heads) : n_valid;  // anchors before it continue the open run
+        if (first > 0 && cur.open) merge(0, first, d, q);  // (no open cluster: tail of a run the previous wave owns)
+        if (!heads) continue;
+        flush();  // the first break ends whatever was open
+        if (overrun) break;  // ... and what follows belongs to the next slice
+        // Most runs are stray seeds (fewer than KP_MIN_ANCHORS anchors) that can never become a task: every head lane
+        // measures its own run, and only runs that are long enough -- or reach the end of the round and may go on --
+        // are visited.
+        const unsigned long long later = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
+        const int my_end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
+        unsigned long long todo = __ballot(head && (my_end - lane >= KP_MIN_ANCHORS || my_end == n_valid));
+        while (todo) {
+            const int pos = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int end = __shfl(my_end, pos);
+            cur.open = true;
+            cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
+            cur.d0 = cur.dprev = __shfl(d, pos);
+            cur.qmin = cur.qmax = __shfl(q, pos);
+            cur.cnt = 1;
+            if (pos + 1 < end) merge(pos + 1, end, d, q);
+            if (end < n_valid) flush();  // the run ends inside the round; otherwise it stays open for the next one
+        }
     }
     flush();
     __syncthreads();
