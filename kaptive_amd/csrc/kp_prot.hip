@@ -74,38 +74,45 @@ struct PCell {
     Pay pm, pd, pi;
 };
 
+__device__ __forceinline__ Pay pick(bool c, const Pay &x, const Pay &y) {
+    return Pay{c ? x.a : y.a, c ? x.g : y.g, c ? x.s : y.s};
+}
+
 // one cell (i, j); `left` = (i, j-1): its M, I and their payloads; `up` = (i-1, j): its M, D and their payloads; the
-// diagonal neighbour (i-1, j-1) is the cell's own previous value.  Same statements as the reference's kernel, see top.
+// diagonal neighbour (i-1, j-1) comes in as c.m / c.pm.  Same statements as the reference's kernel (see top), written
+// as selects: every lane executes the same instructions whatever its cell decides.
 __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, int j, unsigned c1, unsigned c2,
                                           const int8_t *s_mat, int lm, int li, Pay lpm, Pay lpi, int um, int ud, Pay upm,
                                           Pay upd) {
-    int nm = 0, ndv = NEGP, niv = NEGP;
-    Pay npm{0, 0, 0}, npd{0, 0, 0}, npi{0, 0, 0};
-    if (in) {
-        if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};
-        const int d_open = um - GO, d_ext = ud - GE;
-        if (d_open >= d_ext) { ndv = d_open; npd = upm; } else { ndv = d_ext; npd = upd; }
-        npd.g += 1;
-        if (lm == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
-        const int i_open = lm - GO, i_ext = li - GE;
-        if (i_open >= i_ext) { niv = i_open; npi = lpm; } else { niv = i_ext; npi = lpi; }
-        npi.g += 1;
-        Pay dp = c.pm;
-        if (c.m == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
-        const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
-        const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[x1 * 32 + x2];  // 32 marks a byte outside the alphabet
-        int bv = c.m + sc;
-        npm = dp;
-        npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
-        if (ndv > bv) { bv = ndv; npm = npd; }
-        if (niv > bv) { bv = niv; npm = npi; }
-        if (bv > 0) {
-            nm = bv;
-            if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
-        }
-    }
+    // D: gap arriving from above (a path would start at a neighbour whose M is 0)
+    upm = pick(um == 0, Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j}, upm);
+    const int d_open = um - GO, d_ext = ud - GE;
+    int ndv = max(d_open, d_ext);
+    Pay npd = pick(d_open >= d_ext, upm, upd);
+    npd.g += 1;
+    // I: gap arriving from the left
+    lpm = pick(lm == 0, Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)}, lpm);
+    const int i_open = lm - GO, i_ext = li - GE;
+    int niv = max(i_open, i_ext);
+    Pay npi = pick(i_open >= i_ext, lpm, lpi);
+    npi.g += 1;
+    // M: diagonal first, then D, then I, each only if strictly better
+    Pay npm = pick(c.m == 0, Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)}, c.pm);
+    const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
+    const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[(x1 * 32 + x2) & 1023u];  // 32: byte outside the alphabet
+    int bv = c.m + sc;
+    npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
+    const bool take_d = ndv > bv;
+    bv = max(bv, ndv);
+    npm = pick(take_d, npd, npm);
+    const bool take_i = niv > bv;
+    bv = max(bv, niv);
+    npm = pick(take_i, npi, npm);
     // cells outside the matrix or the band take boundary values, exactly as the reference's band array holds them
-    c.m = nm; c.dv = ndv; c.iv = niv; c.pm = npm; c.pd = npd; c.pi = npi;
+    const int nm = in ? max(bv, 0) : 0;
+    if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
+    c.m = nm; c.dv = in ? ndv : NEGP; c.iv = in ? niv : NEGP;
+    c.pm = npm; c.pd = npd; c.pi = npi;
 }
 
 __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
@@ -232,37 +239,16 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
             int db = i - j;
             if (db < 0) db = -db;
             const bool in = x >= 0 && x < width && i <= len1 && db <= k;
-            int nm = 0, ndv = NEGP, niv = NEGP;
-            Pay npm{0, 0, 0}, npd{0, 0, 0}, npi{0, 0, 0};
-            if (in) {
-                if (um == 0) upm = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j};  // path would start there
-                const int d_open = um - GO, d_ext = ud - GE;
-                if (d_open >= d_ext) { ndv = d_open; npd = upm; } else { ndv = d_ext; npd = upd; }
-                npd.g += 1;
-                Pay lpm = pm;
-                if (m == 0) lpm = Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)};
-                const int i_open = m - GO, i_ext = iv - GE;
-                if (i_open >= i_ext) { niv = i_open; npi = lpm; } else { niv = i_ext; npi = pi; }
-                npi.g += 1;
-                Pay dp = dpm;
-                if (dm == 0) dp = Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)};
-                unsigned c2;
+            unsigned c2 = 0;
+            if (x >= 0 && x < width) {
                 if (x < S2_CAP) c2 = s_seq2[x];
                 else { const uint8_t c = s2[j - 1]; c2 = ((unsigned)c << 8) | s_idx[c]; }
-                const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
-                const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[x1 * 32 + x2];
-                int bv = dm + sc;
-                npm = dp;
-                npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
-                if (ndv > bv) { bv = ndv; npm = npd; }
-                if (niv > bv) { bv = niv; npm = npi; }
-                if (bv > 0) {
-                    nm = bv;
-                    if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
-                }
             }
+            PCell cell;  // comes in holding the diagonal neighbour (i-1, j-1), goes out holding (i, j)
+            cell.m = dm; cell.pm = dpm;
+            prot_cell(cell, r, in, i, j, c1, c2, s_mat, m, iv, pm, pi, um, ud, upm, upd);
             dm = raw_um; dpm = raw_upm;  // (i-1, j) is the diagonal neighbour of the next column
-            m = nm; dv = ndv; iv = niv; pm = npm; pd = npd; pi = npi;
+            m = cell.m; dv = cell.dv; iv = cell.iv; pm = cell.pm; pd = cell.pd; pi = cell.pi;
             // hand the strip's last row to the next strip: lane 63 collects its cells in LDS, every 64 columns (and at the
             // end of the row) the whole wave writes them to the row buffer, one column per lane
             const int xo = t - 63;  // lane 63's column index: wave-uniform
