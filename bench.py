@@ -37,6 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+L2_PEAK_BYTES_PER_S = 34.5e12  # aggregate L2 bandwidth (MI355X_MICROARCH.md), served in 128-byte lines
 
 
 def _make_one(job):
@@ -84,10 +85,10 @@ def build_workload(n_asm: int, seed0: int, length: float, workers: int):
 
 
 def pmc_traffic(args):
-    """HBM bytes per scan launch from the PMC counters. Counters cannot be read from inside the process, so this is
-    the figure of the committed offline collection (profiles/scan_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE passes of this same command, gfx950 correction applied as MI355X_MICROARCH.md prescribes); it is
-    reported only when the workload is the one that collection ran, otherwise null."""
+    """PMC figures of the scan kernel (HBM bytes and L2 requests per launch).  Counters cannot be read from inside the
+    process, so these are the figures of the committed offline collection (profiles/scan_pmc.json: separate rocprofv3
+    --pmc passes of this same command, gfx950 correction applied as MI355X_MICROARCH.md prescribes); they are reported
+    only when the workload is the one that collection ran, otherwise null."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_pmc.json")
     try:
         with open(path) as fh:
@@ -96,7 +97,7 @@ def pmc_traffic(args):
         return None
     if pmc["workload"] != {"assemblies": args.assemblies, "length": args.length}:
         return None
-    return pmc["traffic_bytes_per_launch_K_l2"]
+    return pmc
 
 
 def cpu_baseline(dbs, genomes, budget_s: float = 20.0) -> dict:
@@ -233,6 +234,8 @@ def main() -> None:
         scan_ms = float(np.mean(scan_all))
         scan_bytes = float(np.mean([p["bytes_scanned"] for p in prof[0]]))
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
+        pmc = pmc_traffic(args)
+        l2_req = pmc["l2"]["K_l2"]["TCC_REQ_sum"] if pmc else None
         # per database: mean over the timed steps of the sum over sub-batches
         mean_ms = [{k: float(np.sum([p[k] for p in plist])) / args.steps for k in plist[0] if k != "bytes_scanned"}
                    for plist in prof]
@@ -269,8 +272,12 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "kernel": "kp_scan_kernel<0, false> (K database pass)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args), "bytes_per_launch": scan_bytes,
-                "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc["traffic_bytes_per_launch_K_l2"] if pmc else None,
+                "bytes_per_launch": scan_bytes, "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
+                # what actually bounds this kernel: one L2 request per presence-filter gather (PMC: TCC_REQ_sum of the
+                # committed collection) against the L2's 34.5 TB/s in 128-byte lines
+                "l2_requests_per_launch": l2_req,
+                "l2_request_rate_frac": (l2_req / (scan_ms * 1e-3)) / (L2_PEAK_BYTES_PER_S / 128.0) if l2_req else None,
             },
             "dp": {
                 "kernel": "kp_sw_kernel<8|16|32|64>", "cells_per_db_pass": [s["dp_cells"] for s in stats],
