@@ -51,7 +51,8 @@ struct DevBuf {  // growable device allocation
 
 struct kp_ctx {
     int device = 0;
-    int key_bits = 64;             // bits of an anchor key that can be set for this database (bounds the radix sort)
+    int gs_bits = 18;              // bits of the gene/strand field of an anchor key this database can set
+    int max_gene_len = 0;
     hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
     hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
     hipStream_t aux = nullptr;     // forked off `post` for kernels that only fill a few CUs (wide-band proteins)
@@ -97,6 +98,8 @@ struct kp_batch {
     KpBatchView view{};
     // work buffers
     uint32_t anchor_cap = 0, task_cap = 0;
+    int64_t max_asm_bases = 0;  // longest assembly of the batch (padded)
+    KpKeyBits key_bits{16, 30};  // compact anchor keys of the most recent alignment pass
     DevBuf<uint64_t> d_anchors_a, d_anchors_b;
     DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
@@ -216,8 +219,10 @@ int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n, hipStream_t stre
 int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_word_off, const int32_t *ctg_start,
                  const int32_t *ctg_len, const int32_t *asm_first_ctg, const int32_t *n_runs,
                  const int32_t *asm_first_nrun) {
+    b->max_asm_bases = 0;
     for (int a = 0; a < n_asm; ++a) {
         const int64_t words = asm_word_off[a + 1] - asm_word_off[a];
+        b->max_asm_bases = std::max<int64_t>(b->max_asm_bases, words * 16);
         if (words < 0 || (words * 16) % KP_ASM_ALIGN != 0 || (uint64_t)words * 16 > KP_MAX_ASM_LEN)
             return kp_fail(ctx, KP_EINVAL, "assembly length must be a multiple of KP_ASM_ALIGN and <= KP_MAX_ASM_LEN");
         if (asm_first_ctg[a + 1] < asm_first_ctg[a] || asm_first_nrun[a + 1] < asm_first_nrun[a])
@@ -424,8 +429,10 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
                              ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
     ctx->n_genes = n_genes;
-    ctx->key_bits = 46;  // anchor keys: gene/strand index above bit 46 (kp_spec.h)
-    while (ctx->key_bits < 64 && (2ull * (uint64_t)n_genes) >> (ctx->key_bits - 46)) ++ctx->key_bits;
+    ctx->gs_bits = 1;
+    while (ctx->gs_bits < 18 && (2ull * (uint64_t)n_genes) >> ctx->gs_bits) ++ctx->gs_bits;
+    ctx->max_gene_len = 0;
+    for (int len : ctx->gene_len) ctx->max_gene_len = std::max(ctx->max_gene_len, len);
     ctx->n_postings = (int64_t)post.size();
     ctx->has_db = true;
     return KP_OK;
@@ -522,17 +529,22 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
     uint32_t *d_task_count = b->d_counts.p + n_asm;
     const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
+    // compact anchor keys: as many bits per field as this batch and database can set
+    auto bits_for = [](uint64_t max_value) { uint32_t n = 1; while (n < 63 && (max_value >> n)) ++n; return n; };
+    b->key_bits.qb = std::min<uint32_t>(16, bits_for((uint64_t)std::max(ctx->max_gene_len, 1)));
+    b->key_bits.db = std::min<uint32_t>(30, bits_for((uint64_t)b->max_asm_bases + KP_DIAG_BIAS));
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
     kp_launch_scan(b->view, ctx->index, b->d_cand.p, b->d_cand_count.p, b->cand_cap, b->d_anchors_a.p, b->d_sub_counts.p,
-                   sub_cap, ctx->stream, ev ? ev[1] : nullptr);
+                   sub_cap, b->key_bits, ctx->stream, ev ? ev[1] : nullptr);
     kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
                              b->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
     int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
-                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm, ctx->key_bits,
+                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm,
+                             (int)(b->key_bits.qb + b->key_bits.db) + ctx->gs_bits,
                              ctx->stream);
     if (rc) return rc;
     if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
-    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->d_tasks.p,
+    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->key_bits, b->d_tasks.p,
                     d_task_count, b->task_cap, ctx->stream);
     kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + ORDER_HEAD,
                          ctx->stream);
@@ -692,6 +704,7 @@ int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int
         if (hipMemcpy(out, b->d_anchors_a.p + (size_t)a * b->anchor_cap, (size_t)m * sizeof(uint64_t),
                       hipMemcpyDeviceToHost) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "D2H anchors failed");
+        for (int64_t i = 0; i < m; ++i) out[i] = kp_key_unpack(out[i], b->key_bits);  // callers see the spec's layout
     }
     return n;
 }

@@ -1,7 +1,8 @@
 // kp_chain.hip -- sorted anchors -> band tasks (the "chaining" step of the aligner, include/kp_spec.h).
 //
 // Stands in for the chaining stage inside rammappy's map_batch (reference call site
-// src/kaptive/serotyping/core.py:154).  Anchors of an assembly arrive sorted by (gene*2+strand, diagonal, query pos).
+// src/kaptive/serotyping/core.py:154).  Anchors of an assembly arrive sorted by (gene*2+strand, diagonal, query pos),
+// as compact keys (KpKeyBits, kp_internal.h).
 // A run is a maximal stretch without a hard break (new gene/strand, new contig, diagonal jump > KP_DIAG_GAP); a run is
 // cut greedily into clusters whenever it would span more than KP_MAX_SPREAD diagonals; every cluster with enough
 // anchors becomes one task in the list of its band-width class.
@@ -61,7 +62,7 @@ struct Cluster {  // wave-uniform
 };
 
 __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
-                                                      const uint32_t *__restrict__ count, uint32_t cap,
+                                                      const uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb,
                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
                                                       uint32_t task_cap) {
     __shared__ TaskStage st;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
     const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
     const int32_t *starts = b.ctg_start + c0;
     auto contig_of = [&](uint64_t key) {  // last contig starting at or before the anchor's target position
-        const int32_t t = (int32_t)KP_KEY_DIAG(key) - KP_DIAG_BIAS + (int32_t)KP_KEY_QPOS(key);
+        const int32_t t = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + (int32_t)kp_ckey_qpos(key, kb);
         int l = 0, h = nc;
         while (l < h) {
             const int mid = (l + h) >> 1;
@@ -135,13 +136,13 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
         const bool valid = i < n;
         const uint64_t key = next_key;
         next_key = i + 64 < n ? k[i + 64] : 0ull;
-        const uint32_t gs = KP_KEY_GS(key), d = KP_KEY_DIAG(key), q = KP_KEY_QPOS(key);
+        const uint32_t gs = kp_ckey_gs(key, kb), d = kp_ckey_diag(key, kb), q = kp_ckey_qpos(key, kb);
         const int ctg = valid ? contig_of(key) : -1;
         uint64_t pk = ((uint64_t)__shfl_up((uint32_t)(key >> 32), 1) << 32) | __shfl_up((uint32_t)key, 1);
         int pc = __shfl_up(ctg, 1);
         bool has_pred = true;
         if (lane == 0) { pk = prev_key; pc = prev_ctg; has_pred = have_prev; }
-        const bool head = valid && (!has_pred || KP_KEY_GS(pk) != gs || pc != ctg || d - KP_KEY_DIAG(pk) > KP_DIAG_GAP);
+        const bool head = valid && (!has_pred || kp_ckey_gs(pk, kb) != gs || pc != ctg || d - kp_ckey_diag(pk, kb) > KP_DIAG_GAP);
         const unsigned long long heads = __ballot(head);
         const int n_valid = (int)min(64u, n - w);
         prev_key = __shfl(key, n_valid - 1);
@@ -268,8 +269,8 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     KpTask *tasks, uint32_t *task_count, uint32_t task_cap, hipStream_t stream) {
+                     KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, hipStream_t stream) {
     if (b.n_asm == 0) return;
     hipLaunchKernelGGL(kp_chain_kernel, dim3(CHAIN_SLICES, b.n_asm), dim3(64), 0, stream, b, sorted_anchors, anchor_count,
-                       cap, tasks, task_count, task_cap);
+                       cap, key_bits, tasks, task_count, task_cap);
 }

@@ -48,6 +48,24 @@ struct KpGenes {
     int32_t n_genes;
 };
 
+// Anchors are sorted (and chained) on a compact form of the spec's key -- same fields in the same order, but only as
+// many bits per field as this database / batch can set -- so that the radix sort has fewer digits to go through:
+//   [gene*2+strand][diagonal : db bits][query position : qb bits]
+struct KpKeyBits {
+    uint32_t qb, db;  // qb: bits of the longest gene's positions, db: bits of longest assembly + KP_DIAG_BIAS
+};
+__host__ __device__ inline uint64_t kp_key_pack(uint64_t spec_key, KpKeyBits kb) {
+    return ((spec_key >> 46) << (kb.qb + kb.db)) | (((spec_key >> 16) & 0x3FFFFFFFull) << kb.qb) | (spec_key & 0xFFFFull);
+}
+__host__ __device__ inline uint32_t kp_ckey_qpos(uint64_t k, KpKeyBits kb) { return (uint32_t)(k & ((1ull << kb.qb) - 1ull)); }
+__host__ __device__ inline uint32_t kp_ckey_diag(uint64_t k, KpKeyBits kb) {
+    return (uint32_t)((k >> kb.qb) & ((1ull << kb.db) - 1ull));
+}
+__host__ __device__ inline uint32_t kp_ckey_gs(uint64_t k, KpKeyBits kb) { return (uint32_t)(k >> (kb.qb + kb.db)); }
+__host__ __device__ inline uint64_t kp_key_unpack(uint64_t k, KpKeyBits kb) {
+    return ((uint64_t)kp_ckey_gs(k, kb) << 46) | ((uint64_t)kp_ckey_diag(k, kb) << 16) | kp_ckey_qpos(k, kb);
+}
+
 struct KpBatchView {
     const uint32_t *words;          // packed bases of the whole batch
     const int64_t *asm_word_off;    // [n_asm + 1]
@@ -95,13 +113,14 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 //   packs each assembly's slices into one run.  `after_scan` (optional) is recorded between the two passes.
 #define KP_ANCHOR_SUBS 64
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
-                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, hipStream_t stream,
-                    hipEvent_t after_scan);
+                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
+                    hipStream_t stream, hipEvent_t after_scan);
 void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap, hipStream_t stream);
+                     KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
+                     hipStream_t stream);
 // kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order and results at
 // c * task_cap and its count at task_count[c]; one launch covers all four.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,

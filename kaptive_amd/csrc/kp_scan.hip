@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
                                                          const uint32_t *__restrict__ cand_kmer,
                                                          const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                          uint64_t *__restrict__ anchors, uint32_t *__restrict__ sub_count,
-                                                         uint32_t sub_cap) {
+                                                         uint32_t sub_cap, KpKeyBits kb) {
     unsigned long long n = *n_cand;
     if (n > cand_cap) n = cand_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
                 if (sw.start[mid] <= k) lo = mid; else hi = mid;
             }
             const uint32_t j = k - sw.start[lo];
-            if (j < sw.room[lo]) sw.dst[lo][j] = sw.src[lo][j] + sw.shift[lo];
+            if (j < sw.room[lo]) sw.dst[lo][j] = kp_key_pack(sw.src[lo][j] + sw.shift[lo], kb);  // compact sort key
         }
         wave_lds_sync();
     }
@@ -292,8 +292,8 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 }
 
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
-                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, hipStream_t stream,
-                    hipEvent_t after_scan) {
+                    uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
+                    hipStream_t stream, hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
     const char *env_mode = getenv("KAPTIVE_AMD_SCAN_ABLATE"), *env_lds = getenv("KAPTIVE_AMD_NO_LDS_FILTER");
@@ -316,5 +316,5 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
     }
     if (after_scan) (void)hipEventRecord(after_scan, stream);
     hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap,
-                       anchors, sub_count, sub_cap);
+                       anchors, sub_count, sub_cap, key_bits);
 }
