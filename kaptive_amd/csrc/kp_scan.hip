@@ -54,7 +54,8 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 //
 // Two filter tiers.  A database with few k-mers (O loci: tens of thousands) gets a filter small enough for LDS
 // (idx.lds_filter, <= KP_LDS_FILTER_BLOCKS 64-bit blocks): LDSF = true copies it into the block's LDS once and probes it
-// there, so the kernel is no longer limited by how many L1 misses a CU keeps in flight; blocks are 16 waves wide (one
+// there, so the kernel no longer pays one L2 request per selected k-mer (the L2 tier runs at the L2's request rate);
+// blocks are 16 waves wide (one
 // per CU: the filter takes most of its LDS) with a small candidate stage per wave.  Otherwise the 2 MB filter is probed
 // in L2 (LDSF = false, 4-wave blocks, several per CU).
 template <bool LDSF> struct ScanShape {
