@@ -195,6 +195,41 @@ def test_sw_raw_results_match_oracle(ctx, small_setup, small_db):
     batch.close()
 
 
+def test_random_assembly_shapes_match_oracle(ctx, small_setup, small_db):
+    """Fuzz over what shapes the chaining / SW / expansion kernels: divergence up to 25 %, indels, many tiny contigs,
+    N runs, a second partial locus, no locus at all -- anchors, tasks and hits of one batch, all compared."""
+    odb = small_setup
+    rng = np.random.default_rng(2024)
+    asms = []
+    for i in range(28):
+        kw = dict(length=int(rng.integers(30_000, 250_000)), median_contigs=int(rng.choice([1, 3, 12, 80, 400])),
+                  min_contig=int(rng.choice([16, 200])), sub_rate=float(rng.choice([0.0, 0.01, 0.05, 0.12, 0.25])),
+                  p_break=float(rng.choice([0.0, 0.5, 1.0])), p_is=0.3, p_stop=0.3)
+        if i % 5 == 0:
+            kw["n_run"] = int(rng.integers(1, 300))
+        if i % 7 == 0:
+            kw["second_locus"] = int(rng.integers(0, 9))
+        if i % 9 == 0:
+            kw["locus"] = -1
+        if i % 4 == 0:
+            kw["force_split"] = True
+        asms.append(make_assembly(small_db, seed=5000 + i, **kw))
+    packed = [a.packed() for a in asms]
+    batch = ctx.batch(packed)
+    hits, off = batch.align()
+    n_hits = 0
+    for i, pa in enumerate(packed):
+        assert np.array_equal(batch.anchors(i), odb.anchors(pa)), f"anchors of fuzz assembly {i}"
+        want_t = np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names))
+        got_t = np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names))
+        _same_records(got_t, want_t, f"tasks of fuzz assembly {i}")
+        want = odb.align(pa)
+        _same_records(hits[off[i] : off[i + 1]], want, f"hits of fuzz assembly {i}")
+        n_hits += len(want)
+    assert n_hits > 500
+    batch.close()
+
+
 def test_overflow_retry_gives_same_hits(ctx, small_setup, small_db, monkeypatch):
     odb = small_setup
     asm = make_assembly(small_db, seed=11, length=90_000, median_contigs=5, min_contig=200)
