@@ -134,6 +134,20 @@ typedef struct kp_typing_tables {
     const int32_t *prot_off, *prot_len;
 } kp_typing_tables;
 KP_API int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *tables);
+/* Several databases in one context (typing groups).  The reference types an assembly against the K database and then
+ * against the O database, aligning each database's genes in its own map_batch call (src/kaptive/serotyping/cli.py:183-210
+ * runs one Serotyper per database).  Here the genes of all databases can be loaded into one context back to back
+ * (kp_db_load over the concatenation) so that an assembly's bases are scanned, sorted, chained and aligned once; the
+ * hit table is sorted by gene, so every database's reduction gets its own contiguous run of it.
+ *   kp_db_load_typing_group: typing tables of the database whose genes are [gene_lo, gene_hi) of the context's genes
+ *     (tables index genes relative to gene_lo); group is a small caller-chosen index < KP_MAX_TYPING_GROUPS.
+ *     kp_db_load_typing(ctx, t) is kp_db_load_typing_group(ctx, 0, 0, n_genes, t).
+ *   kp_batch_use_group: the group that kp_batch_score / kp_batch_reduce / kp_batch_typing_caps / kp_batch_typing /
+ *     kp_batch_proteins address from now on (0 after kp_batch_create); every group keeps its own results. */
+#define KP_MAX_TYPING_GROUPS 16
+KP_API int kp_db_load_typing_group(kp_ctx *ctx, int32_t group, int32_t gene_lo, int32_t gene_hi,
+                                   const kp_typing_tables *tables);
+KP_API int kp_batch_use_group(kp_ctx *ctx, kp_batch *batch, int32_t group);
 /* After kp_batch_align: finalises the hit tables on the device and returns locus_scores (float64, sum of best query
  * coverages per locus, core.py:188-193) and locus_counts (genes counted, core.py:196-198), both [n_asm][n_loci]. */
 KP_API int kp_batch_score(kp_ctx *ctx, kp_batch *batch, double min_gene_coverage, double *locus_scores,

@@ -26,7 +26,7 @@ EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_db_load", "kp_db_n_postings",
     "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
-    "kp_batch_tasks", "kp_db_load_typing", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
+    "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_free",
 )  # fmt: skip
 
@@ -130,6 +130,7 @@ class Context:
         if rc != 0:
             raise NativeError(f"kp_ctx_create failed ({rc}): {lib().kp_last_error(None).decode()}")
         self.device = device
+        self.group_loci: dict[int, int] = {}  # loci of every typing group's database (shapes of the score arrays)
         self._batches: "weakref.WeakSet" = weakref.WeakSet()
         _live.add(self)
 
@@ -155,8 +156,10 @@ class Context:
         codes, off = _c(gene_codes, np.uint8), _c(gene_off, np.int32)
         self._check(lib().kp_db_load(self._h, _p(codes), _p(off), C.c_int32(len(off) - 1)), "kp_db_load")
 
-    def load_typing(self, db) -> None:
-        """Upload the Database columns the batched reduction reads (kp_db_load_typing)."""
+    def load_typing(self, db, group: int = 0, gene_lo: int = 0, gene_hi: int | None = None) -> None:
+        """Upload the Database columns the batched reduction reads (kp_db_load_typing / kp_db_load_typing_group).  With
+        several databases in one context, ``db``'s genes are ``[gene_lo, gene_hi)`` of the genes given to
+        ``load_genes``."""
         prot = db.translations
         keep = dict(
             gene_locus=_c(db.gene_locus_indices, np.uint16), gene_extra=_c(db.extra_genes, np.uint8),
@@ -165,8 +168,14 @@ class Context:
             prot=_c(prot.seqs, np.uint8), prot_off=_c(prot.offsets, np.int32), prot_len=_c(prot.lengths, np.int32),
         )  # fmt: skip
         t = TypingTables(n_loci=len(db.loci), **{k: _p(v).value for k, v in keep.items()})
-        self._check(lib().kp_db_load_typing(self._h, C.byref(t)), "kp_db_load_typing")
-        self.n_loci = len(db.loci)
+        gene_hi = gene_lo + len(db.genes) if gene_hi is None else gene_hi
+        self._check(
+            lib().kp_db_load_typing_group(self._h, C.c_int32(group), C.c_int32(gene_lo), C.c_int32(gene_hi), C.byref(t)),
+            "kp_db_load_typing_group",
+        )
+        self.group_loci[group] = len(db.loci)
+        if group == 0:
+            self.n_loci = len(db.loci)
 
     @property
     def n_postings(self) -> int:
@@ -256,9 +265,10 @@ class Batch:
         return dict(zip(("anchors", "tasks", "dp_cells", "hits", "retries"), s.tolist()))
 
     # -- batched reduction ------------------------------------------------------------------------------------------
-    def score(self, min_gene_coverage: float) -> tuple[np.ndarray, np.ndarray]:
+    def score(self, min_gene_coverage: float, group: int = 0) -> tuple[np.ndarray, np.ndarray]:
         """(locus_scores f64, locus_counts i32), both [n_asm, n_loci]; finalises the hit tables on the device."""
-        n_loci = self.ctx.n_loci
+        self.use_group(group)
+        n_loci = self.ctx.group_loci[group]
         scores = np.zeros((self.n_asm, n_loci), np.float64)
         counts = np.zeros((self.n_asm, n_loci), np.int32)
         self.ctx._check(
@@ -267,14 +277,20 @@ class Batch:
         )
         return scores, counts
 
-    def reduce_async(self, best_locus: np.ndarray, params: "TypingParams") -> None:
+    def use_group(self, group: int) -> None:
+        """The typing group (database) the score / reduce / typing / proteins calls address (kp_batch_use_group)."""
+        self.ctx._check(lib().kp_batch_use_group(self.ctx._h, self._h, C.c_int32(group)), "kp_batch_use_group")
+
+    def reduce_async(self, best_locus: np.ndarray, params: "TypingParams", group: int = 0) -> None:
+        self.use_group(group)
         best = _c(best_locus, np.int32)
         self.ctx._check(lib().kp_batch_reduce(self.ctx._h, self._h, _p(best), C.byref(params)), "kp_batch_reduce")
 
-    def typing(self):
+    def typing(self, group: int = 0):
         """(summaries [n_asm], kept [n_asm, kept_cap], pieces [n_asm, piece_cap]) as structured arrays."""
         from kaptive_amd.serotyping.batch import KEPT_DTYPE, PIECE_DTYPE, SUMMARY_DTYPE
 
+        self.use_group(group)
         for _ in range(2):  # capacities may grow inside kp_batch_typing when a buffer overflowed
             kc, pc = C.c_int32(0), C.c_int32(0)
             self.ctx._check(lib().kp_batch_typing_caps(self.ctx._h, self._h, C.byref(kc), C.byref(pc)), "typing_caps")
@@ -288,7 +304,8 @@ class Batch:
             return sums, kept, pieces
         raise NativeError("kp_batch_typing: capacities kept changing")
 
-    def proteins(self, asm_index: int, nbytes: int) -> np.ndarray:
+    def proteins(self, asm_index: int, nbytes: int, group: int = 0) -> np.ndarray:
+        self.use_group(group)
         out = np.zeros(nbytes, np.uint8)
         self.ctx._check(lib().kp_batch_proteins(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(nbytes)),
                         "kp_batch_proteins")  # fmt: skip

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 
@@ -49,6 +50,60 @@ struct DevBuf {  // growable device allocation
 
 }  // namespace
 
+// Typing tables of one database.  Its genes are the contiguous range [gene_lo, gene_hi) of the context's genes; all
+// tables use gene indices relative to gene_lo.
+struct KpTypingGroup {
+    int32_t gene_lo = 0, gene_hi = 0;
+    DevBuf<uint16_t> d_gene_locus, d_gene_pos;
+    DevBuf<uint8_t> d_gene_extra, d_prot_db;
+    DevBuf<int8_t> d_gene_strand;
+    DevBuf<int32_t> d_locus_off, d_locus_len, d_prot_db_off, d_prot_db_len;
+    KpTypingDb typing{};
+    int max_db_prot_len = 0;
+    void release() {
+        d_gene_locus.release(); d_gene_pos.release(); d_gene_extra.release(); d_prot_db.release(); d_gene_strand.release();
+        d_locus_off.release(); d_locus_len.release(); d_prot_db_off.release(); d_prot_db_len.release();
+    }
+};
+
+// Reduction state of one (batch, typing group): the group's hits (copied out of the batch's hit table with gene indices
+// rebased) and everything score / reduce / typing produce for it.
+struct KpTypingRun {
+    // every group works on streams of its own (highest priority), so the reductions of several databases over one
+    // batch overlap: they are chains of short, low-occupancy kernels
+    hipStream_t stream = nullptr, aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool split = false;  // d_hits / d_hit_n belong to the batch's most recent alignment pass
+    DevBuf<kp_hit> d_hits;
+    DevBuf<uint32_t> d_hit_n;
+    DevBuf<uint64_t> d_keys;   // cull keys
+    DevBuf<uint32_t> d_order;
+    DevBuf<uint8_t> d_flag;
+    DevBuf<int32_t> d_dp_scratch;
+    int kept_cap = 0, piece_cap = 0, prot_cap = 0;
+    DevBuf<uint32_t> d_pack;  // kept / piece rows cut to the strides the caller asked for (kp_batch_typing)
+    DevBuf<uint8_t> d_prot;
+    DevBuf<double> d_scores;
+    DevBuf<int32_t> d_lcounts, d_best, d_pairs, d_dp;
+    DevBuf<KpKept> d_kept;
+    DevBuf<KpPiece> d_pieces;
+    DevBuf<KpAsmSummary> d_summary;
+    KpTypingParams prm{};
+    bool scored = false, reduced = false;
+    bool sums_valid = false;  // h_sums / max_kept / max_pieces belong to the most recent reduction
+    std::vector<KpAsmSummary> h_sums;
+    int32_t max_kept = 1, max_pieces = 1;
+    void release() {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
+        if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+        if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+        d_keys.release(); d_order.release(); d_flag.release(); d_dp_scratch.release();
+        d_hits.release(); d_hit_n.release(); d_pack.release(); d_prot.release(); d_scores.release(); d_lcounts.release();
+        d_best.release(); d_pairs.release(); d_dp.release(); d_kept.release(); d_pieces.release(); d_summary.release();
+    }
+};
+
 struct kp_ctx {
     int device = 0;
     int gs_bits = 18;              // bits of the gene/strand field of an anchor key this database can set
@@ -77,14 +132,8 @@ struct kp_ctx {
     // sort scratch
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
-    // typing tables (kp_db_load_typing)
-    bool has_typing = false;
-    DevBuf<uint16_t> d_gene_locus, d_gene_pos;
-    DevBuf<uint8_t> d_gene_extra, d_prot_db;
-    DevBuf<int8_t> d_gene_strand;
-    DevBuf<int32_t> d_locus_off, d_locus_len, d_prot_db_off, d_prot_db_len;
-    KpTypingDb typing{};
-    int max_db_prot_len = 0;
+    // typing tables (kp_db_load_typing / kp_db_load_typing_group): one set per database whose genes are in the index
+    std::vector<std::unique_ptr<KpTypingGroup>> groups;
 };
 
 struct kp_batch {
@@ -117,21 +166,9 @@ struct kp_batch {
     DevBuf<uint64_t> d_keys;        // 3 per hit row
     DevBuf<unsigned long long> d_cells;
     DevBuf<int64_t> d_hit_off;
-    // reduction
-    int kept_cap = 0, piece_cap = 0, prot_cap = 0;
-    DevBuf<uint32_t> d_order;
-    DevBuf<uint32_t> d_pack;  // kept / piece rows cut to the strides the caller asked for (kp_batch_typing)
-    DevBuf<uint8_t> d_flag, d_prot;
-    DevBuf<double> d_scores;
-    DevBuf<int32_t> d_lcounts, d_best, d_pairs, d_dp, d_dp_scratch;
-    DevBuf<KpKept> d_kept;
-    DevBuf<KpPiece> d_pieces;
-    DevBuf<KpAsmSummary> d_summary;
-    KpTypingParams prm{};
-    bool scored = false, reduced = false;
-    bool sums_valid = false;  // h_sums / max_kept / max_pieces belong to the most recent reduction
-    std::vector<KpAsmSummary> h_sums;
-    int32_t max_kept = 1, max_pieces = 1;
+    // reduction: one run per typing group, created on first use; `group` is the one score / reduce / typing calls address
+    std::vector<std::unique_ptr<KpTypingRun>> runs;
+    int32_t group = 0;
     // results
     bool aligned = false, finalised = false;
     std::vector<uint32_t> h_counts, h_hit_counts;
@@ -307,9 +344,9 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
-    ctx->d_gene_locus.release(); ctx->d_gene_pos.release(); ctx->d_gene_extra.release(); ctx->d_prot_db.release();
-    ctx->d_gene_strand.release(); ctx->d_locus_off.release(); ctx->d_locus_len.release();
-    ctx->d_prot_db_off.release(); ctx->d_prot_db_len.release();
+    for (auto &g : ctx->groups)
+        if (g) g->release();
+    ctx->groups.clear();
     if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->post) (void)hipStreamDestroy(ctx->post);
@@ -335,7 +372,9 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (n_genes > KP_MAX_GENES) return kp_fail(ctx, KP_EINVAL, "too many genes (KP_MAX_GENES)");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     ctx->has_db = false;
-    ctx->has_typing = false;
+    for (auto &g : ctx->groups)
+        if (g) g->release();
+    ctx->groups.clear();  // typing tables index the genes that are being replaced
     ctx->gene_len.resize((size_t)n_genes);
     std::vector<int32_t> nib_off(2 * (size_t)n_genes);
     size_t n_words = 0;
@@ -496,9 +535,9 @@ void kp_batch_destroy(kp_batch *b) {
     b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
     b->d_results.release(); b->d_task_order.release();
     b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
-    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release(); b->d_order.release(); b->d_pack.release(); b->d_flag.release();
-    b->d_prot.release(); b->d_scores.release(); b->d_lcounts.release(); b->d_best.release(); b->d_pairs.release();
-    b->d_dp.release(); b->d_dp_scratch.release(); b->d_kept.release(); b->d_pieces.release(); b->d_summary.release();
+    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release();
+    for (auto &r : b->runs)
+        if (r) r->release();
     delete b;
 }
 
@@ -569,7 +608,9 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         const uint64_t want = (uint64_t)std::max(b->n_asm, 1) * env_u32("KAPTIVE_AMD_TASKS_PER_ASM", 4096);
         b->task_cap = (uint32_t)std::min<uint64_t>(want, 1u << 28);
     }
-    b->aligned = false; b->finalised = false; b->scored = false; b->reduced = false; b->hits_fetched = false;
+    b->aligned = false; b->finalised = false; b->hits_fetched = false;
+    for (auto &r : b->runs)
+        if (r) { r->split = false; r->scored = false; r->reduced = false; r->sums_valid = false; }
     b->stats[4] = 0;
     int rc = enqueue_align(ctx, b);
     if (rc) return rc;
@@ -736,12 +777,19 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64
 // ---- batched typing ---------------------------------------------------------------------------------------------------
 int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *t) {
     if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    return kp_db_load_typing_group(ctx, 0, 0, ctx->n_genes, t);
+}
+
+int kp_db_load_typing_group(kp_ctx *ctx, int32_t group, int32_t gene_lo, int32_t gene_hi, const kp_typing_tables *t) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
     if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "kp_db_load must come first");
+    if (group < 0 || group >= KP_MAX_TYPING_GROUPS || gene_lo < 0 || gene_hi < gene_lo || gene_hi > ctx->n_genes)
+        return kp_fail(ctx, KP_EINVAL, "bad typing group or gene range");
     if (!t || t->n_loci <= 0 || !t->gene_locus || !t->gene_extra || !t->gene_pos || !t->gene_strand || !t->locus_gene_off ||
         !t->locus_gene_len || !t->prot_off || !t->prot_len)
         return kp_fail(ctx, KP_EINVAL, "bad typing tables");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const size_t G = (size_t)ctx->n_genes, L = (size_t)t->n_loci;
+    const size_t G = (size_t)(gene_hi - gene_lo), L = (size_t)t->n_loci;
     size_t prot_bytes = 0;
     int max_len = 0;
     for (size_t g = 0; g < G; ++g) {
@@ -754,131 +802,187 @@ int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *t) {
         if (t->locus_gene_off[l] < 0 || t->locus_gene_len[l] < 0 || (size_t)t->locus_gene_off[l] + (size_t)t->locus_gene_len[l] > G)
             return kp_fail(ctx, KP_EINVAL, "locus gene range out of bounds");
     if (prot_bytes && !t->prot) return kp_fail(ctx, KP_EINVAL, "null protein data");
+    if (ctx->groups.size() <= (size_t)group) ctx->groups.resize((size_t)group + 1);
+    if (!ctx->groups[(size_t)group]) ctx->groups[(size_t)group].reset(new KpTypingGroup());
+    KpTypingGroup &T = *ctx->groups[(size_t)group];
     int rc;
-    if ((rc = upload(ctx, ctx->d_gene_locus, t->gene_locus, G))) return rc;
-    if ((rc = upload(ctx, ctx->d_gene_extra, t->gene_extra, G))) return rc;
-    if ((rc = upload(ctx, ctx->d_gene_pos, t->gene_pos, G))) return rc;
-    if ((rc = upload(ctx, ctx->d_gene_strand, t->gene_strand, G))) return rc;
-    if ((rc = upload(ctx, ctx->d_locus_off, t->locus_gene_off, L))) return rc;
-    if ((rc = upload(ctx, ctx->d_locus_len, t->locus_gene_len, L))) return rc;
-    if ((rc = upload(ctx, ctx->d_prot_db, t->prot, prot_bytes))) return rc;
-    if ((rc = upload(ctx, ctx->d_prot_db_off, t->prot_off, G))) return rc;
-    if ((rc = upload(ctx, ctx->d_prot_db_len, t->prot_len, G))) return rc;
+    if ((rc = upload(ctx, T.d_gene_locus, t->gene_locus, G))) return rc;
+    if ((rc = upload(ctx, T.d_gene_extra, t->gene_extra, G))) return rc;
+    if ((rc = upload(ctx, T.d_gene_pos, t->gene_pos, G))) return rc;
+    if ((rc = upload(ctx, T.d_gene_strand, t->gene_strand, G))) return rc;
+    if ((rc = upload(ctx, T.d_locus_off, t->locus_gene_off, L))) return rc;
+    if ((rc = upload(ctx, T.d_locus_len, t->locus_gene_len, L))) return rc;
+    if ((rc = upload(ctx, T.d_prot_db, t->prot, prot_bytes))) return rc;
+    if ((rc = upload(ctx, T.d_prot_db_off, t->prot_off, G))) return rc;
+    if ((rc = upload(ctx, T.d_prot_db_len, t->prot_len, G))) return rc;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
-    ctx->typing = KpTypingDb{ctx->d_gene_locus.p, ctx->d_gene_extra.p, ctx->d_gene_pos.p, ctx->d_gene_strand.p,
-                             ctx->d_gene_len.p, ctx->d_locus_off.p, ctx->d_locus_len.p, ctx->d_prot_db.p,
-                             ctx->d_prot_db_off.p, ctx->d_prot_db_len.p, ctx->n_genes, (int32_t)t->n_loci};
-    ctx->max_db_prot_len = max_len;
-    ctx->has_typing = true;
+    T.typing = KpTypingDb{T.d_gene_locus.p, T.d_gene_extra.p, T.d_gene_pos.p, T.d_gene_strand.p,
+                          ctx->d_gene_len.p + gene_lo, T.d_locus_off.p, T.d_locus_len.p, T.d_prot_db.p,
+                          T.d_prot_db_off.p, T.d_prot_db_len.p, (int32_t)G, (int32_t)t->n_loci};
+    T.max_db_prot_len = max_len;
+    T.gene_lo = gene_lo; T.gene_hi = gene_hi;
+    return KP_OK;
+}
+
+// the typing group a batch currently addresses and the batch's run for it (created on first use)
+static KpTypingGroup *typing_group(kp_ctx *ctx, const kp_batch *b) {
+    return (size_t)b->group < ctx->groups.size() ? ctx->groups[(size_t)b->group].get() : nullptr;
+}
+static KpTypingRun &typing_run(kp_batch *b) {
+    if (b->runs.size() <= (size_t)b->group) b->runs.resize((size_t)b->group + 1);
+    if (!b->runs[(size_t)b->group]) b->runs[(size_t)b->group].reset(new KpTypingRun());
+    return *b->runs[(size_t)b->group];
+}
+static int ensure_run_streams(kp_ctx *ctx, KpTypingRun &R) {
+    if (R.stream) return KP_OK;
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KP_HIP_CHECK(ctx, create_priority_stream(&R.stream));
+    KP_HIP_CHECK(ctx, create_priority_stream(&R.aux));
+    KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
+    KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
+    return KP_OK;
+}
+
+int kp_batch_use_group(kp_ctx *ctx, kp_batch *b, int32_t group) {
+    if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
+    if (group < 0 || (size_t)group >= ctx->groups.size() || !ctx->groups[(size_t)group])
+        return kp_fail(ctx, KP_EINVAL, "no typing tables loaded for this group");
+    b->group = group;
+    return KP_OK;
+}
+
+// the group's hits out of the batch's finalised hit table (sorted by gene, so they are one run per assembly), with gene
+// indices made relative to the group's first gene
+static int split_hits(kp_ctx *ctx, kp_batch *b, const KpTypingGroup &T, KpTypingRun &R) {
+    if (R.split) return KP_OK;
+    const size_t n_asm = (size_t)b->n_asm;
+    KP_HIP_CHECK(ctx, R.d_hits.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_hit_n.reserve(n_asm));
+    kp_launch_hit_split(b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, T.gene_lo, T.gene_hi, R.d_hits.p, R.d_hit_n.p,
+                        b->n_asm, R.stream);
+    KP_HIP_CHECK(ctx, hipGetLastError());
+    R.split = true;
     return KP_OK;
 }
 
 int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *locus_scores, int32_t *locus_counts) {
     if (!ctx || !b || b->ctx != ctx || !locus_scores || !locus_counts) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!ctx->has_typing) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
-    int rc = kp_batch_wait(ctx, b);
+    KpTypingGroup *Tp = typing_group(ctx, b);
+    if (!Tp) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
+    KpTypingGroup &T = *Tp;
+    KpTypingRun &R = typing_run(b);
+    int rc = kp_batch_wait(ctx, b);  // hit tables final (and the post stream idle) when this returns
     if (rc) return rc;
-    const size_t n = (size_t)b->n_asm * (size_t)ctx->typing.n_loci;
-    KP_HIP_CHECK(ctx, b->d_scores.reserve(n));
-    KP_HIP_CHECK(ctx, b->d_lcounts.reserve(n));
-    kp_launch_score(b->view, b->d_hits.p, b->d_hit_counts.p + b->n_asm, b->hit_cap, ctx->typing, min_gene_coverage,
-                    b->d_scores.p, b->d_lcounts.p, ctx->post);
+    if ((rc = ensure_run_streams(ctx, R))) return rc;
+    if ((rc = split_hits(ctx, b, T, R))) return rc;
+    const size_t n = (size_t)b->n_asm * (size_t)T.typing.n_loci;
+    KP_HIP_CHECK(ctx, R.d_scores.reserve(n));
+    KP_HIP_CHECK(ctx, R.d_lcounts.reserve(n));
+    kp_launch_score(b->view, R.d_hits.p, R.d_hit_n.p, b->hit_cap, T.typing, min_gene_coverage,
+                    R.d_scores.p, R.d_lcounts.p, R.stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
     if (n) {
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, b->d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, b->d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, R.d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, R.stream));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, R.d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, R.stream));
     }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
-    b->prm.min_gene_coverage = min_gene_coverage;
-    b->scored = true;
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
+    R.prm.min_gene_coverage = min_gene_coverage;
+    R.scored = true;
     return KP_OK;
 }
 
 static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
+    KpTypingGroup &T = *typing_group(ctx, b);
+    KpTypingRun &R = typing_run(b);
     const size_t n_asm = (size_t)b->n_asm;
-    if ((uint64_t)n_asm * (uint64_t)b->prot_cap > 0x7FFFFFFFull)
+    if ((uint64_t)n_asm * (uint64_t)R.prot_cap > 0x7FFFFFFFull)
         return kp_fail(ctx, KP_EOVERFLOW, "protein buffer would exceed 2^31 bytes; use smaller batches");
-    const size_t slots = n_asm * (size_t)b->kept_cap;
-    KP_HIP_CHECK(ctx, b->d_order.reserve(n_asm * b->hit_cap));
-    KP_HIP_CHECK(ctx, b->d_flag.reserve(n_asm * b->hit_cap));
-    KP_HIP_CHECK(ctx, b->d_kept.reserve(slots));
-    KP_HIP_CHECK(ctx, b->d_pieces.reserve(n_asm * (size_t)b->piece_cap));
-    KP_HIP_CHECK(ctx, b->d_summary.reserve(n_asm));
-    KP_HIP_CHECK(ctx, b->d_prot.reserve(n_asm * (size_t)b->prot_cap));
-    KP_HIP_CHECK(ctx, b->d_pairs.reserve(4 * slots + n_asm + 1));
-    KP_HIP_CHECK(ctx, b->d_dp.reserve(8 * slots));
-    int32_t *q_off = b->d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
+    const size_t slots = n_asm * (size_t)R.kept_cap;
+    KP_HIP_CHECK(ctx, R.d_keys.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_order.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_flag.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_kept.reserve(slots));
+    KP_HIP_CHECK(ctx, R.d_pieces.reserve(n_asm * (size_t)R.piece_cap));
+    KP_HIP_CHECK(ctx, R.d_summary.reserve(n_asm));
+    KP_HIP_CHECK(ctx, R.d_prot.reserve(n_asm * (size_t)R.prot_cap));
+    KP_HIP_CHECK(ctx, R.d_pairs.reserve(4 * slots + n_asm + 1));
+    KP_HIP_CHECK(ctx, R.d_dp.reserve(8 * slots));
+    int32_t *q_off = R.d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
     int32_t *pair_base = t_len + slots, *n_pairs = pair_base + n_asm;
-    KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), ctx->post));
-    kp_launch_reduce(b->view, b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, ctx->typing, b->prm, b->d_best.p,
-                     b->d_keys.p, b->d_order.p, b->d_flag.p, b->d_kept.p, b->kept_cap, b->d_pieces.p, b->piece_cap,
-                     b->d_summary.p, b->d_prot.p, b->prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, ctx->post);
+    KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), R.stream));
+    kp_launch_reduce(b->view, R.d_hits.p, R.d_hit_n.p, b->hit_cap, T.typing, R.prm, R.d_best.p,
+                     R.d_keys.p, R.d_order.p, R.d_flag.p, R.d_kept.p, R.kept_cap, R.d_pieces.p, R.piece_cap,
+                     R.d_summary.p, R.d_prot.p, R.prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, R.stream);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
     const int n_blocks = (int)std::min<size_t>(std::max<size_t>(slots, 1), 256 * 24);
     // row buffer of the strip kernel: KP_PROT_ROWBUF_FIELDS ints per column of the database protein, one region per
     // block, and 64 ints for its work counter (kp_prot.hip)
-    const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)ctx->max_db_prot_len + 1);
-    KP_HIP_CHECK(ctx, b->d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks + 64));
-    kp_launch_protein(b->d_prot.p, q_off, q_len, ctx->d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
-                      b->d_dp.p, b->d_dp_scratch.p, scratch_per_block, n_blocks, ctx->post, ctx->aux, ctx->ev_fork,
-                      ctx->ev_join);
-    kp_launch_states(b->view, ctx->typing, b->prm, b->d_kept.p, b->kept_cap, b->d_summary.p, b->d_dp.p, pair_base,
-                     ctx->post);
+    const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)T.max_db_prot_len + 1);
+    KP_HIP_CHECK(ctx, R.d_dp_scratch.reserve(scratch_per_block * (size_t)n_blocks + 64));
+    kp_launch_protein(R.d_prot.p, q_off, q_len, T.d_prot_db.p, t_off, t_len, (int32_t)slots, n_pairs, ctx->d_blosum.p,
+                      R.d_dp.p, R.d_dp_scratch.p, scratch_per_block, n_blocks, R.stream, R.aux, R.ev_fork,
+                      R.ev_join);
+    kp_launch_states(b->view, T.typing, R.prm, R.d_kept.p, R.kept_cap, R.d_summary.p, R.d_dp.p, pair_base,
+                     R.stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
 
 int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const kp_typing_params *prm) {
     if (!ctx || !b || b->ctx != ctx || !prm || (b->n_asm > 0 && !best_locus)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->scored) return kp_fail(ctx, KP_ESTATE, "kp_batch_score has not been called");
+    KpTypingGroup *Tp = typing_group(ctx, b);
+    if (!Tp) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
+    KpTypingRun &R = typing_run(b);
+    if (!R.scored) return kp_fail(ctx, KP_ESTATE, "kp_batch_score has not been called");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     for (int a = 0; a < b->n_asm; ++a)
-        if (best_locus[a] < 0 || best_locus[a] >= ctx->typing.n_loci) return kp_fail(ctx, KP_EINVAL, "best_locus out of range");
-    b->prm = *prm;
-    if (b->kept_cap == 0) b->kept_cap = (int)env_u32("KAPTIVE_AMD_KEPT_CAP", 256);
-    if (b->piece_cap == 0) b->piece_cap = (int)env_u32("KAPTIVE_AMD_PIECE_CAP", 32);
-    if (b->prot_cap == 0) b->prot_cap = (int)env_u32("KAPTIVE_AMD_PROT_CAP", 32768);
-    int rc = upload(ctx, b->d_best, best_locus, (size_t)b->n_asm, ctx->post);
-    if (rc == KP_OK && hipStreamSynchronize(ctx->post) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "H2D best loci failed");
+        if (best_locus[a] < 0 || best_locus[a] >= Tp->typing.n_loci) return kp_fail(ctx, KP_EINVAL, "best_locus out of range");
+    R.prm = *prm;
+    if (R.kept_cap == 0) R.kept_cap = (int)env_u32("KAPTIVE_AMD_KEPT_CAP", 256);
+    if (R.piece_cap == 0) R.piece_cap = (int)env_u32("KAPTIVE_AMD_PIECE_CAP", 32);
+    if (R.prot_cap == 0) R.prot_cap = (int)env_u32("KAPTIVE_AMD_PROT_CAP", 32768);
+    int rc = upload(ctx, R.d_best, best_locus, (size_t)b->n_asm, R.stream);
+    if (rc == KP_OK && hipStreamSynchronize(R.stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "H2D best loci failed");
     if (rc) return rc;
     rc = enqueue_reduce(ctx, b);
     if (rc) return rc;
-    b->reduced = true;
-    b->sums_valid = false;
+    R.reduced = true;
+    R.sums_valid = false;
     return KP_OK;
 }
 
 // waits for the reduction, re-runs it with larger buffers while any assembly overflowed one, and keeps the summaries
 static int fetch_summaries(kp_ctx *ctx, kp_batch *b) {
-    if (b->sums_valid) return KP_OK;
+    KpTypingRun &R = typing_run(b);
+    if (R.sums_valid) return KP_OK;
     const size_t n_asm = (size_t)b->n_asm;
-    b->h_sums.resize(n_asm);
+    R.h_sums.resize(n_asm);
     for (int attempt = 0;; ++attempt) {
         if (n_asm)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_sums.data(), b->d_summary.p, n_asm * sizeof(KpAsmSummary),
-                                             hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(R.h_sums.data(), R.d_summary.p, n_asm * sizeof(KpAsmSummary),
+                                             hipMemcpyDeviceToHost, R.stream));
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
         int flags = 0;
-        for (const auto &s : b->h_sums) flags |= s.overflow;
+        for (const auto &s : R.h_sums) flags |= s.overflow;
         if (!(flags & (1 | 2 | 8))) break;
         if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
         if (attempt >= 8) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
         if (flags & 1) {
-            if (b->kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
-            b->kept_cap = std::min(b->kept_cap * 4, 2048);
+            if (R.kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
+            R.kept_cap = std::min(R.kept_cap * 4, 2048);
         }
-        if (flags & 2) b->piece_cap *= 4;
-        if (flags & 8) b->prot_cap *= 4;
+        if (flags & 2) R.piece_cap *= 4;
+        if (flags & 8) R.prot_cap *= 4;
         b->stats[4] += 1;
         int rc = enqueue_reduce(ctx, b);
         if (rc) return rc;
     }
-    b->max_kept = 1; b->max_pieces = 1;
-    for (const auto &s : b->h_sums) {
-        b->max_kept = std::max(b->max_kept, s.n_kept);
-        b->max_pieces = std::max(b->max_pieces, s.n_pieces);
+    R.max_kept = 1; R.max_pieces = 1;
+    for (const auto &s : R.h_sums) {
+        R.max_kept = std::max(R.max_kept, s.n_kept);
+        R.max_pieces = std::max(R.max_pieces, s.n_pieces);
     }
-    b->sums_valid = true;
+    R.sums_valid = true;
     return KP_OK;
 }
 
@@ -886,30 +990,31 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
                     kp_piece *pieces, int32_t piece_stride) {
     if (!ctx || !b || b->ctx != ctx || (b->n_asm > 0 && (!summaries || !kept || !pieces)))
         return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KpTypingRun &R = typing_run(b);
+    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
     int rc = fetch_summaries(ctx, b);
     if (rc) return rc;
     if (n_asm == 0) return KP_OK;
-    if (kept_stride < b->max_kept || piece_stride < b->max_pieces)
+    if (kept_stride < R.max_kept || piece_stride < R.max_pieces)
         return kp_fail(ctx, KP_EINVAL, "output strides too small (see kp_batch_typing_caps)");
-    std::memcpy(summaries, b->h_sums.data(), n_asm * sizeof(KpAsmSummary));
+    std::memcpy(summaries, R.h_sums.data(), n_asm * sizeof(KpAsmSummary));
     // rows of the device buffers are kept_cap / piece_cap records long; only the first `stride` records of each are
     // wanted (a batch keeps a few dozen hits per assembly, the buffers leave room for hundreds): packed on the device,
     // then one linear copy each
-    const size_t kw = (size_t)std::min(kept_stride, b->kept_cap) * sizeof(KpKept) / 4;
-    const size_t pw = (size_t)std::min(piece_stride, b->piece_cap) * sizeof(KpPiece) / 4;
-    KP_HIP_CHECK(ctx, b->d_pack.reserve(n_asm * ((size_t)kept_stride * sizeof(KpKept) + (size_t)piece_stride * sizeof(KpPiece)) / 4));
-    uint32_t *pk = b->d_pack.p, *pp = pk + n_asm * (size_t)kept_stride * sizeof(KpKept) / 4;
-    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(b->d_kept.p), (size_t)b->kept_cap * sizeof(KpKept) / 4, pk,
-                        (size_t)kept_stride * sizeof(KpKept) / 4, kw, (int)n_asm, ctx->post);
-    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(b->d_pieces.p), (size_t)b->piece_cap * sizeof(KpPiece) / 4, pp,
-                        (size_t)piece_stride * sizeof(KpPiece) / 4, pw, (int)n_asm, ctx->post);
-    KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, pk, n_asm * (size_t)kept_stride * sizeof(KpKept), hipMemcpyDeviceToHost, ctx->post));
+    const size_t kw = (size_t)std::min(kept_stride, R.kept_cap) * sizeof(KpKept) / 4;
+    const size_t pw = (size_t)std::min(piece_stride, R.piece_cap) * sizeof(KpPiece) / 4;
+    KP_HIP_CHECK(ctx, R.d_pack.reserve(n_asm * ((size_t)kept_stride * sizeof(KpKept) + (size_t)piece_stride * sizeof(KpPiece)) / 4));
+    uint32_t *pk = R.d_pack.p, *pp = pk + n_asm * (size_t)kept_stride * sizeof(KpKept) / 4;
+    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(R.d_kept.p), (size_t)R.kept_cap * sizeof(KpKept) / 4, pk,
+                        (size_t)kept_stride * sizeof(KpKept) / 4, kw, (int)n_asm, R.stream);
+    kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(R.d_pieces.p), (size_t)R.piece_cap * sizeof(KpPiece) / 4, pp,
+                        (size_t)piece_stride * sizeof(KpPiece) / 4, pw, (int)n_asm, R.stream);
+    KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, pk, n_asm * (size_t)kept_stride * sizeof(KpKept), hipMemcpyDeviceToHost, R.stream));
     KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, pp, n_asm * (size_t)piece_stride * sizeof(KpPiece), hipMemcpyDeviceToHost,
-                                     ctx->post));
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+                                     R.stream));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
     // identity sums use numpy's float32 association; a few dozen adds per assembly, done here on the copied rows
     std::vector<float> vals;
     for (size_t a = 0; a < n_asm; ++a) {
@@ -925,20 +1030,22 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
 
 int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *b, int32_t *kept_cap, int32_t *piece_cap) {
     if (!ctx || !b || b->ctx != ctx || !kept_cap || !piece_cap) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KpTypingRun &R = typing_run(b);
+    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = fetch_summaries(ctx, b);
     if (rc) return rc;
-    *kept_cap = b->max_kept;
-    *piece_cap = b->max_pieces;
+    *kept_cap = R.max_kept;
+    *piece_cap = R.max_pieces;
     return KP_OK;
 }
 
 int kp_batch_proteins(kp_ctx *ctx, kp_batch *b, int32_t asm_index, uint8_t *out, int64_t cap) {
     if (!ctx || !b || asm_index < 0 || asm_index >= b->n_asm || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
-    const int64_t n = std::min<int64_t>(cap, b->prot_cap);
-    if (n > 0 && hipMemcpy(out, b->d_prot.p + (size_t)asm_index * (size_t)b->prot_cap, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    KpTypingRun &R = typing_run(b);
+    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    const int64_t n = std::min<int64_t>(cap, R.prot_cap);
+    if (n > 0 && hipMemcpy(out, R.d_prot.p + (size_t)asm_index * (size_t)R.prot_cap, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
         return kp_fail(ctx, KP_EHIP, "D2H proteins failed");
     return (int)n;
 }

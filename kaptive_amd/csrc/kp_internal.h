@@ -129,6 +129,10 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);
 // kp_prot.hip
+// kp_reduce.hip: assembly a's hits with gene in [gene_lo, gene_hi) (one run: hits are sorted by gene) -> out rows, gene
+// indices relative to gene_lo; out_n[a] = how many
+void kp_launch_hit_split(const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap, int32_t gene_lo, int32_t gene_hi,
+                         kp_hit *out, uint32_t *out_n, int32_t n_asm, hipStream_t stream);
 void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, size_t dst_pitch, size_t width, int rows,
                          hipStream_t stream);  // kp_reduce.hip: row-wise copy between pitched word matrices
 #define KP_PROT_ROWBUF_FIELDS 8  // ints per column of the strip kernel's row buffer (scratch: fields x (longest target + 1))

@@ -336,6 +336,23 @@ __global__ __launch_bounds__(64) void kp_state_kernel(KpBatchView b, KpTypingDb 
     if (lane == 0) sum->n_final = alive;
 }
 
+// the hits of one typing group: a contiguous run of the assembly's gene-sorted hit list
+__global__ __launch_bounds__(256) void kp_hit_split_kernel(const kp_hit *__restrict__ hits, const uint32_t *__restrict__ n_hits,
+                                                           uint32_t hit_cap, int32_t gene_lo, int32_t gene_hi,
+                                                           kp_hit *__restrict__ out, uint32_t *__restrict__ out_n) {
+    const int a = blockIdx.x;
+    const kp_hit *h = hits + (size_t)a * hit_cap;
+    const int n = (int)n_hits[a];
+    const int first = kp_lower_bound_gene(h, n, gene_lo), last = kp_lower_bound_gene(h, n, gene_hi);
+    kp_hit *o = out + (size_t)a * hit_cap;
+    for (int i = first + (int)threadIdx.x; i < last; i += (int)blockDim.x) {
+        kp_hit x = h[i];
+        x.gene -= gene_lo;
+        o[i - first] = x;
+    }
+    if (threadIdx.x == 0) out_n[a] = (uint32_t)(last - first);
+}
+
 // rows of `width` words from a matrix with row pitch src_pitch into one with row pitch dst_pitch (words beyond `width`
 // of a destination row are zeroed)
 __global__ __launch_bounds__(256) void kp_pack_rows_kernel(const uint32_t *__restrict__ src, size_t src_pitch,
@@ -346,6 +363,13 @@ __global__ __launch_bounds__(256) void kp_pack_rows_kernel(const uint32_t *__res
 }
 
 }  // namespace
+
+void kp_launch_hit_split(const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap, int32_t gene_lo, int32_t gene_hi,
+                         kp_hit *out, uint32_t *out_n, int32_t n_asm, hipStream_t stream) {
+    if (n_asm == 0) return;
+    hipLaunchKernelGGL(kp_hit_split_kernel, dim3(n_asm), dim3(256), 0, stream, hits, n_hits, hit_cap, gene_lo, gene_hi, out,
+                       out_n);
+}
 
 void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, size_t dst_pitch, size_t width, int rows,
                          hipStream_t stream) {

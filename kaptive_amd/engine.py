@@ -22,14 +22,43 @@ from kaptive_amd.pack import pack_sequences_flat
 
 
 class Engine:
-    def __init__(self, db: Database, device: int = 0) -> None:
-        self.db = db
+    """One database -- or several that are typed together (K and O loci) -- resident on one GPU.
+
+    With a list of databases the genes of all of them go into one seed index, so a batch is scanned, chained and
+    aligned once for all of them (the reference runs one ``map_batch`` per database); every database keeps its own
+    typing tables as a *group* of the context and ``view(i)`` gives the engine as database ``i`` sees it.  The
+    single-genome entry points (``align``, ``hits_to_alignments``) are those of a one-database engine."""
+
+    def __init__(self, db: "Database | Sequence[Database]", device: int = 0) -> None:
+        dbs = list(db) if isinstance(db, (list, tuple)) else [db]
+        self.dbs = dbs
+        self.db = dbs[0]
+        self.group = 0
         self.device = device
         self.ctx = _native.Context(device)
-        codes, off = pack_sequences_flat(db.genes)
+        packed = [pack_sequences_flat(d.genes) for d in dbs]
+        counts = [len(d.genes) for d in dbs]
+        self.gene_ranges = [(sum(counts[:i]), sum(counts[: i + 1])) for i in range(len(dbs))]
+        codes = np.concatenate([c for c, _ in packed]) if len(dbs) > 1 else packed[0][0]
+        if len(dbs) > 1:
+            base = np.cumsum([0] + [len(c) for c, _ in packed[:-1]])
+            off = np.concatenate([o[:-1] + b for (_, o), b in zip(packed, base)] + [[len(codes)]]).astype(packed[0][1].dtype)
+        else:
+            off = packed[0][1]
         self.ctx.load_genes(codes, off)
-        self.ctx.load_typing(db)
-        self._gene_names = tuple(str(i) for i in range(len(db.genes)))
+        for g, (d, (lo, hi)) in enumerate(zip(dbs, self.gene_ranges)):
+            self.ctx.load_typing(d, group=g, gene_lo=lo, gene_hi=hi)
+        self._gene_names = tuple(str(i) for i in range(len(self.db.genes)))
+
+    def view(self, group: int) -> "Engine":
+        """This engine as database ``group`` sees it: same context and batches, that database's typing group."""
+        if group == self.group and self.db is self.dbs[group]:
+            return self
+        v = object.__new__(Engine)
+        v.__dict__.update(self.__dict__)
+        v.db, v.group = self.dbs[group], group
+        v._gene_names = tuple(str(i) for i in range(len(v.db.genes)))
+        return v
 
     def close(self) -> None:
         self.ctx.close()
@@ -87,10 +116,10 @@ class Engine:
 
         if not aligned:
             batch.align_async()
-        scores, counts = batch.score(typer.min_gene_coverage)
+        scores, counts = batch.score(typer.min_gene_coverage, self.group)
         best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
-        batch.reduce_async(best, self.typing_params(typer))
-        sums, kept, pieces = batch.typing()
+        batch.reduce_async(best, self.typing_params(typer), self.group)
+        sums, kept, pieces = batch.typing(self.group)
         return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes)
 
     def type_batches(self, typer, batches: Sequence, ids: Sequence[Sequence[str]], aligned: bool = False) -> list:
@@ -102,17 +131,27 @@ class Engine:
     def reduce_batches(self, typer, batches: Sequence, aligned: bool = False) -> list:
         """First half of ``type_batches``: scores back, best loci chosen (numpy), reductions enqueued.  Returns what
         ``collect_batches`` needs; callers driving several databases put the other database's host work in between."""
-        from kaptive_amd.serotyping import batch as B
-
         if not aligned:
             for b in batches:
                 b.align_async()
+        return self.enqueue_reductions(typer, batches, self.score_batches(typer, batches))
+
+    def score_batches(self, typer, batches: Sequence) -> list:
+        """Locus scores of every batch read back and the best loci chosen (numpy argmax: part of the bit-exact
+        contract).  Cheap on the device; callers with several databases score all of them before any reduction is
+        enqueued, so that no database's scores queue up behind another one's reduction kernels."""
+        from kaptive_amd.serotyping import batch as B
+
         staged = []
-        for b in batches:  # score needs the host in the loop (numpy argmax); reductions are enqueued as scores arrive
-            scores, counts = b.score(typer.min_gene_coverage)
+        for b in batches:
+            scores, counts = b.score(typer.min_gene_coverage, self.group)
             best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
-            b.reduce_async(best, self.typing_params(typer))
             staged.append((scores, best))
+        return staged
+
+    def enqueue_reductions(self, typer, batches: Sequence, staged: list) -> list:
+        for b, (_, best) in zip(batches, staged):
+            b.reduce_async(best, self.typing_params(typer), self.group)
         return staged
 
     def collect_batches(self, typer, batches: Sequence, ids: Sequence[Sequence[str]], staged: list) -> list:
@@ -121,7 +160,7 @@ class Engine:
 
         out = []
         for b, i, (scores, best) in zip(batches, ids, staged):
-            sums, kept, pieces = b.typing()
+            sums, kept, pieces = b.typing(self.group)
             out.append(B.BatchTyping(typer, i, sums, kept, pieces, scores, best))
         return out
 

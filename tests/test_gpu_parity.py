@@ -369,6 +369,44 @@ def test_batched_reduction_full_size():
     typer.engine.close()
 
 
+def test_one_alignment_pass_for_two_databases(small_db):
+    """K and O genes in one context (typing groups): every assembly is scanned and aligned once, and each database's
+    records, decisions and TSV rows are those of an engine that holds that database alone."""
+    from kaptive_amd.engine import Engine
+
+    db_o = make_db("kpsc_o", seed=8)
+    genomes = [make_assembly(small_db, seed=900 + i, length=150_000, median_contigs=int(3 + 5 * i), min_contig=200,
+                             sub_rate=0.01 * i, also=(db_o,)) for i in range(10)]  # fmt: skip
+    genomes.append(make_assembly(small_db, seed=950, length=60_000, locus=-1))  # neither locus
+    ids = [g.id for g in genomes]
+    packed = [g.packed() for g in genomes]
+    both = Engine([small_db, db_o])
+    batch = both.ctx.batch(packed)
+    batch.align_async()
+    typers = [Serotyper(small_db), Serotyper(db_o)]
+    together = [both.view(i).type_batch(t, batch, ids, aligned=True) for i, t in enumerate(typers)]
+    # results of a group survive work on the other one
+    sums_k_again = batch.typing(0)[0]
+    assert sums_k_again.tobytes() == together[0].sums.tobytes()
+    for i, (db, typer) in enumerate(zip((small_db, db_o), typers)):
+        alone = Engine(db)
+        b1 = alone.ctx.batch(packed)
+        want = alone.type_batch(typer, b1, ids)
+        got = together[i]
+        assert want.sums.tobytes() == got.sums.tobytes(), f"summaries of database {i}"
+        for a in range(len(ids)):  # rows beyond an assembly's own count are whatever the buffers held
+            nk, npc = int(want.sums["n_kept"][a]), int(want.sums["n_pieces"][a])
+            assert want.kept[a, :nk].tobytes() == got.kept[a, :nk].tobytes(), f"kept hits of database {i}, assembly {a}"
+            assert want.pieces[a, :npc].tobytes() == got.pieces[a, :npc].tobytes(), f"pieces of database {i}, assembly {a}"
+        assert np.array_equal(want.best_locus, got.best_locus) and want.best_score.tobytes() == got.best_score.tobytes()
+        assert want.rows() == got.rows(), f"TSV rows of database {i}"
+        assert any(want.typeable) or i == 1
+        b1.close()
+        alone.close()
+    batch.close()
+    both.close()
+
+
 def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
     monkeypatch.setenv("KAPTIVE_AMD_KEPT_CAP", "4")
     monkeypatch.setenv("KAPTIVE_AMD_PIECE_CAP", "1")
