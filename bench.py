@@ -267,8 +267,12 @@ def main() -> None:
         cells = sum(s["dp_cells"] for s in stats)
         typed = int(sum(bt.typeable.sum() for bt in res))
         t_rows = time.perf_counter()
-        n_rows = sum(len(bt.rows()) for bt in res)  # TSV formatting of the last step, outside the timed region
+        rows = [r for bt in res for r in bt.rows()]  # TSV formatting of the last step, outside the timed region
+        n_rows = len(rows)
         t_rows = time.perf_counter() - t_rows
+        import hashlib
+
+        rows_digest = hashlib.sha1(b"".join(sorted(rows))).hexdigest()  # same workload -> same digest, whatever the schedule
         line = {
             "metric": "assemblies typed/sec (K+O)",
             "value": n_total / elapsed,
@@ -295,6 +299,7 @@ def main() -> None:
                 "parallelism": f"{world} x independent shard, no collective",
                 "typeable_in_last_step": typed,
                 "tsv_rows_per_s_host": round(n_rows / t_rows, 1),
+                "tsv_rows_sha1": rows_digest,
                 "workload_generation_s": round(t_gen, 1),
             },
             "roofline": {
