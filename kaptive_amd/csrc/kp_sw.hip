@@ -269,7 +269,9 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 // run underneath the 16-diagonal class that fills the chip.
 constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
 
-__global__ __launch_bounds__(64) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
+// (64, 4): four waves per SIMD (128 VGPRs; what spills sits outside the step loop) -- the cells of a step depend on each
+// other, so a wave alone cannot keep the SIMD busy: 23.5 ms against 24.0 ms with three waves
+__global__ __launch_bounds__(64, 4) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                    const uint32_t *__restrict__ order,
                                                    KpSwResult *__restrict__ results) {
