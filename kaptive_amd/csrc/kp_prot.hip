@@ -13,7 +13,7 @@
 // every state carries the statistics of the path it came from (same tie rules).
 //
 // Two kernels, same arithmetic:
-//   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 1024 residues -- every full-length gene): 16 lanes
+//   * kp_protein_kernel (band <= 64 diagonals and both proteins <= 768 residues -- every full-length gene): 16 lanes
 //     per pair, four adjacent diagonals per lane, four pairs per wave; state lives in registers; the two neighbour
 //     exchanges per step are DPP row shifts; sequences and a 32x32 BLOSUM62 are staged in LDS; no barrier inside the
 //     step loop.
@@ -29,7 +29,7 @@ namespace {
 constexpr int NEGP = KP_PROT_NEG_INF;
 constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
 constexpr int GE = KP_PROT_GAP_EXT;
-constexpr int REG_MAX_LEN = 1024;  // residues per sequence the register kernel stages (four pairs per block)
+constexpr int REG_MAX_LEN = 768;  // residues per sequence the register kernel stages (four pairs per block: 12 KB of LDS)
 
 struct Pay {  // path statistics: a = matches << 16 | mismatches, g = gaps, s = start_i << 16 | start_j
     unsigned a, g, s;
