@@ -9,6 +9,16 @@
 
 #include "kp_internal.h"
 
+// rocPRIM has no tuned configuration for this key type on gfx950 and falls back to 6-bit digits with 128-thread
+// blocks; an assembly's segment is tens of thousands of keys, so wider digits (fewer passes) and larger blocks pay
+#ifndef KP_SORT_RADIX_BITS
+#define KP_SORT_RADIX_BITS 8
+#define KP_SORT_BLOCK 256
+#define KP_SORT_ITEMS 16
+#endif
+using SortConfig = rocprim::segmented_radix_sort_config<KP_SORT_RADIX_BITS, rocprim::kernel_config<KP_SORT_BLOCK, KP_SORT_ITEMS>,
+                                                        rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>, true>;
+
 void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,
                         hipStream_t stream);
 
@@ -19,7 +29,7 @@ int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const ui
     kp_launch_segments(d_count, cap, n_asm, d_seg_begin, d_seg_end, stream);
     const unsigned int size = (unsigned int)((size_t)n_asm * cap);
     size_t need = 0;
-    KP_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(nullptr, need, keys_in, keys_out, size, (unsigned)n_asm,
+    KP_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys<SortConfig>(nullptr, need, keys_in, keys_out, size, (unsigned)n_asm,
                                                          d_seg_begin, d_seg_end, 0, end_bit, stream));
     if (need > *temp_bytes) {
         if (*temp) KP_HIP_CHECK(ctx, hipFree(*temp));
@@ -27,7 +37,7 @@ int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const ui
         KP_HIP_CHECK(ctx, hipMalloc(temp, need));
         *temp_bytes = need;
     }
-    KP_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(*temp, need, keys_in, keys_out, size, (unsigned)n_asm,
+    KP_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys<SortConfig>(*temp, need, keys_in, keys_out, size, (unsigned)n_asm,
                                                          d_seg_begin, d_seg_end, 0, end_bit, stream));
     return KP_OK;
 }
