@@ -137,8 +137,8 @@ def cpu_baseline(dbs, genomes, budget_s: float = 20.0) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--assemblies", type=int, default=1000, help="assemblies per GPU (resident batch)")
     ap.add_argument("--length", type=float, default=5.0e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
