@@ -65,6 +65,11 @@ typedef struct kp_packed_fasta {
     int32_t *name_off;    /* n_contigs + 1 */
 } kp_packed_fasta;
 KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
+/* The same layout from contigs already in memory (Sequences.seqs / offsets / lengths of the reference's containers,
+ * src/kaptive/core/seq.py:307-325): contig c is seqs[offsets[c] .. offsets[c] + lengths[c]).  names / name_off of the
+ * result are empty. */
+KP_API int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *lengths, int32_t n_contigs,
+                           kp_packed_fasta **out);
 KP_API void kp_fasta_free(kp_packed_fasta *packed);
 
 /* ---- batches of packed assemblies -------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ EXPORTS = (
     "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_free",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_pack_contigs", "kp_fasta_free",
 )  # fmt: skip
 
 
@@ -37,10 +37,41 @@ class PackedFasta(C.Structure):  # kp_packed_fasta
                 ("n_run_pairs", C.POINTER(C.c_int32)), ("names", C.POINTER(C.c_char)), ("name_off", C.POINTER(C.c_int32))]  # fmt: skip
 
 
-def fasta_pack(data: bytes):
-    """FASTA text -> (PackedAssembly, contig names), parsed and packed by the native library (no GPU needed)."""
+def _packed_from(out, want_names: bool):
     from kaptive_amd.pack import PackedAssembly
 
+    p = out.contents
+    nc, nr = p.n_contigs, p.n_runs
+    arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.empty(0, dt)  # noqa: E731
+    words = arr(p.words, p.padded_len // 16, np.uint32)
+    names = ()
+    if want_names:
+        off = arr(p.name_off, nc + 1, np.int32)
+        blob = C.string_at(p.names, int(off[-1])) if nc else b""
+        names = tuple(blob[off[i] : off[i + 1]].decode("utf-8", "replace") for i in range(nc))
+    pa = PackedAssembly(words, int(p.padded_len), arr(p.ctg_start, nc, np.int32), arr(p.ctg_len, nc, np.int32),
+                        arr(p.n_run_pairs, 2 * nr, np.int32).reshape(-1, 2))  # fmt: skip
+    return pa, names
+
+
+def pack_contigs(seqs: np.ndarray, offsets: np.ndarray, lengths: np.ndarray):
+    """Contigs in memory (dense bytes + offsets + lengths) -> PackedAssembly, by the native packer (kp_pack_contigs;
+    about ten times the numpy route)."""
+    h = lib()
+    h.kp_fasta_free.restype = None
+    seqs, offsets, lengths = _c(seqs, np.uint8), _c(offsets, np.int64), _c(lengths, np.int32)
+    out = C.POINTER(PackedFasta)()
+    rc = h.kp_pack_contigs(_p(seqs), _p(offsets), _p(lengths), C.c_int32(len(lengths)), C.byref(out))
+    if rc != 0:
+        raise ValueError("assembly too long for the packed layout (KP_MAX_ASM_LEN)")
+    try:
+        return _packed_from(out, False)[0]
+    finally:
+        h.kp_fasta_free(out)
+
+
+def fasta_pack(data: bytes):
+    """FASTA text -> (PackedAssembly, contig names), parsed and packed by the native library (no GPU needed)."""
     h = lib()
     h.kp_fasta_free.restype = None
     out = C.POINTER(PackedFasta)()
@@ -48,16 +79,7 @@ def fasta_pack(data: bytes):
     if rc != 0:
         raise ValueError(f"kp_fasta_pack failed ({rc}): sequence too long for the packed layout or bad arguments")
     try:
-        p = out.contents
-        nc, nr = p.n_contigs, p.n_runs
-        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.empty(0, dt)  # noqa: E731
-        words = arr(p.words, p.padded_len // 16, np.uint32)
-        off = arr(p.name_off, nc + 1, np.int32)
-        blob = C.string_at(p.names, int(off[-1])) if nc else b""
-        names = tuple(blob[off[i] : off[i + 1]].decode("utf-8", "replace") for i in range(nc))
-        pa = PackedAssembly(words, int(p.padded_len), arr(p.ctg_start, nc, np.int32), arr(p.ctg_len, nc, np.int32),
-                            arr(p.n_run_pairs, 2 * nr, np.int32).reshape(-1, 2))  # fmt: skip
-        return pa, names
+        return _packed_from(out, True)
     finally:
         h.kp_fasta_free(out)
 

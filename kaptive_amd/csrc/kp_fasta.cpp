@@ -16,18 +16,40 @@
 namespace {
 
 struct Tables {
-    uint8_t code[256];
-    bool space[256];
+    uint8_t code[256];  // 0..3 = A C G T/U (either case), 4 = any other symbol (part of an N run), 8 = whitespace
     Tables() {
         std::memset(code, 4, sizeof code);
         const char *acgt = "ACGT";
         for (int i = 0; i < 4; ++i) { code[(uint8_t)acgt[i]] = (uint8_t)i; code[(uint8_t)acgt[i] + 32] = (uint8_t)i; }
         code['U'] = code['u'] = 3;
-        std::memset(space, 0, sizeof space);
-        for (int c : {9, 10, 11, 12, 13, 32}) space[c] = true;
+        for (int c : {9, 10, 11, 12, 13, 32}) code[c] = 8;
     }
 };
 const Tables T;
+
+// 2-bit writer: bases go through a 64-bit accumulator, whole words leave it
+struct Packer {
+    uint32_t *wp;
+    uint64_t acc = 0;
+    int nb = 0;       // bits waiting in acc (even, < 32)
+    int64_t pos = 0;  // bases written (padded space)
+    explicit Packer(uint32_t *w) : wp(w) {}
+    inline void put(uint32_t code) {
+        acc |= (uint64_t)code << nb;
+        nb += 2;
+        if (nb == 32) { *wp++ = (uint32_t)acc; acc = 0; nb = 0; }
+        ++pos;
+    }
+    inline void put16(uint32_t sixteen) {  // 16 bases at once
+        acc |= (uint64_t)sixteen << nb;
+        *wp++ = (uint32_t)acc;
+        acc >>= 32;
+        pos += 16;
+    }
+    inline void pad_to(int64_t align) {
+        while (pos % align) put(0);
+    }
+};
 
 }  // namespace
 
@@ -36,57 +58,71 @@ extern "C" {
 int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
     if (!out || (n > 0 && !data) || n < 0) return KP_EINVAL;
     *out = nullptr;
-    std::vector<uint32_t> words;
+    // every '>' may open a contig (32-base alignment: at most two more words each); sequence bytes give <= n bases
+    size_t marks = 0;
+    for (const uint8_t *p = data, *e = data + n; p < e && (p = (const uint8_t *)std::memchr(p, '>', (size_t)(e - p))); ++p) ++marks;
+    std::vector<uint32_t> words((size_t)n / 16 + 2 * marks + 8, 0u);
     std::vector<int32_t> ctg_start, ctg_len, runs, name_off;
     std::string names;
-    words.reserve((size_t)n / 16 + 64);
-    int64_t pos = 0;  // position in the padded space
-    auto put = [&](uint32_t code) {
-        if ((pos & 15) == 0) words.push_back(0u);
-        words.back() |= code << (2 * (pos & 15));
-        ++pos;
-    };
+    Packer pk(words.data());
     int64_t i = 0;
     while (i < n && data[i] != '>') {  // text before the first header is ignored
-        while (i < n && data[i] != '\n') ++i;
-        ++i;
+        const uint8_t *nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
+        i = nl ? (nl - data) + 1 : n;
     }
-    while (i < n) {
-        // header line
-        int64_t j = i + 1;
-        while (j < n && data[j] != '\n' && !T.space[data[j]]) ++j;
-        name_off.push_back((int32_t)names.size());
-        names.append((const char *)data + i + 1, (size_t)(j - i - 1));
-        while (j < n && data[j] != '\n') ++j;
-        i = j + 1;
-        // sequence lines
-        while (pos % KP_CONTIG_ALIGN) put(0);
-        if (pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
-        const int64_t start = pos;
-        bool in_run = false;
-        bool line_start = true;
-        while (i < n) {
-            const uint8_t c = data[i];
-            if (line_start && c == '>') break;
-            line_start = c == '\n';
-            ++i;
-            if (T.space[c]) continue;
-            const uint8_t code = T.code[c];
-            if (code > 3) {
-                if (!in_run) { runs.push_back((int32_t)pos); runs.push_back((int32_t)pos); in_run = true; }
-                runs.back() = (int32_t)pos + 1;
-                put(0);
+    bool in_run = false;
+    auto slow = [&](const uint8_t *p, const uint8_t *e) {  // symbol by symbol: whitespace dropped, N runs recorded
+        for (; p < e; ++p) {
+            const uint8_t c = T.code[*p];
+            if (c == 8) continue;
+            if (c == 4) {
+                if (!in_run) { runs.push_back((int32_t)pk.pos); runs.push_back((int32_t)pk.pos); in_run = true; }
+                runs.back() = (int32_t)pk.pos + 1;
+                pk.put(0);
             } else {
                 in_run = false;
-                put(code);
+                pk.put(c);
             }
-            if (pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
+        }
+    };
+    while (i < n) {
+        // header line: the record's name is its first word
+        int64_t j = i + 1;
+        while (j < n && T.code[data[j]] != 8) ++j;
+        name_off.push_back((int32_t)names.size());
+        names.append((const char *)data + i + 1, (size_t)(j - i - 1));
+        const uint8_t *nl = (const uint8_t *)std::memchr(data + j, '\n', (size_t)(n - j));
+        i = nl ? (nl - data) + 1 : n;
+        // sequence lines up to the next line that starts with '>'
+        pk.pad_to(KP_CONTIG_ALIGN);
+        if (pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
+        const int64_t start = pk.pos;
+        in_run = false;
+        while (i < n && data[i] != '>') {
+            nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
+            const uint8_t *p = data + i, *e = nl ? nl : data + n;
+            i = nl ? (nl - data) + 1 : n;
+            for (; e - p >= 16; p += 16) {  // 16 symbols at a time while they are plain bases
+                uint32_t w = 0, seen = 0;
+#pragma GCC unroll 16
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t c = T.code[p[k]];
+                    seen |= c;
+                    w |= (c & 3u) << (2 * k);
+                }
+                if (seen & 12u) slow(p, p + 16);
+                else { in_run = false; pk.put16(w); }
+            }
+            slow(p, e);
+            if (pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
         }
         ctg_start.push_back((int32_t)start);
-        ctg_len.push_back((int32_t)(pos - start));
+        ctg_len.push_back((int32_t)(pk.pos - start));
     }
     name_off.push_back((int32_t)names.size());
-    while (pos % KP_ASM_ALIGN) put(0);
+    pk.pad_to(KP_ASM_ALIGN);
+    const int64_t pos = pk.pos;
+    words.resize((size_t)(pos / 16));
 
     kp_packed_fasta *r = new (std::nothrow) kp_packed_fasta();
     if (!r) return KP_ENOMEM;
@@ -104,6 +140,80 @@ int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
     r->n_run_pairs = (int32_t *)dup(runs.data(), runs.size() * 4);
     r->names = (char *)dup(names.data(), names.size());
     r->name_off = (int32_t *)dup(name_off.data(), name_off.size() * 4);
+    if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off) {
+        kp_fasta_free(r);
+        return KP_ENOMEM;
+    }
+    *out = r;
+    return KP_OK;
+}
+
+// Contigs that are already in memory (one byte per base, back to back) -> the same packed layout; names stay with the
+// caller.  Every byte is a base here: whatever is not A C G T/U belongs to an N run.
+int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *lengths, int32_t n_contigs,
+                    kp_packed_fasta **out) {
+    if (!out || n_contigs < 0 || (n_contigs > 0 && (!offsets || !lengths))) return KP_EINVAL;
+    *out = nullptr;
+    size_t total = 0;
+    for (int32_t c = 0; c < n_contigs; ++c) {
+        if (lengths[c] < 0 || offsets[c] < 0 || (lengths[c] > 0 && !seqs)) return KP_EINVAL;
+        total += (size_t)lengths[c];
+    }
+    std::vector<uint32_t> words(total / 16 + 2 * (size_t)n_contigs + 8, 0u);
+    std::vector<int32_t> ctg_start((size_t)n_contigs), ctg_len((size_t)n_contigs), runs;
+    Packer pk(words.data());
+    for (int32_t c = 0; c < n_contigs; ++c) {
+        pk.pad_to(KP_CONTIG_ALIGN);
+        if (pk.pos + lengths[c] > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
+        ctg_start[(size_t)c] = (int32_t)pk.pos;
+        ctg_len[(size_t)c] = lengths[c];
+        bool in_run = false;
+        const uint8_t *p = seqs + offsets[c], *e = p + lengths[c];
+        auto slow = [&](const uint8_t *q, const uint8_t *qe) {
+            for (; q < qe; ++q) {
+                const uint8_t code = T.code[*q];
+                if (code > 3) {
+                    if (!in_run) { runs.push_back((int32_t)pk.pos); runs.push_back((int32_t)pk.pos); in_run = true; }
+                    runs.back() = (int32_t)pk.pos + 1;
+                    pk.put(0);
+                } else {
+                    in_run = false;
+                    pk.put(code);
+                }
+            }
+        };
+        for (; e - p >= 16; p += 16) {
+            uint32_t w = 0, seen = 0;
+#pragma GCC unroll 16
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t code = T.code[p[k]];
+                seen |= code;
+                w |= (code & 3u) << (2 * k);
+            }
+            if (seen & 12u) slow(p, p + 16);
+            else { in_run = false; pk.put16(w); }
+        }
+        slow(p, e);
+    }
+    pk.pad_to(KP_ASM_ALIGN);
+    words.resize((size_t)(pk.pos / 16));
+    kp_packed_fasta *r = new (std::nothrow) kp_packed_fasta();
+    if (!r) return KP_ENOMEM;
+    auto dup = [](const void *src, size_t bytes) -> void * {
+        void *q = std::malloc(bytes ? bytes : 1);
+        if (q && bytes) std::memcpy(q, src, bytes);
+        return q;
+    };
+    r->padded_len = pk.pos;
+    r->n_contigs = n_contigs;
+    r->n_runs = (int32_t)(runs.size() / 2);
+    r->words = (uint32_t *)dup(words.data(), words.size() * 4);
+    r->ctg_start = (int32_t *)dup(ctg_start.data(), ctg_start.size() * 4);
+    r->ctg_len = (int32_t *)dup(ctg_len.data(), ctg_len.size() * 4);
+    r->n_run_pairs = (int32_t *)dup(runs.data(), runs.size() * 4);
+    r->names = (char *)dup("", 0);
+    const int32_t zero = 0;
+    r->name_off = (int32_t *)dup(&zero, 4);
     if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off) {
         kp_fasta_free(r);
         return KP_ENOMEM;

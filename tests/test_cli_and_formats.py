@@ -54,6 +54,48 @@ def test_fasta_parsers_and_native_pack_agree(tmp_path):
         assert len(nm) == len(parse_fasta_bytes(blob)) and pa.padded_len % 64 == 0
 
 
+def test_native_pack_fuzz_against_the_python_packer():
+    """Random FASTA text -- line widths around the packer's 16-symbol blocks, lower case, U, IUPAC / N runs that cross
+    line ends, blanks and tabs inside lines, CR LF, empty records, no final newline -- packs to what the numpy path
+    (parse_fasta_bytes + pack_contigs) gives."""
+    from kaptive_amd.core.seq import SeqRecord, Sequences
+    from kaptive_amd.pack import pack_contigs
+
+    rng = np.random.default_rng(99)
+    alphabet = np.frombuffer(b"ACGTacgtUuNnRYKM-*", np.uint8)
+    for trial in range(60):
+        lines, eol = [], (b"\r\n" if trial % 3 == 0 else b"\n")
+        if trial % 4 == 0:
+            lines.append(b"leading junk line")
+        for r in range(int(rng.integers(0, 6))):
+            n = int(rng.choice([0, 1, 15, 16, 17, 31, 33, 200, 1000]))
+            p_odd = float(rng.choice([0.0, 0.02, 0.3]))
+            seq = np.where(rng.random(n) < p_odd, alphabet[rng.integers(8, len(alphabet), n)], alphabet[rng.integers(0, 8, n)])
+            seq = seq.astype(np.uint8).tobytes()
+            lines.append(b">rec%d_%d %s" % (trial, r, b"desc here" if r % 2 else b""))
+            width = int(rng.choice([1, 7, 16, 17, 32, 60, 61, 80]))
+            for j in range(0, n, width):
+                chunk = seq[j : j + width]
+                if rng.random() < 0.1 and len(chunk) > 2:
+                    k = int(rng.integers(1, len(chunk)))
+                    chunk = chunk[:k] + (b" " if rng.random() < 0.5 else b"\t") + chunk[k:]
+                lines.append(chunk)
+            if rng.random() < 0.3:
+                lines.append(b"")
+        text = eol.join(lines) + (eol if trial % 5 else b"")
+        recs = parse_fasta_bytes(text)
+        want = pack_contigs(Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs]))
+        got, names = _native.fasta_pack(text)
+        seqs = Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs])
+        direct = _native.pack_contigs(seqs.seqs, seqs.offsets, seqs.lengths)  # the same contigs, already in memory
+        assert direct.padded_len == want.padded_len and all(
+            np.array_equal(getattr(direct, f), getattr(want, f)) for f in ("words", "ctg_start", "ctg_len", "n_runs")), trial
+        assert list(names) == [nm for nm, _ in recs], trial
+        assert got.padded_len == want.padded_len, trial
+        for f in ("words", "ctg_start", "ctg_len", "n_runs"):
+            assert np.array_equal(getattr(got, f), getattr(want, f)), (trial, f)
+
+
 @pytest.mark.parametrize("kind", ["kpsc_k", "kpsc_o"])
 def test_genbank_round_trip(kind, tmp_path):
     db = make_db(kind, seed=5, n_loci=6 if kind == "kpsc_k" else None)
