@@ -161,6 +161,8 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     workers = args.workers or max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    if workers == 1:
+        import torch  # noqa: F401  (inline generation loads the native library; under rocprofv3 torch has to come first)
     t_gen = time.perf_counter()
     db_k, db_o, genomes, packed = build_workload(args.assemblies, 200 + rank * args.assemblies, args.length, workers)
     t_gen = time.perf_counter() - t_gen
