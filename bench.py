@@ -1,31 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- assemblies typed per second (K + O databases back to back) on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--assemblies A]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--assemblies A] [--batch B] [--db kpsc|ab_k]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" types every assembly of the rank's resident batch against the synthetic KpSC K-locus database and the
-O-locus database: per database one alignment pass (seed scan -> anchor sort -> chaining -> banded Smith-Waterman), then
-hit finalisation, locus scoring, overlap cull, pieces, translation, protein DP and gene states, all on the GPU; the
-host does three small numpy float steps per database and builds the result objects.  The two databases' passes run on
-their own contexts and streams (`--shared-pass`: one alignment pass over the genes of both databases, see --help).
-Packed assemblies are resident in HBM before the timed region.  Ranks hold disjoint assemblies (weak scaling, no
-collective on the data path; the only torch.distributed calls are the barrier and the max-over-ranks of the elapsed
-time).  Rank 0 prints one JSON line.
+Workload (BASELINE.json config 3): A = 10 000 synthetic ~5 Mbp KpSC assemblies per GPU, typed against the synthetic
+K-locus database and then the O-locus database.  One "step" is one pass of the whole hot path over all A assemblies:
+they go through the context-owned work buffers as A / B batches of B = 1000, per database one alignment pass per batch
+(seed scan -> anchor sort -> chaining -> banded Smith-Waterman), then hit finalisation, locus scoring, overlap cull,
+pieces, translation, protein DP and gene states on the GPU; the host does three small numpy float steps per database
+and batch and formats the TSV rows.  The two databases have their own contexts and streams and share one resident copy
+of the packed assemblies.  `--db ab_k` runs config 4 instead (A. baumannii K database, 4 Mbp, ~1 500 contigs).
+
+Three throughputs are reported in the one JSON line:
+  value                      packed assemblies resident in HBM before the timed region (the contract's number)
+  e2e.from_host_shards       every batch uploaded from pre-packed shards in pinned host memory inside the timed region
+                             (H2D on a copy stream, two batches ahead of the alignment pass), then typed
+  e2e.with_tsv               the same plus the TSV bytes of every row
+Ranks hold disjoint assemblies (weak scaling, no collective on the data path; torch.distributed is used for the
+barrier and the max-over-ranks of the elapsed time only).  Rank 0 prints the line.
 
 Extra objects in the line:
   roofline      seed-scan kernel of the K database pass (the kernel that streams every base against the large
                 database): algorithmic bytes = 4 * packed words per launch, duration = mean over its launches in the
                 timed region, from HIP events the library records on the kernel's own stream (kp_batch_profile), peak =
-                8 TB/s HBM3E; traffic = PMC bytes of the committed offline collection (profiles/scan_pmc.json).
+                8 TB/s HBM3E; traffic = PMC bytes of a committed offline collection (traffic_source names it) or null.
   dp            banded Smith-Waterman kernels: DP cells per second (integer VALU work; no HBM or MFMA roofline applies).
-  cpu_baseline  the CPU oracle (oracle/kp_oracle.c + the numpy reduction) typing a bounded sample of the same
-                assemblies on one host core.
+  cpu_baseline  the CPU oracle (oracle/kp_oracle.c rebuilt -O3 -march=native on this box + the numpy reduction) typing
+                a bounded sample of the same assemblies: on every host core at once (value / cores) and on one core.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,119 +47,139 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-L2_PEAK_BYTES_PER_S = 34.5e12  # aggregate L2 bandwidth (MI355X_MICROARCH.md), served in 128-byte lines
+
+WORKLOADS = {
+    # config 2/3 and config 4
+    "kpsc": dict(main="kpsc_k", main_seed=100, also=("kpsc_o", 101), length=5.0e6, asm_kw={}),
+    "ab_k": dict(main="ab_k", main_seed=102, also=None, length=4.0e6,
+                 asm_kw=dict(median_contigs=1500, min_contig=200, force_split=True)),
+}  # fmt: skip
+
+_DBS: dict = {}
+_WL: dict = {}
+
+
+def _load_dbs(kind: str) -> None:
+    from kaptive_amd.synth import make_db
+
+    wl = WORKLOADS[kind]
+    _WL.update(wl)
+    _DBS["main"] = make_db(wl["main"], seed=wl["main_seed"])
+    _DBS["also"] = make_db(wl["also"][0], seed=wl["also"][1]) if wl["also"] else None
 
 
 def _make_one(job):
-    kind, seed, length = job
+    seed, length = job
     from kaptive_amd.synth import make_assembly
 
-    db = _DBS[kind]
-    g = make_assembly(db, seed=seed, length=length, also=(_DBS["o"],))
-    pa = g.packed()
-    return g.id, g.contigs.ids, g.contigs.seqs, g.contigs.lengths, pa
-
-
-_DBS: dict = {}
+    also = (_DBS["also"],) if _DBS["also"] is not None else ()
+    g = make_assembly(_DBS["main"], seed=seed, length=length, also=also, **_WL["asm_kw"])
+    return g.id, g.packed()
 
 
 def build_workload(n_asm: int, seed0: int, length: float, workers: int):
-    """Synthetic KpSC-shaped databases and assemblies (SURVEY.md section 8d, config 2 inputs), generated before any
-    GPU state exists so that worker processes can be forked safely."""
-    from kaptive_amd.core.genome import GenomeAssembly
-    from kaptive_amd.core.seq import Sequences
-    from kaptive_amd.synth import make_db
-
-    _DBS["k"] = make_db("kpsc_k", seed=100)
-    _DBS["o"] = make_db("kpsc_o", seed=101)
-    jobs = [("k", seed0 + i, length) for i in range(n_asm)]
+    """Synthetic databases and packed assemblies, generated before any GPU state exists (forked workers)."""
+    jobs = [(seed0 + i, length) for i in range(n_asm)]
     if workers > 1 and n_asm > 4:
         pool = get_context("fork").Pool(workers)
         try:
-            rows = pool.map(_make_one, jobs, chunksize=max(1, n_asm // (workers * 4)))
+            rows = pool.map(_make_one, jobs, chunksize=max(1, min(16, n_asm // (workers * 4))))
         finally:  # close + join, never terminate(): a SIGTERM to the workers wedges tools that hook signals (rocprofv3)
             pool.close()
             pool.join()
     else:
         rows = [_make_one(j) for j in jobs]
-    genomes, packed = [], []
-    for gid, ids, seqs, lengths, pa in rows:
-        off = np.zeros(len(lengths), np.int32)
-        if len(lengths) > 1:
-            np.cumsum(lengths[:-1], out=off[1:])
-        g = GenomeAssembly(gid, Sequences(ids, seqs, off, lengths))
-        g._packed.append(pa)
-        genomes.append(g)
-        packed.append(pa)
-    return _DBS["k"], _DBS["o"], genomes, packed
+    return [r[0] for r in rows], [r[1] for r in rows]
 
 
-def pmc_traffic(args):
-    """PMC figures of the scan kernel (HBM bytes and L2 requests per launch).  Counters cannot be read from inside the
-    process, so these are the figures of the committed offline collection (profiles/scan_pmc.json: separate rocprofv3
-    --pmc passes of this same command, gfx950 correction applied as MI355X_MICROARCH.md prescribes); they are reported
-    only when the workload is the one that collection ran, otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_pmc.json")
-    try:
-        with open(path) as fh:
-            pmc = json.load(fh)
-    except OSError:
-        return None
-    if pmc["workload"] != {"assemblies": args.assemblies, "length": args.length}:
-        return None
-    return pmc
-
-
-def cpu_baseline(dbs, genomes, budget_s: float = 20.0) -> dict:
-    """Type a bounded sample with the CPU oracle (C aligner + C protein DP + numpy reduction), one core."""
+# ---- CPU baseline (runs before any GPU state exists; workers are forked) ------------------------------------------------
+def _cpu_worker(job):
+    seeds, length, native_so = job
     from kaptive_amd.core.pairwise import PairwiseAlignments
     from kaptive_amd.pack import pack_sequences_flat
     from kaptive_amd.serotyping.core import Serotyper
+    from kaptive_amd.synth import make_assembly
     from oracle import oracle as O
     from tests.golden_util import hits_to_alignments
+
+    if native_so:
+        O.use_library(native_so)
 
     def oracle_proteins(q, t):
         return PairwiseAlignments.from_table(O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths))
 
+    dbs = [d for d in (_DBS["main"], _DBS["also"]) if d is not None]
     stages = []
     for db in dbs:
         odb = O.OracleDB(*pack_sequences_flat(db.genes))
         stages.append((db, odb, Serotyper(db, aligner=lambda g: None, protein_aligner=oracle_proteins)))
-    n = 0
+    also = (_DBS["also"],) if _DBS["also"] is not None else ()
+    genomes = [make_assembly(_DBS["main"], seed=s, length=length, also=also, **_WL["asm_kw"]) for s in seeds]
+    packed = [g.packed() for g in genomes]
     t0 = time.perf_counter()
-    for g in genomes:
+    for g, pa in zip(genomes, packed):
         for db, odb, typer in stages:
-            hits = odb.align(g.packed())
-            typer.reduce(g, hits_to_alignments(db, g, hits))
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
+            typer.reduce(g, hits_to_alignments(db, g, odb.align(pa)))
+    return len(genomes), time.perf_counter() - t0
+
+
+def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
+    """The CPU oracle (C aligner + C protein DP + numpy reduction) typing the first assemblies of the workload against
+    every database: all host cores at once (one assembly per process at a time), then one core alone."""
+    from oracle import oracle as O
+
+    native = O.build_native()  # -O3 -march=native for this box; None when no compiler is here (then the portable build)
+    flags = "-O3 -march=native" if native else "-O2 (prebuilt; no compiler on this box)"
+    cores = os.cpu_count() or 1
+    n_dbs = 2 if _DBS["also"] is not None else 1
+    jobs = [([seed0 + w * per_worker + i for i in range(per_worker)], length, native) for w in range(cores)]
+    pool = get_context("fork").Pool(cores)
+    try:
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_worker, jobs, chunksize=1)
+        wall = time.perf_counter() - t0
+    finally:
+        pool.close()
+        pool.join()
+    rate_all = sum(n / dt for n, dt in parts)  # workers type concurrently; each one's rate over its own typing time
+    n1, dt1 = _cpu_worker(([seed0 + i for i in range(max(per_worker * 2, 6))], length, native))
+    what = "K then O" if n_dbs == 2 else "K"
     return {
-        "value": n / dt, "unit": "assemblies/s", "cores": 1, "kind": "port",
-        "sample": f"first {n} assemblies of the same batch, K then O, CPU oracle (oracle/kp_oracle.c aligner + protein DP, "
-                  f"numpy reduction), {dt:.1f} s wall on 1 of {os.cpu_count()} host cores",
+        "value": rate_all, "unit": "assemblies/s", "cores": cores, "kind": "port",
+        "sample": f"{cores} processes x {per_worker} assemblies of the same workload each ({what}), all at once: CPU oracle "
+                  f"(oracle/kp_oracle.c aligner + protein DP built {flags}, numpy reduction), {wall:.1f} s wall including "
+                  "input generation; the rate is the sum of the processes' typing rates",
+        "single_core": {"value": n1 / dt1, "unit": "assemblies/s", "cores": 1,
+                        "sample": f"first {n1} assemblies, {dt1:.1f} s on one of {cores} host cores"},
     }  # fmt: skip
+
+
+def offline_pmc(args) -> dict | None:
+    """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
+    collection of this same command (profiles/scan_pmc_r2.json) and are reported only for the workload it ran."""
+    path = ROOT / "profiles" / "scan_pmc_r2.json"
+    try:
+        pmc = json.loads(path.read_text())
+    except OSError:
+        return None
+    if pmc.get("workload") != {"db": args.db, "batch": args.batch, "length": _WL["length"]}:
+        return None
+    return pmc
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--assemblies", type=int, default=1000, help="assemblies per GPU (resident batch)")
-    ap.add_argument("--length", type=float, default=5.0e6)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--assemblies", type=int, default=10000, help="assemblies per GPU (one step types all of them)")
+    ap.add_argument("--batch", type=int, default=1000, help="assemblies per device batch")
+    ap.add_argument("--db", choices=sorted(WORKLOADS), default="kpsc")
+    ap.add_argument("--length", type=float, default=0.0, help="mean assembly length (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
+    ap.add_argument("--e2e-steps", type=int, default=1)
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
-    ap.add_argument("--sub-batches", type=int, default=1,
-                    help="resident device batches per database; they are software-pipelined so that host-side steps of "
-                         "one overlap device work of the next")
-    ap.add_argument("--shared-pass", action="store_true",
-                    help="the genes of both databases share one seed index: every assembly is scanned, chained and "
-                         "aligned once and each database's reduction takes its own run of the gene-sorted hit table "
-                         "(default: one context and one alignment pass per database, as the reference runs them; the "
-                         "shared pass does a tenth less device work, but the small database's pass and reduction "
-                         "otherwise hide completely underneath the large one's alignment, so the step is not shorter)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,18 +188,26 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    workers = args.workers or max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    workers = args.workers or max(1, min(64, (os.cpu_count() or 1) // max(world, 1)))
     if workers == 1:
         import torch  # noqa: F401  (inline generation loads the native library; under rocprofv3 torch has to come first)
+    _load_dbs(args.db)
+    length = args.length or _WL["length"]
+    seed0 = 200 + rank * args.assemblies
     t_gen = time.perf_counter()
-    db_k, db_o, genomes, packed = build_workload(args.assemblies, 200 + rank * args.assemblies, args.length, workers)
+    ids, packed = build_workload(args.assemblies, seed0, length, workers)
     t_gen = time.perf_counter() - t_gen
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(seed0, length)
 
     import torch
     import torch.distributed as dist
 
+    from kaptive_amd import _native
     from kaptive_amd.engine import Engine
     from kaptive_amd.serotyping.core import Serotyper
+    from kaptive_amd.shard import shard_bounds
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (kaptive_amd has no CPU path)")
@@ -186,61 +222,59 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from kaptive_amd.shard import shard_bounds
+    dbs = [d for d in (_DBS["main"], _DBS["also"]) if d is not None]
+    n_batches = max(1, (len(packed) + args.batch - 1) // args.batch)
+    spans = [shard_bounds(len(packed), i, n_batches) for i in range(n_batches)]
+    batch_ids = [ids[lo:hi] for lo, hi in spans]
+    engines = [Engine(db, device=local_rank) for db in dbs]
+    typers = [Serotyper(db, device=local_rank) for db in dbs]
+    for eng, typer in zip(engines, typers):
+        typer._engine = eng
+    # smaller database first when results are collected: its pass ends long before the other's
+    collect_order = sorted(range(len(dbs)), key=lambda k: len(dbs[k].genes))
 
-    n_sub = max(1, min(args.sub_batches, len(packed)))
-    spans = [shard_bounds(len(packed), i, n_sub) for i in range(n_sub)]
-    sub_ids = [[g.id for g in genomes[lo:hi]] for lo, hi in spans]
-    # passes: (engine, resident batches) per alignment pass; stages: (engine as one database sees it, typer, batches)
-    passes, stages = [], []
-    if not args.shared_pass:
-        for db in (db_k, db_o):
-            eng = Engine(db, device=local_rank)
-            batches = [eng.ctx.batch(packed[lo:hi]) for lo, hi in spans]
-            passes.append((eng, batches))
-            stages.append((eng, Serotyper(db, device=local_rank), batches))
-    else:
-        eng = Engine([db_k, db_o], device=local_rank)
-        batches = [eng.ctx.batch(packed[lo:hi]) for lo, hi in spans]
-        passes.append((eng, batches))
-        stages = [(eng.view(i), Serotyper(db, device=local_rank), batches) for i, db in enumerate((db_k, db_o))]
-    for view, typer, _ in stages:
-        typer._engine = view
+    def make_batches(i, pinned=None):
+        """Device batches of shard i, one per database; the later contexts adopt the first one's device words."""
+        lo, hi = spans[i]
+        first = engines[0].ctx.batch(packed[lo:hi], pinned_words=pinned)
+        return [first] + [eng.ctx.batch(packed[lo:hi], device_words=first.device_words, after=first) for eng in engines[1:]]
 
-    def step():
-        # every alignment pass is enqueued up front (contexts have their own streams); then per database: score ->
-        # choice of best locus (numpy) -> reduction -> decisions as columns (BatchTyping)
-        for _, batches in passes:
-            for b in batches:
-                b.align_async()
-        # Reductions of every database are enqueued before any result is collected (typing groups have their own
-        # streams), so the column-wise finishing of one database (host) runs while the device reduces the next.
-        # separate passes: the smaller database first (its pass ends long before the other's); one shared pass: the
-        # larger one first (its reduction is the longer chain and the other one runs beside it)
-        order = sorted(stages, key=lambda st: len(st[0].db.genes), reverse=len(passes) == 1)
-        if len(passes) == 1:  # all scores first (cheap), so that none queues up behind another database's reduction
-            staged = [view.score_batches(typer, batches) for view, typer, batches in order]
-            for (view, typer, batches), st in zip(order, staged):
-                view.enqueue_reductions(typer, batches, st)
-        else:  # a database's reduction is enqueued as soon as its own pass is through
-            staged = [view.reduce_batches(typer, batches, aligned=True) for view, typer, batches in order]
+    prof: list[list[dict]] = [[] for _ in dbs]
+    stats: list[list[dict]] = [[] for _ in dbs]
+
+    def run_pass(get_batches, release=None, rows_sink=None, record=False):
+        """One step: every shard through every database.  Alignment passes run one shard ahead of the reductions."""
         out = []
-        done = list(zip(order, staged))
-        if len(passes) == 1:
-            done.reverse()  # the short chain is finished first: its columns are built while the long one still runs
-        for (view, typer, batches), st in done:
-            out += view.collect_batches(typer, batches, sub_ids, st)
+        live = {0: get_batches(0)}
+        for k, b in enumerate(live[0]):
+            b.align_async()
+        for i in range(n_batches):
+            if i + 1 < n_batches:
+                live[i + 1] = get_batches(i + 1)
+                for b in live[i + 1]:
+                    b.align_async()
+            bs = live[i]
+            staged = {k: engines[k].reduce_batches(typers[k], [bs[k]], aligned=True) for k in collect_order}
+            for k in collect_order:
+                bt = engines[k].collect_batches(typers[k], [bs[k]], [batch_ids[i]], staged[k])[0]
+                if rows_sink is not None:
+                    rows_sink.append(bt.tsv())
+                out.append(bt)
+                if record:
+                    prof[k].append(bs[k].profile())
+                    stats[k].append(bs[k].stats())
+            if release is not None:
+                release(live.pop(i))
         return out
 
+    # ---- leg 1: resident batches (the contract's number) -------------------------------------------------------------------
+    resident = [make_batches(i) for i in range(n_batches)]
     for _ in range(args.warmup):
-        step()
+        run_pass(lambda i: resident[i])
     sync_all()
-    prof = [[] for _ in passes]  # stage timings of every timed launch, per alignment pass
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
-        for plist, (_, batches) in zip(prof, passes):
-            plist += [b.profile() for b in batches]  # events of the passes that just ran; no extra GPU work
+        res = run_pass(lambda i: resident[i], record=True)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -248,35 +282,79 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- legs 2 and 3: from pinned host shards, without and with TSV bytes (one GPU only) -------------------------------------
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        for bs in resident:
+            for b in reversed(bs):
+                b.close()
+        resident = []
+        pins = []
+        t_pin = time.perf_counter()
+        for lo, hi in spans:  # pre-packed shards in page-locked memory
+            pb = _native.PinnedBuffer(sum(len(pa.words) for pa in packed[lo:hi]), np.uint32)
+            at = 0
+            for pa in packed[lo:hi]:
+                pb.array[at : at + len(pa.words)] = pa.words
+                at += len(pa.words)
+            pins.append(pb)
+        t_pin = time.perf_counter() - t_pin
+
+        def close_all(bs):
+            for b in reversed(bs):
+                b.close()
+
+        def timed(with_rows: bool):
+            ahead = {}
+
+            def get(i):  # uploads run two shards ahead of the alignment pass that reads them
+                for j in (i, i + 1, i + 2):
+                    if j < n_batches and j not in ahead:
+                        ahead[j] = make_batches(j, pins[j].array)
+                return ahead.pop(i)
+
+            sink = [] if with_rows else None
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(args.e2e_steps):
+                run_pass(get, release=close_all, rows_sink=sink)
+            sync_all()
+            dt = time.perf_counter() - t1
+            return args.assemblies * args.e2e_steps / dt, sum(len(x) for x in sink) if with_rows else 0
+
+        timed(False)  # warm-up of the upload path (input buffers, pinned staging)
+        v_shards, _ = timed(False)
+        v_tsv, tsv_bytes = timed(True)
+        e2e = {"from_host_shards": v_shards, "with_tsv": v_tsv, "unit": "assemblies/s", "steps": args.e2e_steps,
+               "tsv_bytes_per_step": tsv_bytes // max(args.e2e_steps, 1), "pinning_s": round(t_pin, 1),
+               "note": "shards of --batch pre-packed assemblies in pinned host memory; H2D on a copy stream two shards "
+                       "ahead; with_tsv adds the KaptiveRow bytes of every assembly and database"}  # fmt: skip
+        for pb in pins:
+            pb.close()
+
     if rank == 0:
         n_total = args.assemblies * world * args.steps
-        stats = []
-        for _, batches in passes:  # counters summed over the sub-batches of one alignment pass
-            parts = [b.stats() for b in batches]
-            stats.append({k: sum(p[k] for p in parts) for k in parts[0]})
-        # roofline kernel: kp_scan_kernel<0, false>, the scan with the presence filter in L2 -- every launch of the first
-        # alignment pass (K and O genes together, or the K database's pass) in the timed region.
         scan_all = [p["scan"] for p in prof[0]]
         scan_ms = float(np.mean(scan_all))
         scan_bytes = float(np.mean([p["bytes_scanned"] for p in prof[0]]))
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
-        pmc = pmc_traffic(args)
-        l2_req = pmc["l2"]["K_l2"]["TCC_REQ_sum"] if pmc else None
-        # per database: mean over the timed steps of the sum over sub-batches
+        pmc = offline_pmc(args)
+        # per database: kernel milliseconds per step (sum over the step's batches, mean over steps)
         mean_ms = [{k: float(np.sum([p[k] for p in plist])) / args.steps for k in plist[0] if k != "bytes_scanned"}
                    for plist in prof]
         sw_ms = sum(m["sw16"] + m["sw32"] + m["sw64"] + m["sw128"] for m in mean_ms)
-        cells = sum(s["dp_cells"] for s in stats)
+        per_step = [{k: sum(s[k] for s in slist) // args.steps for k in slist[0]} for slist in stats]
+        cells = sum(s["dp_cells"] for s in per_step)
         typed = int(sum(bt.typeable.sum() for bt in res))
         t_rows = time.perf_counter()
-        rows = [r for bt in res for r in bt.rows()]  # TSV formatting of the last step, outside the timed region
-        n_rows = len(rows)
+        blobs = [bt.tsv() for bt in res]  # TSV bytes of the last step
         t_rows = time.perf_counter() - t_rows
-        import hashlib
-
+        rows = [r for blob in blobs for r in blob.splitlines(keepends=True)]
         rows_digest = hashlib.sha1(b"".join(sorted(rows))).hexdigest()  # same workload -> same digest, whatever the schedule
+        what = ("typed against the synthetic K-locus database, then the O-locus database" if len(dbs) == 2
+                else "typed against the synthetic A. baumannii K-locus database (~1 500 contigs per assembly)")
         line = {
-            "metric": "assemblies typed/sec (K+O)",
+            "metric": "assemblies typed/sec (K+O)" if len(dbs) == 2 else "assemblies typed/sec (K)",
             "value": n_total / elapsed,
             "unit": "assemblies/s",
             "n_gpus": world,
@@ -289,39 +367,37 @@ def main() -> None:
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.assemblies} synthetic {args.length / 1e6:g} Mbp KpSC assemblies per GPU typed against "
-                            "the synthetic K-locus and O-locus databases, packed batch resident in HBM; "
-                            + ("one alignment pass per database" if not args.shared_pass else
-                               "one alignment pass over the genes of both databases, one reduction per database"),
-                "alignment_passes": len(passes),
+                "workload": f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU {what}; one step "
+                            f"= all of them, as {n_batches} batches of {args.batch} through context-owned work buffers; packed "
+                            "assemblies resident in HBM before the timed region (one copy shared by both databases' contexts)",
+                "alignment_passes_per_batch": len(dbs),
                 "assemblies_per_gpu": args.assemblies,
-                "sub_batches": n_sub,
-                "db_k": f"{len(db_k.loci)} loci / {len(db_k.genes)} genes",
-                "db_o": f"{len(db_o.loci)} loci / {len(db_o.genes)} genes",
+                "batch": args.batch,
+                "databases": [f"{d.metadata.keyword}: {len(d.loci)} loci / {len(d.genes)} genes" for d in dbs],
                 "parallelism": f"{world} x independent shard, no collective",
                 "typeable_in_last_step": typed,
-                "tsv_rows_per_s_host": round(n_rows / t_rows, 1),
+                "tsv_rows_per_s_host": round(len(rows) / max(t_rows, 1e-9), 1),
                 "tsv_rows_sha1": rows_digest,
+                "retries_per_step": [s["retries"] for s in per_step],
                 "workload_generation_s": round(t_gen, 1),
             },
+            "e2e": e2e,
             "roofline": {
-                "bound": "hbm", "kernel": "kp_scan_kernel<0, false>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc["traffic_bytes_per_launch_K_l2"] if pmc else None,
+                "bound": "hbm", "kernel": "kp_scan_kernel (K database pass)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic_source": f"offline: {pmc['source']}" if pmc else None,
                 "bytes_per_launch": scan_bytes, "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
-                # what actually bounds this kernel: one L2 request per presence-filter gather (PMC: TCC_REQ_sum of the
-                # committed collection) against the L2's 34.5 TB/s in 128-byte lines
-                "l2_requests_per_launch": l2_req,
-                "l2_request_rate_frac": (l2_req / (scan_ms * 1e-3)) / (L2_PEAK_BYTES_PER_S / 128.0) if l2_req else None,
             },
             "dp": {
-                "kernel": "kp_sw_kernel<8|16|32|64>", "cells_per_pass": [s["dp_cells"] for s in stats],
-                "ms": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
-                "tasks": [s["tasks"] for s in stats], "anchors": [s["anchors"] for s in stats],
+                "kernel": "kp_sw_kernel", "cells_per_step": [s["dp_cells"] for s in per_step],
+                "ms_per_step": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
+                "tasks_per_step": [s["tasks"] for s in per_step], "anchors_per_step": [s["anchors"] for s in per_step],
             },
-            "kernel_ms": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16", "sw32", "sw64", "sw128")},
+            "kernel_ms_per_step": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16")},
         }  # fmt: skip
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline((db_k, db_o), genomes)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -6,12 +6,20 @@
  * maintainer would add.  Conventions: every call returns 0 on success or a negative KP_E* code and records a message
  * retrievable with kp_last_error(); no exceptions cross the boundary; the caller owns every host buffer it passes and
  * may free it as soon as the call returns unless stated otherwise; the library owns all device memory.  A context is
- * bound to one GPU and one HIP stream; calls on one context must be serialised by the caller, distinct contexts are
- * independent (one context per device / per host thread).
+ * bound to one GPU; calls on one context must be serialised by the caller, distinct contexts are independent (one
+ * context per device / per host thread).
+ *
+ * Ownership of device memory.  Work buffers (anchors, band tasks, hit tables, reduction records) belong to the context,
+ * not to a batch: a context owns KP_WORK_SLOTS work sets, kp_batch_align takes the next one round-robin, and the sizes
+ * the library learns for them (overflow -> automatic rerun with more room) are kept for every later batch.  So a stream
+ * of batches allocates nothing after its first few, and the context holds the alignment results of its KP_WORK_SLOTS
+ * most recently aligned batches; calls that read results of a batch displaced since return KP_ESTATE.  The device
+ * copies of batch inputs are recycled through the context in the same way.
  */
 #ifndef KAPTIVE_AMD_H
 #define KAPTIVE_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "kp_spec.h"
@@ -37,8 +45,20 @@ KP_API int kp_ctx_create(int device_id, kp_ctx **out);
 KP_API void kp_ctx_destroy(kp_ctx *ctx);
 /* Message of the last failed call on ctx (ctx may be NULL for a failed kp_ctx_create). Never NULL. */
 KP_API const char *kp_last_error(const kp_ctx *ctx);
-/* The hipStream_t all work of this context is enqueued on (for event timing by the caller). */
+/* The hipStream_t the alignment passes of this context are enqueued on (for event timing by the caller). */
 KP_API void *kp_ctx_stream(kp_ctx *ctx);
+/* Tuning knobs.  Defaults are read from the environment once, in kp_ctx_create (KAPTIVE_AMD_<NAME in upper case>);
+ * names: anchor_cap, tasks_per_asm, hit_cap, kept_cap, piece_cap, prot_cap (initial sizes of the work buffers -- setting
+ * one also forgets what the context has learnt for it), no_lds_filter (seed scan probes the L2 tier of the presence
+ * filter even for small databases), scan_mode (ablation modes of the scan kernel, tools/scan_ablate.py),
+ * sw_blocks_per_cu (grid of the banded Smith-Waterman launch). */
+KP_API int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value);
+#define KP_WORK_SLOTS 2
+
+/* ---- pinned host memory ---------------------------------------------------------------------------------------------------
+ * For callers that stream shards: kp_batch_create_async only overlaps with device work when `words` is page-locked. */
+KP_API int kp_host_alloc(size_t bytes, void **out);
+KP_API void kp_host_free(void *p);
 
 /* ---- database ---------------------------------------------------------------------------------------------------
  * Replaces what Serotyper.__init__ prepares for the aligner -- the list of (name, gene bytes) handed to
@@ -82,13 +102,27 @@ KP_API void kp_fasta_free(kp_packed_fasta *packed);
  *   n_runs         : [start,end) pairs of N runs, sorted per assembly, in the assembly's padded space
  *   asm_first_nrun : n_asm + 1 offsets into n_runs (in runs, not ints)
  * kp_batch_create copies from host memory; kp_batch_create_device adopts `words` already in device memory (it must
- * stay valid until kp_batch_destroy) and copies only the small tables. */
+ * stay valid until kp_batch_destroy) and copies only the small tables.  kp_batch_create_async enqueues the copies on
+ * the context's copy stream and returns: `words` must stay valid and unchanged until kp_batch_upload_wait (or the
+ * batch's first kp_batch_wait) has returned -- the tables may be freed at once; kp_batch_align of the batch waits for
+ * the copies on the device, so the upload of batch i+1 overlaps the alignment pass of batch i. */
 KP_API int kp_batch_create(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
                     const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
                     const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out);
+KP_API int kp_batch_create_async(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
+                          const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                          const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out);
+KP_API int kp_batch_upload_wait(kp_ctx *ctx, kp_batch *batch);
+/* `batch` adopted (kp_batch_create_device) the device words of `other`, a batch of another context on the same GPU whose
+ * upload may still be in flight: alignment passes of `batch` then wait for that upload on the device.  `other` must
+ * outlive `batch`. */
+KP_API int kp_batch_depends_on(kp_ctx *ctx, kp_batch *batch, kp_batch *other);
 KP_API int kp_batch_create_device(kp_ctx *ctx, int32_t n_asm, const uint32_t *d_words, const int64_t *asm_word_off,
                            const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
                            const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out);
+/* Device address of the batch's packed words (valid until kp_batch_destroy): lets a second context on the same GPU
+ * type the same resident assemblies against another database via kp_batch_create_device instead of a second copy. */
+KP_API const void *kp_batch_device_words(const kp_batch *batch);
 KP_API void kp_batch_destroy(kp_batch *batch);
 
 /* ---- alignment --------------------------------------------------------------------------------------------------

@@ -23,8 +23,9 @@ TASK_DTYPE = np.dtype(
 )  # fmt: skip
 
 EXPORTS = (
-    "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_db_load", "kp_db_n_postings",
-    "kp_batch_create", "kp_batch_create_device", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
+    "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
+    "kp_host_free", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
+    "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_pack_contigs", "kp_fasta_free",
@@ -131,6 +132,10 @@ def lib() -> C.CDLL:
                     getattr(h, f).restype = C.c_int64
                 h.kp_ctx_destroy.restype = None
                 h.kp_batch_destroy.restype = None
+                h.kp_batch_device_words.restype = C.c_void_p
+                h.kp_host_free.restype = None
+                h.kp_host_free.argtypes = [C.c_void_p]
+                h.kp_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
                 _lib = h
     return _lib
 
@@ -174,6 +179,10 @@ class Context:
     def stream(self) -> int:
         return int(lib().kp_ctx_stream(self._h) or 0)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning knob of the context (kp_ctx_set_option; names in include/kaptive_amd.h)."""
+        self._check(lib().kp_ctx_set_option(self._h, name.encode(), C.c_int64(int(value))), "kp_ctx_set_option")
+
     def load_genes(self, gene_codes: np.ndarray, gene_off: np.ndarray) -> None:
         codes, off = _c(gene_codes, np.uint8), _c(gene_off, np.int32)
         self._check(lib().kp_db_load(self._h, _p(codes), _p(off), C.c_int32(len(off) - 1)), "kp_db_load")
@@ -215,15 +224,21 @@ class Context:
             )  # fmt: skip
         return out
 
-    def batch(self, packed: list, device_words: int | None = None) -> "Batch":
-        return Batch(self, packed, device_words)
+    def batch(self, packed: list, device_words: int | None = None, pinned_words: "np.ndarray | None" = None,
+              after: "Batch | None" = None) -> "Batch":
+        return Batch(self, packed, device_words, pinned_words, after)
 
 
 class Batch:
     """Packed assemblies resident on the device (kp_batch). ``packed`` is a list of PackedAssembly; with
     ``device_words`` (a device pointer to the concatenated words) nothing but the small tables is copied."""
 
-    def __init__(self, ctx: Context, packed: list, device_words: int | None = None) -> None:
+    def __init__(self, ctx: Context, packed: list, device_words: int | None = None,
+                 pinned_words: "np.ndarray | None" = None, after: "Batch | None" = None) -> None:
+        """``after``: the batch (of another context on the same GPU) whose device words this one adopts while their
+        upload may still be in flight.  ``pinned_words``: the concatenated words of ``packed`` in page-locked memory (``pinned_array``); the upload
+        is then enqueued asynchronously (kp_batch_create_async) and the array must stay alive until ``upload_wait`` or
+        the first ``wait``/``score`` of the batch."""
         self.ctx = ctx
         self.n_asm = len(packed)
         word_off = np.zeros(self.n_asm + 1, np.int64)
@@ -241,7 +256,13 @@ class Batch:
         ctg_len = cat([pa.ctg_len for pa in packed], np.int32)
         n_runs = cat([pa.n_runs.reshape(-1) for pa in packed], np.int32)
         self._h = C.c_void_p()
-        if device_words is None:
+        self._pinned = pinned_words
+        if pinned_words is not None:
+            if pinned_words.dtype != np.uint32 or len(pinned_words) != int(word_off[-1]):
+                raise ValueError("pinned_words must be the uint32 concatenation of the packed assemblies' words")
+            rc = lib().kp_batch_create_async(ctx._h, C.c_int32(self.n_asm), _p(pinned_words), _p(word_off), _p(ctg_start),
+                                             _p(ctg_len), _p(first_ctg), _p(n_runs), _p(first_run), C.byref(self._h))  # fmt: skip
+        elif device_words is None:
             words = cat([pa.words for pa in packed], np.uint32)
             rc = lib().kp_batch_create(ctx._h, C.c_int32(self.n_asm), _p(words), _p(word_off), _p(ctg_start),
                                        _p(ctg_len), _p(first_ctg), _p(n_runs), _p(first_run), C.byref(self._h))  # fmt: skip
@@ -250,6 +271,9 @@ class Batch:
                                               _p(ctg_start), _p(ctg_len), _p(first_ctg), _p(n_runs), _p(first_run),
                                               C.byref(self._h))  # fmt: skip
         ctx._check(rc, "kp_batch_create")
+        self._after = after
+        if after is not None:
+            ctx._check(lib().kp_batch_depends_on(ctx._h, self._h, after._h), "kp_batch_depends_on")
         self.total_words = int(word_off[-1])
         ctx._batches.add(self)
         _live.add(self)
@@ -261,6 +285,14 @@ class Batch:
             self._h = None
 
     __del__ = close
+
+    @property
+    def device_words(self) -> int:
+        """Device address of the packed words (kp_batch_device_words); another context's batch can adopt them."""
+        return int(lib().kp_batch_device_words(self._h) or 0)
+
+    def upload_wait(self) -> None:
+        self.ctx._check(lib().kp_batch_upload_wait(self.ctx._h, self._h), "kp_batch_upload_wait")
 
     def align_async(self) -> None:
         self.ctx._check(lib().kp_batch_align(self.ctx._h, self._h), "kp_batch_align")
@@ -355,6 +387,28 @@ class Batch:
         out = np.zeros(n, TASK_DTYPE)
         lib().kp_batch_tasks(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
         return out
+
+
+class PinnedBuffer:
+    """Page-locked host memory (kp_host_alloc) exposed as a numpy array; freed by ``close`` / garbage collection."""
+
+    def __init__(self, n_items: int, dtype=np.uint32) -> None:
+        self._p = C.c_void_p()
+        dt = np.dtype(dtype)
+        nbytes = max(1, int(n_items) * dt.itemsize)
+        rc = lib().kp_host_alloc(C.c_size_t(nbytes), C.byref(self._p))
+        if rc != 0:
+            raise NativeError(f"kp_host_alloc failed ({rc}): {lib().kp_last_error(None).decode()}")
+        buf = (C.c_uint8 * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(n_items))
+
+    def close(self) -> None:
+        if getattr(self, "_p", None) and self._p.value:
+            self.array = None
+            lib().kp_host_free(self._p)
+            self._p = C.c_void_p()
+
+    __del__ = close
 
 
 _default_ctx: dict[int, Context] = {}

@@ -85,14 +85,26 @@ class ResultExporter:
 
 
 def _add_outputs(p: argparse.ArgumentParser, tsv_flags, include_json: bool) -> None:
+    """Defaults, ``nargs`` and ``const`` follow the reference (src/kaptive/cli.py:424-504): ``-o`` defaults to stdout,
+    ``convert -t`` without a value means stdout, ``-l/-g/-p`` without a value mean the current directory."""
     g = p.add_argument_group("Outputs")
-    g.add_argument(*tsv_flags, metavar="", help="Output file to write/append tabular results to (- for stdout)")
+    if tsv_flags[0] == "-o":
+        g.add_argument(*tsv_flags, metavar="FILE", default="stdout",
+                       help="Write serotyping results as a TSV report to a file (default: %(default)s)")
+    else:
+        g.add_argument(*tsv_flags, metavar="FILE", nargs="?", const="stdout",
+                       help="Write serotyping results as a TSV report to a file (default: %(const)s)")
+    g.add_argument("-l", "--loci", metavar="DIR", nargs="?", const="./", type=Path,
+                   help="Write locus nucleotide fasta files to a directory (default: %(const)s)")
+    g.add_argument("-g", "--genes", metavar="DIR", nargs="?", const="./", type=Path,
+                   help="Write gene nucleotide fasta files to a directory (default: %(const)s)")
+    g.add_argument("-p", "--proteins", metavar="DIR", nargs="?", const="./", type=Path,
+                   help="Write translation amino-acid fasta files to a directory (default: %(const)s)")
     if include_json:
-        g.add_argument("-j", "--json", metavar="", help="Output file for JSON-lines results")
-    g.add_argument("--pha4ge", metavar="", help="Output file for PHA4GE-formatted tabular results")
-    g.add_argument("-l", "--loci", metavar="", help="Directory for locus nucleotide fasta files")
-    g.add_argument("-g", "--genes", metavar="", help="Directory for gene nucleotide fasta files")
-    g.add_argument("-p", "--proteins", metavar="", help="Directory for protein fasta files")
+        g.add_argument("-j", "--json", metavar="FILE", nargs="?", const="kaptive_results.jsonl",
+                       help="Write serialised results to a newline-delimited JSON (default: %(const)s)")
+    g.add_argument("--pha4ge", metavar="FILE", nargs="?", const="kaptive_results.pha4ge", type=Path,
+                   help="Write PHA4GE-compliant serotyping report to a TSV file (default: %(const)s)")
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -153,23 +165,61 @@ def run_type(args: argparse.Namespace) -> int:
         g.packed()
         return g
 
-    def type_chunk(job):
-        k, paths = job
-        with ThreadPoolExecutor(max_workers=max(1, threads // len(devices))) as pool:
-            genomes = list(pool.map(load, paths))
-        return typers[k % len(typers)].type_many(genomes)
+    for t in typers:
+        _ = t.engine  # contexts are created here, on the main thread, before any worker runs
 
+    # One worker thread per device, bound to it for the whole run: a context is only ever driven by its own thread
+    # (include/kaptive_amd.h: calls on one context are serialised).  Workers take the next chunk off a shared queue;
+    # results are written in input order.
+    import queue
+    import threading
+
+    todo: "queue.Queue" = queue.Queue()
+    for job in enumerate(chunks):
+        todo.put(job)
+    finished: dict = {}
+    cond = threading.Condition()
+
+    def worker(typer):
+        with ThreadPoolExecutor(max_workers=max(1, threads // len(devices))) as readers:
+            while True:
+                try:
+                    k, paths = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    out = typer.type_many(list(readers.map(load, paths)))
+                except BaseException as e:  # handed to the main thread, which re-raises it in input order
+                    out = e
+                with cond:
+                    finished[k] = out
+                    cond.notify_all()
+
+    workers = [threading.Thread(target=worker, args=(t,), daemon=True) for t in typers]
     done = 0
     try:
-        # one host thread per device; chunks are handed out round-robin and written back in input order
-        with ThreadPoolExecutor(max_workers=len(devices)) as pool:
-            for results in pool.map(type_chunk, enumerate(chunks)):
-                for r in results:
-                    exporter(r)
-                done += len(results)
-                if args.verbose:
-                    print(f"\r{done}/{len(args.genomes)}", end="", file=sys.stderr, flush=True)
+        for w in workers:
+            w.start()
+        for k in range(len(chunks)):
+            with cond:
+                cond.wait_for(lambda: k in finished)
+                results = finished.pop(k)
+            if isinstance(results, BaseException):
+                raise results
+            for r in results:
+                exporter(r)
+            done += len(results)
+            if args.verbose:
+                print(f"\r{done}/{len(args.genomes)}", end="", file=sys.stderr, flush=True)
     finally:
+        while True:  # nothing more is started after a failure
+            try:
+                todo.get_nowait()
+            except queue.Empty:
+                break
+        for w in workers:
+            if w.is_alive() or w.ident is not None:
+                w.join()
         exporter.close()
         for t in typers:
             if t._engine is not None:

@@ -73,7 +73,9 @@ struct KpTypingRun {
     // batch overlap: they are chains of short, low-occupancy kernels
     hipStream_t stream = nullptr, aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool split = false;  // d_hits / d_hit_n belong to the batch's most recent alignment pass
+    bool split = false;  // hits / hit_n belong to the work set's most recent alignment pass
+    const kp_hit *hits = nullptr;    // the group's hit rows: d_hits, or the work set's table itself when the group
+    const uint32_t *hit_n = nullptr;  // spans every gene of the context (no copy)
     DevBuf<kp_hit> d_hits;
     DevBuf<uint32_t> d_hit_n;
     DevBuf<uint64_t> d_keys;   // cull keys
@@ -104,6 +106,83 @@ struct KpTypingRun {
     }
 };
 
+struct kp_batch;
+
+// Options of a context: defaults come from the environment once, at kp_ctx_create; kp_ctx_set_option changes them.
+struct KpOptions {
+    uint32_t anchor_cap = 1u << 17, tasks_per_asm = 4096, hit_cap = 4096;
+    uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
+    int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
+    int no_lds_filter = 0;       // tests compare the two filter tiers
+    int sw_blocks_per_cu = 256;
+};
+
+// Device copy of one batch's input (packed words + tables).  Recycled through the context (hipFree synchronises the
+// device, so a stream of batches must not free anything).
+struct KpInput {
+    DevBuf<uint32_t> d_words;
+    DevBuf<int64_t> d_asm_word_off;
+    DevBuf<int32_t> d_ctg_start, d_ctg_len, d_asm_first_ctg, d_n_runs, d_asm_first_nrun;
+    uint8_t *h_stage = nullptr;  // pinned staging of the tables (the caller's copies may be freed on return)
+    size_t h_stage_bytes = 0;
+    hipEvent_t ready = nullptr;  // recorded on the copy stream after the last H2D copy of the batch
+    void release() {
+        d_words.release(); d_asm_word_off.release(); d_ctg_start.release(); d_ctg_len.release();
+        d_asm_first_ctg.release(); d_n_runs.release(); d_asm_first_nrun.release();
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr; h_stage_bytes = 0;
+        if (ready) (void)hipEventDestroy(ready);
+        ready = nullptr;
+    }
+};
+
+// Work set: every device buffer an alignment pass and the reductions after it write, and the results they leave.  A
+// context owns KP_WORK_SLOTS of them and hands them to batches round-robin at kp_batch_align, so a stream of batches
+// allocates nothing after the first few and keeps what it learnt about buffer sizes (the caps live in the context).
+struct KpWork {
+    kp_batch *owner = nullptr;
+    KpKeyBits key_bits{16, 30};  // compact anchor keys of the most recent alignment pass
+    uint32_t anchor_cap = 0, task_cap = 0, hit_cap = 0;  // what the buffers of the most recent pass were sized for
+    uint64_t cand_cap = 0;
+    DevBuf<uint64_t> d_anchors_a, d_anchors_b;
+    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
+    DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
+    DevBuf<uint64_t> d_cand;        // candidates of the scan: [cand_cap] positions, then [cand_cap] u32 k-mers; d_cand_count[0] = how many
+    DevBuf<unsigned long long> d_cand_count;
+    DevBuf<uint32_t> d_seg;     // [2 * n_asm]
+    DevBuf<KpTask> d_tasks;
+    DevBuf<KpSwResult> d_results;
+    DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
+    // device-side hit tables (per-assembly regions of hit_cap rows)
+    DevBuf<kp_hit> d_hits_raw, d_hits;
+    DevBuf<uint32_t> d_hit_counts;  // [n_asm] raw, then [n_asm] final
+    DevBuf<uint64_t> d_keys;        // 3 per hit row
+    DevBuf<unsigned long long> d_cells;
+    // reduction: one run per typing group, created on first use
+    std::vector<std::unique_ptr<KpTypingRun>> runs;
+    // results
+    bool aligned = false, finalised = false;
+    std::vector<uint32_t> h_counts, h_hit_counts;
+    std::vector<KpTask> h_tasks[KP_N_CLASSES];
+    std::vector<int64_t> hit_off;
+    int64_t stats[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[4 + KP_N_CLASSES] = {};  // stage boundaries of the most recent alignment pass; the last one marks its end
+    bool have_events = false;
+    void release() {
+        d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
+        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_order.release();
+        d_hits_raw.release(); d_hits.release(); d_hit_counts.release(); d_keys.release(); d_cells.release();
+        for (auto &r : runs)
+            if (r) r->release();
+        runs.clear();
+        if (have_events)
+            for (auto &e : ev) (void)hipEventDestroy(e);
+        have_events = false;
+    }
+};
+
+#define KP_INPUT_POOL 6
+
 struct kp_ctx {
     int device = 0;
     int gs_bits = 18;              // bits of the gene/strand field of an anchor key this database can set
@@ -111,8 +190,14 @@ struct kp_ctx {
     hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
     hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
     hipStream_t aux = nullptr;     // forked off `post` for kernels that only fill a few CUs (wide-band proteins)
+    hipStream_t copy = nullptr;    // H2D copies of batch inputs (overlap with the passes of earlier batches)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string error;
+    KpOptions opt;
+    // learnt buffer sizes (0 = not yet sized: first use takes the option's value); they only grow
+    uint32_t anchor_cap = 0, hit_cap = 0;
+    uint32_t tasks_per_asm = 0;  // task_cap of a pass = n_asm * tasks_per_asm
+    double cand_frac = 0.0;      // cand_cap of a pass = total selected positions * cand_frac
     // resident database
     bool has_db = false;
     int32_t n_genes = 0;
@@ -134,51 +219,27 @@ struct kp_ctx {
     size_t sort_temp_bytes = 0;
     // typing tables (kp_db_load_typing / kp_db_load_typing_group): one set per database whose genes are in the index
     std::vector<std::unique_ptr<KpTypingGroup>> groups;
+    // per typing group: learnt sizes of the reduction buffers
+    struct RunCaps { int kept_cap = 0, piece_cap = 0, prot_cap = 0; };
+    std::vector<RunCaps> run_caps;
+    // work sets and recycled inputs
+    KpWork work[KP_WORK_SLOTS];
+    uint32_t next_slot = 0;
+    std::vector<KpInput *> free_inputs;
+    std::vector<kp_batch *> batches;  // live batches (a context destroyed first detaches them)
 };
 
 struct kp_batch {
     kp_ctx *ctx = nullptr;
     int32_t n_asm = 0;
-    bool owns_words = false;
-    uint32_t *d_words = nullptr;
-    DevBuf<int64_t> d_asm_word_off;
-    DevBuf<int32_t> d_ctg_start, d_ctg_len, d_asm_first_ctg, d_n_runs, d_asm_first_nrun;
-    std::vector<int32_t> h_asm_first_ctg, h_ctg_start;
+    KpInput *in = nullptr;       // device copy of the input (returned to the context's pool by kp_batch_destroy)
+    const uint32_t *d_words = nullptr;  // in->d_words.p, or the caller's device pointer (kp_batch_create_device)
     KpBatchView view{};
-    // work buffers
-    uint32_t anchor_cap = 0, task_cap = 0;
     int64_t max_asm_bases = 0;  // longest assembly of the batch (padded)
-    KpKeyBits key_bits{16, 30};  // compact anchor keys of the most recent alignment pass
-    DevBuf<uint64_t> d_anchors_a, d_anchors_b;
-    DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
-    DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
-    DevBuf<uint64_t> d_cand;        // candidates of the scan: [cand_cap] positions, then [cand_cap] u32 k-mers; d_cand_count[0] = how many
-    DevBuf<unsigned long long> d_cand_count;
-    uint64_t cand_cap = 0;
-    DevBuf<uint32_t> d_seg;     // [2 * n_asm]
-    DevBuf<KpTask> d_tasks;
-    DevBuf<KpSwResult> d_results;
-    DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
-    // device-side hit tables (per-assembly regions of hit_cap rows)
-    uint32_t hit_cap = 0;
-    DevBuf<kp_hit> d_hits_raw, d_hits, d_hits_packed;
-    DevBuf<uint32_t> d_hit_counts;  // [n_asm] raw, then [n_asm] final
-    DevBuf<uint64_t> d_keys;        // 3 per hit row
-    DevBuf<unsigned long long> d_cells;
-    DevBuf<int64_t> d_hit_off;
-    // reduction: one run per typing group, created on first use; `group` is the one score / reduce / typing calls address
-    std::vector<std::unique_ptr<KpTypingRun>> runs;
-    int32_t group = 0;
-    // results
-    bool aligned = false, finalised = false;
-    std::vector<uint32_t> h_counts, h_hit_counts;
-    std::vector<KpTask> h_tasks[KP_N_CLASSES];
-    std::vector<kp_hit> hits;
-    bool hits_fetched = false;
-    std::vector<int64_t> hit_off;
-    int64_t stats[5] = {0, 0, 0, 0, 0};
-    hipEvent_t ev[4 + KP_N_CLASSES] = {};  // stage boundaries of the most recent alignment pass; the last one marks its end
-    bool have_events = false;
+    KpWork *w = nullptr;        // the work set holding this batch's alignment results, while it still does
+    KpWork *last_w = nullptr;   // the work set of its most recent pass (for completion waits; may have a new owner)
+    kp_batch *after = nullptr;  // its words are another batch's device copy: passes wait for that batch's upload
+    int32_t group = 0;          // the typing group score / reduce / typing calls address
 };
 
 int kp_fail(kp_ctx *ctx, int code, const std::string &msg) {
@@ -206,6 +267,19 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     if (!v || !*v) return dflt;
     const long long x = std::atoll(v);
     return x > 0 ? (uint32_t)x : dflt;
+}
+
+// the environment is read here, once per context, and nowhere else
+void options_from_env(KpOptions &o) {
+    o.anchor_cap = env_u32("KAPTIVE_AMD_ANCHOR_CAP", o.anchor_cap);
+    o.tasks_per_asm = env_u32("KAPTIVE_AMD_TASKS_PER_ASM", o.tasks_per_asm);
+    o.hit_cap = env_u32("KAPTIVE_AMD_HIT_CAP", o.hit_cap);
+    o.kept_cap = env_u32("KAPTIVE_AMD_KEPT_CAP", o.kept_cap);
+    o.piece_cap = env_u32("KAPTIVE_AMD_PIECE_CAP", o.piece_cap);
+    o.prot_cap = env_u32("KAPTIVE_AMD_PROT_CAP", o.prot_cap);
+    o.scan_mode = (int)env_u32("KAPTIVE_AMD_SCAN_ABLATE", 0);
+    o.no_lds_filter = (int)env_u32("KAPTIVE_AMD_NO_LDS_FILTER", 0);
+    o.sw_blocks_per_cu = (int)env_u32("KAPTIVE_AMD_SW_BLOCKS_PER_CU", (uint32_t)o.sw_blocks_per_cu);
 }
 
 // BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
@@ -253,6 +327,27 @@ int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n, hipStream_t stre
     return KP_OK;
 }
 
+// ---- batch inputs ---------------------------------------------------------------------------------------------------------
+KpInput *acquire_input(kp_ctx *ctx) {
+    if (!ctx->free_inputs.empty()) {
+        KpInput *in = ctx->free_inputs.back();
+        ctx->free_inputs.pop_back();
+        return in;
+    }
+    KpInput *in = new (std::nothrow) KpInput();
+    if (in && hipEventCreateWithFlags(&in->ready, hipEventDisableTiming) != hipSuccess) { delete in; in = nullptr; }
+    return in;
+}
+
+void recycle_input(kp_ctx *ctx, KpInput *in) {
+    if (!in) return;
+    if (ctx && ctx->free_inputs.size() < KP_INPUT_POOL) { ctx->free_inputs.push_back(in); return; }
+    in->release();
+    delete in;
+}
+
+// Validates the tables, stages them in the input's pinned buffer and enqueues their H2D copies on the copy stream (the
+// caller's arrays may be freed as soon as this returns).
 int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_word_off, const int32_t *ctg_start,
                  const int32_t *ctg_len, const int32_t *asm_first_ctg, const int32_t *n_runs,
                  const int32_t *asm_first_nrun) {
@@ -271,36 +366,101 @@ int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_wor
                 return kp_fail(ctx, KP_EINVAL, "contig table violates the packed layout (kp_spec.h)");
         }
     }
+    KpInput &in = *b->in;
     const size_t n_ctg = (size_t)asm_first_ctg[n_asm], n_run = (size_t)asm_first_nrun[n_asm];
+    const size_t na1 = (size_t)n_asm + 1;
+    // staging layout: asm_word_off (8-byte entries first), then the int32 tables
+    const size_t bytes = na1 * 8 + (2 * n_ctg + 2 * na1 + 2 * n_run) * 4;
+    if (bytes > in.h_stage_bytes) {
+        if (in.h_stage) (void)hipHostFree(in.h_stage);
+        in.h_stage = nullptr; in.h_stage_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        KP_HIP_CHECK(ctx, hipHostMalloc((void **)&in.h_stage, want, hipHostMallocDefault));
+        in.h_stage_bytes = want;
+    }
+    uint8_t *p = in.h_stage;
+    auto stage = [&](auto &buf, const auto *src, size_t n) -> int {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(src)>>;
+        if (n) std::memcpy(p, src, n * sizeof(T));
+        const int rc = upload(ctx, buf, reinterpret_cast<const T *>(p), n, ctx->copy);
+        p += n * sizeof(T);
+        return rc;
+    };
     int rc;
-    if ((rc = upload(ctx, b->d_asm_word_off, asm_word_off, (size_t)n_asm + 1))) return rc;
-    if ((rc = upload(ctx, b->d_ctg_start, ctg_start, n_ctg))) return rc;
-    if ((rc = upload(ctx, b->d_ctg_len, ctg_len, n_ctg))) return rc;
-    if ((rc = upload(ctx, b->d_asm_first_ctg, asm_first_ctg, (size_t)n_asm + 1))) return rc;
-    if ((rc = upload(ctx, b->d_n_runs, n_runs, 2 * n_run))) return rc;
-    if ((rc = upload(ctx, b->d_asm_first_nrun, asm_first_nrun, (size_t)n_asm + 1))) return rc;
-    b->h_asm_first_ctg.assign(asm_first_ctg, asm_first_ctg + n_asm + 1);
-    b->h_ctg_start.assign(ctg_start, ctg_start + n_ctg);
+    if ((rc = stage(in.d_asm_word_off, asm_word_off, na1))) return rc;
+    if ((rc = stage(in.d_ctg_start, ctg_start, n_ctg))) return rc;
+    if ((rc = stage(in.d_ctg_len, ctg_len, n_ctg))) return rc;
+    if ((rc = stage(in.d_asm_first_ctg, asm_first_ctg, na1))) return rc;
+    if ((rc = stage(in.d_n_runs, n_runs, 2 * n_run))) return rc;
+    if ((rc = stage(in.d_asm_first_nrun, asm_first_nrun, na1))) return rc;
     b->view.words = b->d_words;
-    b->view.asm_word_off = b->d_asm_word_off.p;
-    b->view.ctg_start = b->d_ctg_start.p;
-    b->view.ctg_len = b->d_ctg_len.p;
-    b->view.asm_first_ctg = b->d_asm_first_ctg.p;
-    b->view.n_runs = b->d_n_runs.p;
-    b->view.asm_first_nrun = b->d_asm_first_nrun.p;
+    b->view.asm_word_off = in.d_asm_word_off.p;
+    b->view.ctg_start = in.d_ctg_start.p;
+    b->view.ctg_len = in.d_ctg_len.p;
+    b->view.asm_first_ctg = in.d_asm_first_ctg.p;
+    b->view.n_runs = in.d_n_runs.p;
+    b->view.asm_first_nrun = in.d_asm_first_nrun.p;
     b->view.n_asm = n_asm;
     b->view.total_words = asm_word_off[n_asm];
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // host tables may be freed by the caller after return
+    KP_HIP_CHECK(ctx, hipEventRecord(in.ready, ctx->copy));
     return KP_OK;
 }
 
-int batch_new(kp_ctx *ctx, int32_t n_asm, const int64_t *asm_word_off, kp_batch **out) {
+void detach_batch(kp_ctx *ctx, kp_batch *b) {
+    auto &v = ctx->batches;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+}
+
+// everything this batch enqueued has finished (its pass, its hit finalisation, its reductions)
+void quiesce_batch(kp_batch *b) {
+    KpWork *w = b->last_w;
+    if (!w) return;
+    if (w->have_events) (void)hipEventSynchronize(w->ev[3 + KP_N_CLASSES]);  // end of the slot's most recent pass
+    if (b->ctx) (void)hipStreamSynchronize(b->ctx->post);
+    for (auto &r : w->runs)
+        if (r && r->stream) { (void)hipStreamSynchronize(r->stream); if (r->aux) (void)hipStreamSynchronize(r->aux); }
+}
+
+int batch_make(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, bool words_on_device, const int64_t *asm_word_off,
+               const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg, const int32_t *n_runs,
+               const int32_t *asm_first_nrun, kp_batch **out) {
     if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
     if (!out || n_asm < 0 || !asm_word_off) return kp_fail(ctx, KP_EINVAL, "bad batch arguments");
-    if (asm_word_off[0] != 0) return kp_fail(ctx, KP_EINVAL, "asm_word_off[0] must be 0");
     *out = nullptr;
+    if (asm_word_off[0] != 0) return kp_fail(ctx, KP_EINVAL, "asm_word_off[0] must be 0");
+    if (!asm_first_ctg || !asm_first_nrun) return kp_fail(ctx, KP_EINVAL, "null offset table");
+    if (asm_word_off[n_asm] > 0 && !words) return kp_fail(ctx, KP_EINVAL, "null words");
+    if (words_on_device && ((uintptr_t)words & 15u) != 0) return kp_fail(ctx, KP_EINVAL, "device words must be 16-byte aligned");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    kp_batch *b = new (std::nothrow) kp_batch();
+    if (!b) return kp_fail(ctx, KP_ENOMEM, "out of host memory");
+    b->ctx = ctx; b->n_asm = n_asm;
+    b->in = acquire_input(ctx);
+    if (!b->in) { delete b; return kp_fail(ctx, KP_ENOMEM, "out of memory (batch input)"); }
+    ctx->batches.push_back(b);
+    if (words_on_device) {
+        b->d_words = words;
+    } else {
+        const size_t nw = (size_t)asm_word_off[n_asm];
+        hipError_t e = b->in->d_words.reserve(std::max<size_t>(nw, 4));
+        if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_ENOMEM, std::string("hipMalloc(words): ") + hipGetErrorString(e)); }
+        if (nw) e = hipMemcpyAsync(b->in->d_words.p, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy);
+        if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_EHIP, std::string("H2D words: ") + hipGetErrorString(e)); }
+        b->d_words = b->in->d_words.p;
+    }
+    const int rc = batch_tables(ctx, b, n_asm, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun);
+    if (rc) { const std::string msg = ctx->error; kp_batch_destroy(b); ctx->error = msg; return rc; }
+    *out = b;
     return KP_OK;
 }
+
+KpWork *work_of(kp_ctx *ctx, kp_batch *b) {  // null: never aligned, or its results have been displaced
+    (void)ctx;
+    return (b->w && b->w->owner == b) ? b->w : nullptr;
+}
+
+const char *const NO_RESULTS = "this batch has no resident alignment results (not aligned yet, or displaced: a context keeps "
+                               "the results of its KP_WORK_SLOTS most recently aligned batches)";
 
 }  // namespace
 
@@ -317,7 +477,9 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     kp_ctx *ctx = new (std::nothrow) kp_ctx();
     if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
     ctx->device = device_id;
+    options_from_env(ctx->opt);
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking)) != hipSuccess ||
         (e = create_priority_stream(&ctx->post)) != hipSuccess || (e = create_priority_stream(&ctx->aux)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) {
@@ -338,9 +500,15 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
 void kp_ctx_destroy(kp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->post) (void)hipStreamSynchronize(ctx->post);
-    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+    (void)hipDeviceSynchronize();
+    for (kp_batch *b : ctx->batches) {  // batches that outlive their context keep nothing on the device
+        if (b->in) { b->in->release(); delete b->in; b->in = nullptr; }
+        b->ctx = nullptr; b->w = nullptr; b->last_w = nullptr;
+    }
+    ctx->batches.clear();
+    for (KpInput *in : ctx->free_inputs) { in->release(); delete in; }
+    ctx->free_inputs.clear();
+    for (auto &w : ctx->work) w.release();
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
@@ -349,6 +517,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->groups.clear();
     if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->post) (void)hipStreamDestroy(ctx->post);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -366,6 +535,37 @@ const char *kp_last_error(const kp_ctx *ctx) {
 
 void *kp_ctx_stream(kp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
+    if (!name || value < 0) return kp_fail(ctx, KP_EINVAL, "bad option");
+    const std::string n(name);
+    KpOptions &o = ctx->opt;
+    // buffer-size options also reset what the context has learnt, so the next pass starts from the new value
+    if (n == "anchor_cap") { o.anchor_cap = (uint32_t)std::max<int64_t>(value, 1); ctx->anchor_cap = 0; }
+    else if (n == "tasks_per_asm") { o.tasks_per_asm = (uint32_t)std::max<int64_t>(value, 1); ctx->tasks_per_asm = 0; }
+    else if (n == "hit_cap") { o.hit_cap = (uint32_t)std::max<int64_t>(value, 1); ctx->hit_cap = 0; }
+    else if (n == "kept_cap") { o.kept_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.kept_cap = 0; }
+    else if (n == "piece_cap") { o.piece_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.piece_cap = 0; }
+    else if (n == "prot_cap") { o.prot_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.prot_cap = 0; }
+    else if (n == "scan_mode") o.scan_mode = (int)value;
+    else if (n == "no_lds_filter") o.no_lds_filter = value != 0;
+    else if (n == "sw_blocks_per_cu") o.sw_blocks_per_cu = (int)std::max<int64_t>(value, 1);
+    else return kp_fail(ctx, KP_EINVAL, "unknown option: " + n);
+    return KP_OK;
+}
+
+int kp_host_alloc(size_t bytes, void **out) {
+    if (!out) return kp_fail(nullptr, KP_EINVAL, "out is null");
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) return kp_fail(nullptr, KP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return KP_OK;
+}
+
+void kp_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, int32_t n_genes) {
     if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
     if (!gene_off || n_genes < 0 || (n_genes > 0 && !gene_codes)) return kp_fail(ctx, KP_EINVAL, "bad database arguments");
@@ -375,6 +575,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     for (auto &g : ctx->groups)
         if (g) g->release();
     ctx->groups.clear();  // typing tables index the genes that are being replaced
+    ctx->run_caps.clear();
     ctx->gene_len.resize((size_t)n_genes);
     std::vector<int32_t> nib_off(2 * (size_t)n_genes);
     size_t n_words = 0;
@@ -479,239 +680,274 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
 
 int64_t kp_db_n_postings(const kp_ctx *ctx) { return ctx && ctx->has_db ? ctx->n_postings : 0; }
 
+int kp_batch_create_async(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
+                          const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
+                          const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out) {
+    return batch_make(ctx, n_asm, words, false, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun, out);
+}
+
 int kp_batch_create(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, const int64_t *asm_word_off,
                     const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
                     const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out) {
-    int rc = batch_new(ctx, n_asm, asm_word_off, out);
+    const int rc = batch_make(ctx, n_asm, words, false, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun, out);
     if (rc) return rc;
-    if (!asm_first_ctg || !asm_first_nrun) return kp_fail(ctx, KP_EINVAL, "null offset table");
-    if (asm_word_off[n_asm] > 0 && !words) return kp_fail(ctx, KP_EINVAL, "null words");
-    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    kp_batch *b = new (std::nothrow) kp_batch();
-    if (!b) return kp_fail(ctx, KP_ENOMEM, "out of host memory");
-    b->ctx = ctx; b->n_asm = n_asm; b->owns_words = true;
-    const size_t nw = (size_t)asm_word_off[n_asm];
-    hipError_t e = hipMalloc((void **)&b->d_words, std::max<size_t>(nw, 4) * sizeof(uint32_t));
-    if (e != hipSuccess) { delete b; return kp_fail(ctx, KP_ENOMEM, std::string("hipMalloc(words): ") + hipGetErrorString(e)); }
-    if (nw) e = hipMemcpyAsync(b->d_words, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_EHIP, std::string("H2D words: ") + hipGetErrorString(e)); }
-    rc = batch_tables(ctx, b, n_asm, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun);
-    if (rc) { kp_batch_destroy(b); return rc; }
-    *out = b;
+    // the caller may free `words` on return
+    if (hipStreamSynchronize(ctx->copy) != hipSuccess) {
+        kp_batch_destroy(*out);
+        *out = nullptr;
+        return kp_fail(ctx, KP_EHIP, "H2D copy of the batch failed");
+    }
     return KP_OK;
 }
 
 int kp_batch_create_device(kp_ctx *ctx, int32_t n_asm, const uint32_t *d_words, const int64_t *asm_word_off,
                            const int32_t *ctg_start, const int32_t *ctg_len, const int32_t *asm_first_ctg,
                            const int32_t *n_runs, const int32_t *asm_first_nrun, kp_batch **out) {
-    int rc = batch_new(ctx, n_asm, asm_word_off, out);
-    if (rc) return rc;
-    if (!asm_first_ctg || !asm_first_nrun) return kp_fail(ctx, KP_EINVAL, "null offset table");
-    if (asm_word_off[n_asm] > 0 && !d_words) return kp_fail(ctx, KP_EINVAL, "null words");
-    if (((uintptr_t)d_words & 15u) != 0) return kp_fail(ctx, KP_EINVAL, "device words must be 16-byte aligned");
-    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    kp_batch *b = new (std::nothrow) kp_batch();
-    if (!b) return kp_fail(ctx, KP_ENOMEM, "out of host memory");
-    b->ctx = ctx; b->n_asm = n_asm; b->owns_words = false;
-    b->d_words = const_cast<uint32_t *>(d_words);
-    rc = batch_tables(ctx, b, n_asm, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun);
-    if (rc) { kp_batch_destroy(b); return rc; }
-    *out = b;
+    return batch_make(ctx, n_asm, d_words, true, asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun, out);
+}
+
+int kp_batch_depends_on(kp_ctx *ctx, kp_batch *b, kp_batch *other) {
+    if (!ctx || !b || b->ctx != ctx || !other || !other->ctx) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    if (other->ctx->device != ctx->device) return kp_fail(ctx, KP_EINVAL, "batches live on different devices");
+    b->after = other;
     return KP_OK;
 }
+
+int kp_batch_upload_wait(kp_ctx *ctx, kp_batch *b) {
+    if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KP_HIP_CHECK(ctx, hipEventSynchronize(b->in->ready));
+    return KP_OK;
+}
+
+const void *kp_batch_device_words(const kp_batch *b) { return b ? (const void *)b->d_words : nullptr; }
 
 void kp_batch_destroy(kp_batch *b) {
     if (!b) return;
-    if (b->ctx) {
-        (void)hipSetDevice(b->ctx->device);
-        (void)hipStreamSynchronize(b->ctx->stream);
-        (void)hipStreamSynchronize(b->ctx->post);
+    kp_ctx *ctx = b->ctx;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (b->in && b->in->ready) (void)hipEventSynchronize(b->in->ready);  // an upload still in flight
+        quiesce_batch(b);
+        if (b->w && b->w->owner == b) { b->w->owner = nullptr; b->w->aligned = false; b->w->finalised = false; }
+        recycle_input(ctx, b->in);
+        detach_batch(ctx, b);
     }
-    if (b->owns_words && b->d_words) (void)hipFree(b->d_words);
-    if (b->have_events)
-        for (auto &e : b->ev) (void)hipEventDestroy(e);
-    b->d_asm_word_off.release(); b->d_ctg_start.release(); b->d_ctg_len.release(); b->d_asm_first_ctg.release();
-    b->d_n_runs.release(); b->d_asm_first_nrun.release(); b->d_anchors_a.release(); b->d_anchors_b.release();
-    b->d_counts.release(); b->d_sub_counts.release(); b->d_cand.release(); b->d_cand_count.release(); b->d_seg.release(); b->d_tasks.release();
-    b->d_results.release(); b->d_task_order.release();
-    b->d_hits_raw.release(); b->d_hits.release(); b->d_hits_packed.release(); b->d_hit_counts.release();
-    b->d_keys.release(); b->d_cells.release(); b->d_hit_off.release();
-    for (auto &r : b->runs)
-        if (r) r->release();
     delete b;
 }
 
-static int enqueue_align(kp_ctx *ctx, kp_batch *b) {
+static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     const size_t n_asm = (size_t)b->n_asm;
-    if (!b->have_events) {
-        for (auto &e : b->ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
-        b->have_events = true;
+    if (!w->have_events) {
+        for (auto &e : w->ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
+        w->have_events = true;
     }
-    hipEvent_t *ev = b->ev;
-    if ((uint64_t)n_asm * b->anchor_cap > 0xFFFFFFF0ull)
+    hipEvent_t *ev = w->ev;
+    if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
-    KP_HIP_CHECK(ctx, b->d_anchors_a.reserve(n_asm * b->anchor_cap));
-    KP_HIP_CHECK(ctx, b->d_anchors_b.reserve(n_asm * b->anchor_cap));
-    KP_HIP_CHECK(ctx, b->d_counts.reserve(2 * n_asm + KP_N_CLASSES));
-    KP_HIP_CHECK(ctx, b->d_sub_counts.reserve(n_asm * KP_ANCHOR_SUBS));
-    KP_HIP_CHECK(ctx, b->d_seg.reserve(2 * n_asm));
-    KP_HIP_CHECK(ctx, b->d_tasks.reserve(KP_N_CLASSES * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, b->d_results.reserve(KP_N_CLASSES * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, b->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)b->task_cap));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
-    if (b->cand_cap == 0)  // a quarter of the positions are selected; room for 3 % of those to pass the filter
-        b->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)(b->view.total_words * 4 * 0.03));
-    KP_HIP_CHECK(ctx, b->d_cand.reserve(b->cand_cap + (b->cand_cap + 1) / 2));  // u64 positions, then u32 k-mers
-    KP_HIP_CHECK(ctx, b->d_cand_count.reserve(1));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
-    uint32_t *d_task_count = b->d_counts.p + n_asm;
-    const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
+    KP_HIP_CHECK(ctx, w->d_anchors_a.reserve(n_asm * w->anchor_cap));
+    KP_HIP_CHECK(ctx, w->d_anchors_b.reserve(n_asm * w->anchor_cap));
+    KP_HIP_CHECK(ctx, w->d_counts.reserve(2 * n_asm + KP_N_CLASSES));
+    KP_HIP_CHECK(ctx, w->d_sub_counts.reserve(n_asm * KP_ANCHOR_SUBS));
+    KP_HIP_CHECK(ctx, w->d_seg.reserve(2 * n_asm));
+    KP_HIP_CHECK(ctx, w->d_tasks.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap + (w->cand_cap + 1) / 2));  // u64 positions, then u32 k-mers
+    KP_HIP_CHECK(ctx, w->d_cand_count.reserve(1));
+    KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->in->ready, 0));  // the batch's H2D copies
+    if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->after->in->ready, 0));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
+    uint32_t *d_task_count = w->d_counts.p + n_asm;
+    const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
     auto bits_for = [](uint64_t max_value) { uint32_t n = 1; while (n < 63 && (max_value >> n)) ++n; return n; };
-    b->key_bits.qb = std::min<uint32_t>(16, bits_for((uint64_t)std::max(ctx->max_gene_len, 1)));
-    b->key_bits.db = std::min<uint32_t>(30, bits_for((uint64_t)b->max_asm_bases + KP_DIAG_BIAS));
-    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-    kp_launch_scan(b->view, ctx->index, b->d_cand.p, b->d_cand_count.p, b->cand_cap, b->d_anchors_a.p, b->d_sub_counts.p,
-                   sub_cap, b->key_bits, ctx->stream, ev ? ev[1] : nullptr);
-    kp_launch_anchor_compact(b->view, b->d_anchors_a.p, b->d_sub_counts.p, sub_cap, b->d_anchors_b.p, b->d_counts.p,
-                             b->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
-    int rc = kp_sort_anchors(ctx, b->d_anchors_b.p, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->n_asm,
-                             &ctx->sort_temp, &ctx->sort_temp_bytes, b->d_seg.p, b->d_seg.p + n_asm,
-                             (int)(b->key_bits.qb + b->key_bits.db) + ctx->gs_bits,
+    w->key_bits.qb = std::min<uint32_t>(16, bits_for((uint64_t)std::max(ctx->max_gene_len, 1)));
+    w->key_bits.db = std::min<uint32_t>(30, bits_for((uint64_t)b->max_asm_bases + KP_DIAG_BIAS));
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+    kp_launch_scan(b->view, ctx->index, w->d_cand.p, w->d_cand_count.p, w->cand_cap, w->d_anchors_a.p, w->d_sub_counts.p,
+                   sub_cap, w->key_bits, ctx->opt.scan_mode, ctx->opt.no_lds_filter != 0, ctx->stream, ev[1]);
+    kp_launch_anchor_compact(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_counts.p,
+                             w->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
+    int rc = kp_sort_anchors(ctx, w->d_anchors_b.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, b->n_asm,
+                             &ctx->sort_temp, &ctx->sort_temp_bytes, w->d_seg.p, w->d_seg.p + n_asm,
+                             (int)(w->key_bits.qb + w->key_bits.db) + ctx->gs_bits,
                              ctx->stream);
     if (rc) return rc;
-    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
-    kp_launch_chain(b->view, b->d_anchors_a.p, b->d_counts.p, b->anchor_cap, b->key_bits, b->d_tasks.p,
-                    d_task_count, b->task_cap, ctx->stream);
-    kp_launch_task_order(ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p, b->d_task_order.p + ORDER_HEAD,
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+    kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
+                    d_task_count, w->task_cap, ctx->stream);
+    kp_launch_task_order(ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
                          ctx->stream);
-    if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
     // all four band classes in one launch (kp_sw.hip); the per-class event slots stay in the layout: the whole launch is
     // booked on the first one, the others read 0
-    kp_launch_sw(b->view, ctx->genes, b->d_tasks.p, d_task_count, b->task_cap, b->d_task_order.p + ORDER_HEAD,
-                 b->d_results.p, ctx->stream);
-    for (int c = 0; c < KP_N_CLASSES; ++c)
-        if (ev) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
+    kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p + ORDER_HEAD,
+                 w->d_results.p, ctx->opt.sw_blocks_per_cu, ctx->stream);
+    for (int c = 0; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
+}
+
+// sizes of the pass's buffers from what the context has learnt so far (first use: the options)
+static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
+    if (ctx->anchor_cap == 0) ctx->anchor_cap = ctx->opt.anchor_cap;
+    ctx->anchor_cap = std::max<uint32_t>((ctx->anchor_cap + KP_ANCHOR_SUBS - 1) / KP_ANCHOR_SUBS, 16u) * KP_ANCHOR_SUBS;
+    if (ctx->tasks_per_asm == 0) ctx->tasks_per_asm = ctx->opt.tasks_per_asm;
+    if (ctx->cand_frac <= 0.0) ctx->cand_frac = 0.03;  // a quarter of the positions are selected; 3 % of those pass the filter
+    if (ctx->hit_cap == 0) ctx->hit_cap = ctx->opt.hit_cap;
+    w->anchor_cap = ctx->anchor_cap;
+    w->task_cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max(b->n_asm, 1) * ctx->tasks_per_asm, 1u << 28);
+    w->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)((double)b->view.total_words * 4.0 * ctx->cand_frac));
+    w->hit_cap = ctx->hit_cap;
 }
 
 int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
     if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
     if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "no database loaded");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (b->anchor_cap == 0) b->anchor_cap = env_u32("KAPTIVE_AMD_ANCHOR_CAP", 1u << 17);
-    b->anchor_cap = std::max<uint32_t>((b->anchor_cap + KP_ANCHOR_SUBS - 1) / KP_ANCHOR_SUBS, 16u) * KP_ANCHOR_SUBS;
-    if (b->task_cap == 0) {
-        const uint64_t want = (uint64_t)std::max(b->n_asm, 1) * env_u32("KAPTIVE_AMD_TASKS_PER_ASM", 4096);
-        b->task_cap = (uint32_t)std::min<uint64_t>(want, 1u << 28);
+    KpWork *w = work_of(ctx, b);
+    if (!w) {  // next work set, round-robin; whoever held it loses its results
+        w = &ctx->work[ctx->next_slot++ % KP_WORK_SLOTS];
+        if (w->owner) {
+            // its reductions may still be reading the hit tables this pass's finalisation will rewrite
+            KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+            for (auto &r : w->runs)
+                if (r && r->stream) { KP_HIP_CHECK(ctx, hipStreamSynchronize(r->stream)); if (r->aux) KP_HIP_CHECK(ctx, hipStreamSynchronize(r->aux)); }
+            w->owner->w = nullptr;
+        }
+        w->owner = b;
+        b->w = w; b->last_w = w;
     }
-    b->aligned = false; b->finalised = false; b->hits_fetched = false;
-    for (auto &r : b->runs)
+    size_work(ctx, b, w);
+    w->aligned = false; w->finalised = false;
+    for (auto &v : w->h_tasks) v.clear();
+    for (auto &r : w->runs)
         if (r) { r->split = false; r->scored = false; r->reduced = false; r->sums_valid = false; }
-    b->stats[4] = 0;
-    int rc = enqueue_align(ctx, b);
+    w->stats[4] = 0;
+    int rc = enqueue_align(ctx, b, w);
     if (rc) return rc;
-    b->aligned = true;
+    w->aligned = true;
     return KP_OK;
 }
 
 // hit-table finalisation on the device: compaction of the band-task results into per-assembly lists, emission order,
 // duplicates, mapq.  Grows hit_cap and repeats if an assembly produced more hits than its region holds.
-static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b) {
+static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     const size_t n_asm = (size_t)b->n_asm;
-    if (b->hit_cap == 0) b->hit_cap = env_u32("KAPTIVE_AMD_HIT_CAP", 4096);
     for (int attempt = 0;; ++attempt) {
-        KP_HIP_CHECK(ctx, b->d_hits_raw.reserve(n_asm * b->hit_cap));
-        KP_HIP_CHECK(ctx, b->d_hits.reserve(n_asm * b->hit_cap));
-        KP_HIP_CHECK(ctx, b->d_keys.reserve(n_asm * b->hit_cap * 3));
-        KP_HIP_CHECK(ctx, b->d_hit_counts.reserve(2 * n_asm));
-        KP_HIP_CHECK(ctx, b->d_cells.reserve(1));
-        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->post));
-        KP_HIP_CHECK(ctx, hipMemsetAsync(b->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
-        kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, b->d_tasks.p, b->d_results.p, b->d_counts.p + n_asm,
-                               b->task_cap, b->d_hits_raw.p, b->d_hit_counts.p, b->hit_cap, b->d_keys.p, b->d_hits.p,
-                               b->d_hit_counts.p + n_asm, b->d_cells.p, ctx->post);
+        KP_HIP_CHECK(ctx, w->d_hits_raw.reserve(n_asm * w->hit_cap));
+        KP_HIP_CHECK(ctx, w->d_hits.reserve(n_asm * w->hit_cap));
+        KP_HIP_CHECK(ctx, w->d_keys.reserve(n_asm * w->hit_cap * 3));
+        KP_HIP_CHECK(ctx, w->d_hit_counts.reserve(2 * n_asm));
+        KP_HIP_CHECK(ctx, w->d_cells.reserve(1));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->post));
+        KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
+        kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, w->d_tasks.p, w->d_results.p, w->d_counts.p + n_asm,
+                               w->task_cap, w->d_hits_raw.p, w->d_hit_counts.p, w->hit_cap, w->d_keys.p, w->d_hits.p,
+                               w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->post);
         KP_HIP_CHECK(ctx, hipGetLastError());
-        b->h_hit_counts.resize(2 * n_asm);
+        w->h_hit_counts.resize(2 * n_asm);
         unsigned long long cells = 0;
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_hit_counts.data(), b->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t),
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_hit_counts.data(), w->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, b->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, w->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         uint32_t max_raw = 0;
-        for (size_t a = 0; a < n_asm; ++a) max_raw = std::max(max_raw, b->h_hit_counts[a]);
-        if (max_raw <= b->hit_cap) { b->stats[2] = (int64_t)cells; break; }
+        for (size_t a = 0; a < n_asm; ++a) max_raw = std::max(max_raw, w->h_hit_counts[a]);
+        if (max_raw <= w->hit_cap) { w->stats[2] = (int64_t)cells; break; }
         if (attempt >= 2) return kp_fail(ctx, KP_EOVERFLOW, "hit buffers overflowed repeatedly");
-        b->hit_cap = (max_raw + 255u) & ~255u;
-        b->stats[4] += 1;
+        w->hit_cap = (max_raw + max_raw / 4 + 255u) & ~255u;  // a quarter of headroom: later batches differ a little
+        ctx->hit_cap = std::max(ctx->hit_cap, w->hit_cap);
+        w->stats[4] += 1;
     }
-    b->hit_off.assign(n_asm + 1, 0);
-    for (size_t a = 0; a < n_asm; ++a) b->hit_off[a + 1] = b->hit_off[a] + (int64_t)b->h_hit_counts[n_asm + a];
+    w->hit_off.assign(n_asm + 1, 0);
+    for (size_t a = 0; a < n_asm; ++a) w->hit_off[a + 1] = w->hit_off[a] + (int64_t)w->h_hit_counts[n_asm + a];
     return KP_OK;
 }
 
 int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     if (!ctx || !b || b->ctx != ctx) return kp_fail(ctx, KP_EINVAL, "bad context/batch");
-    if (!b->aligned) return kp_fail(ctx, KP_ESTATE, "kp_batch_align has not been called");
-    if (b->finalised) return KP_OK;
+    KpWork *w = work_of(ctx, b);
+    if (!w || !w->aligned) return kp_fail(ctx, KP_ESTATE, w ? "kp_batch_align has not been called" : NO_RESULTS);
+    if (w->finalised) return KP_OK;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
     for (int attempt = 0;; ++attempt) {
         // the post stream picks up where this batch's alignment pass ends; later passes on ctx->stream are not waited for
-        KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->post, b->ev[3 + KP_N_CLASSES], 0));
-        b->h_counts.resize(2 * n_asm + KP_N_CLASSES);
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(b->h_counts.data(), b->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
+        KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->post, w->ev[3 + KP_N_CLASSES], 0));
+        w->h_counts.resize(2 * n_asm + KP_N_CLASSES);
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->post));
         unsigned long long n_cand = 0;
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&n_cand, b->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&n_cand, w->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         uint32_t max_slice = 0, max_task = 0;
-        for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, b->h_counts[n_asm + KP_N_CLASSES + a]);
-        for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, b->h_counts[n_asm + c]);
-        const uint32_t sub_cap = b->anchor_cap / KP_ANCHOR_SUBS;
-        if (max_slice <= sub_cap && max_task <= b->task_cap && n_cand <= b->cand_cap) break;
+        for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
+        for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);
+        const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
+        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap) break;
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
-        // a region overflowed: counts kept counting, so they say how much room a clean rerun needs
-        if (n_cand > b->cand_cap) b->cand_cap = n_cand + n_cand / 8;
-        if (max_slice > sub_cap) b->anchor_cap = ((max_slice + 15u) & ~15u) * KP_ANCHOR_SUBS;
-        if (max_task > b->task_cap) b->task_cap = (max_task + 1023u) & ~1023u;
-        b->stats[4] += 1;
-        int rc = enqueue_align(ctx, b);
+        // a region overflowed: counts kept counting, so they say how much room a clean rerun needs.  The context
+        // remembers it (with some headroom, later batches differ a little) for every later pass.
+        if (n_cand > w->cand_cap) {
+            w->cand_cap = n_cand + n_cand / 8;
+            ctx->cand_frac = std::max(ctx->cand_frac, (double)w->cand_cap / ((double)b->view.total_words * 4.0) * 1.0001);
+        }
+        if (max_slice > sub_cap) {
+            w->anchor_cap = ((max_slice + max_slice / 4 + 15u) & ~15u) * KP_ANCHOR_SUBS;
+            ctx->anchor_cap = std::max(ctx->anchor_cap, w->anchor_cap);
+        }
+        if (max_task > w->task_cap) {
+            w->task_cap = (max_task + max_task / 8 + 1023u) & ~1023u;
+            ctx->tasks_per_asm = std::max<uint32_t>(ctx->tasks_per_asm, (uint32_t)((w->task_cap + n_asm - 1) / std::max<size_t>(n_asm, 1)));
+        }
+        w->stats[4] += 1;
+        int rc = enqueue_align(ctx, b, w);
         if (rc) return rc;
     }
     int64_t n_anchor = 0, n_task = 0;
-    for (size_t a = 0; a < n_asm; ++a) n_anchor += b->h_counts[a];
-    for (int c = 0; c < KP_N_CLASSES; ++c) n_task += b->h_counts[n_asm + c];
-    for (auto &v : b->h_tasks) v.clear();
-    int rc = finalise_hits_on_device(ctx, b);
+    for (size_t a = 0; a < n_asm; ++a) n_anchor += w->h_counts[a];
+    for (int c = 0; c < KP_N_CLASSES; ++c) n_task += w->h_counts[n_asm + c];
+    for (auto &v : w->h_tasks) v.clear();
+    int rc = finalise_hits_on_device(ctx, b, w);
     if (rc) return rc;
-    b->stats[0] = n_anchor; b->stats[1] = n_task; b->stats[3] = b->hit_off[n_asm];
-    b->hits_fetched = false;
-    b->finalised = true;
+    w->stats[0] = n_anchor; w->stats[1] = n_task; w->stats[3] = w->hit_off[n_asm];
+    w->finalised = true;
     return KP_OK;
 }
 
+// the batch's work set with finalised hit tables, or null after recording the error
+static KpWork *finalised_work(kp_ctx *ctx, kp_batch *b) {
+    KpWork *w = work_of(ctx, b);
+    if (!w) { kp_fail(ctx, KP_ESTATE, NO_RESULTS); return nullptr; }
+    if (!w->finalised) { kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed"); return nullptr; }
+    return w;
+}
+
 int kp_batch_hit_offsets(kp_ctx *ctx, kp_batch *b, int64_t *hit_off) {
-    if (!ctx || !b || !hit_off) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
-    std::memcpy(hit_off, b->hit_off.data(), b->hit_off.size() * sizeof(int64_t));
+    if (!ctx || !b || b->ctx != ctx || !hit_off) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    std::memcpy(hit_off, w->hit_off.data(), w->hit_off.size() * sizeof(int64_t));
     return KP_OK;
 }
 
 int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
-    if (!ctx || !b || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    if (!ctx || !b || b->ctx != ctx || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
     const size_t n_asm = (size_t)b->n_asm;
-    const int64_t total = b->hit_off[n_asm];
+    const int64_t total = w->hit_off[n_asm];
     if (cap < total) return kp_fail(ctx, KP_EINVAL, "hit buffer too small");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     for (size_t a = 0; a < n_asm; ++a) {  // regions are contiguous per assembly; copy each used prefix
-        const int64_t n = b->hit_off[a + 1] - b->hit_off[a];
+        const int64_t n = w->hit_off[a + 1] - w->hit_off[a];
         if (n > 0)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(out + b->hit_off[a], b->d_hits.p + a * (size_t)b->hit_cap,
+            KP_HIP_CHECK(ctx, hipMemcpyAsync(out + w->hit_off[a], w->d_hits.p + a * (size_t)w->hit_cap,
                                              (size_t)n * sizeof(kp_hit), hipMemcpyDeviceToHost, ctx->post));
     }
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
@@ -719,51 +955,55 @@ int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
 }
 
 int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
-    if (!ctx || !b || !stats5) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
-    std::memcpy(stats5, b->stats, sizeof b->stats);
+    if (!ctx || !b || b->ctx != ctx || !stats5) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    std::memcpy(stats5, w->stats, sizeof w->stats);
     return KP_OK;
 }
 
 int kp_batch_profile(kp_ctx *ctx, kp_batch *b, float *ms7, int64_t *bytes_scanned) {
     if (!ctx || !b || b->ctx != ctx || !ms7) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised || !b->have_events) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     for (int i = 0; i < 3 + KP_N_CLASSES; ++i)
-        if (hipEventElapsedTime(&ms7[i], b->ev[i], b->ev[i + 1]) != hipSuccess)
+        if (hipEventElapsedTime(&ms7[i], w->ev[i], w->ev[i + 1]) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "event timing failed");
     if (bytes_scanned) *bytes_scanned = 4 * b->view.total_words;
     return KP_OK;
 }
 
 int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int64_t cap) {
-    if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
-    const int64_t n = b->h_counts[(size_t)a];
+    if (!ctx || !b || b->ctx != ctx || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    const int64_t n = w->h_counts[(size_t)a];
     const int64_t m = std::min(n, cap);
     if (out && m > 0) {
-        if (hipMemcpy(out, b->d_anchors_a.p + (size_t)a * b->anchor_cap, (size_t)m * sizeof(uint64_t),
+        if (hipMemcpy(out, w->d_anchors_a.p + (size_t)a * w->anchor_cap, (size_t)m * sizeof(uint64_t),
                       hipMemcpyDeviceToHost) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "D2H anchors failed");
-        for (int64_t i = 0; i < m; ++i) out[i] = kp_key_unpack(out[i], b->key_bits);  // callers see the spec's layout
+        for (int64_t i = 0; i < m; ++i) out[i] = kp_key_unpack(out[i], w->key_bits);  // callers see the spec's layout
     }
     return n;
 }
 
 int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
-    if (!ctx || !b || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    if (!b->finalised) return kp_fail(ctx, KP_ESTATE, "kp_batch_wait has not completed");
+    if (!ctx || !b || b->ctx != ctx || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
     for (int c = 0; c < KP_N_CLASSES; ++c) {  // fetched on first use: only the stage tests look at tasks
-        const size_t nt = b->h_counts[(size_t)b->n_asm + c];
-        if (b->h_tasks[c].size() == nt) continue;
-        b->h_tasks[c].resize(nt);
-        if (nt && hipMemcpy(b->h_tasks[c].data(), b->d_tasks.p + (size_t)c * b->task_cap, nt * sizeof(KpTask),
+        const size_t nt = w->h_counts[(size_t)b->n_asm + c];
+        if (w->h_tasks[c].size() == nt) continue;
+        w->h_tasks[c].resize(nt);
+        if (nt && hipMemcpy(w->h_tasks[c].data(), w->d_tasks.p + (size_t)c * w->task_cap, nt * sizeof(KpTask),
                             hipMemcpyDeviceToHost) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "D2H tasks failed");
     }
     int64_t n = 0;
     for (int c = 0; c < KP_N_CLASSES; ++c)
-        for (const KpTask &t : b->h_tasks[c]) {
+        for (const KpTask &t : w->h_tasks[c]) {
             if (t.asm_id != a) continue;
             if (out7 && n < cap) {
                 int32_t *o = out7 + 7 * n;
@@ -799,8 +1039,12 @@ int kp_db_load_typing_group(kp_ctx *ctx, int32_t group, int32_t gene_lo, int32_t
         max_len = std::max(max_len, t->prot_len[g]);
     }
     for (size_t l = 0; l < L; ++l)
+    {
         if (t->locus_gene_off[l] < 0 || t->locus_gene_len[l] < 0 || (size_t)t->locus_gene_off[l] + (size_t)t->locus_gene_len[l] > G)
             return kp_fail(ctx, KP_EINVAL, "locus gene range out of bounds");
+        if (t->locus_gene_len[l] > KP_MAX_LOCUS_GENES)
+            return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES (width of the missing-gene mask)");
+    }
     if (prot_bytes && !t->prot) return kp_fail(ctx, KP_EINVAL, "null protein data");
     if (ctx->groups.size() <= (size_t)group) ctx->groups.resize((size_t)group + 1);
     if (!ctx->groups[(size_t)group]) ctx->groups[(size_t)group].reset(new KpTypingGroup());
@@ -815,7 +1059,7 @@ int kp_db_load_typing_group(kp_ctx *ctx, int32_t group, int32_t gene_lo, int32_t
     if ((rc = upload(ctx, T.d_prot_db, t->prot, prot_bytes))) return rc;
     if ((rc = upload(ctx, T.d_prot_db_off, t->prot_off, G))) return rc;
     if ((rc = upload(ctx, T.d_prot_db_len, t->prot_len, G))) return rc;
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     T.typing = KpTypingDb{T.d_gene_locus.p, T.d_gene_extra.p, T.d_gene_pos.p, T.d_gene_strand.p,
                           ctx->d_gene_len.p + gene_lo, T.d_locus_off.p, T.d_locus_len.p, T.d_prot_db.p,
                           T.d_prot_db_off.p, T.d_prot_db_len.p, (int32_t)G, (int32_t)t->n_loci};
@@ -824,14 +1068,22 @@ int kp_db_load_typing_group(kp_ctx *ctx, int32_t group, int32_t gene_lo, int32_t
     return KP_OK;
 }
 
-// the typing group a batch currently addresses and the batch's run for it (created on first use)
+// the typing group a batch currently addresses and the run of the batch's work set for it (created on first use)
 static KpTypingGroup *typing_group(kp_ctx *ctx, const kp_batch *b) {
     return (size_t)b->group < ctx->groups.size() ? ctx->groups[(size_t)b->group].get() : nullptr;
 }
-static KpTypingRun &typing_run(kp_batch *b) {
-    if (b->runs.size() <= (size_t)b->group) b->runs.resize((size_t)b->group + 1);
-    if (!b->runs[(size_t)b->group]) b->runs[(size_t)b->group].reset(new KpTypingRun());
-    return *b->runs[(size_t)b->group];
+static KpTypingRun &typing_run(KpWork *w, int32_t group) {
+    if (w->runs.size() <= (size_t)group) w->runs.resize((size_t)group + 1);
+    if (!w->runs[(size_t)group]) w->runs[(size_t)group].reset(new KpTypingRun());
+    return *w->runs[(size_t)group];
+}
+static kp_ctx::RunCaps &run_caps(kp_ctx *ctx, int32_t group) {
+    if (ctx->run_caps.size() <= (size_t)group) ctx->run_caps.resize((size_t)group + 1);
+    kp_ctx::RunCaps &c = ctx->run_caps[(size_t)group];
+    if (c.kept_cap == 0) c.kept_cap = (int)ctx->opt.kept_cap;
+    if (c.piece_cap == 0) c.piece_cap = (int)ctx->opt.piece_cap;
+    if (c.prot_cap == 0) c.prot_cap = (int)ctx->opt.prot_cap;
+    return c;
 }
 static int ensure_run_streams(kp_ctx *ctx, KpTypingRun &R) {
     if (R.stream) return KP_OK;
@@ -852,15 +1104,22 @@ int kp_batch_use_group(kp_ctx *ctx, kp_batch *b, int32_t group) {
 }
 
 // the group's hits out of the batch's finalised hit table (sorted by gene, so they are one run per assembly), with gene
-// indices made relative to the group's first gene
-static int split_hits(kp_ctx *ctx, kp_batch *b, const KpTypingGroup &T, KpTypingRun &R) {
+// indices made relative to the group's first gene.  A group that spans every gene of the context reads the table in place.
+static int split_hits(kp_ctx *ctx, kp_batch *b, KpWork *w, const KpTypingGroup &T, KpTypingRun &R) {
     if (R.split) return KP_OK;
     const size_t n_asm = (size_t)b->n_asm;
-    KP_HIP_CHECK(ctx, R.d_hits.reserve(n_asm * b->hit_cap));
-    KP_HIP_CHECK(ctx, R.d_hit_n.reserve(n_asm));
-    kp_launch_hit_split(b->d_hits.p, b->d_hit_counts.p + n_asm, b->hit_cap, T.gene_lo, T.gene_hi, R.d_hits.p, R.d_hit_n.p,
-                        b->n_asm, R.stream);
-    KP_HIP_CHECK(ctx, hipGetLastError());
+    if (T.gene_lo == 0 && T.gene_hi == ctx->n_genes) {
+        R.hits = w->d_hits.p;
+        R.hit_n = w->d_hit_counts.p + n_asm;
+    } else {
+        KP_HIP_CHECK(ctx, R.d_hits.reserve(n_asm * w->hit_cap));
+        KP_HIP_CHECK(ctx, R.d_hit_n.reserve(n_asm));
+        kp_launch_hit_split(w->d_hits.p, w->d_hit_counts.p + n_asm, w->hit_cap, T.gene_lo, T.gene_hi, R.d_hits.p, R.d_hit_n.p,
+                            b->n_asm, R.stream);
+        KP_HIP_CHECK(ctx, hipGetLastError());
+        R.hits = R.d_hits.p;
+        R.hit_n = R.d_hit_n.p;
+    }
     R.split = true;
     return KP_OK;
 }
@@ -870,15 +1129,16 @@ int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *l
     KpTypingGroup *Tp = typing_group(ctx, b);
     if (!Tp) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
     KpTypingGroup &T = *Tp;
-    KpTypingRun &R = typing_run(b);
     int rc = kp_batch_wait(ctx, b);  // hit tables final (and the post stream idle) when this returns
     if (rc) return rc;
+    KpWork *w = work_of(ctx, b);
+    KpTypingRun &R = typing_run(w, b->group);
     if ((rc = ensure_run_streams(ctx, R))) return rc;
-    if ((rc = split_hits(ctx, b, T, R))) return rc;
+    if ((rc = split_hits(ctx, b, w, T, R))) return rc;
     const size_t n = (size_t)b->n_asm * (size_t)T.typing.n_loci;
     KP_HIP_CHECK(ctx, R.d_scores.reserve(n));
     KP_HIP_CHECK(ctx, R.d_lcounts.reserve(n));
-    kp_launch_score(b->view, R.d_hits.p, R.d_hit_n.p, b->hit_cap, T.typing, min_gene_coverage,
+    kp_launch_score(b->view, R.hits, R.hit_n, w->hit_cap, T.typing, min_gene_coverage,
                     R.d_scores.p, R.d_lcounts.p, R.stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
     if (n) {
@@ -891,16 +1151,18 @@ int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *l
     return KP_OK;
 }
 
-static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
+static int enqueue_reduce(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KpTypingGroup &T = *typing_group(ctx, b);
-    KpTypingRun &R = typing_run(b);
+    KpTypingRun &R = typing_run(w, b->group);
+    const kp_ctx::RunCaps caps = run_caps(ctx, b->group);
+    R.kept_cap = caps.kept_cap; R.piece_cap = caps.piece_cap; R.prot_cap = caps.prot_cap;
     const size_t n_asm = (size_t)b->n_asm;
     if ((uint64_t)n_asm * (uint64_t)R.prot_cap > 0x7FFFFFFFull)
         return kp_fail(ctx, KP_EOVERFLOW, "protein buffer would exceed 2^31 bytes; use smaller batches");
     const size_t slots = n_asm * (size_t)R.kept_cap;
-    KP_HIP_CHECK(ctx, R.d_keys.reserve(n_asm * b->hit_cap));
-    KP_HIP_CHECK(ctx, R.d_order.reserve(n_asm * b->hit_cap));
-    KP_HIP_CHECK(ctx, R.d_flag.reserve(n_asm * b->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_keys.reserve(n_asm * w->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_order.reserve(n_asm * w->hit_cap));
+    KP_HIP_CHECK(ctx, R.d_flag.reserve(n_asm * w->hit_cap));
     KP_HIP_CHECK(ctx, R.d_kept.reserve(slots));
     KP_HIP_CHECK(ctx, R.d_pieces.reserve(n_asm * (size_t)R.piece_cap));
     KP_HIP_CHECK(ctx, R.d_summary.reserve(n_asm));
@@ -910,7 +1172,7 @@ static int enqueue_reduce(kp_ctx *ctx, kp_batch *b) {
     int32_t *q_off = R.d_pairs.p, *q_len = q_off + slots, *t_off = q_len + slots, *t_len = t_off + slots;
     int32_t *pair_base = t_len + slots, *n_pairs = pair_base + n_asm;
     KP_HIP_CHECK(ctx, hipMemsetAsync(n_pairs, 0, sizeof(int32_t), R.stream));
-    kp_launch_reduce(b->view, R.d_hits.p, R.d_hit_n.p, b->hit_cap, T.typing, R.prm, R.d_best.p,
+    kp_launch_reduce(b->view, R.hits, R.hit_n, w->hit_cap, T.typing, R.prm, R.d_best.p,
                      R.d_keys.p, R.d_order.p, R.d_flag.p, R.d_kept.p, R.kept_cap, R.d_pieces.p, R.piece_cap,
                      R.d_summary.p, R.d_prot.p, R.prot_cap, q_off, q_len, t_off, t_len, n_pairs, pair_base, R.stream);
     // protein DP of every kept hit against its database protein (pair list is compact; its length lives on the device)
@@ -932,19 +1194,18 @@ int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const k
     if (!ctx || !b || b->ctx != ctx || !prm || (b->n_asm > 0 && !best_locus)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     KpTypingGroup *Tp = typing_group(ctx, b);
     if (!Tp) return kp_fail(ctx, KP_ESTATE, "kp_db_load_typing has not been called");
-    KpTypingRun &R = typing_run(b);
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    KpTypingRun &R = typing_run(w, b->group);
     if (!R.scored) return kp_fail(ctx, KP_ESTATE, "kp_batch_score has not been called");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     for (int a = 0; a < b->n_asm; ++a)
         if (best_locus[a] < 0 || best_locus[a] >= Tp->typing.n_loci) return kp_fail(ctx, KP_EINVAL, "best_locus out of range");
     R.prm = *prm;
-    if (R.kept_cap == 0) R.kept_cap = (int)env_u32("KAPTIVE_AMD_KEPT_CAP", 256);
-    if (R.piece_cap == 0) R.piece_cap = (int)env_u32("KAPTIVE_AMD_PIECE_CAP", 32);
-    if (R.prot_cap == 0) R.prot_cap = (int)env_u32("KAPTIVE_AMD_PROT_CAP", 32768);
     int rc = upload(ctx, R.d_best, best_locus, (size_t)b->n_asm, R.stream);
     if (rc == KP_OK && hipStreamSynchronize(R.stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "H2D best loci failed");
     if (rc) return rc;
-    rc = enqueue_reduce(ctx, b);
+    rc = enqueue_reduce(ctx, b, w);
     if (rc) return rc;
     R.reduced = true;
     R.sums_valid = false;
@@ -952,8 +1213,8 @@ int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const k
 }
 
 // waits for the reduction, re-runs it with larger buffers while any assembly overflowed one, and keeps the summaries
-static int fetch_summaries(kp_ctx *ctx, kp_batch *b) {
-    KpTypingRun &R = typing_run(b);
+static int fetch_summaries(kp_ctx *ctx, kp_batch *b, KpWork *w) {
+    KpTypingRun &R = typing_run(w, b->group);
     if (R.sums_valid) return KP_OK;
     const size_t n_asm = (size_t)b->n_asm;
     R.h_sums.resize(n_asm);
@@ -964,17 +1225,18 @@ static int fetch_summaries(kp_ctx *ctx, kp_batch *b) {
         KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
         int flags = 0;
         for (const auto &s : R.h_sums) flags |= s.overflow;
-        if (!(flags & (1 | 2 | 8))) break;
         if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
+        if (!(flags & (1 | 2 | 8))) break;
         if (attempt >= 8) return kp_fail(ctx, KP_EOVERFLOW, "reduction buffers overflowed repeatedly");
+        kp_ctx::RunCaps &caps = run_caps(ctx, b->group);
         if (flags & 1) {
-            if (R.kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
-            R.kept_cap = std::min(R.kept_cap * 4, 2048);
+            if (caps.kept_cap >= 2048) return kp_fail(ctx, KP_EOVERFLOW, "more than 2048 non-overlapping hits in one assembly");
+            caps.kept_cap = std::min(caps.kept_cap * 4, 2048);
         }
-        if (flags & 2) R.piece_cap *= 4;
-        if (flags & 8) R.prot_cap *= 4;
-        b->stats[4] += 1;
-        int rc = enqueue_reduce(ctx, b);
+        if (flags & 2) caps.piece_cap *= 4;
+        if (flags & 8) caps.prot_cap *= 4;
+        w->stats[4] += 1;
+        int rc = enqueue_reduce(ctx, b, w);
         if (rc) return rc;
     }
     R.max_kept = 1; R.max_pieces = 1;
@@ -986,15 +1248,27 @@ static int fetch_summaries(kp_ctx *ctx, kp_batch *b) {
     return KP_OK;
 }
 
+// the run of the batch's current group after kp_batch_reduce, or null after recording the error
+static KpTypingRun *reduced_run(kp_ctx *ctx, kp_batch *b, KpWork **w_out) {
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return nullptr;
+    KpTypingRun &R = typing_run(w, b->group);
+    if (!R.reduced) { kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called"); return nullptr; }
+    *w_out = w;
+    return &R;
+}
+
 int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept *kept, int32_t kept_stride,
                     kp_piece *pieces, int32_t piece_stride) {
     if (!ctx || !b || b->ctx != ctx || (b->n_asm > 0 && (!summaries || !kept || !pieces)))
         return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    KpTypingRun &R = typing_run(b);
-    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KpWork *w = nullptr;
+    KpTypingRun *Rp = reduced_run(ctx, b, &w);
+    if (!Rp) return KP_ESTATE;
+    KpTypingRun &R = *Rp;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t n_asm = (size_t)b->n_asm;
-    int rc = fetch_summaries(ctx, b);
+    int rc = fetch_summaries(ctx, b, w);
     if (rc) return rc;
     if (n_asm == 0) return KP_OK;
     if (kept_stride < R.max_kept || piece_stride < R.max_pieces)
@@ -1030,20 +1304,24 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
 
 int kp_batch_typing_caps(kp_ctx *ctx, kp_batch *b, int32_t *kept_cap, int32_t *piece_cap) {
     if (!ctx || !b || b->ctx != ctx || !kept_cap || !piece_cap) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    KpTypingRun &R = typing_run(b);
-    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    KpWork *w = nullptr;
+    KpTypingRun *Rp = reduced_run(ctx, b, &w);
+    if (!Rp) return KP_ESTATE;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    int rc = fetch_summaries(ctx, b);
+    int rc = fetch_summaries(ctx, b, w);
     if (rc) return rc;
-    *kept_cap = R.max_kept;
-    *piece_cap = R.max_pieces;
+    *kept_cap = Rp->max_kept;
+    *piece_cap = Rp->max_pieces;
     return KP_OK;
 }
 
 int kp_batch_proteins(kp_ctx *ctx, kp_batch *b, int32_t asm_index, uint8_t *out, int64_t cap) {
-    if (!ctx || !b || asm_index < 0 || asm_index >= b->n_asm || (!out && cap > 0)) return kp_fail(ctx, KP_EINVAL, "bad arguments");
-    KpTypingRun &R = typing_run(b);
-    if (!R.reduced) return kp_fail(ctx, KP_ESTATE, "kp_batch_reduce has not been called");
+    if (!ctx || !b || b->ctx != ctx || asm_index < 0 || asm_index >= b->n_asm || (!out && cap > 0))
+        return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = nullptr;
+    KpTypingRun *Rp = reduced_run(ctx, b, &w);
+    if (!Rp) return KP_ESTATE;
+    KpTypingRun &R = *Rp;
     const int64_t n = std::min<int64_t>(cap, R.prot_cap);
     if (n > 0 && hipMemcpy(out, R.d_prot.p + (size_t)asm_index * (size_t)R.prot_cap, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
         return kp_fail(ctx, KP_EHIP, "D2H proteins failed");

@@ -114,7 +114,7 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 #define KP_ANCHOR_SUBS 64
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
                     uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
-                    hipStream_t stream, hipEvent_t after_scan);
+                    int ablate_mode, bool no_lds_filter, hipStream_t stream, hipEvent_t after_scan);
 void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
@@ -124,7 +124,7 @@ void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const
 // kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order and results at
 // c * task_cap and its count at task_count[c]; one launch covers all four.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, hipStream_t stream);
+                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, int blocks_per_cu, hipStream_t stream);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);

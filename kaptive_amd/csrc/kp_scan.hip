@@ -11,8 +11,6 @@
 // quarter of positions goes on to the blocked-Bloom presence filter (2 MB, stays in each XCD's L2; kp_internal.h).  What passes
 // the filter is only recorded (kp_scan_kernel); a second, perfectly balanced kernel (kp_expand_kernel) probes the
 // k-mer table (tens of MB, Infinity Cache), validates and expands the postings into anchors.
-#include <cstdlib>
-
 #include "kp_internal.h"
 
 namespace {
@@ -294,12 +292,9 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
                     uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
-                    hipStream_t stream, hipEvent_t after_scan) {
+                    int mode, bool no_lds, hipStream_t stream, hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
-    const char *env_mode = getenv("KAPTIVE_AMD_SCAN_ABLATE"), *env_lds = getenv("KAPTIVE_AMD_NO_LDS_FILTER");
-    const int mode = env_mode ? atoi(env_mode) : 0;
-    const bool no_lds = env_lds && atoi(env_lds);  // tests compare the two filter tiers
     uint32_t *cand_kmer = reinterpret_cast<uint32_t *>(cand + cand_cap);  // second half of the candidate buffer
     if (idx.lds_filter_blocks && !no_lds && mode == 0) {
         // one 16-wave block per CU (the filter fills most of its LDS); a few blocks per CU in the grid even out the tail

@@ -292,11 +292,10 @@ __global__ __launch_bounds__(64, 4) void kp_sw_kernel(KpBatchView b, KpGenes gen
 }  // namespace
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, hipStream_t stream) {
+                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, int blocks_per_cu, hipStream_t stream) {
     // many short-lived single-wave blocks (each strides over a quad or two): CU slots turn over every few hundred
     // microseconds, so the tail is even and the high-priority streams of other batches' reductions get their turn
     // (measured: 24.0 ms with 256 blocks per CU against 28-32 ms with 16 persistent ones, K pass of the bench)
-    const char *env = getenv("KAPTIVE_AMD_SW_BLOCKS_PER_CU");
-    const dim3 grid(3 * WIDE_BLOCKS + 256 * (env ? atoi(env) : 256)), block(64);
+    const dim3 grid(3 * WIDE_BLOCKS + 256 * (unsigned)(blocks_per_cu > 0 ? blocks_per_cu : 256)), block(64);
     hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, results);
 }

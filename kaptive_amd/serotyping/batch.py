@@ -204,6 +204,10 @@ class BatchTyping:
 
         return [bytes(KaptiveRow.from_result(self.result(i))) for i in range(len(self))]
 
+    def tsv(self) -> bytes:
+        """The TSV lines of the whole batch as one byte string (what ``kaptive assembly -o`` appends per batch)."""
+        return b"".join(self.rows())
+
 
 class _HitsView:
     """The one attribute ``Serotyper._phenotype`` reads off a GeneHits."""

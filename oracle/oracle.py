@@ -7,6 +7,7 @@ package (kaptive_amd/) never does.  See kp_oracle.c for what each entry point re
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -34,14 +35,41 @@ def build(force: bool = False) -> Path:
     return so
 
 
+def build_native() -> str | None:
+    """-O3 -march=native build for the box this runs on (bench.py's cpu_baseline leg; the committed recipe's portable
+    build travels with the tree, a -march=native one must not).  Written to the temp dir; None without a compiler."""
+    import shutil
+    import tempfile
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        return None
+    out = Path(tempfile.gettempdir()) / f"libkp_oracle_native_{os.getpid()}.so"
+    r = subprocess.run([cc, "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-fvisibility=hidden",
+                        f"-I{_HERE.parent / 'include'}", "-o", str(out), str(_HERE / "kp_oracle.c")], capture_output=True)
+    return str(out) if r.returncode == 0 else None
+
+
+def use_library(path: str) -> None:
+    """Load the oracle from ``path`` instead of the committed recipe's build (before the first call into it)."""
+    global _LIB
+    _LIB = None
+    _load(Path(path))
+
+
+def _load(path: Path) -> None:
+    global _LIB
+    _LIB = C.CDLL(str(path))
+    _LIB.kpo_db_create.restype = C.c_void_p
+    _LIB.kpo_db_n_postings.restype = C.c_int64
+    for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract"):
+        getattr(_LIB, f).restype = C.c_int64
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(str(build()))
-        _LIB.kpo_db_create.restype = C.c_void_p
-        _LIB.kpo_db_n_postings.restype = C.c_int64
-        for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract"):
-            getattr(_LIB, f).restype = C.c_int64
+        _load(build())
     return _LIB
 
 

@@ -154,3 +154,17 @@ def test_cli_parser_matches_reference_flags():
     assert a.below_threshold and a.threads == 4 and a.partial_edge_tolerance == 9 and a.out == "out.tsv"
     b = ap.parse_args(["type", "db.npz", "x.fa"])
     assert b.func is a.func and b.max_other_genes == 1 and b.min_completeness == 0.5 and not b.below_threshold
+    # defaults, nargs and const of the output flags as the reference declares them (src/kaptive/cli.py:424-504):
+    # -o defaults to stdout; the others are off unless given, and take their const when given without a value
+    assert b.out == "stdout" and b.json is None and b.pha4ge is None and b.loci is None and b.genes is None and b.proteins is None
+    from pathlib import Path
+
+    c = ap.parse_args(["type", "db.npz", "x.fa", "-l", "-g", "-p", "-j", "--pha4ge"])
+    assert c.loci == Path("./") and c.genes == Path("./") and c.proteins == Path("./")
+    assert c.json == "kaptive_results.jsonl" and c.pha4ge == Path("kaptive_results.pha4ge") and c.out == "stdout"
+    d = ap.parse_args(["convert", "r.jsonl"])
+    assert d.tsv is None and d.loci is None
+    e = ap.parse_args(["convert", "r.jsonl", "-t"])
+    assert e.tsv == "stdout"
+    f = ap.parse_args(["convert", "r.jsonl", "-t", "x.tsv", "-g", "genes"])
+    assert f.tsv == "x.tsv" and f.genes == Path("genes")

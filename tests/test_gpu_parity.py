@@ -169,9 +169,12 @@ def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
     packed = [a.packed() for a in asms]
     lds = ctx.batch(packed)
     hits_lds, off_lds = lds.align()
-    monkeypatch.setenv("KAPTIVE_AMD_NO_LDS_FILTER", "1")
-    l2 = ctx.batch(packed)
-    hits_l2, off_l2 = l2.align()
+    ctx.set_option("no_lds_filter", 1)
+    try:
+        l2 = ctx.batch(packed)
+        hits_l2, off_l2 = l2.align()
+    finally:
+        ctx.set_option("no_lds_filter", 0)
     assert np.array_equal(off_lds, off_l2)
     _same_records(hits_lds, hits_l2, "LDS vs L2 filter tier")
     for i in range(len(packed)):
@@ -233,11 +236,13 @@ def test_random_assembly_shapes_match_oracle(ctx, small_setup, small_db):
 def test_overflow_retry_gives_same_hits(ctx, small_setup, small_db, monkeypatch):
     odb = small_setup
     asm = make_assembly(small_db, seed=11, length=90_000, median_contigs=5, min_contig=200)
-    monkeypatch.setenv("KAPTIVE_AMD_ANCHOR_CAP", "1024")
-    monkeypatch.setenv("KAPTIVE_AMD_TASKS_PER_ASM", "8")
+    ctx.set_option("anchor_cap", 1024)
+    ctx.set_option("tasks_per_asm", 8)
     batch = ctx.batch([asm.packed()])
     hits, _ = batch.align()
     assert batch.stats()["retries"] >= 1
+    ctx.set_option("anchor_cap", 1 << 17)
+    ctx.set_option("tasks_per_asm", 4096)
     _same_records(hits, odb.align(asm.packed()), "hits after overflow retry")
     batch.close()
 
@@ -445,3 +450,178 @@ def test_cli_types_fasta_files_like_the_reference(tmp_path):
     assert len(js.read_bytes().splitlines()) == len(names)
     assert (tmp_path / "genes" / "k_plain1_kaptive_results.ffn").stat().st_size > 1000
     assert main(["assembly", str(tmp_path / "missing.npz"), paths[0], "-o", str(out)]) == 1
+
+
+# ---- BASELINE.json configs at their real shape --------------------------------------------------------------------------
+def _oracle_typer(db, oracle):
+    """Host reduction (the golden-pinned statement) fed by the oracle's aligner and protein DP: the expected rows."""
+    from kaptive_amd.core.pairwise import PairwiseAlignments
+    from tests.golden_util import hits_to_alignments
+
+    odb = oracle.OracleDB(*pack_sequences_flat(db.genes))
+    typer = Serotyper(
+        db,
+        aligner=lambda g: hits_to_alignments(db, g, odb.align(g.packed())),
+        protein_aligner=lambda q, t: PairwiseAlignments.from_table(
+            oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)),
+    )  # fmt: skip
+    return odb, typer
+
+
+def _rows_of(results):
+    from kaptive_amd.serotyping.io import KaptiveRow
+
+    return [bytes(KaptiveRow.from_result(r)) for r in results]
+
+
+def test_config3_k_and_o_at_full_size(oracle):
+    """Config 3 shape: 5 Mbp assemblies that carry a K and an O locus, typed against both databases -- by one context
+    per database sharing one device copy of the batch (as bench.py does) and by one shared alignment pass.  Hit tables
+    equal the oracle's for both databases; TSV rows equal the host reduction's."""
+    from kaptive_amd.engine import Engine
+
+    db_k, db_o = make_db("kpsc_k", seed=100), make_db("kpsc_o", seed=101)
+    genomes = [make_assembly(db_k, seed=7000 + i, also=(db_o,)) for i in range(4)]
+    ids = [g.id for g in genomes]
+    packed = [g.packed() for g in genomes]
+    want_rows = []
+    engines = [Engine(db_k), Engine(db_o)]
+    first = engines[0].ctx.batch(packed)
+    batches = [first, engines[1].ctx.batch(packed, device_words=first.device_words, after=first)]
+    for b in batches:
+        b.align_async()
+    for db, eng, b in zip((db_k, db_o), engines, batches):
+        odb, cpu = _oracle_typer(db, oracle)
+        b.wait()
+        hits, off = b.hits()
+        for i, pa in enumerate(packed):
+            _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"{db.metadata.keyword} hits of {ids[i]}")
+        typer = Serotyper(db)
+        typer._engine = eng
+        got = eng.type_batch(typer, b, ids, aligned=True)
+        want = _rows_of([cpu(g) for g in genomes])
+        assert got.rows() == want, f"rows of {db.metadata.keyword}"
+        assert got.tsv() == b"".join(want)
+        want_rows.append(want)
+    assert sum(b"Typeable" in r for r in want_rows[0]) >= 3 and sum(b"Typeable" in r for r in want_rows[1]) >= 3
+    for b in reversed(batches):
+        b.close()
+    for e in engines:
+        e.close()
+    # the same through one alignment pass over the genes of both databases
+    both = Engine([db_k, db_o])
+    batch = both.ctx.batch(packed)
+    batch.align_async()
+    for i, db in enumerate((db_k, db_o)):
+        typer = Serotyper(db)
+        assert both.view(i).type_batch(typer, batch, ids, aligned=True).rows() == want_rows[i], f"shared pass, database {i}"
+    batch.close()
+    both.close()
+
+
+def test_config4_acinetobacter_at_full_size(oracle):
+    """Config 4 shape: the 240-locus A. baumannii-shaped K database, 4 Mbp assemblies at GC 0.39 in ~1 500 contigs,
+    every locus split across contigs."""
+    from kaptive_amd.engine import Engine
+
+    db = make_db("ab_k", seed=102)
+    assert len(db.loci) == 240
+    genomes = [make_assembly(db, seed=8000 + i, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True)
+               for i in range(3)]  # fmt: skip
+    assert min(len(g.contigs) for g in genomes) > 700
+    ids = [g.id for g in genomes]
+    packed = [g.packed() for g in genomes]
+    odb, cpu = _oracle_typer(db, oracle)
+    eng = Engine(db)
+    batch = eng.ctx.batch(packed)
+    hits, off = batch.align()
+    for i, pa in enumerate(packed):
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {ids[i]}")
+    typer = Serotyper(db)
+    typer._engine = eng
+    got = eng.type_batch(typer, batch, ids, aligned=True)
+    want = [cpu(g) for g in genomes]
+    assert got.rows() == _rows_of(want)
+    assert all(len(r.locus_pieces) >= 2 for r in want)  # fragmented loci: the '?' problem is exercised
+    batch.close()
+    eng.close()
+
+
+def test_many_hit_stress_forces_every_fallback(oracle):
+    """A full-size assembly carrying five K loci: more hits than the LDS sort stage holds (SORT_LDS = 4096), with hit,
+    kept, piece and protein buffers started far too small, so every grow-and-rerun path runs at full size."""
+    from kaptive_amd.engine import Engine
+    from kaptive_amd.synth import mutate
+
+    db = make_db("kpsc_k", seed=100)
+    rng = np.random.default_rng(99)
+    base = make_assembly(db, seed=9100, locus=3, p_break=0.0, p_is=0.0)
+    seqs = [np.frombuffer(r.seq, np.uint8).copy() for r in base.contigs]
+    big = int(np.argmax([len(s) for s in seqs]))
+    extra = []
+    for li in (10, 50, 90, 130):  # further loci appended as contigs of their own
+        o, n = int(db.loci.offsets[li]), int(db.loci.lengths[li])
+        extra.append(SeqRecord(f"extra_{li}", mutate(rng, db.loci.seqs[o : o + n], 0.01).tobytes()))
+    recs = [SeqRecord(f"c{i}", s.tobytes()) for i, s in enumerate(seqs)] + extra
+    assert len(seqs[big]) > 1000
+    genome = GenomeAssembly("five_loci", Sequences.from_records(recs))
+    plain = make_assembly(db, seed=9101)
+    packed = [genome.packed(), plain.packed()]
+    odb, cpu = _oracle_typer(db, oracle)
+    eng = Engine(db)
+    for name, v in (("hit_cap", 512), ("kept_cap", 8), ("piece_cap", 1), ("prot_cap", 2048), ("tasks_per_asm", 256)):
+        eng.ctx.set_option(name, v)
+    batch = eng.ctx.batch(packed)
+    hits, off = batch.align()
+    assert off[1] > 4096, f"{off[1]} hits: the stress case no longer exceeds SORT_LDS"
+    for i, pa in enumerate(packed):
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of assembly {i}")
+    typer = Serotyper(db)
+    typer._engine = eng
+    got = eng.type_batch(typer, batch, [genome.id, plain.id], aligned=True)
+    assert batch.stats()["retries"] >= 3
+    assert got.rows() == _rows_of([cpu(genome), cpu(plain)])
+    batch.close()
+    eng.close()
+
+
+# ---- context-owned work sets, streaming uploads --------------------------------------------------------------------------
+def test_work_slots_rotate_and_displaced_results_raise(ctx, small_setup, small_db):
+    odb = small_setup
+    asms = [make_assembly(small_db, seed=600 + i, length=60_000, median_contigs=4, min_contig=200) for i in range(3)]
+    batches = [ctx.batch([a.packed()]) for a in asms]
+    for b in batches:
+        b.align_async()  # three passes through two work sets: the first batch's results are displaced
+    for b, a in zip(batches[1:], asms[1:]):
+        b.wait()
+        hits, _ = b.hits()
+        _same_records(hits, odb.align(a.packed()), a.id)
+    with pytest.raises(_native.NativeError, match="no resident alignment results"):
+        batches[0].wait()
+    hits, _ = batches[0].align()  # aligned again it takes the next work set
+    _same_records(hits, odb.align(asms[0].packed()), asms[0].id)
+    for b in batches:
+        b.close()
+
+
+def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, small_setup, small_db):
+    odb = small_setup
+    asms = [make_assembly(small_db, seed=700 + i, length=80_000, median_contigs=6, min_contig=200) for i in range(4)]
+    packed = [a.packed() for a in asms]
+    pin = _native.PinnedBuffer(sum(len(p.words) for p in packed), np.uint32)
+    pin.array[:] = np.concatenate([p.words for p in packed])
+    up = ctx.batch(packed, pinned_words=pin.array)
+    hits, off = up.align()  # the pass waits for the copy on the device
+    other = _native.Context(0)
+    codes, goff = pack_sequences_flat(small_db.genes)
+    other.load_genes(codes, goff)
+    twin = other.batch(packed, device_words=up.device_words, after=up)
+    hits2, off2 = twin.align()
+    assert np.array_equal(off, off2)
+    _same_records(hits, hits2, "second context on the same device words")
+    for i, pa in enumerate(packed):
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), asms[i].id)
+    twin.close()
+    other.close()
+    up.close()
+    pin.close()
