@@ -130,7 +130,7 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
 
     native = O.build_native()  # -O3 -march=native for this box; None when no compiler is here (then the portable build)
     flags = "-O3 -march=native" if native else "-O2 (prebuilt; no compiler on this box)"
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n_dbs = 2 if _DBS["also"] is not None else 1
     jobs = [([seed0 + w * per_worker + i for i in range(per_worker)], length, native) for w in range(cores)]
     pool = get_context("fork").Pool(cores)
@@ -189,8 +189,9 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     workers = args.workers or max(1, min(64, (os.cpu_count() or 1) // max(world, 1)))
-    if workers == 1:
-        import torch  # noqa: F401  (inline generation loads the native library; under rocprofv3 torch has to come first)
+    # torch (and with it the HIP runtime it bundles) has to be loaded before libkaptive_amd.so, which the packer below
+    # already needs: in the other order the process ends up with two HIP runtimes and sees no device
+    import torch  # noqa: F401
     _load_dbs(args.db)
     length = args.length or _WL["length"]
     seed0 = 200 + rank * args.assemblies

@@ -586,8 +586,14 @@ def test_many_hit_stress_forces_every_fallback(oracle):
 
 
 # ---- context-owned work sets, streaming uploads --------------------------------------------------------------------------
-def test_work_slots_rotate_and_displaced_results_raise(ctx, small_setup, small_db):
-    odb = small_setup
+def _reload_small(ctx, oracle, small_db):
+    codes, off = pack_sequences_flat(small_db.genes)
+    ctx.load_genes(codes, off)  # earlier tests of the module left other databases in the shared context
+    return oracle.OracleDB(codes, off)
+
+
+def test_work_slots_rotate_and_displaced_results_raise(ctx, oracle, small_db):
+    odb = _reload_small(ctx, oracle, small_db)
     asms = [make_assembly(small_db, seed=600 + i, length=60_000, median_contigs=4, min_contig=200) for i in range(3)]
     batches = [ctx.batch([a.packed()]) for a in asms]
     for b in batches:
@@ -604,8 +610,8 @@ def test_work_slots_rotate_and_displaced_results_raise(ctx, small_setup, small_d
         b.close()
 
 
-def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, small_setup, small_db):
-    odb = small_setup
+def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, oracle, small_db):
+    odb = _reload_small(ctx, oracle, small_db)
     asms = [make_assembly(small_db, seed=700 + i, length=80_000, median_contigs=6, min_contig=200) for i in range(4)]
     packed = [a.packed() for a in asms]
     pin = _native.PinnedBuffer(sum(len(p.words) for p in packed), np.uint32)
