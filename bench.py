@@ -180,6 +180,11 @@ def main() -> None:
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
     ap.add_argument("--e2e-steps", type=int, default=1)
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
+    ap.add_argument("--separate-passes", action="store_true",
+                    help="one context and one alignment pass per database, as the reference runs them (default: the genes "
+                         "of both databases share one seed index, so every assembly is scanned, chained and aligned once; "
+                         "each database's reduction takes its own run of the gene-sorted hit table -- identical results, "
+                         "tests/test_gpu_parity.py::test_one_alignment_pass_for_two_databases)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,55 +232,91 @@ def main() -> None:
     n_batches = max(1, (len(packed) + args.batch - 1) // args.batch)
     spans = [shard_bounds(len(packed), i, n_batches) for i in range(n_batches)]
     batch_ids = [ids[lo:hi] for lo, hi in spans]
-    engines = [Engine(db, device=local_rank) for db in dbs]
+    shared = len(dbs) > 1 and not args.separate_passes
+    if shared:  # one context, one seed index over the genes of all databases; engines[k] = the engine as database k sees it
+        both = Engine(dbs, device=local_rank)
+        engines = [both.view(k) for k in range(len(dbs))]
+    else:
+        engines = [Engine(db, device=local_rank) for db in dbs]
     typers = [Serotyper(db, device=local_rank) for db in dbs]
     for eng, typer in zip(engines, typers):
         typer._engine = eng
-    # smaller database first when results are collected: its pass ends long before the other's
+    n_passes = 1 if shared else len(dbs)
+    # results are collected smaller database first: with separate passes its pass ends long before the other's, with a
+    # shared pass its reduction is the shorter chain
     collect_order = sorted(range(len(dbs)), key=lambda k: len(dbs[k].genes))
 
     def make_batches(i, pinned=None):
-        """Device batches of shard i, one per database; the later contexts adopt the first one's device words."""
+        """Device batches of shard i, one per alignment pass; further contexts adopt the first one's device words.
+        Returns one batch per database (the same object for all of them when the pass is shared)."""
         lo, hi = spans[i]
         first = engines[0].ctx.batch(packed[lo:hi], pinned_words=pinned)
+        if shared:
+            return [first] * len(dbs)
         return [first] + [eng.ctx.batch(packed[lo:hi], device_words=first.device_words, after=first) for eng in engines[1:]]
 
-    prof: list[list[dict]] = [[] for _ in dbs]
-    stats: list[list[dict]] = [[] for _ in dbs]
+    def distinct(bs):
+        return bs[:n_passes] if not shared else bs[:1]
+
+    prof: list[list[dict]] = [[] for _ in range(n_passes)]
+    stats: list[list[dict]] = [[] for _ in range(n_passes)]
+
+    debug = bool(os.environ.get("BENCH_DEBUG"))
+
+    def mark(what, t_ref=[time.perf_counter()]):
+        if debug:
+            now = time.perf_counter()
+            print(f"[bench] {what}: +{(now - t_ref[0]) * 1e3:.1f} ms", file=sys.stderr)
+            t_ref[0] = now
 
     def run_pass(get_batches, release=None, rows_sink=None, record=False):
         """One step: every shard through every database.  Alignment passes run one shard ahead of the reductions."""
         out = []
+        mark("step begins")
         live = {0: get_batches(0)}
-        for k, b in enumerate(live[0]):
+        for b in distinct(live[0]):
             b.align_async()
         for i in range(n_batches):
             if i + 1 < n_batches:
                 live[i + 1] = get_batches(i + 1)
-                for b in live[i + 1]:
+                for b in distinct(live[i + 1]):
                     b.align_async()
+                mark(f"align {i + 1} enqueued")
             bs = live[i]
-            staged = {k: engines[k].reduce_batches(typers[k], [bs[k]], aligned=True) for k in collect_order}
+            if shared:  # all scores first (cheap), so that none queues up behind another database's reduction kernels
+                scored = {k: engines[k].score_batches(typers[k], [bs[k]]) for k in reversed(collect_order)}
+                staged = {k: engines[k].enqueue_reductions(typers[k], [bs[k]], scored[k]) for k in reversed(collect_order)}
+            else:
+                staged = {k: engines[k].reduce_batches(typers[k], [bs[k]], aligned=True) for k in collect_order}
+            mark(f"reductions of {i} enqueued")
             for k in collect_order:
                 bt = engines[k].collect_batches(typers[k], [bs[k]], [batch_ids[i]], staged[k])[0]
                 if rows_sink is not None:
                     rows_sink.append(bt.tsv())
                 out.append(bt)
-                if record:
-                    prof[k].append(bs[k].profile())
-                    stats[k].append(bs[k].stats())
+                if record and (not shared or k == collect_order[-1]):
+                    prof[k if not shared else 0].append(bs[k].profile())
+                    stats[k if not shared else 0].append(bs[k].stats())
+            mark(f"results of {i} collected")
             if release is not None:
                 release(live.pop(i))
         return out
 
     # ---- leg 1: resident batches (the contract's number) -------------------------------------------------------------------
+    def close_all(bs):
+        for b in reversed(distinct(bs)):
+            b.close()
+
     resident = [make_batches(i) for i in range(n_batches)]
     for _ in range(args.warmup):
         run_pass(lambda i: resident[i])
     sync_all()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         res = run_pass(lambda i: resident[i], record=True)
+        step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))  # host view, no synchronisation added
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -287,8 +328,7 @@ def main() -> None:
     e2e = None
     if world == 1 and not args.no_e2e:
         for bs in resident:
-            for b in reversed(bs):
-                b.close()
+            close_all(bs)
         resident = []
         pins = []
         t_pin = time.perf_counter()
@@ -300,10 +340,6 @@ def main() -> None:
                 at += len(pa.words)
             pins.append(pb)
         t_pin = time.perf_counter() - t_pin
-
-        def close_all(bs):
-            for b in reversed(bs):
-                b.close()
 
         def timed(with_rows: bool):
             ahead = {}
@@ -362,6 +398,7 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_each_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -370,8 +407,10 @@ def main() -> None:
             "config": {
                 "workload": f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU {what}; one step "
                             f"= all of them, as {n_batches} batches of {args.batch} through context-owned work buffers; packed "
-                            "assemblies resident in HBM before the timed region (one copy shared by both databases' contexts)",
-                "alignment_passes_per_batch": len(dbs),
+                            "assemblies resident in HBM before the timed region; "
+                            + ("one alignment pass over the genes of both databases, one reduction per database" if shared
+                               else "one context and alignment pass per database, one device copy of the assemblies"),
+                "alignment_passes_per_batch": n_passes,
                 "assemblies_per_gpu": args.assemblies,
                 "batch": args.batch,
                 "databases": [f"{d.metadata.keyword}: {len(d.loci)} loci / {len(d.genes)} genes" for d in dbs],
@@ -379,12 +418,12 @@ def main() -> None:
                 "typeable_in_last_step": typed,
                 "tsv_rows_per_s_host": round(len(rows) / max(t_rows, 1e-9), 1),
                 "tsv_rows_sha1": rows_digest,
-                "retries_per_step": [s["retries"] for s in per_step],
+                "buffer_growth_reruns_in_timed_steps": [sum(s["retries"] for s in slist) for slist in stats],
                 "workload_generation_s": round(t_gen, 1),
             },
             "e2e": e2e,
             "roofline": {
-                "bound": "hbm", "kernel": "kp_scan_kernel (K database pass)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": "kp_scan_kernel (" + ("pass over K and O genes" if shared else "K database pass") + ")", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "traffic_source": f"offline: {pmc['source']}" if pmc else None,
@@ -395,7 +434,7 @@ def main() -> None:
                 "ms_per_step": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
                 "tasks_per_step": [s["tasks"] for s in per_step], "anchors_per_step": [s["anchors"] for s in per_step],
             },
-            "kernel_ms_per_step": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16")},
+            "kernel_ms_per_step": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16", "sw32")},
         }  # fmt: skip
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -48,7 +48,8 @@ KP_API const char *kp_last_error(const kp_ctx *ctx);
 /* The hipStream_t the alignment passes of this context are enqueued on (for event timing by the caller). */
 KP_API void *kp_ctx_stream(kp_ctx *ctx);
 /* Tuning knobs.  Defaults are read from the environment once, in kp_ctx_create (KAPTIVE_AMD_<NAME in upper case>);
- * names: anchor_cap, tasks_per_asm, hit_cap, kept_cap, piece_cap, prot_cap (initial sizes of the work buffers -- setting
+ * names: anchor_cap, tasks_per_asm, hit_cap, trace_kb_per_asm, kept_cap, piece_cap, prot_cap (initial sizes of the work
+ * buffers; trace_kb_per_asm: direction bits of the banded Smith-Waterman, KiB per assembly of a batch -- setting
  * one also forgets what the context has learnt for it), no_lds_filter (seed scan probes the L2 tier of the presence
  * filter even for small databases), scan_mode (ablation modes of the scan kernel, tools/scan_ablate.py),
  * sw_blocks_per_cu (grid of the banded Smith-Waterman launch). */
@@ -141,8 +142,8 @@ KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 
 /* Stage durations of the most recent alignment pass of this batch (valid after kp_batch_wait), from HIP events the
  * library records on the context's stream around every pass: ms7 = seed scan (kp_scan_kernel), candidate expansion +
- * anchor compaction + sort, chaining + task ordering, banded SW (all band widths run in one launch: its duration is in
- * ms7[3], ms7[4..6] are 0 and kept for layout stability).  bytes_scanned receives the algorithmic bytes the scan kernel
+ * anchor compaction + sort, chaining + task ordering, banded SW fill (all band widths run in one launch: ms7[3]), its
+ * traceback (ms7[4]); ms7[5..6] are 0 and kept for layout stability.  bytes_scanned receives the algorithmic bytes the scan kernel
  * streams (4 * total words). */
 KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms7, int64_t *bytes_scanned);
 

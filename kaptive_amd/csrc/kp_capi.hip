@@ -111,6 +111,7 @@ struct kp_batch;
 // Options of a context: defaults come from the environment once, at kp_ctx_create; kp_ctx_set_option changes them.
 struct KpOptions {
     uint32_t anchor_cap = 1u << 17, tasks_per_asm = 4096, hit_cap = 4096;
+    uint32_t trace_kb_per_asm = 2048;  // first guess for the DP trace buffer (a 5 Mbp K-locus assembly needs ~12 MB)
     uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
     int no_lds_filter = 0;       // tests compare the two filter tiers
@@ -152,6 +153,9 @@ struct KpWork {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
+    DevBuf<KpSwEnd> d_ends;
+    DevBuf<unsigned long long> d_trace_top;
+    uint64_t trace_cap = 0;  // 16-byte units the trace buffer was sized for in the most recent pass
     DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
     // device-side hit tables (per-assembly regions of hit_cap rows)
     DevBuf<kp_hit> d_hits_raw, d_hits;
@@ -171,6 +175,7 @@ struct KpWork {
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
         d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_order.release();
+        d_ends.release(); d_trace_top.release();
         d_hits_raw.release(); d_hits.release(); d_hit_counts.release(); d_keys.release(); d_cells.release();
         for (auto &r : runs)
             if (r) r->release();
@@ -198,6 +203,10 @@ struct kp_ctx {
     uint32_t anchor_cap = 0, hit_cap = 0;
     uint32_t tasks_per_asm = 0;  // task_cap of a pass = n_asm * tasks_per_asm
     double cand_frac = 0.0;      // cand_cap of a pass = total selected positions * cand_frac
+    uint64_t trace_units_per_asm = 0;  // trace buffer of a pass = n_asm * this many 16-byte units
+    // direction bits of the banded Smith-Waterman: written by the fill kernel, read by the traceback that follows it on
+    // the same stream, so one buffer serves every work set
+    DevBuf<uint4> d_trace;
     // resident database
     bool has_db = false;
     int32_t n_genes = 0;
@@ -274,6 +283,7 @@ void options_from_env(KpOptions &o) {
     o.anchor_cap = env_u32("KAPTIVE_AMD_ANCHOR_CAP", o.anchor_cap);
     o.tasks_per_asm = env_u32("KAPTIVE_AMD_TASKS_PER_ASM", o.tasks_per_asm);
     o.hit_cap = env_u32("KAPTIVE_AMD_HIT_CAP", o.hit_cap);
+    o.trace_kb_per_asm = env_u32("KAPTIVE_AMD_TRACE_KB_PER_ASM", o.trace_kb_per_asm);
     o.kept_cap = env_u32("KAPTIVE_AMD_KEPT_CAP", o.kept_cap);
     o.piece_cap = env_u32("KAPTIVE_AMD_PIECE_CAP", o.piece_cap);
     o.prot_cap = env_u32("KAPTIVE_AMD_PROT_CAP", o.prot_cap);
@@ -511,7 +521,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (auto &w : ctx->work) w.release();
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
-    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release();
+    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_trace.release();
     for (auto &g : ctx->groups)
         if (g) g->release();
     ctx->groups.clear();
@@ -544,6 +554,7 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
     if (n == "anchor_cap") { o.anchor_cap = (uint32_t)std::max<int64_t>(value, 1); ctx->anchor_cap = 0; }
     else if (n == "tasks_per_asm") { o.tasks_per_asm = (uint32_t)std::max<int64_t>(value, 1); ctx->tasks_per_asm = 0; }
     else if (n == "hit_cap") { o.hit_cap = (uint32_t)std::max<int64_t>(value, 1); ctx->hit_cap = 0; }
+    else if (n == "trace_kb_per_asm") { o.trace_kb_per_asm = (uint32_t)std::max<int64_t>(value, 1); ctx->trace_units_per_asm = 0; }
     else if (n == "kept_cap") { o.kept_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.kept_cap = 0; }
     else if (n == "piece_cap") { o.piece_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.piece_cap = 0; }
     else if (n == "prot_cap") { o.prot_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.prot_cap = 0; }
@@ -755,12 +766,16 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap + (w->cand_cap + 1) / 2));  // u64 positions, then u32 k-mers
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(1));
+    KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_trace_top.reserve(1));
+    KP_HIP_CHECK(ctx, ctx->d_trace.reserve(w->trace_cap));
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->in->ready, 0));  // the batch's H2D copies
     if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->after->in->ready, 0));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, sizeof(unsigned long long), ctx->stream));
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
@@ -783,11 +798,12 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     kp_launch_task_order(ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
                          ctx->stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
-    // all four band classes in one launch (kp_sw.hip); the per-class event slots stay in the layout: the whole launch is
-    // booked on the first one, the others read 0
+    // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
+    // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p + ORDER_HEAD,
-                 w->d_results.p, ctx->opt.sw_blocks_per_cu, ctx->stream);
-    for (int c = 0; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
+                 w->d_ends.p, ctx->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->opt.sw_blocks_per_cu,
+                 ctx->stream, ev[4]);
+    for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -803,6 +819,8 @@ static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
     w->task_cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max(b->n_asm, 1) * ctx->tasks_per_asm, 1u << 28);
     w->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)((double)b->view.total_words * 4.0 * ctx->cand_frac));
     w->hit_cap = ctx->hit_cap;
+    if (ctx->trace_units_per_asm == 0) ctx->trace_units_per_asm = (uint64_t)ctx->opt.trace_kb_per_asm * 64;
+    w->trace_cap = std::max<uint64_t>(4096, (uint64_t)std::max(b->n_asm, 1) * ctx->trace_units_per_asm);
 }
 
 int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
@@ -882,14 +900,15 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         w->h_counts.resize(2 * n_asm + KP_N_CLASSES);
         KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->post));
-        unsigned long long n_cand = 0;
+        unsigned long long n_cand = 0, trace_need = 0;
         KP_HIP_CHECK(ctx, hipMemcpyAsync(&n_cand, w->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost, ctx->post));
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(&trace_need, w->d_trace_top.p, sizeof trace_need, hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);
         const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
-        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap) break;
+        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap) break;
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
         // a region overflowed: counts kept counting, so they say how much room a clean rerun needs.  The context
         // remembers it (with some headroom, later batches differ a little) for every later pass.
@@ -900,6 +919,11 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         if (max_slice > sub_cap) {
             w->anchor_cap = ((max_slice + max_slice / 4 + 15u) & ~15u) * KP_ANCHOR_SUBS;
             ctx->anchor_cap = std::max(ctx->anchor_cap, w->anchor_cap);
+        }
+        if (trace_need > w->trace_cap) {  // (a pass cut short by another overflow reports less than it will need)
+            if (trace_need > (1ull << 32)) return kp_fail(ctx, KP_EOVERFLOW, "DP trace would exceed 64 GB; use smaller batches");
+            w->trace_cap = std::min<uint64_t>(trace_need + trace_need / 4, 1ull << 32);  // later batches differ by a few per cent
+            ctx->trace_units_per_asm = std::max<uint64_t>(ctx->trace_units_per_asm, (w->trace_cap + n_asm - 1) / std::max<size_t>(n_asm, 1));
         }
         if (max_task > w->task_cap) {
             w->task_cap = (max_task + max_task / 8 + 1023u) & ~1023u;

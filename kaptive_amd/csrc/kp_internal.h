@@ -20,9 +20,17 @@
 #define KP_FILTER_LOG2 24
 #define KP_FILTER_K 4
 __host__ __device__ inline uint32_t kp_filter_block(uint32_t kmer) { return (kmer * 2654435769u) >> (32 - (KP_FILTER_LOG2 - 6)); }
-__host__ __device__ inline uint64_t kp_filter_mask(uint32_t kmer) {
+// the k-mer's KP_FILTER_K bits of its block: two in each 32-bit half, so that a probe is 32-bit arithmetic throughout
+__host__ __device__ inline uint2 kp_filter_mask2(uint32_t kmer) {
     const uint32_t h = kmer * 0x85EBCA6Bu;
-    return (1ull << (h >> 26)) | (1ull << ((h >> 20) & 63u)) | (1ull << ((h >> 14) & 63u)) | (1ull << ((h >> 8) & 63u));
+    uint2 m;
+    m.x = (1u << (h >> 27)) | (1u << ((h >> 22) & 31u));
+    m.y = (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+    return m;
+}
+__host__ __device__ inline uint64_t kp_filter_mask(uint32_t kmer) {
+    const uint2 m = kp_filter_mask2(kmer);
+    return ((uint64_t)m.y << 32) | m.x;
 }
 // Small databases also get an LDS-sized copy of the filter: lds_filter_blocks 64-bit blocks (0 = none), block of a
 // k-mer = high word of hash * lds_filter_blocks, same KP_FILTER_K bits within the block.
@@ -95,6 +103,14 @@ struct KpSwResult {
     int32_t score, q_start, q_end, t_start, t_end, matches, block_len;
 };
 
+// What the fill kernel leaves per task: the best cell and where the task's direction bits are (16-byte units).
+struct KpSwEnd {
+    int32_t score;  // 0 when the trace buffer had no room for the task (the host grows it and reruns the pass)
+    int32_t er, eb; // row and band index of the best cell; eb also carries KP_SWEND_HAS_N
+    uint32_t trace_off;
+};
+#define KP_SWEND_HAS_N 0x100  // the gene or the task's target window holds an N (matches are then counted base by base)
+
 #define KP_HIP_CHECK(ctx, expr)                                                                     \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
@@ -121,10 +137,13 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
                      hipStream_t stream);
-// kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order and results at
-// c * task_cap and its count at task_count[c]; one launch covers all four.
+// kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order, ends and
+// results at c * task_cap and its count at task_count[c]; one fill launch covers all four, one traceback launch follows.
+// `trace` holds trace_cap_units 16-byte units; *trace_top (zeroed by the caller) ends up as the units the pass needs.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
-                  uint32_t task_cap, const uint32_t *order, KpSwResult *results, int blocks_per_cu, hipStream_t stream);
+                  uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
+                  uint64_t trace_cap_units, KpSwResult *results, int blocks_per_cu, hipStream_t stream,
+                  hipEvent_t after_fill);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);

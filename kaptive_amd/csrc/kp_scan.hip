@@ -15,8 +15,6 @@
 
 namespace {
 
-constexpr int PROBES = 8;
-
 // LDS written by some lanes of a wave, read by others of the same wave (no block barrier: waves loop independently)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -50,19 +48,24 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 // MODE 0 = product; 1 = no filter reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for the
 // ablation in tools/scan_ablate.py and write a checksum so that the work is not optimised away.
 //
+// A lane's 64 positions are handled as two halves of 32 (two packed words each): the selected positions of a half are
+// one 32-bit mask (word 0's at the even bits, word 1's at the odd bits), and the lane walks exactly its own set bits,
+// PROBES at a time, so that a round's filter reads are all in flight before the first is looked at.  (The round-1 kernel
+// ran 8 probe slots per word and round whatever the word had selected: three quarters of its instructions were idle.)
+//
 // Two filter tiers.  A database with few k-mers (O loci: tens of thousands) gets a filter small enough for LDS
 // (idx.lds_filter, <= KP_LDS_FILTER_BLOCKS 64-bit blocks): LDSF = true copies it into the block's LDS once and probes it
 // there, so the kernel no longer pays one L2 request per selected k-mer (the L2 tier runs at the L2's request rate);
-// blocks are 16 waves wide (one
-// per CU: the filter takes most of its LDS) with a small candidate stage per wave.  Otherwise the 2 MB filter is probed
-// in L2 (LDSF = false, 4-wave blocks, several per CU).
+// blocks are 16 waves wide (one per CU: the filter takes most of its LDS) with a small candidate stage per wave.
+// Otherwise the 2 MB filter is probed in L2 (LDSF = false, 4-wave blocks, several per CU).
 template <bool LDSF> struct ScanShape {
     static constexpr int WAVES = LDSF ? 16 : 4;
-    // a round of PROBES positions per lane adds at most 64 * PROBES = 512 entries (flush after the round); the LDS tier
-    // flushes inside the round, whenever fewer than 64 free entries are left
-    static constexpr int STAGE = LDSF ? 192 : 768;
+    // a round of PROBES positions per lane adds at most 64 * PROBES entries (flush after the round)
+    static constexpr int STAGE = LDSF ? 320 : 768;
     static constexpr int FILTER_BLOCKS = LDSF ? KP_LDS_FILTER_BLOCKS : 1;
 };
+
+constexpr int PROBES = 4;
 
 template <int MODE, bool LDSF>
 __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx,
@@ -73,9 +76,11 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
     constexpr int WAVES = ScanShape<LDSF>::WAVES, STAGE_PER_WAVE = ScanShape<LDSF>::STAGE;
     __shared__ uint64_t s_stage[WAVES][STAGE_PER_WAVE];
     __shared__ uint32_t s_stage_kmer[WAVES][STAGE_PER_WAVE];
-    __shared__ uint64_t s_filter[ScanShape<LDSF>::FILTER_BLOCKS];
+    __shared__ uint2 s_filter[ScanShape<LDSF>::FILTER_BLOCKS];
+    const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
     if (LDSF) {
-        for (uint32_t i = threadIdx.x; i < idx.lds_filter_blocks; i += blockDim.x) s_filter[i] = idx.lds_filter[i];
+        const uint2 *src = reinterpret_cast<const uint2 *>(idx.lds_filter);
+        for (uint32_t i = threadIdx.x; i < idx.lds_filter_blocks; i += blockDim.x) s_filter[i] = src[i];
         __syncthreads();
     }
     uint32_t checksum = 0;
@@ -105,45 +110,51 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
         if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
         const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
         if (MODE == 2) { checksum += v.x ^ v.y ^ v.z ^ v.w ^ next; continue; }
+        uint32_t sel[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t lo = w[k], hi = w[k + 1];
             // 2-bit lanes: x = c[p] ^ c[p+1] ^ c[p+3] for the 16 positions of this word
             const uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, lo, 2) ^ __builtin_amdgcn_alignbit(hi, lo, 6);
-            uint32_t sel = x & ~(x >> 1) & 0x55555555u;  // value 01: low bit set, high bit clear
-            const uint64_t both = ((uint64_t)hi << 32) | lo;
-            const uint64_t word_base = (uint64_t)((u << 2) + k) << 4;  // batch-wide position of the word's first base
-            while (__any(sel != 0)) {  // wave-uniform: lanes that ran out of selected positions idle along
-                // up to PROBES selected positions at a time: all their filter words are requested before any is
-                // looked at, so a lane keeps several independent L2 reads in flight
-                uint32_t filt[PROBES], kmers[PROBES];
-                int bit[PROBES];
+            sel[k] = x & ~(x >> 1) & 0x55555555u;  // value 01: low bit set, high bit clear
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t w0 = w[2 * half], w1 = w[2 * half + 1], w2 = w[2 * half + 2];
+            uint32_t m = sel[2 * half] | (sel[2 * half + 1] << 1);  // bit 2i: word 0 position i; bit 2i + 1: word 1 position i
+            const uint64_t half_base = (uint64_t)((u << 2) + 2 * half) << 4;  // batch-wide position of the half's first base
+            while (__any(m != 0)) {  // wave-uniform: a lane that ran out of selected positions idles along
+                uint32_t kmers[PROBES], pos[PROBES], pass[PROBES];
+                uint2 got[PROBES];
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
-                    const bool have = sel != 0;
-                    bit[j] = have ? __builtin_ctz(sel) : 0;
-                    sel &= sel - 1;  // no-op once sel is 0
-                    const uint32_t kmer = kmers[j] = (uint32_t)(both >> bit[j]) & KP_KMER_MASK;
+                    const bool have = m != 0;
+                    const int bit = have ? __builtin_ctz(m) : 0;
+                    m &= m - 1;  // no-op once m is 0
+                    const bool odd = bit & 1;
+                    const uint32_t lo = odd ? w1 : w0, hi = odd ? w2 : w1;
+                    const uint32_t kmer = kmers[j] = __builtin_amdgcn_alignbit(hi, lo, bit & 30) & KP_KMER_MASK;
+                    pos[j] = (uint32_t)(bit >> 1) + (odd ? 16u : 0u);
+                    pass[j] = have ? 1u : 0u;
+                    if (MODE == 1) { checksum += have ? kmer * 2654435769u : 0u; continue; }
                     const uint32_t blk = LDSF ? kp_lds_filter_block(kmer, idx.lds_filter_blocks) : kp_filter_block(kmer);
-                    const uint64_t need = kp_filter_mask(kmer);
-                    if (MODE == 1) { checksum += have ? blk + (uint32_t)need : 0u; filt[j] = 0; continue; }
-                    const uint64_t got = LDSF ? s_filter[blk] : (have ? idx.filter[blk] : 0ull);
-                    filt[j] = (have && (got & need) == need) ? 1u : 0u;
+                    got[j] = LDSF ? s_filter[blk] : (have ? g_filter[blk] : make_uint2(0u, 0u));
                 }
                 if (MODE != 0) continue;
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
-                    const unsigned long long pass = __ballot(filt[j] != 0);
-                    if (!pass) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
-                    if (filt[j]) {
-                        const uint32_t at = staged + (uint32_t)__builtin_popcountll(pass & below);
-                        stage[at] = word_base + (uint64_t)(bit[j] >> 1);
+                    const uint2 need = kp_filter_mask2(kmers[j]);
+                    const bool hit = pass[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
+                    const unsigned long long ballot = __ballot(hit);
+                    if (!ballot) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
+                    if (hit) {
+                        const uint32_t at = staged + (uint32_t)__builtin_popcountll(ballot & below);
+                        stage[at] = half_base + pos[j];
                         stage_kmer[at] = kmers[j];  // the expansion pass does not have to touch the bases again
                     }
-                    staged += (uint32_t)__builtin_popcountll(pass);
-                    if (LDSF && staged > STAGE_PER_WAVE - 64) flush();
+                    staged += (uint32_t)__builtin_popcountll(ballot);
                 }
-                if (!LDSF && staged > STAGE_PER_WAVE - 64 * PROBES) flush();
+                if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
             }
         }
     }
