@@ -203,6 +203,35 @@ KP_API int kp_batch_typing(kp_ctx *ctx, kp_batch *batch, kp_asm_summary *summari
 /* Translated proteins of one assembly (kp_kept.prot_off/prot_len index into it); returns bytes copied. */
 KP_API int kp_batch_proteins(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint8_t *out, int64_t cap);
 
+/* ---- report rows (host only) -----------------------------------------------------------------------------------------------
+ * Replaces KaptiveRow.from_result + bytes(row) per genome (src/kaptive/serotyping/io.py:191-296, 37-43): the TSV lines
+ * of a whole batch from the records kp_batch_typing returned and the per-assembly decisions the caller finished
+ * (phenotype rules, typeability, problems: src/kaptive/serotyping/core.py:398-459, models.py:538-558).  Strings are
+ * byte blobs with n + 1 offsets.  Returns the number of bytes the rows need (written to `out` while they fit `cap`), or
+ * a negative error code.  No GPU involved. */
+typedef struct kp_row_tables {   /* per database */
+    const char *prefix;          /* "<Kaptive version>\t<database name>\t<database version>\t" */
+    int32_t prefix_len;
+    const char *gene_ids;        /* Database.genes.ids */
+    const int32_t *gene_id_off;
+    const char *locus_names;     /* Database.loci.ids */
+    const int32_t *locus_name_off;
+    const int32_t *locus_gene_off, *locus_gene_len;
+} kp_row_tables;
+typedef struct kp_row_columns {  /* per assembly of the batch */
+    const char *asm_ids;
+    const int32_t *asm_id_off;
+    const char *phenotypes;      /* Best match type */
+    const int32_t *phenotype_off;
+    const int32_t *best_locus;
+    const uint8_t *typeable;
+    const int32_t *problems;     /* bit 0..4 = ? + - * ! */
+    const double *identity, *coverage, *length_discrepancy; /* NaN discrepancy -> n/a */
+} kp_row_columns;
+KP_API int64_t kp_format_rows(const kp_row_tables *tables, int32_t n_asm, const kp_asm_summary *summaries,
+                              const kp_kept *kept, int32_t kept_stride, const kp_row_columns *columns, char *out,
+                              int64_t cap);
+
 /* ---- protein alignment ------------------------------------------------------------------------------------------
  * Replaces PairwiseAligner.__call__ / _batched_banded_gotoh (src/kaptive/core/pairwise.py:255-325, 395-584) in its
  * unseeded mode with the defaults gap_open 11, gap_extend 1, k 20.  Sequences are raw bytes (amino-acid letters).

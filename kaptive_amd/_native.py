@@ -29,6 +29,7 @@ EXPORTS = (
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_pack_contigs", "kp_fasta_free",
+    "kp_format_rows",
 )  # fmt: skip
 
 
@@ -89,6 +90,75 @@ class TypingTables(C.Structure):  # kp_typing_tables
     _fields_ = [("gene_locus", C.c_void_p), ("gene_extra", C.c_void_p), ("gene_pos", C.c_void_p),
                 ("gene_strand", C.c_void_p), ("locus_gene_off", C.c_void_p), ("locus_gene_len", C.c_void_p),
                 ("n_loci", C.c_int32), ("prot", C.c_void_p), ("prot_off", C.c_void_p), ("prot_len", C.c_void_p)]  # fmt: skip
+
+
+class RowTables(C.Structure):  # kp_row_tables
+    _fields_ = [("prefix", C.c_char_p), ("prefix_len", C.c_int32), ("gene_ids", C.c_void_p), ("gene_id_off", C.c_void_p),
+                ("locus_names", C.c_void_p), ("locus_name_off", C.c_void_p), ("locus_gene_off", C.c_void_p),
+                ("locus_gene_len", C.c_void_p)]  # fmt: skip
+
+
+class RowColumns(C.Structure):  # kp_row_columns
+    _fields_ = [("asm_ids", C.c_void_p), ("asm_id_off", C.c_void_p), ("phenotypes", C.c_void_p),
+                ("phenotype_off", C.c_void_p), ("best_locus", C.c_void_p), ("typeable", C.c_void_p),
+                ("problems", C.c_void_p), ("identity", C.c_void_p), ("coverage", C.c_void_p),
+                ("length_discrepancy", C.c_void_p)]  # fmt: skip
+
+
+def _blob(strings) -> tuple[np.ndarray, np.ndarray]:
+    """utf-8 strings -> (bytes back to back, n + 1 offsets)."""
+    enc = [s if isinstance(s, bytes) else str(s).encode("utf-8") for s in strings]
+    off = np.zeros(len(enc) + 1, np.int32)
+    if enc:
+        np.cumsum([len(e) for e in enc], out=off[1:])
+    return np.frombuffer(b"".join(enc) or b"\0", np.uint8), off
+
+
+class RowFormatter:
+    """KaptiveRow bytes for whole batches (kp_format_rows); the database's string tables are prepared once."""
+
+    def __init__(self, db, kaptive_version: str) -> None:
+        meta = db.metadata
+        self._prefix = f"{kaptive_version}\t{meta.name}\t{meta.version}\t".encode("utf-8")
+        self._keep = dict(
+            gene_ids=_blob(db.genes.ids), locus_names=_blob(db.loci.ids),
+            locus_gene_off=_c(db.locus_gene_offsets, np.int32), locus_gene_len=_c(db.locus_gene_lengths, np.int32),
+        )  # fmt: skip
+        k = self._keep
+        self._tables = RowTables(
+            prefix=self._prefix, prefix_len=len(self._prefix), gene_ids=_p(k["gene_ids"][0]).value,
+            gene_id_off=_p(k["gene_ids"][1]).value, locus_names=_p(k["locus_names"][0]).value,
+            locus_name_off=_p(k["locus_names"][1]).value, locus_gene_off=_p(k["locus_gene_off"]).value,
+            locus_gene_len=_p(k["locus_gene_len"]).value,
+        )  # fmt: skip
+
+    def format(self, ids, phenotypes, sums, kept, best_locus, typeable, problems, identity, coverage, discrepancy) -> bytes:
+        n = len(sums)
+        if n == 0:
+            return b""
+        ids_b, ids_o = _blob(ids)
+        ph_b, ph_o = _blob(phenotypes)
+        cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
+                    identity=_c(identity, np.float64), coverage=_c(coverage, np.float64),
+                    discrepancy=_c(discrepancy, np.float64))  # fmt: skip
+        c = RowColumns(asm_ids=_p(ids_b).value, asm_id_off=_p(ids_o).value, phenotypes=_p(ph_b).value,
+                       phenotype_off=_p(ph_o).value, best_locus=_p(cols["best"]).value, typeable=_p(cols["typeable"]).value,
+                       problems=_p(cols["problems"]).value, identity=_p(cols["identity"]).value,
+                       coverage=_p(cols["coverage"]).value, length_discrepancy=_p(cols["discrepancy"]).value)  # fmt: skip
+        sums, kept = np.ascontiguousarray(sums), np.ascontiguousarray(kept)
+        stride = kept.shape[1] if kept.ndim == 2 else 0
+        h = lib()
+        h.kp_format_rows.restype = C.c_int64
+        out = np.empty(max(4096, 1200 * n), np.uint8)
+        for _ in range(2):
+            need = h.kp_format_rows(C.byref(self._tables), C.c_int32(n), _p(sums), _p(kept), C.c_int32(stride), C.byref(c),
+                                    _p(out), C.c_int64(len(out)))
+            if need < 0:
+                raise ValueError(f"kp_format_rows failed ({need})")
+            if need <= len(out):
+                return out[:need].tobytes()
+            out = np.empty(int(need), np.uint8)
+        raise NativeError("kp_format_rows: size kept changing")
 
 
 class TypingParams(C.Structure):  # kp_typing_params

@@ -205,8 +205,16 @@ class BatchTyping:
         return [bytes(KaptiveRow.from_result(self.result(i))) for i in range(len(self))]
 
     def tsv(self) -> bytes:
-        """The TSV lines of the whole batch as one byte string (what ``kaptive assembly -o`` appends per batch)."""
-        return b"".join(self.rows())
+        """The TSV lines of the whole batch as one byte string (what ``kaptive assembly -o`` appends per batch), formatted
+        by the native library from the device records and the columns above (kp_format_rows); byte for byte what
+        ``KaptiveRow.from_result`` gives for ``result(i)`` (reference: src/kaptive/serotyping/io.py:191-296)."""
+        fmt = getattr(self.typer, "_row_formatter", None)
+        if fmt is None:
+            from kaptive_amd import KAPTIVE_COMPAT_VERSION, _native
+
+            fmt = self.typer._row_formatter = _native.RowFormatter(self.typer._db, KAPTIVE_COMPAT_VERSION)
+        return fmt.format(self.ids, self.phenotype, self.sums, self.kept, self.best_locus, self.typeable, self.problems,
+                          self.percent_identity, self.percent_coverage, self.length_discrepancy)  # fmt: skip
 
 
 class _HitsView:

@@ -106,6 +106,13 @@ def test_batch_columns_match_reference(key, oracle):
                          ("best_score", res.best_locus_score)):  # fmt: skip
             assert np.float64(getattr(bt, col)[i]).tobytes() == np.float64(val).tobytes(), (names[i], col)
         assert bt.n_hits[i] == len(res.gene_hits) and bt.n_pieces[i] == len(res.locus_pieces)
+    # the native batch formatter (kp_format_rows) gives the reference's TSV bytes for every assembly, in one call
+    from kaptive_amd import KAPTIVE_COMPAT_VERSION
+
+    want = b"".join(bytes(exp["kaptive_row"]).replace(scalars["kaptive_version"].encode(), KAPTIVE_COMPAT_VERSION.encode(), 1)
+                    for exp, scalars in exps)
+    assert bt.tsv() == want
+    assert bt.tsv() == b"".join(bt.rows())
 
 
 def test_float32_sum_has_numpys_association():
