@@ -1,0 +1,80 @@
+/* kp_mapq.h -- mapping quality of a primary hit (kp-align v2), shared by the HIP kernels and the CPU oracle.
+ *
+ * Modelled on minimap2's mm_set_mapq (the published source of the aligner the reference's rammappy wheel is described as
+ * following: docs/serotyping/method.md:23-28 "minimap2-based"), restated from its formula with the quantities this
+ * aligner has: the reported alignment score stands for minimap2's chain score and DP score alike, the seeds of the band
+ * task for the chain's anchor count, the best secondary's score for subsc / dp_max2.  It cannot be checked against
+ * rammappy here (parity unpinned); what it buys is a mapq that varies with the evidence instead of
+ * the round-1 constant 60 / 0.  The reference reads mapq only as the third cull key (src/kaptive/core/alignment.py:669-675).
+ *
+ *   pen_s1 = score > 100 ? 1 : 0.01 * score            pen_cm = seeds > 10 ? 1 : 0.1 * seeds;  pen_cm = min(pen_s1, pen_cm)
+ *   identity = matches / block_len                     subsc = max(sub, KP_MIN_CHAIN_SCORE)
+ *   sub > 0:  x = sub * subsc / score / score;  q = identity * pen_cm * 40 * (1 - x * x) * ln(score / match)
+ *             q = min(q, int(6.02 * identity^2 * (score - sub) / match + 0.499))
+ *   else:     x = subsc / score;                q = identity * pen_cm * 40 * (1 - x) * ln(score / match)
+ *   q -= int(4.343 * ln(n_sub + 1) + 0.499);  clamp to [0, 60];  q == 0 and score > sub -> 1
+ *
+ * All arithmetic is float32 in exactly this order (no fused multiply-add: the function switches contraction off for
+ * clang; gcc in ISO C mode does not contract).  The two logarithms come from tables the caller fills with logf on the
+ * host (ln_half[i] = logf(i / 2.0f), ln_int[i] = logf(i)), so device and host see the same values.
+ */
+#ifndef KP_MAPQ_H
+#define KP_MAPQ_H
+
+#include <stdint.h>
+
+#include "kp_spec.h"
+
+#ifndef KP_MAPQ_FN
+#define KP_MAPQ_FN static inline
+#endif
+
+#define KP_MAPQ_LN_HALF_SIZE 131072 /* scores are at most 2 * KP_MAX_GENE_LEN plus the two-piece credit of long gaps */
+#define KP_MAPQ_LN_INT_SIZE 4096
+
+KP_MAPQ_FN int kp_mapq_value(int score, int seeds, int matches, int block_len, int sub, int n_sub, const float *ln_half,
+                             const float *ln_int) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const float pen_s1 = score > 100 ? 1.0f : 0.01f * (float)score;
+    float pen_cm = seeds > 10 ? 1.0f : 0.1f * (float)seeds;
+    pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+    const float identity = (float)matches / (float)block_len;
+    const int subsc = sub > KP_MIN_CHAIN_SCORE ? sub : KP_MIN_CHAIN_SCORE;
+    const float lg = ln_half[score < KP_MAPQ_LN_HALF_SIZE ? score : KP_MAPQ_LN_HALF_SIZE - 1];
+    int q;
+    if (sub > 0) {
+        const float x = (float)sub * (float)subsc / (float)score / (float)score;
+        float v = identity * pen_cm;
+        v = v * 40.0f;
+        v = v * (1.0f - x * x);
+        v = v * lg;
+        q = (int)v;
+        float alt = 6.02f * identity;
+        alt = alt * identity;
+        alt = alt * (float)(score - sub);
+        alt = alt / (float)KP_SC_MATCH;
+        alt = alt + 0.499f;
+        const int q_alt = (int)alt;
+        q = q < q_alt ? q : q_alt;
+    } else {
+        const float x = (float)subsc / (float)score;
+        float v = identity * pen_cm;
+        v = v * 40.0f;
+        v = v * (1.0f - x);
+        v = v * lg;
+        q = (int)v;
+    }
+    {
+        float pen = 4.343f * ln_int[(n_sub + 1) < KP_MAPQ_LN_INT_SIZE ? (n_sub + 1) : KP_MAPQ_LN_INT_SIZE - 1];
+        pen = pen + 0.499f;
+        q -= (int)pen;
+    }
+    q = q > 0 ? q : 0;
+    q = q < 60 ? q : 60;
+    if (q == 0 && score > sub) q = 1;
+    return q;
+}
+
+#endif /* KP_MAPQ_H */

@@ -1,4 +1,4 @@
-/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v1") and of the packed data layout.
+/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v2") and of the packed data layout.
  *
  * The reference delegates gene-vs-contig alignment to the third-party rammappy 0.1.3 wheel
  * (src/kaptive/serotyping/core.py:147-155), whose source is not in the reference tree; parity at that stage is
@@ -65,13 +65,25 @@
  * F (gap in target, moves along the query) = max(Hup - (O+X), Fup - X).  Opening wins ties against extending; the
  * diagonal wins ties against E, E against F; a cell whose best is <= 0 is a restart cell.  The reported cell is the
  * first maximum in (query row, target column) order.  Cells outside the band or the contig read as H=0, E=F=-inf.
- * Hits scoring below KP_MIN_DP_SCORE are dropped. */
+ * Hits whose cell score is below KP_MIN_DP_SCORE are dropped.
+ *
+ * The recurrence charges a gap of length n with KP_GAP_OPEN + n * KP_GAP_EXT (minimap2's first affine piece).  The score a
+ * hit REPORTS is that of its path under minimap2's two-piece cost min(4 + 2n, 24 + n): every gap longer than
+ * KP_GAP_LONG = 20 columns is credited n - 20 during the traceback (minimap2 itself re-scores the finished path with the
+ * two-piece cost for its reported DP score).  Gaps that long need a 32-diagonal band or wider and are rare; the path is
+ * still the one-piece optimum. */
 #define KP_SC_MATCH 2
 #define KP_SC_MISMATCH (-4)
 #define KP_SC_N (-1) /* either base is N */
 #define KP_GAP_OPEN 4
 #define KP_GAP_EXT 2
+#define KP_GAP_OPEN2 24
+#define KP_GAP_EXT2 1
+#define KP_GAP_LONG ((KP_GAP_OPEN2 - KP_GAP_OPEN) / (KP_GAP_EXT - KP_GAP_EXT2)) /* from here on the second piece is cheaper */
 #define KP_MIN_DP_SCORE 80
+#define KP_MIN_CHAIN_SCORE 40 /* minimap2 -m: floor of the secondary score in the mapping quality (kp_mapq.h) */
+#define KP_MASK_LEVEL_NUM 1   /* a hit is secondary to a better hit of its gene that covers more than */
+#define KP_MASK_LEVEL_DEN 2   /* KP_MASK_LEVEL_NUM / KP_MASK_LEVEL_DEN of the shorter one's query span (minimap2 -M 0.5) */
 #define KP_NEG_INF (-(1 << 29))
 
 /* ---- protein alignment (restates src/kaptive/core/pairwise.py:395-584) ------------------------------------------------ */
@@ -82,7 +94,11 @@
 #define KP_PROT_FILL (-128) /* BLOSUM62 lookup value for bytes outside ARNDCQEGHILKMFPSTWYVBJZX* */
 
 /* ---- hit record (one per reported alignment; emission order: gene asc, score desc, contig asc, t_start asc,
- * forward strand first, q_start asc; exact duplicates are emitted once) -------------------------------------------- */
+ * forward strand first, q_start asc, q_end asc, t_end asc, matches desc, block_len asc, seeds desc; hits with the same
+ * span -- gene, contig, strand and both intervals -- are emitted once, the first of them in that order).
+ * Mapping quality: walking a gene's hits in emission order, a hit is SECONDARY (mapq 0) when its query span overlaps
+ * that of an earlier primary hit of the gene by more than KP_MASK_LEVEL of the shorter span; it then counts towards that
+ * primary's n_sub and best secondary score.  Every other hit is PRIMARY, mapq = kp_mapq_value (kp_mapq.h). ------------ */
 typedef struct kp_hit {
     int32_t gene;    /* database gene index */
     int32_t contig;  /* contig index within the assembly */
@@ -94,8 +110,9 @@ typedef struct kp_hit {
     int32_t matches;   /* identical aligned bases */
     int32_t block_len; /* alignment columns */
     int8_t strand;     /* +1 / -1 */
-    uint8_t mapq;      /* 60 for the first (best) hit of a gene in emission order, else 0 */
-    uint8_t pad_[2];
+    uint8_t mapq;      /* kp_mapq.h; 0 for secondary hits */
+    uint8_t n_seeds;   /* anchors of the band task behind the hit, capped at 255 */
+    uint8_t pad_;
 } kp_hit;
 
 /* ---- records of the batched reduction (one assembly = one summary, its kept hits and its locus pieces) ------------------

@@ -15,7 +15,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
 
 HIT_DTYPE = np.dtype(
     [("gene", "<i4"), ("contig", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("t_start", "<i4"), ("t_end", "<i4"),
-     ("score", "<i4"), ("matches", "<i4"), ("block_len", "<i4"), ("strand", "i1"), ("mapq", "u1"), ("pad", "u1", 2)]
+     ("score", "<i4"), ("matches", "<i4"), ("block_len", "<i4"), ("strand", "i1"), ("mapq", "u1"), ("n_seeds", "u1"), ("pad", "u1")]
 )  # fmt: skip
 TASK_DTYPE = np.dtype(
     [("gs", "<i4"), ("contig", "<i4"), ("lo", "<i4"), ("width", "<i4"), ("n_anchors", "<i4"), ("qmin", "<i4"),

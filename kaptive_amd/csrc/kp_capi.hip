@@ -1,6 +1,7 @@
 // kp_capi.hip -- the C ABI of libkaptive_amd.so (include/kaptive_amd.h): context, resident database, batches,
 // orchestration of the alignment kernels on the context's stream, and host-side finalisation of the hit table.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +15,8 @@
 // kp_reduce.hip
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
-                            uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells, hipStream_t stream);
+                            uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells, const float *ln_half,
+                            const float *ln_int, hipStream_t stream);
 void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
                      const KpTypingDb &db, double min_cov, double *scores, int32_t *counts, hipStream_t stream);
 void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
@@ -221,6 +223,7 @@ struct kp_ctx {
     KpGenes genes{};
     // protein stage
     DevBuf<int8_t> d_blosum;
+    DevBuf<float> d_ln;  // logarithm tables of the mapping quality (kp_mapq.h): ln(i / 2), then ln(i), from the host's logf
     DevBuf<uint8_t> d_pq, d_pt;
     DevBuf<int32_t> d_pmeta, d_pout, d_pscratch;
     // sort scratch
@@ -498,7 +501,11 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     }
     std::vector<int8_t> m(256 * 256);
     fill_blosum(m.data());
-    if (upload(ctx, ctx->d_blosum, m.data(), m.size()) != KP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    std::vector<float> ln(KP_MAPQ_LN_HALF_SIZE + KP_MAPQ_LN_INT_SIZE, 0.0f);
+    for (int i = 1; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln[(size_t)i] = logf((float)i / 2.0f);
+    for (int i = 1; i < KP_MAPQ_LN_INT_SIZE; ++i) ln[(size_t)KP_MAPQ_LN_HALF_SIZE + i] = logf((float)i);
+    if (upload(ctx, ctx->d_blosum, m.data(), m.size()) != KP_OK || upload(ctx, ctx->d_ln, ln.data(), ln.size()) != KP_OK ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
         std::string msg = ctx->error;
         kp_ctx_destroy(ctx);
         return kp_fail(nullptr, KP_EHIP, "substitution table upload failed: " + msg);
@@ -521,7 +528,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (auto &w : ctx->work) w.release();
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
-    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_trace.release();
+    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_trace.release(); ctx->d_ln.release();
     for (auto &g : ctx->groups)
         if (g) g->release();
     ctx->groups.clear();
@@ -866,7 +873,7 @@ static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
         kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, w->d_tasks.p, w->d_results.p, w->d_counts.p + n_asm,
                                w->task_cap, w->d_hits_raw.p, w->d_hit_counts.p, w->hit_cap, w->d_keys.p, w->d_hits.p,
-                               w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->post);
+                               w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->d_ln.p, ctx->d_ln.p + KP_MAPQ_LN_HALF_SIZE, ctx->post);
         KP_HIP_CHECK(ctx, hipGetLastError());
         w->h_hit_counts.resize(2 * n_asm);
         unsigned long long cells = 0;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
         if (hit && slot < hit_cap) {
             const int32_t cs = b.ctg_start[b.asm_first_ctg[t.asm_id] + t.contig];
             raw[(size_t)t.asm_id * hit_cap + slot] =
-                kp_make_hit(t.gs, t.contig, cs, qlen, r.score, r.q_start, r.q_end, r.t_start, r.t_end, r.matches, r.block_len);
+                kp_make_hit(t.gs, t.contig, cs, qlen, r.score, r.q_start, r.q_end, r.t_start, r.t_end, r.matches, r.block_len,
+                            t.n_anchors);
         }
     }
     if (my_cells) atomicAdd(cells, my_cells);
@@ -67,13 +68,15 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
 // ---- 2. emission order, duplicates, mapq (kp_spec.h) -------------------------------------------------------------------
 // One block per assembly: rank sort (leading keys in LDS, every thread counts the hits that precede its own), then the
 // duplicate / mapq pass on neighbours of the sorted list (kp_same_span is an equivalence, so "equal to the last kept
-// hit" is "equal to the predecessor") with a block prefix sum for the compaction.  `raw` is scratch once the ranks are
+// hit" is "equal to the predecessor") with a block prefix sum for the compaction, then the mapping qualities per gene.  `raw` is scratch once the ranks are
 // known: the compacted list is built there and copied back.
 constexpr int SORT_THREADS = 256;
 
 __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__restrict__ raw, const uint32_t *__restrict__ n_raw,
                                                                    uint32_t hit_cap, uint64_t *__restrict__ keys,
-                                                                   kp_hit *__restrict__ hits, uint32_t *__restrict__ n_hits) {
+                                                                   kp_hit *__restrict__ hits, uint32_t *__restrict__ n_hits,
+                                                                   const float *__restrict__ ln_half,
+                                                                   const float *__restrict__ ln_int) {
     const int a = blockIdx.x, tid = threadIdx.x;
     uint32_t n = n_raw[a];
     if (n > hit_cap) n = hit_cap;
@@ -99,13 +102,14 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (o[u] < mine[0]) ++rank;
-                else if (o[u] == mine[0]) rank += kp_keys_less(k + 3 * (size_t)(j + u), j + u, mine, i) ? 1u : 0u;
+                else if (o[u] == mine[0])
+                    rank += kp_keys_less(k + 3 * (size_t)(j + u), src[j + u].n_seeds, j + u, mine, src[i].n_seeds, i) ? 1u : 0u;
             }
         }
         for (; j < n; ++j) {
             const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
             if (other < mine[0]) ++rank;
-            else if (other == mine[0]) rank += kp_keys_less(k + 3 * (size_t)j, j, mine, i) ? 1u : 0u;
+            else if (other == mine[0]) rank += kp_keys_less(k + 3 * (size_t)j, src[j].n_seeds, j, mine, src[i].n_seeds, i) ? 1u : 0u;
         }
         dst[rank] = src[i];
     }
@@ -126,14 +130,23 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
     uint32_t m = s_scan[tid] - kept;  // first output slot of this thread
     for (uint32_t i = lo; i < hi; ++i) {
         if (i > 0 && kp_same_span(dst[i - 1], dst[i])) continue;
-        kp_hit h = dst[i];
-        h.mapq = (i == 0 || dst[i - 1].gene != h.gene) ? 60 : 0;  // a dropped predecessor has its keeper's gene
-        src[m++] = h;
+        src[m++] = dst[i];
     }
     const uint32_t total = s_scan[SORT_THREADS - 1];
     __syncthreads();
     for (uint32_t i = tid; i < total; i += SORT_THREADS) dst[i] = src[i];
     if (tid == 0) n_hits[a] = total;
+    __syncthreads();
+    // mapping qualities: every gene's run of the list is walked by the thread that holds its first hit (a run is a few
+    // hits long: a gene, its fragments and its paralogues in one assembly); scratch = the sort keys, no longer needed
+    int32_t *scratch = reinterpret_cast<int32_t *>(k);  // 6 ints per hit row available, 3 used
+    for (uint32_t i = tid; i < total; i += SORT_THREADS) {
+        if (i > 0 && dst[i - 1].gene == dst[i].gene) continue;
+        uint32_t j = i + 1;
+        while (j < total && dst[j].gene == dst[i].gene) ++j;
+        kp_assign_mapq(dst + i, (int)(j - i), scratch + 3 * (size_t)i, scratch + 3 * (size_t)i + (j - i),
+                       scratch + 3 * (size_t)i + 2 * (size_t)(j - i), ln_half, ln_int);
+    }
 }
 
 // ---- 3. locus scores (core.py:164-198) ---------------------------------------------------------------------------------
@@ -380,12 +393,12 @@ void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, s
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells,
-                            hipStream_t stream) {
+                            const float *ln_half, const float *ln_int, hipStream_t stream) {
     if (b.n_asm == 0) return;
     hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
                        task_cap, raw, n_raw, hit_cap, cells);
     hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(SORT_THREADS), 0, stream, raw, n_raw, hit_cap, keys, hits,
-                       n_hits);
+                       n_hits, ln_half, ln_int);
 }
 
 void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,

@@ -17,6 +17,8 @@
 #else
 #define KP_HD inline
 #endif
+#define KP_MAPQ_FN KP_HD
+#include "../../include/kp_mapq.h"
 
 // ---- records (public layouts live in include/kp_spec.h) -----------------------------------------------------------------
 typedef kp_kept KpKept;
@@ -40,7 +42,7 @@ typedef struct KpTypingDb {  // device-resident views of the Database arrays the
 // ---- hit finalisation -----------------------------------------------------------------------------------------------
 // task result -> hit record (strand flip, contig-local coordinates); mapq is filled after sorting
 KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int score, int q_start, int q_end,
-                         int t_start, int t_end, int matches, int block_len) {
+                         int t_start, int t_end, int matches, int block_len, int n_anchors) {
     kp_hit h;
     const int rev = gs & 1;
     h.gene = gs >> 1; h.contig = contig;
@@ -48,7 +50,7 @@ KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int sc
     h.q_end = rev ? qlen - q_start : q_end;
     h.t_start = t_start - ctg_start; h.t_end = t_end - ctg_start;
     h.score = score; h.matches = matches; h.block_len = block_len;
-    h.strand = rev ? -1 : 1; h.mapq = 0; h.pad_[0] = h.pad_[1] = 0;
+    h.strand = rev ? -1 : 1; h.mapq = 0; h.n_seeds = (uint8_t)(n_anchors < 255 ? n_anchors : 255); h.pad_ = 0;
     return h;
 }
 
@@ -60,11 +62,41 @@ KP_HD void kp_hit_keys(const kp_hit &h, uint64_t k[3]) {
     k[2] = ((uint64_t)(uint32_t)h.t_end << 32) | ((uint64_t)(0xFFFFu - (uint32_t)h.matches) << 16) | (uint32_t)h.block_len;
 }
 
-KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t ia, const uint64_t b[3], uint32_t ib) {
+// (seeds: the last criterion of the emission order -- more seeds first; the records' own indices break what is left,
+// which are hits equal in every field)
+KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t seeds_a, uint32_t ia, const uint64_t b[3], uint32_t seeds_b, uint32_t ib) {
     if (a[0] != b[0]) return a[0] < b[0];
     if (a[1] != b[1]) return a[1] < b[1];
     if (a[2] != b[2]) return a[2] < b[2];
+    if (seeds_a != seeds_b) return seeds_a > seeds_b;
     return ia < ib;
+}
+
+// Primary / secondary and mapping quality of one gene's hits, in emission order (kp_spec.h).  `parent`, `sub`, `n_sub`:
+// scratch of n ints each.
+KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *sub, int32_t *n_sub, const float *ln_half,
+                          const float *ln_int) {
+    for (int i = 0; i < n; ++i) { sub[i] = 0; n_sub[i] = 0; }
+    for (int i = 0; i < n; ++i) {
+        parent[i] = i;
+        const int li = h[i].q_end - h[i].q_start;
+        for (int j = 0; j < i; ++j) {
+            if (parent[j] != j) continue;
+            const int lj = h[j].q_end - h[j].q_start;
+            const int ol = (h[i].q_end < h[j].q_end ? h[i].q_end : h[j].q_end) - (h[i].q_start > h[j].q_start ? h[i].q_start : h[j].q_start);
+            const int mn = li < lj ? li : lj;
+            if (ol > 0 && (int64_t)ol * KP_MASK_LEVEL_DEN > (int64_t)mn * KP_MASK_LEVEL_NUM) {
+                parent[i] = j;
+                if (h[i].score > sub[j]) sub[j] = h[i].score;
+                n_sub[j]++;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        h[i].mapq = parent[i] != i ? (uint8_t)0
+                                    : (uint8_t)kp_mapq_value(h[i].score, h[i].n_seeds, h[i].matches, h[i].block_len, sub[i],
+                                                             n_sub[i], ln_half, ln_int);
 }
 
 KP_HD bool kp_same_span(const kp_hit &x, const kp_hit &y) {

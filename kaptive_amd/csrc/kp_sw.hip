@@ -380,7 +380,7 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
         const int n_runs = b.asm_first_nrun[tk.asm_id + 1] - r0;
         const int32_t *runs = b.n_runs + 2 * (size_t)r0;
         const uint4 *tw = reinterpret_cast<const uint4 *>(trace) + e.trace_off;  // piece j of lane l at [j * P + l]
-        int r = e.er, bi = eb, state = 0, cols = 0, matches = 0, diag = 0, gap_cost = 0;
+        int r = e.er, bi = eb, state = 0, cols = 0, matches = 0, diag = 0, gap_cost = 0, gap = 0, credit = 0;
         int sr = r, sb = bi;
         // cur = the piece the walk stands in, nxt = the one before it in the same lane stream (requested ahead)
         uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
@@ -430,18 +430,19 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
                     state = (int)src - 1;  // 1 = E, 2 = F: the gap's columns are counted in that state
                 }
             } else if (state == 1) {  // E: gap in the query; this cell's E came from H (opened) or E (extended) of the left cell
-                ++cols; gap_cost += EX;
+                ++cols; ++gap; gap_cost += EX;
                 --bi;
-                if (nib & 2u) { state = 0; gap_cost += KP_GAP_OPEN; }
+                if (nib & 2u) { state = 0; gap_cost += KP_GAP_OPEN; credit += max(gap - KP_GAP_LONG, 0); gap = 0; }
             } else {  // F: gap in the target
-                ++cols; gap_cost += EX;
+                ++cols; ++gap; gap_cost += EX;
                 --r; ++bi;
-                if (nib & 1u) { state = 0; gap_cost += KP_GAP_OPEN; }
+                if (nib & 1u) { state = 0; gap_cost += KP_GAP_OPEN; credit += max(gap - KP_GAP_LONG, 0); gap = 0; }
             }
         }
         if (!have) continue;
         if (e.score < KP_MIN_DP_SCORE) { results[at] = out; continue; }
         if (!has_n) matches = (e.score + 4 * diag + gap_cost) / 6;
+        out.score = e.score + credit;  // the path under the two-piece gap cost (kp_spec.h): long gaps get their credit
         out.q_start = sr; out.q_end = e.er + 1;
         out.t_start = sr + tk.lo + sb; out.t_end = e.er + tk.lo + eb + 1;
         out.matches = matches; out.block_len = cols;

@@ -22,7 +22,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include "../include/kp_spec.h"
+#include "../include/kp_mapq.h"
 
 #define KPO_API __attribute__((visibility("default")))
 
@@ -427,7 +430,7 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
 /* Banded local alignment of one task with stored traceback.  out: score, q_start, q_end, t_start, t_end (query in the
  * orientation given, target in assembly coordinates), matches, block_len. */
 static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstart, int64_t cend, int lo, int w,
-                    int32_t *out7) {
+                    int32_t *out7 /* [8] */) {
     const size_t cells = (size_t)qlen * (size_t)w;
     int32_t *H = malloc(cells * 4), *E = malloc(cells * 4), *F = malloc(cells * 4);
     uint8_t *tH = malloc(cells), *tE = malloc(cells), *tF = malloc(cells);
@@ -462,6 +465,7 @@ static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstar
     }
     int r = best_r, b = best_b, state = 0, matches = 0, cols = 0;
     int sr = best_r, sb = best_b; /* first aligned cell seen so far */
+    int gap = 0, credit = 0;      /* columns of the gap being walked; two-piece credit of the gaps closed so far */
     while (best_s > 0) {
         if (state == 0) {
             if (!VALID(r, b) || tH[AT(r, b)] == 3) break;
@@ -472,20 +476,67 @@ static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstar
                 r--; /* diagonal: same band index, previous row */
             } else state = tb;
         } else if (state == 1) { /* E: came from the left (same row, target - 1) */
-            int tb = tE[AT(r, b)]; cols++; b--; if (tb == 0) state = 0;
+            int tb = tE[AT(r, b)]; cols++; gap++; b--;
+            if (tb == 0) { state = 0; if (gap > KP_GAP_LONG) credit += gap - KP_GAP_LONG; gap = 0; }
         } else { /* F: came from above (row - 1, same target => band index + 1) */
-            int tb = tF[AT(r, b)]; cols++; r--; b++; if (tb == 0) state = 0;
+            int tb = tF[AT(r, b)]; cols++; gap++; r--; b++;
+            if (tb == 0) { state = 0; if (gap > KP_GAP_LONG) credit += gap - KP_GAP_LONG; gap = 0; }
         }
     }
 #undef AT
 #undef VALID
-    out7[0] = best_s;
+    out7[0] = best_s; /* cell score of the one-piece recurrence: what KP_MIN_DP_SCORE is compared with */
+    out7[7] = best_s + credit; /* reported score: the path under the two-piece gap cost (kp_spec.h) */
     if (best_s > 0) {
         out7[1] = sr; out7[2] = best_r + 1;
         out7[3] = (int32_t)((int64_t)sr + lo + sb); out7[4] = (int32_t)((int64_t)best_r + lo + best_b + 1);
     } else out7[1] = out7[2] = out7[3] = out7[4] = 0;
     out7[5] = matches; out7[6] = cols;
     free(H); free(E); free(F); free(tH); free(tE); free(tF);
+}
+
+static const float *ln_half_table(void) {
+    static float *t = NULL;
+    if (!t) {
+        t = malloc(sizeof(float) * KP_MAPQ_LN_HALF_SIZE);
+        for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; i++) t[i] = i ? logf((float)i / 2.0f) : 0.0f;
+    }
+    return t;
+}
+static const float *ln_int_table(void) {
+    static float *t = NULL;
+    if (!t) {
+        t = malloc(sizeof(float) * KP_MAPQ_LN_INT_SIZE);
+        for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; i++) t[i] = i ? logf((float)i) : 0.0f;
+    }
+    return t;
+}
+
+/* primary / secondary and mapping quality of one gene's hits (emission order), kp_spec.h */
+static void assign_mapq(kp_hit *h, int n) {
+    int *parent = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *sub = calloc((size_t)(n > 0 ? n : 1), sizeof(int)),
+        *n_sub = calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    for (int i = 0; i < n; i++) {
+        parent[i] = i;
+        const int li = h[i].q_end - h[i].q_start;
+        for (int j = 0; j < i; j++) {
+            if (parent[j] != j) continue;
+            const int lj = h[j].q_end - h[j].q_start;
+            const int ol = (h[i].q_end < h[j].q_end ? h[i].q_end : h[j].q_end) - (h[i].q_start > h[j].q_start ? h[i].q_start : h[j].q_start);
+            const int mn = li < lj ? li : lj;
+            if (ol > 0 && (int64_t)ol * KP_MASK_LEVEL_DEN > (int64_t)mn * KP_MASK_LEVEL_NUM) {
+                parent[i] = j;
+                if (h[i].score > sub[j]) sub[j] = h[i].score;
+                n_sub[j]++;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n; i++)
+        h[i].mapq = parent[i] != i ? 0
+                                    : (uint8_t)kp_mapq_value(h[i].score, h[i].n_seeds, h[i].matches, h[i].block_len, sub[i], n_sub[i],
+                                                             ln_half_table(), ln_int_table());
+    free(parent); free(sub); free(n_sub);
 }
 
 static int cmp_hit(const void *a, const void *b) {
@@ -499,7 +550,8 @@ static int cmp_hit(const void *a, const void *b) {
     if (x->q_end != y->q_end) return x->q_end < y->q_end ? -1 : 1;
     if (x->t_end != y->t_end) return x->t_end < y->t_end ? -1 : 1;
     if (x->matches != y->matches) return x->matches > y->matches ? -1 : 1;
-    return x->block_len < y->block_len ? -1 : (x->block_len > y->block_len);
+    if (x->block_len != y->block_len) return x->block_len < y->block_len ? -1 : 1;
+    return x->n_seeds > y->n_seeds ? -1 : (x->n_seeds < y->n_seeds);
 }
 
 static int same_span(const kp_hit *x, const kp_hit *y) {
@@ -548,7 +600,9 @@ KPO_API int64_t kpo_sw(const kpo_db *db, const uint32_t *words, int64_t padded_l
         int g = t->gs >> 1, qlen = db->off[g + 1] - db->off[g];
         const uint8_t *q = ((t->gs & 1) ? db->rc : db->codes) + db->off[g];
         int64_t cs = ctg_start[t->contig];
-        sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, out7 + 7 * i);
+        int32_t r8[8];
+        sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, r8);
+        memcpy(out7 + 7 * i, r8, 7 * sizeof(int32_t));
     }
     free(a.codes);
     return n_tasks;
@@ -568,7 +622,7 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         int g = t->gs >> 1, rev = t->gs & 1, qlen = db->off[g + 1] - db->off[g];
         const uint8_t *q = (rev ? db->rc : db->codes) + db->off[g];
         int64_t cs = ctg_start[t->contig];
-        int32_t r[7];
+        int32_t r[8];
         sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, r);
         cells += (int64_t)qlen * t->width;
         if (r[0] < KP_MIN_DP_SCORE) continue;
@@ -578,15 +632,20 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         h->q_start = rev ? qlen - r[2] : r[1];
         h->q_end = rev ? qlen - r[1] : r[2];
         h->t_start = (int32_t)(r[3] - cs); h->t_end = (int32_t)(r[4] - cs);
-        h->score = r[0]; h->matches = r[5]; h->block_len = r[6];
+        h->score = r[7]; h->matches = r[5]; h->block_len = r[6];
+        h->n_seeds = (uint8_t)(t->n_anchors < 255 ? t->n_anchors : 255);
     }
     qsort(hits, (size_t)nh, sizeof(kp_hit), cmp_hit);
     int64_t m = 0;
-    for (int64_t i = 0; i < nh; i++) { /* drop exact duplicates, then mark the first hit of each gene */
+    for (int64_t i = 0; i < nh; i++) { /* hits with the same span are emitted once */
         if (m > 0 && same_span(&hits[m - 1], &hits[i])) continue;
-        hits[m] = hits[i];
-        hits[m].mapq = (m == 0 || hits[m - 1].gene != hits[m].gene) ? 60 : 0;
-        m++;
+        hits[m++] = hits[i];
+    }
+    for (int64_t i = 0; i < m;) { /* mapping qualities, gene by gene */
+        int64_t j = i;
+        while (j < m && hits[j].gene == hits[i].gene) j++;
+        assign_mapq(hits + i, (int)(j - i));
+        i = j;
     }
     if (out) memcpy(out, hits, (size_t)(m < cap ? m : cap) * sizeof(kp_hit));
     if (stats) { stats[0] = n; stats[1] = nt; stats[2] = cells; }

@@ -18,7 +18,7 @@ _LIB = None
 
 HIT_DTYPE = np.dtype(
     [("gene", "<i4"), ("contig", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("t_start", "<i4"), ("t_end", "<i4"),
-     ("score", "<i4"), ("matches", "<i4"), ("block_len", "<i4"), ("strand", "i1"), ("mapq", "u1"), ("pad", "u1", 2)]
+     ("score", "<i4"), ("matches", "<i4"), ("block_len", "<i4"), ("strand", "i1"), ("mapq", "u1"), ("n_seeds", "u1"), ("pad", "u1")]
 )  # fmt: skip
 TASK_DTYPE = np.dtype(
     [("gs", "<i4"), ("contig", "<i4"), ("lo", "<i4"), ("width", "<i4"), ("n_anchors", "<i4"), ("qmin", "<i4"),
@@ -30,7 +30,8 @@ def build(force: bool = False) -> Path:
     so = _HERE / "libkp_oracle.so"
     src = _HERE / "kp_oracle.c"
     spec = _HERE.parent / "include" / "kp_spec.h"
-    if force or not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, spec.stat().st_mtime):
+    mapq = _HERE.parent / "include" / "kp_mapq.h"
+    if force or not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, spec.stat().st_mtime, mapq.stat().st_mtime):
         subprocess.run(["make", "-C", str(_HERE), "-B", "libkp_oracle.so"], check=True, capture_output=True)
     return so
 
@@ -46,7 +47,7 @@ def build_native() -> str | None:
         return None
     out = Path(tempfile.gettempdir()) / f"libkp_oracle_native_{os.getpid()}.so"
     r = subprocess.run([cc, "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-fvisibility=hidden",
-                        f"-I{_HERE.parent / 'include'}", "-o", str(out), str(_HERE / "kp_oracle.c")], capture_output=True)
+                        f"-I{_HERE.parent / 'include'}", "-o", str(out), str(_HERE / "kp_oracle.c"), "-lm"], capture_output=True)
     return str(out) if r.returncode == 0 else None
 
 

@@ -2,6 +2,7 @@
 // the same sequence of core calls the HIP kernels of kp_reduce.hip make, serially.  It lets the GPU-less container
 // check the reduction logic against the golden vectors.  It is not part of the product and is never loaded by it.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -16,15 +17,25 @@ int kph_finalise_hits(kp_hit *hits, int n) {
     for (int i = 0; i < n; ++i) kp_hit_keys(raw[i], &keys[3 * (size_t)i]);
     for (int i = 0; i < n; ++i) {  // rank sort, as the kernel does
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += kp_keys_less(&keys[3 * (size_t)j], j, &keys[3 * (size_t)i], i);
+        for (int j = 0; j < n; ++j)
+            rank += kp_keys_less(&keys[3 * (size_t)j], raw[j].n_seeds, j, &keys[3 * (size_t)i], raw[i].n_seeds, i);
         sorted[(size_t)rank] = raw[i];
     }
     int m = 0;
     for (int i = 0; i < n; ++i) {
         if (m > 0 && kp_same_span(hits[m - 1], sorted[i])) continue;
-        hits[m] = sorted[i];
-        hits[m].mapq = (m == 0 || hits[m - 1].gene != hits[m].gene) ? 60 : 0;
-        ++m;
+        hits[m++] = sorted[i];
+    }
+    std::vector<float> ln_half(KP_MAPQ_LN_HALF_SIZE), ln_int(KP_MAPQ_LN_INT_SIZE);
+    for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln_half[i] = i ? logf((float)i / 2.0f) : 0.0f;
+    for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; ++i) ln_int[i] = i ? logf((float)i) : 0.0f;
+    std::vector<int32_t> scratch(3 * (size_t)(m > 0 ? m : 1));
+    for (int i = 0; i < m;) {
+        int j = i;
+        while (j < m && hits[j].gene == hits[i].gene) ++j;
+        kp_assign_mapq(hits + i, j - i, scratch.data(), scratch.data() + m, scratch.data() + 2 * (size_t)m, ln_half.data(),
+                       ln_int.data());
+        i = j;
     }
     return m;
 }
