@@ -84,8 +84,16 @@ typedef struct kp_packed_fasta {
     int32_t *n_run_pairs; /* 2 * n_runs */
     char *names;          /* contig names back to back (first word of each header), not NUL-terminated */
     int32_t *name_off;    /* n_contigs + 1 */
+    uint8_t *seqs;        /* KP_FASTA_KEEP_TEXT: the contigs' symbols as written, whitespace removed, back to back */
+    int64_t n_seq_bytes;  /*   (contig c = seqs[sum of ctg_len[0..c) .. + ctg_len[c]]); NULL / 0 otherwise */
 } kp_packed_fasta;
 KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
+/* The same from a file's bytes as they are on disk: KP_FASTA_GZIP inflates first (zlib; gzip or zlib framing, several
+ * members), KP_FASTA_KEEP_TEXT also returns the sequence text, which is what GenomeAssembly.from_file needs next to the
+ * packed form (src/kaptive/core/genome.py:194-214: open by suffix, read everything, parse). */
+#define KP_FASTA_GZIP 1
+#define KP_FASTA_KEEP_TEXT 2
+KP_API int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out);
 /* The same layout from contigs already in memory (Sequences.seqs / offsets / lengths of the reference's containers,
  * src/kaptive/core/seq.py:307-325): contig c is seqs[offsets[c] .. offsets[c] + lengths[c]).  names / name_off of the
  * result are empty. */

@@ -28,15 +28,16 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_pack_contigs", "kp_fasta_free",
-    "kp_format_rows",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_pack_contigs",
+    "kp_fasta_free", "kp_format_rows",
 )  # fmt: skip
 
 
 class PackedFasta(C.Structure):  # kp_packed_fasta
     _fields_ = [("padded_len", C.c_int64), ("n_contigs", C.c_int32), ("n_runs", C.c_int32),
                 ("words", C.POINTER(C.c_uint32)), ("ctg_start", C.POINTER(C.c_int32)), ("ctg_len", C.POINTER(C.c_int32)),
-                ("n_run_pairs", C.POINTER(C.c_int32)), ("names", C.POINTER(C.c_char)), ("name_off", C.POINTER(C.c_int32))]  # fmt: skip
+                ("n_run_pairs", C.POINTER(C.c_int32)), ("names", C.POINTER(C.c_char)), ("name_off", C.POINTER(C.c_int32)),
+                ("seqs", C.POINTER(C.c_uint8)), ("n_seq_bytes", C.c_int64)]  # fmt: skip
 
 
 def _packed_from(out, want_names: bool):
@@ -68,6 +69,25 @@ def pack_contigs(seqs: np.ndarray, offsets: np.ndarray, lengths: np.ndarray):
         raise ValueError("assembly too long for the packed layout (KP_MAX_ASM_LEN)")
     try:
         return _packed_from(out, False)[0]
+    finally:
+        h.kp_fasta_free(out)
+
+
+def fasta_ingest(data: bytes, gzipped: bool = False):
+    """A FASTA file's bytes -> (PackedAssembly, contig names, sequence text uint8, contig lengths int32) in one native
+    pass (kp_fasta_ingest: inflate if gzipped, split records, strip whitespace, pack; no GPU needed)."""
+    h = lib()
+    h.kp_fasta_free.restype = None
+    out = C.POINTER(PackedFasta)()
+    rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32((1 if gzipped else 0) | 2), C.byref(out))
+    if rc != 0:
+        raise ValueError(f"kp_fasta_ingest failed ({rc}): not a readable FASTA / gzip stream, or longer than KP_MAX_ASM_LEN")
+    try:
+        pa, names = _packed_from(out, True)
+        p = out.contents
+        n = int(p.n_seq_bytes)
+        seqs = np.ctypeslib.as_array(p.seqs, shape=(n,)).copy() if n else np.empty(0, np.uint8)
+        return pa, names, seqs, pa.ctg_len.copy()
     finally:
         h.kp_fasta_free(out)
 

@@ -124,8 +124,23 @@ class GenomeAssembly:
         m = _FASTA_NAME.search(filepath.name)
         if not m:
             raise NotImplementedError(f"Unsupported format: {filepath}")
-        with _OPENERS.get(m.group("compression"), open)(filepath, mode="rb") as handle:
-            return cls.from_stream(handle, filepath.name.removesuffix(m.group()))
+        # One native pass from the file's bytes to contigs + packed form (kp_fasta_ingest; zlib inflates .gz there).  The
+        # reference opens by suffix, reads everything and hands the bytes to rammappy's parser (genome.py:194-214, 35-46).
+        from kaptive_amd import _native
+
+        comp = m.group("compression")
+        if comp in ("bz2", "xz"):
+            with _OPENERS[comp](filepath, mode="rb") as handle:
+                data = handle.read()
+        else:
+            data = filepath.read_bytes()
+        pa, names, seqs, lengths = _native.fasta_ingest(data, gzipped=comp == "gz")
+        offsets = np.zeros(len(lengths), np.int32)
+        if len(lengths) > 1:
+            np.cumsum(lengths[:-1], out=offsets[1:])
+        g = cls(filepath.name.removesuffix(m.group()), Sequences(tuple(names), seqs, offsets, lengths.astype(np.int32)))
+        g._packed.append(pa)
+        return g
 
     @classmethod
     def from_stream(cls, handle: IO[bytes], id_: str | None = None) -> "GenomeAssembly":

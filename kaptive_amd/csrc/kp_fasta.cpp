@@ -5,6 +5,9 @@
 // row (f1).  Record name = first word of the header line; sequence = every following line up to the next '>' with
 // whitespace removed; A C G T/U (either case) -> 0..3, anything else is an N run.  No GPU involved; ctypes releases the
 // GIL, so callers pack many files from a thread pool.
+#include <zlib.h>
+
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -51,6 +54,38 @@ struct Packer {
     }
 };
 
+// gzip / zlib stream(s) -> bytes (concatenated gzip members are read through, as gzip.open does)
+int inflate_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
+    out.clear();
+    out.reserve((size_t)n * 4 + 1024);
+    int64_t at = 0;
+    while (at < n) {
+        z_stream z;
+        std::memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 15 + 32) != Z_OK) return KP_ENOMEM;  // + 32: gzip or zlib header, detected
+        z.next_in = const_cast<Bytef *>(data + at);
+        z.avail_in = (uInt)std::min<int64_t>(n - at, 1 << 30);
+        int rc = Z_OK;
+        while (rc != Z_STREAM_END) {
+            const size_t have = out.size();
+            out.resize(have + std::max<size_t>(1 << 20, have / 2));
+            z.next_out = out.data() + have;
+            z.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+            const size_t room = z.avail_out;
+            rc = inflate(&z, Z_NO_FLUSH);
+            out.resize(have + (room - z.avail_out));
+            if (rc != Z_OK && rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && z.avail_in > 0)) { inflateEnd(&z); return KP_EINVAL; }
+            if (rc == Z_BUF_ERROR && z.avail_in == 0) { inflateEnd(&z); return KP_EINVAL; }  // truncated input
+        }
+        at = (int64_t)(z.next_in - data);
+        inflateEnd(&z);
+        while (at < n && data[at] == 0) ++at;  // zero padding between / after members
+    }
+    return KP_OK;
+}
+
+int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **out);
+
 }  // namespace
 
 extern "C" {
@@ -58,12 +93,34 @@ extern "C" {
 int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
     if (!out || (n > 0 && !data) || n < 0) return KP_EINVAL;
     *out = nullptr;
+    return pack_text(data, n, false, out);
+}
+
+int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out) {
+    if (!out || (n > 0 && !data) || n < 0) return KP_EINVAL;
+    *out = nullptr;
+    if (flags & KP_FASTA_GZIP) {
+        std::vector<uint8_t> text;
+        const int rc = inflate_all(data, n, text);
+        if (rc) return rc;
+        return pack_text(text.data(), (int64_t)text.size(), (flags & KP_FASTA_KEEP_TEXT) != 0, out);
+    }
+    return pack_text(data, n, (flags & KP_FASTA_KEEP_TEXT) != 0, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **out) {
     // every '>' may open a contig (32-base alignment: at most two more words each); sequence bytes give <= n bases
     size_t marks = 0;
     for (const uint8_t *p = data, *e = data + n; p < e && (p = (const uint8_t *)std::memchr(p, '>', (size_t)(e - p))); ++p) ++marks;
     std::vector<uint32_t> words((size_t)n / 16 + 2 * marks + 8, 0u);
     std::vector<int32_t> ctg_start, ctg_len, runs, name_off;
     std::string names;
+    std::vector<uint8_t> dense;  // keep_text: the contigs' symbols as written (whitespace removed), back to back
+    if (keep_text) dense.reserve((size_t)n);
     Packer pk(words.data());
     int64_t i = 0;
     while (i < n && data[i] != '>') {  // text before the first header is ignored
@@ -75,6 +132,7 @@ int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
         for (; p < e; ++p) {
             const uint8_t c = T.code[*p];
             if (c == 8) continue;
+            if (keep_text) dense.push_back(*p);
             if (c == 4) {
                 if (!in_run) { runs.push_back((int32_t)pk.pos); runs.push_back((int32_t)pk.pos); in_run = true; }
                 runs.back() = (int32_t)pk.pos + 1;
@@ -111,7 +169,11 @@ int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
                     w |= (c & 3u) << (2 * k);
                 }
                 if (seen & 12u) slow(p, p + 16);
-                else { in_run = false; pk.put16(w); }
+                else {
+                    in_run = false;
+                    pk.put16(w);
+                    if (keep_text) dense.insert(dense.end(), p, p + 16);
+                }
             }
             slow(p, e);
             if (pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
@@ -140,13 +202,19 @@ int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
     r->n_run_pairs = (int32_t *)dup(runs.data(), runs.size() * 4);
     r->names = (char *)dup(names.data(), names.size());
     r->name_off = (int32_t *)dup(name_off.data(), name_off.size() * 4);
-    if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off) {
+    r->seqs = keep_text ? (uint8_t *)dup(dense.data(), dense.size()) : nullptr;
+    r->n_seq_bytes = keep_text ? (int64_t)dense.size() : 0;
+    if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off || (keep_text && !r->seqs)) {
         kp_fasta_free(r);
         return KP_ENOMEM;
     }
     *out = r;
     return KP_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 // Contigs that are already in memory (one byte per base, back to back) -> the same packed layout; names stay with the
 // caller.  Every byte is a base here: whatever is not A C G T/U belongs to an N run.
@@ -212,6 +280,8 @@ int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *
     r->ctg_len = (int32_t *)dup(ctg_len.data(), ctg_len.size() * 4);
     r->n_run_pairs = (int32_t *)dup(runs.data(), runs.size() * 4);
     r->names = (char *)dup("", 0);
+    r->seqs = nullptr;
+    r->n_seq_bytes = 0;
     const int32_t zero = 0;
     r->name_off = (int32_t *)dup(&zero, 4);
     if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off) {
@@ -225,7 +295,7 @@ int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *
 void kp_fasta_free(kp_packed_fasta *p) {
     if (!p) return;
     std::free(p->words); std::free(p->ctg_start); std::free(p->ctg_len); std::free(p->n_run_pairs);
-    std::free(p->names); std::free(p->name_off);
+    std::free(p->names); std::free(p->name_off); std::free(p->seqs);
     delete p;
 }
 

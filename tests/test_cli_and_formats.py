@@ -9,6 +9,7 @@ import pytest
 from kaptive_amd import _native
 from kaptive_amd.cli import build_parser, result_to_json, run_convert
 from kaptive_amd.core.genome import GenomeAssembly, parse_fasta_bytes
+from kaptive_amd.core.seq import SeqRecord, Sequences
 from kaptive_amd.db import Database
 from kaptive_amd.db.genbank import database_from_genbank, write_genbank
 from kaptive_amd.serotyping.io import KaptiveRow
@@ -168,3 +169,40 @@ def test_cli_parser_matches_reference_flags():
     assert e.tsv == "stdout"
     f = ap.parse_args(["convert", "r.jsonl", "-t", "x.tsv", "-g", "genes"])
     assert f.tsv == "x.tsv" and f.genes == Path("genes")
+
+
+def test_from_file_goes_through_the_native_ingest(tmp_path):
+    """GenomeAssembly.from_file = one native pass (kp_fasta_ingest: zlib for .gz, record split, whitespace strip, 2-bit
+    pack).  Contigs and packed form equal what the numpy parser + kp_pack_contigs give, for every suffix the reference
+    opens (src/kaptive/core/genome.py:194-214), odd formatting, several gzip members; a truncated stream raises."""
+    import bz2
+    import gzip
+    import lzma
+
+    db = make_db("kpsc_k", seed=7, n_loci=3)
+    genome = make_assembly(db, seed=3, length=300_000, median_contigs=9, n_run=40)
+    fa = genome.contigs.to_fasta()
+    messy = (b"junk before\r\n" + fa[:20000].replace(b"\n", b"\r\n") + b">empty\n>sp ace desc\nAC GT\tNNRY acgu\n" + fa[20000:])
+    for stem, data in (("a.fasta", fa), ("b.fna", messy)):
+        recs = parse_fasta_bytes(data)
+        want = Sequences.from_records([SeqRecord(n, s) for n, s in recs])
+        want_packed = _native.pack_contigs(want.seqs, want.offsets, want.lengths)
+        for ext, squeeze in (("", None), (".gz", gzip.compress), (".bz2", bz2.compress), (".xz", lzma.compress)):
+            path = tmp_path / (stem + ext)
+            path.write_bytes(squeeze(data) if squeeze else data)
+            got = GenomeAssembly.from_file(path)
+            assert got.id == stem.rsplit(".", 1)[0] and got.contigs.ids == want.ids, path
+            assert np.array_equal(got.contigs.seqs, want.seqs) and np.array_equal(got.contigs.offsets, want.offsets)
+            assert np.array_equal(got.contigs.lengths, want.lengths)
+            pg = got.packed()
+            assert np.array_equal(pg.words, want_packed.words) and np.array_equal(pg.n_runs, want_packed.n_runs)
+            assert np.array_equal(pg.ctg_start, want_packed.ctg_start) and pg.padded_len == want_packed.padded_len
+    two = tmp_path / "two.fa.gz"
+    two.write_bytes(gzip.compress(fa[:10000]) + gzip.compress(fa[10000:]))
+    assert np.array_equal(GenomeAssembly.from_file(two).contigs.seqs, genome.contigs.seqs)
+    cut = tmp_path / "cut.fa.gz"
+    cut.write_bytes(gzip.compress(fa)[:3000])
+    with pytest.raises(ValueError):
+        GenomeAssembly.from_file(cut)
+    with pytest.raises(NotImplementedError):
+        GenomeAssembly.from_file(tmp_path / "x.txt")
