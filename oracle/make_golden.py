@@ -323,9 +323,38 @@ def save_case(name, key, genome, hits, exp) -> None:
     )  # fmt: skip
 
 
+def gen_genbank() -> None:
+    """tests/golden/db_genbank_expected.npz: what the REFERENCE's Database.from_genbank (src/kaptive/db/core.py:289-507)
+    compiles from the hand-written tests/golden/handwritten_db.gbk + .toml.  The gb-io wheel is absent here, so the
+    flat file reaches the reference through oracle/refshim/gb_io (this repository's reader behind gb-io's record
+    surface): every derived array -- ids, positions, vocabularies, intervals, gene and protein sequences, phenotype
+    masks -- is the reference's own output."""
+    db = RefDatabase.from_genbank(OUT / "handwritten_db.gbk")
+    ph = db.phenotypes
+    np.savez_compressed(
+        OUT / "db_genbank_expected.npz",
+        locus_ids=np.array(db.loci.ids), serotypes=np.array(db.serotypes), gene_ids=np.array(db.genes.ids),
+        loci_seqs=db.loci.seqs, loci_offsets=db.loci.offsets, loci_lengths=db.loci.lengths,
+        gene_seqs=db.genes.seqs, gene_offsets=db.genes.offsets, gene_lengths=db.genes.lengths,
+        prot_seqs=db.translations.seqs, prot_offsets=db.translations.offsets, prot_lengths=db.translations.lengths,
+        gene_starts=db.gene_intervals.starts, gene_ends=db.gene_intervals.ends, gene_strands=db.gene_intervals.strands,
+        gene_positions=db.gene_positions, extra_genes=db.extra_genes, gene_locus_indices=db.gene_locus_indices,
+        locus_gene_offsets=db.locus_gene_offsets, locus_gene_lengths=db.locus_gene_lengths,
+        gene_cluster_ids=db.gene_cluster_ids, gene_description_ids=db.gene_description_ids,
+        cluster_keys=np.array(db.cluster_keys), description_keys=np.array(db.description_keys),
+        max_locus_length=np.int64(db.max_locus_length), id_threshold=np.float64(db.metadata.id_threshold),
+        pheno_ids=np.array(ph.ids), pheno_locus_masks=ph.locus_masks, pheno_extra_masks=ph.extra_masks,
+        pheno_inactive_masks=ph.inactive_masks, pheno_extra_counts=ph.extra_counts, pheno_priorities=ph.priorities,
+        pheno_as_suffix=ph.as_suffix,
+    )  # fmt: skip
+    print(f"genbank: {len(db.loci)} loci, {len(db.genes)} genes, {len(ph)} phenotype rules")
+
+
 def main() -> None:
     OUT.mkdir(parents=True, exist_ok=True)
-    what = set(sys.argv[1:]) or {"protein", "intervals", "seqs", "typing"}
+    what = set(sys.argv[1:]) or {"protein", "intervals", "seqs", "typing", "genbank"}
+    if "genbank" in what:
+        gen_genbank()
     if "protein" in what:
         gen_protein_dp(np.random.default_rng(1))
     if "intervals" in what:
