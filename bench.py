@@ -154,6 +154,12 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
     }  # fmt: skip
 
 
+def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
+    """First assembly seed of a rank: ranks hold disjoint, consecutive runs of the one seeded assembly series (weak
+    scaling: every rank types `assemblies_per_rank` of its own; rank r of any world size holds the same assemblies)."""
+    return 200 + rank * assemblies_per_rank
+
+
 def offline_pmc(args) -> dict | None:
     """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
     collection of this same command (profiles/scan_pmc_r2.json) and are reported only for the workload it ran."""
@@ -180,6 +186,11 @@ def main() -> None:
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
     ap.add_argument("--e2e-steps", type=int, default=1)
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend of the barrier and the max-over-ranks of the elapsed time (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="ranks take device LOCAL_RANK modulo the visible devices (tests of the multi-process path on a "
+                         "one-GPU box; use with --dist-backend gloo, RCCL refuses two ranks on one device)")
     ap.add_argument("--separate-passes", action="store_true",
                     help="one context and one alignment pass per database, as the reference runs them (default: the genes "
                          "of both databases share one seed index, so every assembly is scanned, chained and aligned once; "
@@ -199,7 +210,7 @@ def main() -> None:
     import torch  # noqa: F401
     _load_dbs(args.db)
     length = args.length or _WL["length"]
-    seed0 = 200 + rank * args.assemblies
+    seed0 = rank_seed0(rank, args.assemblies)
     t_gen = time.perf_counter()
     ids, packed = build_workload(args.assemblies, seed0, length, workers)
     t_gen = time.perf_counter() - t_gen
@@ -217,10 +228,15 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (kaptive_amd has no CPU path)")
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -320,9 +336,11 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        digests = [None] * world  # every rank's row digest, so that rank 0 can report what the whole job typed
+        dist.all_gather_object(digests, hashlib.sha1(b"".join(sorted(r for bt in res for r in bt.tsv().splitlines(keepends=True)))).hexdigest())
 
     # ---- legs 2 and 3: from pinned host shards, without and with TSV bytes (one GPU only) -------------------------------------
     e2e = None
@@ -418,6 +436,7 @@ def main() -> None:
                 "typeable_in_last_step": typed,
                 "tsv_rows_per_s_host": round(len(rows) / max(t_rows, 1e-9), 1),
                 "tsv_rows_sha1": rows_digest,
+                "tsv_rows_sha1_per_rank": digests if world > 1 else None,
                 "buffer_growth_reruns_in_timed_steps": [sum(s["retries"] for s in slist) for slist in stats],
                 "workload_generation_s": round(t_gen, 1),
             },

@@ -1,11 +1,11 @@
-"""Alignments: SoA table of gene-vs-contig hits, plus the CIGAR helpers.
+"""Alignments: SoA table of gene-vs-contig hits.
 
 Column names follow the reference's ``kaptive.core.alignment.Alignments`` (src/kaptive/core/alignment.py:262-317) so
-code written against it keeps working. Two ways in:
-
-* ``from_hit_table`` -- the native path: the HIP aligner already returns columns, nothing is parsed per hit.
-* ``from_mapping_iterators`` -- the reference's ingest of per-query iterators of hit objects
-  (src/kaptive/core/alignment.py:392-474), kept for callers that still hold such objects.
+code written against it keeps working.  The way in is ``from_hit_table``: the HIP aligner already returns columns,
+nothing is parsed per hit (the reference loops over hit objects, alignment.py:392-474).  The aligner produces no CIGAR
+strings -- the reference parses them and never reads them on the typing path -- so the ``cigars``
+column exists for shape compatibility only and is always empty; the reference's CIGAR parser, ``swap_sides`` and ``best``
+have no counterpart here.
 
 The reductions used by typing (``q_covs``, ``cull_overlaps``, ``is_partial``) follow
 src/kaptive/core/alignment.py:355-367, 643-686 and 774-809.
@@ -14,49 +14,11 @@ src/kaptive/core/alignment.py:355-367, 643-686 and 774-809.
 from __future__ import annotations
 
 from dataclasses import dataclass, fields
-from enum import IntEnum
 from typing import Any, Iterable, NamedTuple
 
 import numpy as np
 
 from kaptive_amd.core.interval import Intervals, Strand
-
-_CIGAR_OPS = b"MIDNSHP=XB"
-
-
-class CigarOp(IntEnum):
-    M = 0
-    I = 1  # noqa: E741
-    D = 2
-    N = 3
-    S = 4
-    H = 5
-    P = 6
-    EQ = 7
-    X = 8
-    B = 9
-
-    @property
-    def char(self) -> str:
-        return chr(_CIGAR_OPS[self.value])
-
-
-def parse_cigar_string(cigar: bytes) -> np.ndarray:
-    """ASCII CIGAR -> BAM-packed uint32 (``len << 4 | op``); unknown letters are skipped, digits keep accumulating
-    (reference: src/kaptive/core/alignment.py:872-938)."""
-    out = []
-    run = 0
-    for ch in cigar:
-        if 48 <= ch <= 57:
-            run = run * 10 + (ch - 48)
-            continue
-        op = _CIGAR_OPS.find(ch)
-        if op < 0:
-            continue
-        out.append(((run << 4) | op) & 0xFFFFFFFF)
-        run = 0
-    return np.array(out, dtype=np.uint32)
-
 
 def _ragged_take(data: np.ndarray, offsets: np.ndarray, lengths: np.ndarray, idx: np.ndarray):
     new_len = lengths[idx]
@@ -111,12 +73,6 @@ class Cigars:
     @classmethod
     def concat(cls, batches: Iterable["Cigars"]) -> "Cigars":
         return cls.from_lists([b[i] for b in batches for i in range(len(b))])
-
-    def swap_sides(self) -> "Cigars":
-        op = self.data & 0xF
-        swapped = np.where(op == 1, 2, np.where(op == 2, 1, op)).astype(np.uint32)
-        return Cigars((self.data & ~np.uint32(0xF)) | swapped, self.offsets, self.lengths)
-
 
 class Alignment(NamedTuple):
     idx: int
@@ -230,30 +186,6 @@ class Alignments:
         )  # fmt: skip
 
     @classmethod
-    def from_mapping_iterators(cls, queries: list[tuple[str, int]], iterators: Iterable[Any]) -> "Alignments":
-        """One iterator of hit objects per query, in query order; attribute names as in SURVEY.md Appendix B."""
-        rows: list[tuple] = []
-        cigars: list[np.ndarray] = []
-        q_index: dict[str, int] = {}
-        t_index: dict[str, int] = {}
-        for (q_name, q_len), hits in zip(queries, iterators):
-            qi = q_index.setdefault(q_name, len(q_index))
-            for h in hits:
-                ti = t_index.setdefault(h.target_name.decode("ascii"), len(t_index))
-                rows.append((
-                    qi, q_len, h.query_start, h.query_end, ti, h.target_len, h.target_start, h.target_end,
-                    1 if "Forward" in repr(h.strand) else -1, h.block_len, h.matches, h.edit_distance, h.score,
-                    h.mapq, h.is_primary, h.is_supplementary, h.is_spliced, h.divergence, h.cs, h.md,
-                ))  # fmt: skip
-                cigars.append(parse_cigar_string(h.cigar) if h.cigar else np.empty(0, np.uint32))
-        if not rows:
-            return cls.empty()
-        cols = {k: np.array([r[i] for r in rows], dtype=dt) for i, (k, dt) in enumerate(_DTYPES.items())}
-        return cls(
-            q_names_dict=tuple(q_index), t_names_dict=tuple(t_index), cigars=Cigars.from_lists(cigars), **cols
-        )
-
-    @classmethod
     def from_records(cls, records: Iterable[Alignment]) -> "Alignments":
         recs = list(records)
         if not recs:
@@ -349,16 +281,6 @@ class Alignments:
         return Intervals(s, e, self.strands, np.arange(len(self), dtype=np.int32))
 
     # -- reductions ---------------------------------------------------------------------------------------------
-    def best(self, by_query: bool = True) -> "Alignments":
-        if len(self) == 0:
-            return self
-        names = self.q_name_ids if by_query else self.t_name_ids
-        # NB: negating the uint8 MAPQ column wraps (0 stays 0, 255 -> 1 ...) exactly as the reference does
-        order = np.lexsort((-self.qualities, -self.matches, -self.scores, names))
-        sorted_names = names[order]
-        lead = np.r_[True, sorted_names[1:] != sorted_names[:-1]]
-        return self[np.sort(order[lead])]  # type: ignore[return-value]
-
     def cull_order(self, priority_mask: np.ndarray | None = None) -> np.ndarray:
         """Visit order of the overlap cull: score (+1e9 when prioritised) desc, matches desc, then the uint8-wrapped
         negated MAPQ (reference: src/kaptive/core/alignment.py:669-675)."""
@@ -385,15 +307,6 @@ class Alignments:
             secondary_group_by=np.zeros(n, np.int32) if group_by is None else group_by,
         )
         return self[kept]  # type: ignore[return-value]
-
-    def swap_sides(self) -> "Alignments":
-        cols = {k: getattr(self, k) for k in _DTYPES}
-        for a, b in (("q_name_ids", "t_name_ids"), ("q_lengths", "t_lengths"), ("q_starts", "t_starts"),
-                     ("q_ends", "t_ends")):  # fmt: skip
-            cols[a], cols[b] = cols[b], cols[a]
-        return Alignments(
-            q_names_dict=self.t_names_dict, t_names_dict=self.q_names_dict, cigars=self.cigars.swap_sides(), **cols
-        )
 
     def is_partial_left(self, edge_tolerance: int = 0) -> np.ndarray:
         clipped = np.where(self.strands == 1, self.q_starts > 0, self.q_ends < self.q_lengths)

@@ -96,6 +96,16 @@ class Serotyper:
 
     # -- public API -----------------------------------------------------------------------------------------------
     def __call__(self, genome: GenomeAssembly | str | Path) -> SerotypingResult | None:
+        """One genome: a batch of one through the same device path as ``type_many`` (alignment, reduction, translation,
+        protein DP and gene states on the GPU).  With an injected ``aligner`` / ``protein_aligner`` (tests, the oracle)
+        the golden-pinned host statement of the reduction, ``reduce``, runs instead."""
+        genome = GenomeAssembly.ensure(genome)
+        if self._aligner is None and self._protein_aligner is None:
+            return self.engine.type_many(self, [genome])[0]
+        return self.reduce(genome, self.align(genome))
+
+    def call_with_host_reduction(self, genome: GenomeAssembly | str | Path) -> SerotypingResult:
+        """GPU alignment and protein DP, reduction in numpy (``reduce``): what tests compare the device reduction with."""
         genome = GenomeAssembly.ensure(genome)
         return self.reduce(genome, self.align(genome))
 

@@ -296,8 +296,8 @@ def test_typing_end_to_end_matches_reference(name):
     the reference's Serotyper produced (its aligner stage replaced by the oracle's hit table, see make_golden.py)."""
     key, genome, hits, exp, scalars, kwargs = load_case(name)
     typer = Serotyper(load_db(key), **kwargs)
-    res = typer(genome)
-    check_result_against_golden(res, exp, scalars)
+    check_result_against_golden(typer(genome), exp, scalars)  # a batch of one: reduction on the device
+    check_result_against_golden(typer.call_with_host_reduction(genome), exp, scalars)
     typer.engine.close()
 
 
@@ -307,7 +307,8 @@ def test_type_many_equals_single_calls():
     genomes = [load_case(n)[1] for n in ("k_plain1", "k_split", "k_nolocus", "k_is")]
     many = typer.type_many(genomes)
     for g, r in zip(genomes, many):
-        single = typer(g)
+        single = typer(g)  # a batch of one
+        _results_equal(r, typer.call_with_host_reduction(g), g.id)
         assert r.to_dict().keys() == single.to_dict().keys()
         assert r.best_locus_name == single.best_locus_name and r.phenotype == single.phenotype
         assert np.array_equal(r.gene_hits.t_starts, single.gene_hits.t_starts)
@@ -353,7 +354,7 @@ def test_batched_device_reduction_matches_host_reduction_on_synthetic_batch(smal
                                                       min_contig=200, sub_rate=0.02 * i) for i in range(8)]  # fmt: skip
     many = typer.type_many(genomes)
     for g, r in zip(genomes, many):
-        _results_equal(r, typer(g), g.id)
+        _results_equal(r, typer.call_with_host_reduction(g), g.id)
     typer.engine.close()
 
 
@@ -370,7 +371,7 @@ def test_batched_reduction_full_size():
     typer = Serotyper(db)
     genomes = [make_assembly(db, seed=200 + i) for i in range(4)]
     for g, r in zip(genomes, typer.type_many(genomes)):
-        _results_equal(r, typer(g), g.id)
+        _results_equal(r, typer.call_with_host_reduction(g), g.id)
     typer.engine.close()
 
 
@@ -422,7 +423,7 @@ def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
     many = typer.type_many(genomes)
     monkeypatch.undo()
     for g, r in zip(genomes, many):
-        _results_equal(r, typer(g), g.id)
+        _results_equal(r, typer.call_with_host_reduction(g), g.id)
     typer.engine.close()
 
 

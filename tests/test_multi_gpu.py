@@ -1,0 +1,83 @@
+"""Multi-process / multi-device paths on real hardware (-m gpu).
+
+A one-GPU box can still run the two-process form of bench.py: both ranks share device 0 (--share-gpu) and the barrier /
+max-reduce run over gloo (RCCL refuses two ranks on one device).  That exercises what the 8-GPU scaling run does per
+rank -- one process, one context, its own assemblies, no collective on the data path -- with two HIP contexts alive at
+once.  The tests that need two devices are skipped below that."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _device_count() -> int:
+    import torch
+
+    return torch.cuda.device_count()
+
+
+def _run_bench(nproc: int, extra: list[str]) -> dict:
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc), "--assemblies",
+           "48", "--batch", "24", "--length", "400000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+           "--workers", "1", *extra]  # fmt: skip
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_share_one_gpu_over_gloo():
+    two = _run_bench(2, ["--dist-backend", "gloo", "--share-gpu"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    # rank 0 of the two-process job types the same assemblies as a one-process job: same rows
+    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--assemblies", "48", "--batch", "24", "--length", "400000",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--workers", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)  # fmt: skip
+    assert one.returncode == 0, one.stderr[-3000:]
+    single = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    digests = two["config"]["tsv_rows_sha1_per_rank"]
+    assert len(digests) == 2 and digests[0] == single["config"]["tsv_rows_sha1"] and digests[1] != digests[0]
+    assert two["config"]["typeable_in_last_step"] > 0
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_two_ranks_two_gpus_over_rccl():
+    two = _run_bench(2, [])
+    assert two["n_gpus"] == 2 and len(two["config"]["tsv_rows_sha1_per_rank"]) == 2
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_cli_types_across_two_devices(tmp_path):
+    """`--devices 0,1`: one worker thread bound to each device; rows come back in input order and equal the one-device
+    run's."""
+    from kaptive_amd.cli import main
+    from kaptive_amd.synth import make_assembly, make_db
+
+    db = make_db("kpsc_k", seed=7, n_loci=9)
+    db_path = db.save(tmp_path / "db.npz")
+    paths = []
+    for i in range(10):
+        g = make_assembly(db, seed=30 + i, length=80_000, median_contigs=5, min_contig=200)
+        p = tmp_path / f"{g.id}.fasta"
+        p.write_bytes(g.contigs.to_fasta())
+        paths.append(str(p))
+    out1, out2 = tmp_path / "one.tsv", tmp_path / "two.tsv"
+    assert main(["assembly", str(db_path), *paths, "-o", str(out1), "--batch-size", "3"]) == 0
+    assert main(["assembly", str(db_path), *paths, "-o", str(out2), "--batch-size", "3", "--devices", "0,1"]) == 0
+    assert out1.read_bytes() == out2.read_bytes()

@@ -75,3 +75,48 @@ def test_two_rank_sharded_typing_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert rows == _rows_for(CASES)
+
+
+def _bench_partition_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bench._load_dbs("kpsc")
+    # bench.py's own partition: every rank generates `assemblies` of its own from rank_seed0
+    ids, packed = bench.build_workload(3, bench.rank_seed0(rank, 3), 60_000.0, workers=1)
+    mine = [(i, int(p.words.sum())) for i, p in zip(ids, packed)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        q.put(everyone)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_ranks_hold_disjoint_consecutive_assemblies():
+    """bench.py --gpus N: rank r types assemblies seeded rank_seed0(r, A) .. + A; the ranks of a 2-process gloo job hold
+    what one process generating all 2 * A holds, split in rank order, with nothing shared."""
+    import bench
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_partition_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    per_rank = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bench._load_dbs("kpsc")
+    ids, packed = bench.build_workload(6, bench.rank_seed0(0, 3), 60_000.0, workers=1)
+    whole = [(i, int(p.words.sum())) for i, p in zip(ids, packed)]
+    assert per_rank[0] + per_rank[1] == whole
+    assert len({i for i, _ in whole}) == 6
