@@ -246,6 +246,26 @@ KP_API int64_t kp_format_rows(const kp_row_tables *tables, int32_t n_asm, const 
  *   out8 : n rows of score, matches, mismatches, gaps, q_start, q_end, t_start, t_end  */
 KP_API int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                      const int32_t *t_off, const int32_t *t_len, int32_t n, int32_t *out8);
+/* The seeded mode of the same kernel (pairwise.py:449-451, PairwiseAligner.align_seeds; caller compare.LocusComparator,
+ * src/kaptive/compare.py:360-366): the band is k diagonals either side of the seed diagonal of every pair,
+ * |j - (i - diagonal_offsets[p])| <= k, and no longer widens with the length difference. */
+KP_API int kp_protein_align_seeded(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len,
+                                   const uint8_t *t, const int32_t *t_off, const int32_t *t_len, int32_t n,
+                                   const int32_t *diagonal_offsets, int32_t k, int32_t *out8);
+
+/* ---- locus comparison seeds (host only) -------------------------------------------------------------------------------------
+ * Replace the numba kernels of kaptive.core.kmers.RandstrobeIndex that compare.LocusComparator uses
+ * (src/kaptive/core/kmers.py:997-1155, 779-819, 1158-1282; src/kaptive/compare.py:343-358).
+ * kp_randstrobes: records {hash u64, seq_idx u32, pos1 u32, pos2 u32} (20 bytes, packed) of every sequence, in sequence
+ *   and position order, or stably sorted by hash; returns how many there are (written when they fit `cap`).
+ * kp_randstrobe_top_hits: per query sequence the target sequence sharing most record hashes (first maximum), that count
+ *   and the diagonal offset pos1(query) - pos1(target) of the first shared record met; queries without records get 0. */
+KP_API int64_t kp_randstrobes(const uint8_t *seqs, const int32_t *offsets, const int32_t *lengths, int32_t n_seqs,
+                              const uint8_t *lut256, int32_t k, int32_t s, int32_t w_min, int32_t w_max,
+                              int32_t sort_by_hash, void *out_records, int64_t cap);
+KP_API int kp_randstrobe_top_hits(const void *query_records, int64_t n_query_records, int32_t n_queries,
+                                  const void *target_records_sorted, int64_t n_target_records, int32_t n_targets,
+                                  uint32_t *best_target, uint32_t *best_score, int32_t *diagonal_offset);
 
 #ifdef __cplusplus
 }

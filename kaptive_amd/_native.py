@@ -29,7 +29,7 @@ EXPORTS = (
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_pack_contigs",
-    "kp_fasta_free", "kp_format_rows",
+    "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
 
@@ -314,6 +314,20 @@ class Context:
             )  # fmt: skip
         return out
 
+    def protein_align_seeded(self, q, q_off, q_len, t, t_off, t_len, offsets, k: int) -> np.ndarray:
+        """Seeded mode (kp_protein_align_seeded): band ``k`` around the diagonal ``offsets[p]`` of every pair."""
+        n = len(q_off)
+        out = np.zeros((n, 8), np.int32)
+        if n:
+            q, t = _c(q, np.uint8), _c(t, np.uint8)
+            self._check(
+                lib().kp_protein_align_seeded(self._h, _p(q), _p(_c(q_off, np.int32)), _p(_c(q_len, np.int32)), _p(t),
+                                              _p(_c(t_off, np.int32)), _p(_c(t_len, np.int32)), C.c_int32(n),
+                                              _p(_c(offsets, np.int32)), C.c_int32(int(k)), _p(out)),
+                "kp_protein_align_seeded",
+            )  # fmt: skip
+        return out
+
     def batch(self, packed: list, device_words: int | None = None, pinned_words: "np.ndarray | None" = None,
               after: "Batch | None" = None) -> "Batch":
         return Batch(self, packed, device_words, pinned_words, after)
@@ -477,6 +491,37 @@ class Batch:
         out = np.zeros(n, TASK_DTYPE)
         lib().kp_batch_tasks(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
         return out
+
+
+RANDSTROBE_DTYPE = np.dtype([("hash", "<u8"), ("seq_idx", "<u4"), ("pos1", "<u4"), ("pos2", "<u4")])
+
+
+def randstrobes(seqs, offsets, lengths, lut, k: int, s: int, w_min: int, w_max: int, sort_by_hash: bool) -> np.ndarray:
+    """Randstrobe records of a batch of sequences (kp_randstrobes; host only)."""
+    h = lib()
+    h.kp_randstrobes.restype = C.c_int64
+    seqs, offsets, lengths, lut = _c(seqs, np.uint8), _c(offsets, np.int32), _c(lengths, np.int32), _c(lut, np.uint8)
+    args = (_p(seqs), _p(offsets), _p(lengths), C.c_int32(len(offsets)), _p(lut), C.c_int32(k), C.c_int32(s),
+            C.c_int32(w_min), C.c_int32(w_max), C.c_int32(int(sort_by_hash)))  # fmt: skip
+    n = h.kp_randstrobes(*args, None, C.c_int64(0))
+    if n < 0:
+        raise ValueError(f"kp_randstrobes failed ({n})")
+    out = np.empty(int(n), RANDSTROBE_DTYPE)
+    if n:
+        h.kp_randstrobes(*args, _p(out), C.c_int64(n))
+    return out
+
+
+def randstrobe_top_hits(q_records: np.ndarray, n_queries: int, t_records: np.ndarray, n_targets: int):
+    """(best target u32, score u32, diagonal offset i32) per query sequence (kp_randstrobe_top_hits; host only)."""
+    q_records, t_records = np.ascontiguousarray(q_records), np.ascontiguousarray(t_records)
+    best_t, score = np.zeros(n_queries, np.uint32), np.zeros(n_queries, np.uint32)
+    off = np.zeros(n_queries, np.int32)
+    rc = lib().kp_randstrobe_top_hits(_p(q_records), C.c_int64(len(q_records)), C.c_int32(n_queries), _p(t_records),
+                                      C.c_int64(len(t_records)), C.c_int32(n_targets), _p(best_t), _p(score), _p(off))  # fmt: skip
+    if rc != 0:
+        raise ValueError(f"kp_randstrobe_top_hits failed ({rc})")
+    return best_t, score, off
 
 
 class PinnedBuffer:

@@ -1359,8 +1359,9 @@ int kp_batch_proteins(kp_ctx *ctx, kp_batch *b, int32_t asm_index, uint8_t *out,
     return (int)n;
 }
 
-int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
-                     const int32_t *t_off, const int32_t *t_len, int32_t n, int32_t *out8) {
+static int protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                         const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *seed_off, int32_t seed_k,
+                         int32_t *out8) {
     if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");
     if (n < 0 || (n > 0 && (!q_off || !q_len || !t_off || !t_len || !out8))) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     if (n == 0) return KP_OK;
@@ -1377,11 +1378,12 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     if ((q_bytes && !q) || (t_bytes && !t)) return kp_fail(ctx, KP_EINVAL, "null sequence data");
     const int n_blocks = std::max(1, std::min(n, 256 * 16));
     const size_t scratch_per_block = (size_t)KP_PROT_ROWBUF_FIELDS * ((size_t)max_t_len + 1);  // see kp_prot.hip
-    std::vector<int32_t> meta(4 * (size_t)n);
+    std::vector<int32_t> meta(5 * (size_t)n, 0);
     std::memcpy(meta.data(), q_off, (size_t)n * 4);
     std::memcpy(meta.data() + n, q_len, (size_t)n * 4);
     std::memcpy(meta.data() + 2 * (size_t)n, t_off, (size_t)n * 4);
     std::memcpy(meta.data() + 3 * (size_t)n, t_len, (size_t)n * 4);
+    if (seed_off) std::memcpy(meta.data() + 4 * (size_t)n, seed_off, (size_t)n * 4);
     int rc;
     if ((rc = upload(ctx, ctx->d_pq, q, q_bytes))) return rc;
     if ((rc = upload(ctx, ctx->d_pt, t, t_bytes))) return rc;
@@ -1390,12 +1392,25 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
     KP_HIP_CHECK(ctx, ctx->d_pscratch.reserve(scratch_per_block * (size_t)n_blocks + 64));
     kp_launch_protein(ctx->d_pq.p, ctx->d_pmeta.p, ctx->d_pmeta.p + n, ctx->d_pt.p, ctx->d_pmeta.p + 2 * (size_t)n,
                       ctx->d_pmeta.p + 3 * (size_t)n, n, nullptr, ctx->d_blosum.p, ctx->d_pout.p, ctx->d_pscratch.p,
-                      scratch_per_block, n_blocks, ctx->stream, nullptr, nullptr, nullptr);
+                      scratch_per_block, n_blocks, ctx->stream, nullptr, nullptr, nullptr,
+                      seed_off ? ctx->d_pmeta.p + 4 * (size_t)n : nullptr, seed_k);
     KP_HIP_CHECK(ctx, hipGetLastError());
     KP_HIP_CHECK(ctx, hipMemcpyAsync(out8, ctx->d_pout.p, 8 * (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost,
                                      ctx->stream));
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return KP_OK;
+}
+
+int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                     const int32_t *t_off, const int32_t *t_len, int32_t n, int32_t *out8) {
+    return protein_align(ctx, q, q_off, q_len, t, t_off, t_len, n, nullptr, 0, out8);
+}
+
+int kp_protein_align_seeded(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                            const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *diagonal_offsets,
+                            int32_t k, int32_t *out8) {
+    if (ctx && n > 0 && (!diagonal_offsets || k < 0 || k > 16000)) return kp_fail(ctx, KP_EINVAL, "bad seed arguments");
+    return protein_align(ctx, q, q_off, q_len, t, t_off, t_len, n, diagonal_offsets, k, out8);
 }
 
 }  // extern "C"

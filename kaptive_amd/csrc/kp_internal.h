@@ -158,7 +158,8 @@ void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, s
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,
                        int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream,
-                       hipStream_t aux, hipEvent_t fork, hipEvent_t join);  // aux != null: wide-band kernel runs beside the other
+                       hipStream_t aux, hipEvent_t fork, hipEvent_t join,  // aux != null: wide-band kernel runs beside the other
+                       const int32_t *seed_off = nullptr, int seed_k = 0);  // seeded mode: one diagonal offset per pair, band k
 // kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
 int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
                     int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,

@@ -1,8 +1,10 @@
 // kp_prot.hip -- batched banded Smith-Waterman-Gotoh on proteins with full traceback statistics.
 //
-// Restates the reference's numba kernel _batched_banded_gotoh in its unseeded mode
-// (src/kaptive/core/pairwise.py:395-584): BLOSUM62 via a 256x256 byte lookup (pairwise.py:343-391), gap open 11 +
-// extend 1, band |i-j| <= k with k = max(20, |len1-len2|+1), cells outside the band read as M=0 / D=I=-1e9, ties:
+// Restates the reference's numba kernel _batched_banded_gotoh (src/kaptive/core/pairwise.py:395-584), both modes:
+// unseeded -- band |i-j| <= k with k = max(20, |len1-len2|+1) -- and seeded (pairwise.py:449-451; used by
+// compare.LocusComparator) -- band |j - (i - offset)| <= k with the caller's k and one diagonal offset per pair ("shift"
+// below; 0 in the unseeded mode).  BLOSUM62 via a 256x256 byte lookup (pairwise.py:343-391), gap open 11 +
+// extend 1, cells outside the band read as M=0 / D=I=-1e9, ties:
 // opening a gap beats extending it, diagonal beats D (vertical) beats I (horizontal), best<=0 restarts, the reported
 // cell is the first maximum in row-major order, and matches / mismatches / gaps / start are what the reference's
 // traceback loop would count.
@@ -116,14 +118,14 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
 }
 
 __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
-                                                         const int8_t *s_mat, int len1, int len2, int k, int l,
-                                                         int max_steps) {
+                                                         const int8_t *s_mat, int len1, int len2, int k, int shift,
+                                                         int l, int max_steps) {
     const int nb = 2 * k + 1;
     PCell A{0, NEGP, NEGP, Pay{0, 0, 0}, Pay{0, 0, 0}, Pay{0, 0, 0}};
     PCell B = A, C = A, D = A;
     Result r{0, 0, 0, Pay{0, 0, 0}};
     for (int m = 0; m < max_steps; ++m) {  // max_steps is wave-uniform (the longest pair of the quad)
-        const int i = m - l + 1, j0 = i + 4 * l - k;  // column of cell A
+        const int i = m - l + 1, j0 = i - shift + 4 * l - k;  // column of cell A
         const bool row_ok = i >= 1 && i <= len1;
         const unsigned c1 = row_ok ? s_seq1[i - 1] : 0u;
         unsigned c2[4];
@@ -186,12 +188,12 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
                                                       uint16_t *s_seq2,
                                                       const uint8_t *s_idx, const int8_t *s_mat,
                                                       const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
-                                                      int len1, int len2, int k, int lane) {
+                                                      int len1, int len2, int k, int shift, int lane) {
     Result r{0, 0, 0, Pay{0, 0, 0}};
     int pj_lo = 1, pj_hi = 0;  // columns the previous strip left in the row buffer (none yet)
     for (int i0 = 1; i0 <= len1; i0 += 64) {
         const int i = i0 + lane;
-        const int j_lo = max(1, i0 - k), j_hi = min(len2, i0 + 63 + k);
+        const int j_lo = max(1, i0 - shift - k), j_hi = min(len2, i0 + 63 - shift + k);
         const int width = j_hi - j_lo + 1;
         const bool last_strip = i0 + 64 > len1;
         __threadfence();  // the previous strip's row-buffer stores (lane 63) are visible to every lane's loads
@@ -236,7 +238,7 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
             }
             const int raw_um = um;
             const Pay raw_upm = upm;
-            int db = i - j;
+            int db = i - shift - j;
             if (db < 0) db = -db;
             const bool in = x >= 0 && x < width && i <= len1 && db <= k;
             unsigned c2 = 0;
@@ -325,7 +327,8 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
                                                         const uint8_t *__restrict__ t, const int32_t *__restrict__ t_off,
                                                         const int32_t *__restrict__ t_len, int32_t n_host,
                                                         const int32_t *__restrict__ n_dev,
-                                                        const int8_t *__restrict__ blosum, int32_t *__restrict__ out8) {
+                                                        const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
+                                                        const int32_t *__restrict__ seed_off, int seed_k) {
     __shared__ uint16_t s_seq1[4][REG_MAX_LEN], s_seq2[4][REG_MAX_LEN];
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
         const bool empty = p < n && (len1 == 0 || len2 == 0);  // nothing to align: all zeros
         int d = len1 - len2;
         if (d < 0) d = -d;
-        const int k = max(KP_PROT_K, d + 1);
+        const int k = seed_off ? seed_k : max(KP_PROT_K, d + 1);
+        const int shift = (seed_off && p < n) ? seed_off[p] : 0;
         const bool mine = p < n && !empty && fits_registers(len1, len2, 2 * k + 1);  // else kp_protein_wide_kernel's
         __syncthreads();
         if (mine) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
         int steps = mine ? len1 + QP - 1 : 0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
-        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, mine ? len1 : 0, mine ? len2 : 0, k, l, steps);
+        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, mine ? len1 : 0, mine ? len2 : 0, k, shift, l, steps);
         store_result(r, l, out8 + 8 * (size_t)(p < n ? p : 0), QP, mine || empty);
     }
 }
@@ -368,7 +372,8 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
                                                              const int32_t *__restrict__ n_dev,
                                                              const int8_t *__restrict__ blosum, int32_t *__restrict__ out8,
                                                              int32_t *__restrict__ scratch, size_t scratch_ints_per_block,
-                                                             int32_t *__restrict__ queue) {
+                                                             int32_t *__restrict__ queue,
+                                                             const int32_t *__restrict__ seed_off, int seed_k) {
     __shared__ int s_chunk[RB_FIELDS][RB_CHUNK], s_out[RB_FIELDS][RB_CHUNK];
     __shared__ uint16_t s_seq2[S2_CAP];
     __shared__ int8_t s_mat[32 * 32];
@@ -386,12 +391,13 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
             if (len1 == 0 || len2 == 0) continue;
             int d = len1 - len2;
             if (d < 0) d = -d;
-            const int k = max(KP_PROT_K, d + 1);
+            const int k = seed_off ? seed_k : max(KP_PROT_K, d + 1);
+            const int shift = seed_off ? seed_off[p] : 0;
             if (fits_registers(len1, len2, 2 * k + 1)) continue;
             if (!staged) { stage_blosum(blosum, s_mat, s_idx, lane); staged = true; }  // many blocks find nothing to do
             const RowBuf rb{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1};
             const Result r = protein_pair_strips(rb, s_chunk, s_out, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2,
-                                                 k, lane);
+                                                 k, shift, lane);
             store_result(r, lane, out8 + 8 * (size_t)p);
         }
     }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
 void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                        const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *n_dev, const int8_t *blosum,
                        int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream,
-                       hipStream_t aux, hipEvent_t fork, hipEvent_t join) {
+                       hipStream_t aux, hipEvent_t fork, hipEvent_t join, const int32_t *seed_off, int seed_k) {
     if (n == 0) return;
     // The wide-band kernel is a handful of long-running waves (its duration is one pair's time-step chain), the
     // register kernel fills the chip: with a second stream they run side by side, joined before `stream` goes on.
@@ -416,9 +422,9 @@ void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_
     int32_t *queue = scratch + (size_t)n_blocks * scratch_ints_per_block;  // callers leave 64 ints behind the regions
     (void)hipMemsetAsync(queue, 0, sizeof(int32_t), wide);
     hipLaunchKernelGGL(kp_protein_wide_kernel, dim3(n_blocks), dim3(64), 0, wide, q, q_off, q_len, t, t_off, t_len, n, n_dev,
-                       blosum, out8, scratch, scratch_ints_per_block, queue);
+                       blosum, out8, scratch, scratch_ints_per_block, queue, seed_off, seed_k);
     hipLaunchKernelGGL(kp_protein_kernel, dim3(std::min(n_blocks, (n + 3) / 4)), dim3(64), 0, stream, q, q_off, q_len, t,
-                       t_off, t_len, n, n_dev, blosum, out8);
+                       t_off, t_len, n, n_dev, blosum, out8, seed_off, seed_k);
     if (aux) {
         (void)hipEventRecord(join, aux);
         (void)hipStreamWaitEvent(stream, join, 0);

@@ -7,6 +7,8 @@
  *   kpo_protein_align   reference src/kaptive/core/pairwise.py:395-584 (_batched_banded_gotoh, unseeded mode), with
  *                       the BLOSUM62 lookup of pairwise.py:343-391.  PINNED against tests/golden/protein_dp.npz,
  *                       produced by running the reference itself (oracle/make_golden.py).
+ *   kpo_protein_align_seeded  the same kernel's seeded mode (pairwise.py:449-451).  PINNED against
+ *                       tests/golden/compare.npz (the reference's PairwiseAligner.align_seeds on randstrobe seeds).
  *   kpo_cull_overlaps   reference src/kaptive/core/interval.py:698-751.          PINNED (tests/golden/intervals.npz)
  *   kpo_cluster         reference src/kaptive/core/interval.py:595-639.          PINNED (tests/golden/intervals.npz)
  *   kpo_translate       reference src/kaptive/core/seq.py:671-741.               PINNED (tests/golden/seqs.npz)
@@ -81,12 +83,15 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
 /* One pair; follows the reference loop structure (band stored as rows x (2k+3) with per-row origin). */
-static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int k, int go, int ge,
-                         int32_t *out8 /* score, matches, mismatches, gaps, qs, qe, ts, te */) {
+/* seeded != 0: the band is k diagonals either side of the seed diagonal (centre column i - offset, pairwise.py:449-451);
+ * otherwise it is centred on 0 and absorbs the length difference (pairwise.py:452-454) */
+static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int k, int go, int ge, int seeded,
+                         int offset, int32_t *out8 /* score, matches, mismatches, gaps, qs, qe, ts, te */) {
     const int rows = len1 + 1, cols = len2 + 1;
     int d = len1 - len2;
     if (d < 0) d = -d;
-    const int kl = imax(k, d + 1);
+    const int kl = seeded ? k : imax(k, d + 1);
+    if (!seeded) offset = 0;
     const int bw = 2 * kl + 3;
     const size_t cells = (size_t)rows * (size_t)bw;
     int32_t *M = malloc(cells * sizeof(int32_t)), *I = malloc(cells * sizeof(int32_t)),
@@ -94,7 +99,7 @@ static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len
     uint8_t *tM = malloc(cells), *tD = malloc(cells), *tI = malloc(cells);
 #define AT(i, jm) ((size_t)(i) * (size_t)bw + (size_t)(jm))
     for (int i = 0; i < rows; i++) { /* band-only initialisation, pairwise.py:466-479 */
-        int sj = imax(0, i - kl - 1), ej = imin(cols, i + kl + 2);
+        int sj = imax(0, i - offset - kl - 1), ej = imin(cols, i - offset + kl + 2);
         if (sj >= cols || ej <= 0) continue;
         for (int j = sj; j < ej; j++) {
             int jm = j - sj;
@@ -106,9 +111,9 @@ static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len
     }
     int max_score = 0, max_i = 0, max_j = 0;
     for (int i = 1; i < rows; i++) { /* fill, pairwise.py:486-535 */
-        int sj = imax(1, i - kl), ej = imin(cols, i + kl + 1);
+        int sj = imax(1, i - offset - kl), ej = imin(cols, i - offset + kl + 1);
         if (sj >= cols || ej <= 1) continue;
-        int sp = imax(0, i - 1 - kl - 1), sc = imax(0, i - kl - 1);
+        int sp = imax(0, i - 1 - offset - kl - 1), sc = imax(0, i - offset - kl - 1);
         for (int j = sj; j < ej; j++) {
             int jt = j - sp, jm = j - sc, jl = j - 1 - sc, jd = j - 1 - sp;
             int d_open = M[AT(i - 1, jt)] - go - ge, d_ext = D[AT(i - 1, jt)] - ge;
@@ -129,7 +134,7 @@ static void protein_pair(const uint8_t *s1, int len1, const uint8_t *s2, int len
     }
     int i = max_i, j = max_j, matches = 0, mism = 0, gaps = 0, state = 0; /* traceback, pairwise.py:538-572 */
     while (i > 0 && j > 0) {
-        int sc = imax(0, i - kl - 1), jm = j - sc;
+        int sc = imax(0, i - offset - kl - 1), jm = j - sc;
         if (state == 0) {
             int tb = tM[AT(i, jm)];
             if (tb == 3) break;
@@ -148,7 +153,17 @@ KPO_API void kpo_protein_align(const uint8_t *q, const int32_t *q_off, const int
                                const int32_t *t_off, const int32_t *t_len, int n, int32_t *out /* [n][8] */) {
     if (!g_blosum_ready) blosum_init();
     for (int x = 0; x < n; x++)
-        protein_pair(q + q_off[x], q_len[x], t + t_off[x], t_len[x], KP_PROT_K, KP_PROT_GAP_OPEN, KP_PROT_GAP_EXT,
+        protein_pair(q + q_off[x], q_len[x], t + t_off[x], t_len[x], KP_PROT_K, KP_PROT_GAP_OPEN, KP_PROT_GAP_EXT, 0, 0,
+                     out + 8 * (size_t)x);
+}
+
+/* the seeded mode (PairwiseAligner.align_seeds, pairwise.py:327-339): one diagonal offset per pair, band k */
+KPO_API void kpo_protein_align_seeded(const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
+                                      const int32_t *t_off, const int32_t *t_len, int n, const int32_t *offsets, int k,
+                                      int32_t *out /* [n][8] */) {
+    if (!g_blosum_ready) blosum_init();
+    for (int x = 0; x < n; x++)
+        protein_pair(q + q_off[x], q_len[x], t + t_off[x], t_len[x], k, KP_PROT_GAP_OPEN, KP_PROT_GAP_EXT, 1, offsets[x],
                      out + 8 * (size_t)x);
 }
 

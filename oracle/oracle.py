@@ -100,6 +100,18 @@ def protein_align(q, q_off, q_len, t, t_off, t_len) -> np.ndarray:
     return out
 
 
+def protein_align_seeded(q, q_off, q_len, t, t_off, t_len, offsets, k=20) -> np.ndarray:
+    """Seeded mode: band ``k`` around the diagonal ``offsets[p]`` of every pair.  Same columns as protein_align."""
+    n = len(q_off)
+    out = np.zeros((n, 8), np.int32)
+    if n:
+        q, t = _c(q, np.uint8), _c(t, np.uint8)
+        lib().kpo_protein_align_seeded(_p(q), _p(_c(q_off, np.int32)), _p(_c(q_len, np.int32)), _p(t),
+                                       _p(_c(t_off, np.int32)), _p(_c(t_len, np.int32)), C.c_int(n),
+                                       _p(_c(offsets, np.int32)), C.c_int(int(k)), _p(out))  # fmt: skip
+    return out
+
+
 def cull_overlaps(order, g1, g2, starts, ends, max_frac=0.1) -> np.ndarray:
     n = len(starts)
     kept = np.zeros(n, np.uint8)
