@@ -154,6 +154,32 @@ class Intervals:
             self.original_indices,
         )
 
+    def arrange(self, indices: np.ndarray, order: np.ndarray, starts: np.ndarray, ends: np.ndarray, strands: np.ndarray,
+                gap: int = 500) -> "Intervals":
+        """Lay intervals that live on several pieces (contig fragments of a locus) out on one axis: pieces in ``order``,
+        ``gap`` apart, reverse-strand pieces mirrored (reference: src/kaptive/core/interval.py:529-591).
+        ``indices[i]`` = piece of interval i."""
+        if len(self) == 0:
+            return self
+        starts, ends = np.asarray(starts, np.int64), np.asarray(ends, np.int64)
+        plot_start = np.zeros(len(starts), np.int64)
+        x = 0
+        for i in np.asarray(order).tolist():
+            plot_start[i] = x
+            x += int(ends[i] - starts[i]) + gap
+        piece = np.asarray(indices)
+        placed = (piece >= 0) & (piece < len(starts))  # an interval of no piece stays at 0, as in the reference
+        p = np.where(placed, piece, 0)
+        forward = np.asarray(strands)[p] >= 0
+        new_starts = np.where(forward, plot_start[p] + (self.starts - starts[p]), plot_start[p] + (ends[p] - self.ends))
+        new_ends = np.where(forward, plot_start[p] + (self.ends - starts[p]), plot_start[p] + (ends[p] - self.starts))
+        new_strands = np.where(forward, self.strands, -self.strands)
+        zero = ~placed
+        return Intervals(
+            np.where(zero, 0, new_starts).astype(np.int32), np.where(zero, 0, new_ends).astype(np.int32),
+            np.where(zero, 0, new_strands).astype(np.int8), self.original_indices,
+        )  # fmt: skip
+
     # -- reductions ---------------------------------------------------------------------------------------------
     def cull_overlaps(
         self,

@@ -87,7 +87,8 @@ class PairwiseAlignments:
 
 @dataclass(frozen=True, slots=True)
 class PairwiseAligner:
-    """Batched protein aligner on the GPU. Only the reference's default parameters are built into the kernel."""
+    """Batched protein aligner on the GPU (reference: src/kaptive/core/pairwise.py:240-339).  The gap penalties are
+    built into the kernel (11 / 1, the reference's defaults); ``k`` is free in the seeded mode and 20 otherwise."""
 
     gap_open: int = 11
     gap_extend: int = 1
@@ -97,15 +98,23 @@ class PairwiseAligner:
     def __call__(self, queries: Sequences, targets: Sequences, seeds: Any = None) -> PairwiseAlignments:
         if len(queries.offsets) != len(targets.offsets):
             raise ValueError("Query and target batches must have the same number of sequences.")
-        if seeds is not None:
-            raise NotImplementedError("seeded mode belongs to compare.py (SURVEY.md section 8 row f4)")
-        if (self.gap_open, self.gap_extend, self.k) != (11, 1, 20):
-            raise NotImplementedError("the HIP kernel is built for gap 11/1, k=20")
+        if (self.gap_open, self.gap_extend) != (11, 1) or (seeds is None and self.k != 20):
+            raise NotImplementedError("the HIP kernel is built for gap 11/1 (and k=20 in the unseeded mode)")
         if len(queries.offsets) == 0:
             return PairwiseAlignments.empty()
         from kaptive_amd import _native
 
-        table = _native.protein_align(
-            self.device, queries.seqs, queries.offsets, queries.lengths, targets.seqs, targets.offsets, targets.lengths
-        )
+        ctx = _native.default_context(self.device)
+        if seeds is not None:  # band k around each pair's seed diagonal (pairwise.py:449-451)
+            table = ctx.protein_align_seeded(queries.seqs, queries.offsets, queries.lengths, targets.seqs, targets.offsets,
+                                             targets.lengths, seeds.offsets, self.k)  # fmt: skip
+        else:
+            table = ctx.protein_align(queries.seqs, queries.offsets, queries.lengths, targets.seqs, targets.offsets,
+                                      targets.lengths)  # fmt: skip
         return PairwiseAlignments.from_table(table)
+
+    def align_seeds(self, queries: Sequences, targets: Sequences, seeds: Any) -> PairwiseAlignments:
+        """One alignment per seed: query ``seeds.query_indices[i]`` against target ``seeds.target_indices[i]``
+        (pairwise.py:327-339)."""
+        paired_queries, paired_targets = seeds.extract_sequences(queries, targets)
+        return self(paired_queries, paired_targets, seeds)

@@ -350,9 +350,83 @@ def gen_genbank() -> None:
     print(f"genbank: {len(db.loci)} loci, {len(db.genes)} genes, {len(ph)} phenotype rules")
 
 
+def gen_compare() -> None:
+    """tests/golden/compare.npz: the REFERENCE's compare.LocusComparator (src/kaptive/compare.py:195-396) -- randstrobe
+    records and top-hit seeds (src/kaptive/core/kmers.py), seeded protein alignments (pairwise.py align_seeds) and the
+    normalised gene coordinates -- on five loci of a synthetic K database (proteins truncated to 200
+    residues so that the pure-Python fallback of the numba kernels finishes in minutes).  Locus 2 is given as two pieces
+    on two contigs, the second on the reverse strand, with byte-string descriptions and gene states."""
+    from kaptive.compare import LocusComparator as RefComparator
+    from kaptive.compare import LocusData as RefLocusData
+    from kaptive.core.kmers import RandstrobeIndex as RefRandstrobeIndex
+    from kaptive.serotyping.models import LocusPieces as RefLocusPieces
+
+    n_loci = 5
+    db = make_db("kpsc_k", seed=11, n_loci=n_loci)
+    inputs, raw = [], {}
+    for li in range(n_loci):
+        g0, n = int(db.locus_gene_offsets[li]), int(db.locus_gene_lengths[li])
+        ids, chunks = [], []
+        for g in range(g0, g0 + n):
+            o, ln = int(db.translations.offsets[g]), int(db.translations.lengths[g])
+            chunks.append(db.translations.seqs[o : o + min(ln, 200)])
+            ids.append(db.genes.ids[g])
+        lengths = np.array([len(c) for c in chunks], np.int32)
+        offsets = np.zeros(n, np.int32)
+        np.cumsum(lengths[:-1], out=offsets[1:])
+        seqs = np.concatenate(chunks)
+        starts = db.gene_intervals.starts[g0 : g0 + n].astype(np.int32) + 1000 * li
+        ends = db.gene_intervals.ends[g0 : g0 + n].astype(np.int32) + 1000 * li
+        strands = db.gene_intervals.strands[g0 : g0 + n].astype(np.int8)
+        raw[f"l{li}.ids"], raw[f"l{li}.seqs"], raw[f"l{li}.offsets"], raw[f"l{li}.lengths"] = np.array(ids), seqs, offsets, lengths
+        raw[f"l{li}.starts"], raw[f"l{li}.ends"], raw[f"l{li}.strands"] = starts, ends, strands
+        kw = {}
+        if li == 2:  # fragmented: genes 0..4 on contig 3, the rest on contig 7 (reverse strand)
+            cut = int(ends[4]) + 10
+            kw["pieces"] = RefLocusPieces(np.array([3, 7], np.uint32), np.array([int(starts[0]) - 5, cut], np.int32),
+                                          np.array([cut, int(ends[-1]) + 20], np.int32), np.array([1, -1], np.int8))
+            kw["gene_ctg_indices"] = np.array([3] * 5 + [7] * (n - 5), np.uint32)
+            kw["gene_states"] = (np.arange(n) % 4).astype(np.int8)
+            kw["gene_descriptions"] = np.array([f"product {x}".encode() for x in range(n)], dtype="S64")
+            for key in ("gene_ctg_indices", "gene_states", "gene_descriptions"):
+                raw[f"l{li}.{key}"] = kw[key]
+            raw["l2.piece_ctg"], raw["l2.piece_starts"], raw["l2.piece_ends"], raw["l2.piece_strands"] = (
+                kw["pieces"].ctg_indices, kw["pieces"].starts, kw["pieces"].ends, kw["pieces"].strands)
+        inputs.append(RefLocusData(proteins=ref_sequences(ids, seqs, offsets, lengths), name=db.loci.ids[li],
+                                   backbone=RefIntervals(starts, ends, strands), **kw))
+    t0 = time.time()
+    for li, inp in enumerate(inputs):
+        raw[f"l{li}.records"] = RefRandstrobeIndex.build(inp.proteins, k=10, s=5, sort_by_hash=False).records
+        raw[f"l{li}.records_sorted"] = RefRandstrobeIndex.build(inp.proteins, k=10, s=5, sort_by_hash=True).records
+    for i in range(n_loci):
+        for j in range(i + 1, n_loci):
+            t = RefRandstrobeIndex.build(inputs[j].proteins, k=10, s=5, sort_by_hash=True)
+            q = RefRandstrobeIndex.build(inputs[i].proteins, k=10, s=5, sort_by_hash=False)
+            sd = t.top_hits(q, min_score=1)
+            raw[f"seeds.{i}.{j}"] = np.stack([sd.query_indices.astype(np.int64), sd.target_indices.astype(np.int64),
+                                              sd.scores.astype(np.int64), sd.offsets.astype(np.int64)])
+    res = RefComparator()(inputs)
+    e = res.edges
+    for col in ("query_locus_indices", "target_locus_indices", "query_indices", "target_indices", "global_query_indices",
+                "global_target_indices"):
+        raw[f"edges.{col}"] = getattr(e, col)
+    raw["edges.alignments"] = np.stack([getattr(e.alignments, c) for c in
+                                        ("scores", "matches", "mismatches", "gaps", "q_starts", "q_ends", "t_starts", "t_ends")], axis=1)
+    raw["locus_names"], raw["locus_lengths"], raw["locus_offsets"] = np.array(res.locus_names), res.locus_lengths, res.locus_offsets
+    raw["gene_names"] = np.array([str(x) for x in res.gene_names])
+    raw["gene_descriptions"] = np.array([str(x) for x in res.gene_descriptions])
+    raw["gene_states"] = res.gene_states
+    gi = res.gene_intervals
+    raw["gi.starts"], raw["gi.ends"], raw["gi.strands"], raw["gi.original_indices"] = gi.starts, gi.ends, gi.strands, gi.original_indices
+    np.savez_compressed(OUT / "compare.npz", **raw)
+    print(f"compare: {len(e)} edges between {n_loci} loci ({time.time() - t0:.0f} s)")
+
+
 def main() -> None:
     OUT.mkdir(parents=True, exist_ok=True)
-    what = set(sys.argv[1:]) or {"protein", "intervals", "seqs", "typing", "genbank"}
+    what = set(sys.argv[1:]) or {"protein", "intervals", "seqs", "typing", "genbank", "compare"}
+    if "compare" in what:
+        gen_compare()
     if "genbank" in what:
         gen_genbank()
     if "protein" in what:
