@@ -231,6 +231,11 @@ def main() -> None:
     if args.share_gpu:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # torch initialises its HIP state lazily, at the first call that needs it -- which would be the synchronize() that
+    # opens the timed region, with a second or so of one-off work trailing into the first timed step: do it here instead
+    torch.cuda.init()
+    torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":

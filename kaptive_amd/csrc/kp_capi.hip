@@ -150,7 +150,7 @@ struct KpWork {
     DevBuf<uint64_t> d_anchors_a, d_anchors_b;
     DevBuf<uint32_t> d_counts;  // [n_asm] anchor counts, [KP_N_CLASSES] task counts, [n_asm] largest sub-slice demand
     DevBuf<uint32_t> d_sub_counts;  // [n_asm * KP_ANCHOR_SUBS]
-    DevBuf<uint64_t> d_cand;        // candidates of the scan: [cand_cap] positions, then [cand_cap] u32 k-mers; d_cand_count[0] = how many
+    DevBuf<uint64_t> d_cand;        // candidates of the scan (kp_cand_pack); d_cand_count[0] = how many
     DevBuf<unsigned long long> d_cand_count;
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
@@ -215,7 +215,7 @@ struct kp_ctx {
     int64_t n_postings = 0;
     std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
     DevBuf<uint2> d_slots;
-    DevBuf<uint64_t> d_filter, d_lds_filter;
+    DevBuf<uint64_t> d_filter, d_filter2, d_lds_filter;
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
@@ -526,7 +526,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (KpInput *in : ctx->free_inputs) { in->release(); delete in; }
     ctx->free_inputs.clear();
     for (auto &w : ctx->work) w.release();
-    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
+    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_trace.release(); ctx->d_ln.release();
     for (auto &g : ctx->groups)
@@ -651,7 +651,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if (log_slots > 30) return kp_fail(ctx, KP_EINVAL, "seed index too large");
     const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
     std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
-    std::vector<uint64_t> filter((size_t)1 << (KP_FILTER_LOG2 - 6), 0ull);
+    std::vector<uint64_t> filter((size_t)1 << (KP_FILTER_LOG2 - 6), 0ull), filter2((size_t)1 << (KP_FILTER2_LOG2 - 6), 0ull);
     // LDS tier of the filter for databases with few k-mers: >= 10 bits per k-mer must fit KP_LDS_FILTER_BLOCKS blocks
     uint32_t lds_blocks = 0;
     if (n_unique > 0 && n_unique * 10 <= (size_t)KP_LDS_FILTER_BLOCKS * 64)
@@ -666,6 +666,10 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         while (slots[slot].x != 0xFFFFFFFFu) slot = (slot + 1) & mask;
         slots[slot] = make_uint2(post[i].key, (uint32_t)flat.size());
         filter[kp_filter_block(post[i].key)] |= kp_filter_mask(post[i].key);
+        {
+            const uint2 m2 = kp_filter2_mask2(post[i].key);
+            filter2[kp_filter2_block(post[i].key)] |= ((uint64_t)m2.y << 32) | m2.x;
+        }
         if (lds_blocks) lds_filter[kp_lds_filter_block(post[i].key, lds_blocks)] |= kp_filter_mask(post[i].key);
         flat.push_back((uint64_t)(j - i));
         for (size_t x = i; x < j; ++x)
@@ -677,13 +681,14 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     int rcode;
     if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_filter, filter.data(), filter.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_filter2, filter2.data(), filter2.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_lds_filter, lds_filter.data(), lds_filter.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->index = KpSeedIndex{ctx->d_filter.p, lds_blocks ? ctx->d_lds_filter.p : nullptr, lds_blocks, ctx->d_slots.p,
+    ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_filter2.p, lds_blocks ? ctx->d_lds_filter.p : nullptr, lds_blocks, ctx->d_slots.p,
                              ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
     ctx->n_genes = n_genes;
@@ -763,6 +768,8 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     hipEvent_t *ev = w->ev;
     if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
+    if (((uint64_t)b->view.total_words << 4) >> KP_CAND_POS_BITS)
+        return kp_fail(ctx, KP_EOVERFLOW, "a batch holds at most 2^33 bases (candidate positions); use smaller batches");
     KP_HIP_CHECK(ctx, w->d_anchors_a.reserve(n_asm * w->anchor_cap));
     KP_HIP_CHECK(ctx, w->d_anchors_b.reserve(n_asm * w->anchor_cap));
     KP_HIP_CHECK(ctx, w->d_counts.reserve(2 * n_asm + KP_N_CLASSES));
@@ -771,7 +778,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_tasks.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
-    KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap + (w->cand_cap + 1) / 2));  // u64 positions, then u32 k-mers
+    KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(1));
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_trace_top.reserve(1));
@@ -820,7 +827,7 @@ static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
     if (ctx->anchor_cap == 0) ctx->anchor_cap = ctx->opt.anchor_cap;
     ctx->anchor_cap = std::max<uint32_t>((ctx->anchor_cap + KP_ANCHOR_SUBS - 1) / KP_ANCHOR_SUBS, 16u) * KP_ANCHOR_SUBS;
     if (ctx->tasks_per_asm == 0) ctx->tasks_per_asm = ctx->opt.tasks_per_asm;
-    if (ctx->cand_frac <= 0.0) ctx->cand_frac = 0.03;  // a quarter of the positions are selected; 3 % of those pass the filter
+    if (ctx->cand_frac <= 0.0) ctx->cand_frac = 0.012;  // a quarter of the positions are selected; ~1 % of those pass both filters
     if (ctx->hit_cap == 0) ctx->hit_cap = ctx->opt.hit_cap;
     w->anchor_cap = ctx->anchor_cap;
     w->task_cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max(b->n_asm, 1) * ctx->tasks_per_asm, 1u << 28);

@@ -32,6 +32,24 @@ __host__ __device__ inline uint64_t kp_filter_mask(uint32_t kmer) {
     const uint2 m = kp_filter_mask2(kmer);
     return ((uint64_t)m.y << 32) | m.x;
 }
+// Second filter, consulted only for what passed the first (a few per cent of the selected k-mers): 2^KP_FILTER2_LOG2 bits
+// in 64-bit blocks, own hashes.  It runs when a wave flushes its staged candidates -- dense, every lane busy, many reads
+// in flight -- and removes most of the first filter's false positives before they are written: the candidate list
+// shrinks to roughly the k-mers that really are in the index, which is what the scan kernel writes to HBM and what
+// kp_expand_kernel has to probe the table for.
+#define KP_FILTER2_LOG2 23
+__host__ __device__ inline uint32_t kp_filter2_block(uint32_t kmer) { return (kmer * 0xC2B2AE35u) >> (32 - (KP_FILTER2_LOG2 - 6)); }
+__host__ __device__ inline uint2 kp_filter2_mask2(uint32_t kmer) {
+    const uint32_t h = kmer * 0x27D4EB2Fu;
+    uint2 m;
+    m.x = (1u << (h >> 27)) | (1u << ((h >> 22) & 31u));
+    m.y = (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+    return m;
+}
+// A candidate is one word: batch-wide base position (33 bits: a batch holds less than 2^33 bases) and the k-mer (30 bits).
+#define KP_CAND_POS_BITS 33
+__host__ __device__ inline uint64_t kp_cand_pack(uint64_t pos, uint32_t kmer) { return (pos << 30) | kmer; }
+
 // Small databases also get an LDS-sized copy of the filter: lds_filter_blocks 64-bit blocks (0 = none), block of a
 // k-mer = high word of hash * lds_filter_blocks, same KP_FILTER_K bits within the block.
 #define KP_LDS_FILTER_BLOCKS 12288  // 96 KB
@@ -40,6 +58,7 @@ __host__ __device__ inline uint32_t kp_lds_filter_block(uint32_t kmer, uint32_t 
 }
 struct KpSeedIndex {
     const uint64_t *filter;    // [2^KP_FILTER_LOG2 / 64] presence filter over the indexed k-mers
+    const uint64_t *filter2;   // [2^KP_FILTER2_LOG2 / 64] recheck filter (see above)
     const uint64_t *lds_filter;  // [lds_filter_blocks] or null
     uint32_t lds_filter_blocks;
     const uint2 *slots;        // [n_slots], key == 0xFFFFFFFF marks an empty slot
@@ -122,8 +141,8 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
 // kp_scan.hip: pass 1 streams the packed contigs and records candidate positions (selected k-mers that pass the presence
-//   filter) in `cand` (room for cand_cap u64 positions followed by cand_cap u32 k-mers; n_cand keeps counting past
-//   cand_cap = overflow); pass 2 turns candidates into anchor keys.  Each
+//   filters) in `cand` (cand_cap words, kp_cand_pack; n_cand keeps counting past cand_cap = overflow); pass 2 turns
+//   candidates into anchor keys.  Each
 //   assembly's anchor region of sub_cap * KP_ANCHOR_SUBS keys is cut into KP_ANCHOR_SUBS sub-slices with their own
 //   counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past sub_cap = overflow); kp_launch_anchor_compact then
 //   packs each assembly's slices into one run.  `after_scan` (optional) is recorded between the two passes.

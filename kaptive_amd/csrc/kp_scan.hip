@@ -61,7 +61,7 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 template <bool LDSF> struct ScanShape {
     static constexpr int WAVES = LDSF ? 16 : 4;
     // a round of PROBES positions per lane adds at most 64 * PROBES entries (flush after the round)
-    static constexpr int STAGE = LDSF ? 320 : 768;
+    static constexpr int STAGE = LDSF ? 320 : 1024;
     static constexpr int FILTER_BLOCKS = LDSF ? KP_LDS_FILTER_BLOCKS : 1;
 };
 
@@ -70,12 +70,10 @@ constexpr int PROBES = 4;
 template <int MODE, bool LDSF>
 __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx,
                                                                               uint64_t *__restrict__ cand,
-                                                                              uint32_t *__restrict__ cand_kmer,
                                                                               unsigned long long *__restrict__ n_cand,
                                                                               uint64_t cand_cap) {
     constexpr int WAVES = ScanShape<LDSF>::WAVES, STAGE_PER_WAVE = ScanShape<LDSF>::STAGE;
     __shared__ uint64_t s_stage[WAVES][STAGE_PER_WAVE];
-    __shared__ uint32_t s_stage_kmer[WAVES][STAGE_PER_WAVE];
     __shared__ uint2 s_filter[ScanShape<LDSF>::FILTER_BLOCKS];
     const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
     if (LDSF) {
@@ -90,16 +88,33 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
     const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t *stage = s_stage[wave];
-    uint32_t *stage_kmer = s_stage_kmer[wave];
     uint32_t staged = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
+    const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
 
+    // The staged candidates go through the second filter (one read each, all lanes busy), the survivors are packed to the
+    // front of the stage and leave with one atomic for the whole flush.
     auto flush = [&]() {
+        uint32_t kept = 0;  // wave-uniform
+        for (uint32_t i0 = 0; i0 < staged; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint64_t c = 0;
+            bool ok = false;
+            if (i < staged) {
+                c = stage[i];
+                const uint32_t kmer = (uint32_t)c & KP_KMER_MASK;
+                const uint2 got = g_filter2[kp_filter2_block(kmer)], need = kp_filter2_mask2(kmer);
+                ok = (got.x & need.x) == need.x && (got.y & need.y) == need.y;
+            }
+            const unsigned long long pass = __ballot(ok);
+            if (ok) stage[kept + (uint32_t)__builtin_popcountll(pass & below)] = c;  // kept <= i0: never ahead of the reads
+            kept += (uint32_t)__builtin_popcountll(pass);
+        }
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(n_cand, (unsigned long long)staged);
+        if (lane == 0 && kept) base = atomicAdd(n_cand, (unsigned long long)kept);
         base = __shfl(base, 0);
-        for (uint32_t i = lane; i < staged; i += 64)
-            if (base + i < cand_cap) { cand[base + i] = stage[i]; cand_kmer[base + i] = stage_kmer[i]; }
+        for (uint32_t i = lane; i < kept; i += 64)
+            if (base + i < cand_cap) cand[base + i] = stage[i];
         staged = 0;
     };
 
@@ -147,11 +162,8 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
                     const bool hit = pass[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
                     const unsigned long long ballot = __ballot(hit);
                     if (!ballot) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
-                    if (hit) {
-                        const uint32_t at = staged + (uint32_t)__builtin_popcountll(ballot & below);
-                        stage[at] = half_base + pos[j];
-                        stage_kmer[at] = kmers[j];  // the expansion pass does not have to touch the bases again
-                    }
+                    if (hit)  // position and k-mer in one word: the expansion pass does not touch the bases again
+                        stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] = kp_cand_pack(half_base + pos[j], kmers[j]);
                     staged += (uint32_t)__builtin_popcountll(ballot);
                 }
                 if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
@@ -170,7 +182,6 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
 // KP_ANCHOR_SUBS counters because all hits of an assembly come in one burst (the typed locus) and would otherwise
 // serialise on a single atomic word.
 __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedIndex idx, const uint64_t *__restrict__ cand,
-                                                         const uint32_t *__restrict__ cand_kmer,
                                                          const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                          uint64_t *__restrict__ anchors, uint32_t *__restrict__ sub_count,
                                                          uint32_t sub_cap, KpKeyBits kb) {
@@ -192,9 +203,9 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
         uint32_t first_posting = 0xFFFFFFFFu, cnt = 0, base = 0, t = 0;
         size_t slice = 0;
         if (i < n) {
-            const uint64_t pos = cand[i];
+            const uint64_t pos = cand[i] >> 30;
             const int64_t word = (int64_t)(pos >> 4);
-            const uint32_t kmer = cand_kmer[i];
+            const uint32_t kmer = (uint32_t)cand[i] & KP_KMER_MASK;
             uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
             for (;;) {
                 const uint2 e = idx.slots[slot];
@@ -306,22 +317,20 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
                     int mode, bool no_lds, hipStream_t stream, hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
-    uint32_t *cand_kmer = reinterpret_cast<uint32_t *>(cand + cand_cap);  // second half of the candidate buffer
     if (idx.lds_filter_blocks && !no_lds && mode == 0) {
         // one 16-wave block per CU (the filter fills most of its LDS); a few blocks per CU in the grid even out the tail
         int64_t blocks = (n_units + 1023) / 1024;
         if (blocks > 256 * 4) blocks = 256 * 4;
-        hipLaunchKernelGGL((kp_scan_kernel<0, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, b, idx, cand, cand_kmer,
-                           n_cand, cand_cap);
+        hipLaunchKernelGGL((kp_scan_kernel<0, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, b, idx, cand, n_cand, cand_cap);
     } else {
         int64_t blocks = (n_units + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
         const dim3 grid((unsigned)blocks), block(256);
-        if (mode == 1) hipLaunchKernelGGL((kp_scan_kernel<1, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
-        else if (mode == 2) hipLaunchKernelGGL((kp_scan_kernel<2, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
-        else hipLaunchKernelGGL((kp_scan_kernel<0, false>), grid, block, 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap);
+        if (mode == 1) hipLaunchKernelGGL((kp_scan_kernel<1, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+        else if (mode == 2) hipLaunchKernelGGL((kp_scan_kernel<2, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+        else hipLaunchKernelGGL((kp_scan_kernel<0, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
     }
     if (after_scan) (void)hipEventRecord(after_scan, stream);
-    hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, cand_kmer, n_cand, cand_cap,
+    hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap,
                        anchors, sub_count, sub_cap, key_bits);
 }
