@@ -79,13 +79,12 @@ struct Cell {
 
 // Direction nibble of a cell, most significant bit first: [source:2][E opened][F opened];
 // source 0 = diagonal, 1 = diagonal from a restart cell (the path starts here), 2 = E, 3 = F.
-__device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned inv_r, unsigned prof, unsigned tsh, int l_hmoe,
-                                        int l_gmex, int u_hmoe, int u_gmex) {
-    // E: gap in the query, arrives from the left; F: gap in the target, arrives from above (open wins ties)
-    const unsigned long long eo = __builtin_amdgcn_ballot_w64(l_hmoe >= l_gmex);
-    const int e = max(l_hmoe, l_gmex);
-    const unsigned long long fo = __builtin_amdgcn_ballot_w64(u_hmoe >= u_gmex);
-    const int f = max(u_hmoe, u_gmex);
+// e / f: the gap states arriving from the left / from above, eo / fo: lane masks "the gap was opened there" (open wins
+// ties) -- computed by the caller, which also knows the band's edge lanes.
+// (Measured and rejected: one bit plane per compare, shifted in without the scalar mask arithmetic in between -- one more
+// vector instruction per cell, 14.8 ms against 13.5 ms per pass.)
+__device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned inv_r, unsigned prof, unsigned tsh, int e,
+                                        unsigned long long eo, int f, unsigned long long fo) {
     const int s = __builtin_amdgcn_sbfe((int)prof, tsh, 6u);
     const unsigned long long fresh = __builtin_amdgcn_ballot_w64(c.h == 0);
     const int d = c.h + s;  // diagonal: the lane's own previous row
@@ -107,20 +106,28 @@ struct State {
 };
 
 template <int P>
-__device__ __forceinline__ void dp_step(State &s, unsigned &acc, int m, int l, unsigned prof_in, unsigned t_in) {
+__device__ __forceinline__ void dp_step(State &s, unsigned &acc, int m, int l, unsigned prof_in, unsigned t_in,
+                                        unsigned long long first_lanes, unsigned long long last_lanes) {
     constexpr bool ROW = P <= 16;
     const unsigned q_shift = (unsigned)from_lower<ROW>((int)s.qb);
     s.qb = (l == 0) ? prof_in : q_shift;  // profile of row m enters at lane 0
     const unsigned inv_r = (unsigned)(32767 - (m - l)) & 32767u;
 
-    int l_hmoe = from_lower<ROW>(s.D.hmoe), l_gmex = from_lower<ROW>(s.D.emex);  // lane l-1's D of the previous step
-    if (l == 0) { l_hmoe = -OE; l_gmex = NEG; }
-    dp_cell(s.A, acc, inv_r, s.qb, s.t0, l_hmoe, l_gmex, s.B.hmoe, s.B.fmex);
-    dp_cell(s.B, acc, inv_r, s.qb, s.t1, s.A.hmoe, s.A.emex, s.C.hmoe, s.C.fmex);
-    dp_cell(s.C, acc, inv_r, s.qb, s.t2, s.B.hmoe, s.B.emex, s.D.hmoe, s.D.fmex);
-    int u_hmoe = from_upper<ROW>(s.A.hmoe), u_gmex = from_upper<ROW>(s.A.fmex);  // lane l+1's A of this step
-    if (l == P - 1) { u_hmoe = -OE; u_gmex = NEG; }
-    dp_cell(s.D, acc, inv_r, s.qb, s.t3, s.C.hmoe, s.C.emex, u_hmoe, u_gmex);
+    // A: the left neighbour is lane l-1's D of the previous step; left of the band's first diagonal H = 0, E = -inf, so
+    // the band's first lane takes E = -(open + ext), "opened" (one select on the result instead of one per operand)
+    const int l_hmoe = from_lower<ROW>(s.D.hmoe), l_gmex = from_lower<ROW>(s.D.emex);
+    const int eA = (l == 0) ? -OE : max(l_hmoe, l_gmex);
+    const unsigned long long eoA = __builtin_amdgcn_ballot_w64(l_hmoe >= l_gmex) | first_lanes;
+    dp_cell(s.A, acc, inv_r, s.qb, s.t0, eA, eoA, max(s.B.hmoe, s.B.fmex), __builtin_amdgcn_ballot_w64(s.B.hmoe >= s.B.fmex));
+    dp_cell(s.B, acc, inv_r, s.qb, s.t1, max(s.A.hmoe, s.A.emex), __builtin_amdgcn_ballot_w64(s.A.hmoe >= s.A.emex),
+            max(s.C.hmoe, s.C.fmex), __builtin_amdgcn_ballot_w64(s.C.hmoe >= s.C.fmex));
+    dp_cell(s.C, acc, inv_r, s.qb, s.t2, max(s.B.hmoe, s.B.emex), __builtin_amdgcn_ballot_w64(s.B.hmoe >= s.B.emex),
+            max(s.D.hmoe, s.D.fmex), __builtin_amdgcn_ballot_w64(s.D.hmoe >= s.D.fmex));
+    // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal the same boundary applies
+    const int u_hmoe = from_upper<ROW>(s.A.hmoe), u_gmex = from_upper<ROW>(s.A.fmex);
+    const int fD = (l == P - 1) ? -OE : max(u_hmoe, u_gmex);
+    const unsigned long long foD = __builtin_amdgcn_ballot_w64(u_hmoe >= u_gmex) | last_lanes;
+    dp_cell(s.D, acc, inv_r, s.qb, s.t3, max(s.C.hmoe, s.C.emex), __builtin_amdgcn_ballot_w64(s.C.hmoe >= s.C.emex), fD, foD);
 
     const unsigned t_shift = (unsigned)from_upper<ROW>((int)s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
     s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
@@ -150,6 +157,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 
     const int lane = threadIdx.x;
     const int g = lane / P, l = lane % P;
+    const unsigned long long first_lanes = __builtin_amdgcn_ballot_w64(l == 0), last_lanes = __builtin_amdgcn_ballot_w64(l == P - 1);
 
     for (uint32_t quad = block; (uint64_t)quad * G < n_tasks; quad += n_blocks) {
         const uint32_t slot = quad * G + g;
@@ -234,23 +242,39 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                 if (l + i * P < NTW) s_tw[g][l + i * P] = treg[i];
             __syncthreads();
             {
+                // codes of the window, four at a time (one 32-bit LDS store): byte y of the padded row = position
+                // p0 + y - PAD.  Whole groups inside the contig of an assembly without N runs -- nearly all -- are cut
+                // out of the packed words with one funnel shift and spread to bytes; the rest go base by base.
                 const int p0 = lo + m0, w0 = p0 >> 4;
-                for (int x = l; x < TW; x += P) {
-                    const int t = p0 + x;
-                    unsigned code = 5u;
-                    if (have && t >= cstart && t < cend) {
-                        code = (s_tw[g][(t >> 4) - w0] >> (2 * (t & 15))) & 3u;
-                        if (n_runs > 0) {  // rare: assemblies with scaffold gaps
-                            int a = 0, z = n_runs;
-                            while (a < z) {
-                                const int mid = (a + z) >> 1;
-                                if (runs[2 * mid + 1] <= t) a = mid + 1; else z = mid;
+                for (int y = 4 * l; y < TROW; y += 4 * P) {
+                    const int t0 = p0 + y - PAD;
+                    uint32_t four;
+                    if (have && n_runs == 0 && y >= PAD && t0 >= cstart && t0 + 3 < cend) {
+                        const int wi = (t0 >> 4) - w0;
+                        const uint32_t lo_w = s_tw[g][wi], hi_w = wi + 1 < NTW ? s_tw[g][wi + 1] : 0u;
+                        const uint32_t v = __builtin_amdgcn_alignbit(hi_w, lo_w, 2 * (t0 & 15)) & 255u;
+                        four = ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18)) * 6u;
+                    } else {
+                        four = 0;
+                        for (int i = 0; i < 4; ++i) {
+                            const int t = t0 + i;
+                            unsigned code = 5u;
+                            if (have && t >= p0 && t >= cstart && t < cend) {  // (bytes before the window are never read)
+                                code = (s_tw[g][(t >> 4) - w0] >> (2 * (t & 15))) & 3u;
+                                if (n_runs > 0) {  // rare: assemblies with scaffold gaps
+                                    int a = 0, z = n_runs;
+                                    while (a < z) {
+                                        const int mid = (a + z) >> 1;
+                                        if (runs[2 * mid + 1] <= t) a = mid + 1; else z = mid;
+                                    }
+                                    if (a < n_runs && runs[2 * a] <= t) code = 4u;
+                                }
                             }
-                            if (a < n_runs && runs[2 * a] <= t) code = 4u;
+                            four |= (code < 5u ? 6u * code : T_OUT) << (8 * i);
+                            saw_n |= code == 4u;
                         }
                     }
-                    s_t[g][x + PAD] = (uint8_t)(code < 5u ? 6u * code : T_OUT);
-                    saw_n |= code == 4u;
+                    *reinterpret_cast<uint32_t *>(&s_t[g][y]) = four;
                 }
             }
             __syncthreads();
@@ -266,10 +290,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                     const int mm = m + 4 * half;
                     const uint4 pr = *reinterpret_cast<const uint4 *>(&s_prof[g][mm - m0]);
                     const uint32_t tc = *reinterpret_cast<const uint32_t *>(&s_t[g][mm - m0 + 3 * P + 1 + PAD]);
-                    dp_step<P>(st, acc[2 * half], mm, l, pr.x, tc & 255u);
-                    dp_step<P>(st, acc[2 * half], mm + 1, l, pr.y, (tc >> 8) & 255u);
-                    dp_step<P>(st, acc[2 * half + 1], mm + 2, l, pr.z, (tc >> 16) & 255u);
-                    dp_step<P>(st, acc[2 * half + 1], mm + 3, l, pr.w, tc >> 24);
+                    dp_step<P>(st, acc[2 * half], mm, l, pr.x, tc & 255u, first_lanes, last_lanes);
+                    dp_step<P>(st, acc[2 * half], mm + 1, l, pr.y, (tc >> 8) & 255u, first_lanes, last_lanes);
+                    dp_step<P>(st, acc[2 * half + 1], mm + 2, l, pr.z, (tc >> 16) & 255u, first_lanes, last_lanes);
+                    dp_step<P>(st, acc[2 * half + 1], mm + 3, l, pr.w, tc >> 24, first_lanes, last_lanes);
                 }
                 const int j = m >> 3;
                 if (fits && j < n_chunks) my_trace[(size_t)j * P] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
