@@ -329,7 +329,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 // run underneath the 16-diagonal class that fills the chip.
 constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
 
-__global__ __launch_bounds__(64, 5) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
+#ifndef KP_SW_WAVES
+#define KP_SW_WAVES 5  // waves per SIMD the register budget is set for (96 VGPRs; measured against 4, 6 and 8: profiles/)
+#endif
+__global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                    const uint32_t *__restrict__ order, KpSwEnd *__restrict__ ends,
                                                    uint4 *__restrict__ trace, unsigned long long *__restrict__ trace_top,
