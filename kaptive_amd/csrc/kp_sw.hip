@@ -1,4 +1,4 @@
-// kp_sw.hip -- banded local alignment (Smith-Waterman-Gotoh, affine gaps, int32) of every band task.
+// kp_sw.hip -- banded local alignment (Smith-Waterman-Gotoh, affine gaps) of every band task.
 //
 // Stands in for the extension half of rammappy's map_batch (reference call site src/kaptive/serotyping/core.py:154;
 // fields consumed at src/kaptive/core/alignment.py:415-446).  Recurrence, tie rules and scores: include/kp_spec.h.
@@ -6,137 +6,232 @@
 // Two kernels.  kp_sw_kernel fills the band and leaves, per task, the best cell and four direction bits per cell in a
 // trace buffer in HBM (288 GB: a pass of 1000 assemblies writes ~12 GB of them); kp_sw_traceback_kernel walks the path
 // of every task that reaches the score cut-off, one lane per task, and writes the hit coordinates, matches and columns.
-// The fill kernel is bound by integer VALU issue (SQ counters: profiles/), so it carries nothing but scores: ~21 vector
-// instructions per cell, against ~70 executed per cell by the round-1 kernel that carried start / matches / columns
-// through the recurrence.
 //
-// Fill kernel mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
-//   * a task's band has W = 4P diagonals; P lanes own it, lane l holds the four adjacent diagonals 4l .. 4l+3 (cells
-//     A..D); a 64-lane wave therefore runs 64/P tasks side by side (P = 4/8/16/32 for W = 16/32/64/128).
+// What the fill kernel is built around (measured on the MI355X, tools/microbench/valu_rate*.hip, profiles/valu_rate*_r2.txt):
+// a gfx950 SIMD issues a wave64 v_add_u32 / v_sub_u32 / v_and / v_or / v_xor / v_lshrrev / v_mov (VGPR or constant
+// operands) in 2 cycles, but v_max / v_min, every compare, v_addc, v_cndmask, v_bfe, every VOP3 and VOP3P (packed 16-bit)
+// instruction, DPP and SDWA forms, and anything with an SGPR operand in 4.  The round's first fill kernel (int32 scores, one
+// compare plus one carry push per direction bit) priced at 82 cycles per cell by that table and ran at exactly that.
+// This one keeps TWO tasks in every register -- task X in the low 16 bits, task Y in the high 16 -- so that
+//   * additions and subtractions of scores are one 2-cycle v_add_u32 for two cells (all values are kept biased into
+//     [0, 32767], so no carry or borrow ever crosses bit 16),
+//   * maxima are one v_pk_max_u16 for two cells,
+//   * a comparison a >= b is (a | 0x80008000) - b: two 2-cycle instructions leave the answer for both cells in bits 15
+//     and 31 (the guard bit survives exactly when no borrow reaches it) -- no v_cmp, no lane mask, no carry push,
+//   * the four direction bits of a cell are merged from those words with shifts and v_bfi,
+//   * every cross-lane move (DPP) and every band-edge select serves two cells.
+// ~55 issue cycles per cell instead of 82.
+//
+// Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
+//   * a task's band has W = 4P diagonals; P lanes own a PAIR of tasks of that width (neighbours in the length-ordered task
+//     list), lane l holds the four adjacent diagonals 4l .. 4l+3 (cells A..D) of both; a wave runs 2 * 64/P tasks.
 //   * time is skewed by lane: at step m lane l works on query row r = m - l, cells A, B, C, D in that order.  With
 //     that skew A's left neighbour is lane l-1's D of the previous step, D's upper neighbour is lane l+1's A of the
 //     same step, and every other neighbour is one of the lane's own registers -- two one-lane shifts per step, both
 //     done with DPP (v_mov_b32_dpp row_shr:1 / row_shl:1, wave_* for the 32-lane class), all state stays in registers.
-//   * sequences are streamed systolically: the query enters at lane 0 as a per-row score profile (five 6-bit signed
-//     fields indexed by the target code, so a substitution score is one v_bfe_i32) and moves up one lane per step, the
-//     target code enters at lane P-1 and moves down; both are staged per chunk in LDS and read four steps at a time.
-//   * no boundary masks: rows outside the gene carry a profile of -32 in every field and columns outside the contig score
+//   * sequences are streamed systolically: the query enters at lane 0 as a per-row score profile (five 3-bit fields per
+//     task, score + 4, indexed by the target code: a substitution score is one v_pk_lshrrev_b16 and one v_and for two
+//     cells) and moves up one lane per step, the target code (as the shift amount 3 * code) enters at lane P-1 and moves
+//     down; both are staged per chunk in LDS.
+//   * no boundary masks: rows outside the gene carry a profile of -4 in every field and columns outside the contig score
 //     like N (-1).  Substitution scores <= 0 are all it takes: cells before the contig or above the gene then hold H = 0
 //     and gap states <= -(open + ext), which is what kp_spec.h prescribes for their neighbours inside (H = 0, E = F = -inf
 //     gives the same E, F and diagonal there); cells past the contig's end or below the gene only ever feed further such
 //     cells, hold values strictly below the inside cell they derive from, so none becomes the best cell, and the
 //     traceback, which only moves up and left, cannot reach them.
-//   * the gap states are kept pre-charged (H - open - ext, E - ext, F - ext), so E and F of a neighbour are one max.
-//   * best cell: per lane and cell one v_max_u32 on (score << 15 | 32767 - row): first maximum in row order for free.
-//   * direction bits: the compares that decide a cell (open/extend for E and F, which of diagonal/E/F wins, "the diagonal
-//     predecessor is a restart cell") stay in SGPR lane masks, are combined by scalar instructions, and each bit is
-//     shifted into the lane's trace word by one v_addc_co_u32 (x + x + carry-in): 4 bits per cell, 16 bytes per lane
-//     per 8 steps, written as one global_store_dwordx4 into the lane's own stream of the task's trace block.
+//   * biases: H is kept as H + 8; the candidates of a cell (diagonal, E, F) and the pre-charged gap states (H - open - ext,
+//     E - ext, F - ext) as value + 12.  The smallest value the recurrence can produce is -(open + 2 ext) = -8, and "no
+//     gap yet" is represented by exactly that (it loses every maximum it takes part in, like -inf), so everything is >= 0;
+//     the largest is 2 * length + 14 < 32768 (KP_MAX_GENE_LEN).
+//   * best cell: per lane and task the running maximum of its four cells, the step at which it last rose and the four H
+//     of that step (packed max, guard compare, v_pk_ashrrev_i16 to a half-word mask, v_bfi selects): first maximum in
+//     row order, then the first of the lane's cells that holds it.
+//   * direction nibbles, four steps per 16 bits, eight steps per 32-bit word and cell: the two tasks' halves are
+//     separated with v_perm_b32 every eight steps and each task's 16 bytes go to its own trace block.
 #include "kp_internal.h"
 
 namespace {
 
 constexpr int CH = 64;  // steps staged per chunk (multiple of 8)
-constexpr int NEG = KP_NEG_INF;
 constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
-constexpr unsigned T_OUT = 24u;  // columns outside the contig read the N field: any score <= 0 does (see below)
-// score profile of a query row: field t (6 bits, signed, at bit 6t) = score against target code t (0..3 ACGT, 4 = N)
-constexpr unsigned PROF_N = 0x3FFFFFFFu;  // KP_SC_N in every field
-constexpr unsigned PROF_MISMATCH = 0x3Cu | (0x3Cu << 6) | (0x3Cu << 12) | (0x3Cu << 18) | (0x3Fu << 24);
-constexpr unsigned PROF_OUT = 0x20u | (0x20u << 6) | (0x20u << 12) | (0x20u << 18) | (0x20u << 24);  // -32 everywhere
-static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1, "profile constants encode these scores");
-static_assert(KP_MAX_GENE_LEN <= 32767, "the best-cell key holds the row in 15 bits and the score (<= 2 * length) in 16");
+static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1 && OE == 6 && EX == 2,
+              "the profile fields and the biases below encode these scores");
+static_assert(2 * KP_MAX_GENE_LEN + 14 < 32768, "biased scores must leave bit 15 of a half-word free for the guard");
+
+constexpr unsigned K1 = 0x00010001u;                        // a value in both halves: x * K1
+constexpr unsigned GUARD = 0x80008000u;
+constexpr unsigned HB = 8, CB = 12;                         // bias of H, bias of candidates and gap states
+constexpr unsigned H_ZERO = HB * K1;                        // H = 0
+constexpr unsigned GAP_NONE = (CB - OE - EX) * K1;          // "no gap": -(open + 2 ext), biased
+constexpr unsigned GAP_EDGE = (CB - OE) * K1;               // the gap state a band-edge cell sees: opened from H = 0
+constexpr unsigned T_OUT = 12u;                             // shift amount of the N field: columns outside the contig
+// profile of a query row, per task 15 bits: field t (3 bits at 3t) = score against target code t (0..3 ACGT, 4 = N) + 4
+constexpr unsigned PROF_N = 3u | (3u << 3) | (3u << 6) | (3u << 9) | (3u << 12);
+constexpr unsigned PROF_OUT = 0u;  // -4 everywhere
 
 // One-lane shifts.  The lane without a source reads 0 (bound_ctrl); every group-edge lane overrides what it receives
 // anyway.  Groups of up to 16 lanes never straddle a DPP row, so the row shifts do; the 32-lane class needs wave shifts.
 template <bool ROW>
-__device__ __forceinline__ int from_lower(int v) {  // lane i <- lane i-1
-    return ROW ? __builtin_amdgcn_mov_dpp(v, 0x111 /*row_shr:1*/, 0xf, 0xf, true)
-               : __builtin_amdgcn_mov_dpp(v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+__device__ __forceinline__ unsigned from_lower(unsigned v) {  // lane i <- lane i-1
+    return (unsigned)(ROW ? __builtin_amdgcn_mov_dpp((int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true)
+                          : __builtin_amdgcn_mov_dpp((int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
 }
 template <bool ROW>
-__device__ __forceinline__ int from_upper(int v) {  // lane i <- lane i+1
-    return ROW ? __builtin_amdgcn_mov_dpp(v, 0x101 /*row_shl:1*/, 0xf, 0xf, true)
-               : __builtin_amdgcn_mov_dpp(v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+__device__ __forceinline__ unsigned from_upper(unsigned v) {  // lane i <- lane i+1
+    return (unsigned)(ROW ? __builtin_amdgcn_mov_dpp((int)v, 0x101 /*row_shl:1*/, 0xf, 0xf, true)
+                          : __builtin_amdgcn_mov_dpp((int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ unsigned nibble(unsigned word, int i) { return (word >> (4 * i)) & 15u; }
 __device__ __forceinline__ unsigned row_profile(unsigned qcode) {
-    return qcode < 4u ? (PROF_MISMATCH ^ (0x3Eu << (6u * qcode))) : PROF_N;  // -4 ^ 0x3E = +2 in the matching field
+    return qcode < 4u ? ((6u << (3u * qcode)) | (3u << 12)) : PROF_N;
 }
 
-// acc = 2 * acc + (this lane's bit of `mask`): one VALU instruction, the mask stays in SGPRs
-__device__ __forceinline__ void push_bit(unsigned &acc, unsigned long long mask) {
-    unsigned long long carry_out;
-    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
+// The instructions of the cell, spelled out so that constants stay literals of 2-cycle VOP2 encodings (an SGPR operand
+// makes them 4-cycle) and packed operations are not taken apart.  Plain asm (not volatile): the compiler schedules them.
+template <unsigned LIT>
+__device__ __forceinline__ unsigned add_k(unsigned a) {  // a + LIT (also a - x as a + (2^32 - x): same 32-bit result)
+    unsigned r;
+    asm("v_add_u32_e32 %0, %2, %1" : "=v"(r) : "v"(a), "n"(LIT));
+    return r;
 }
+template <unsigned LIT>
+__device__ __forceinline__ unsigned or_k(unsigned a) {
+    unsigned r;
+    asm("v_or_b32_e32 %0, %2, %1" : "=v"(r) : "v"(a), "n"(LIT));
+    return r;
+}
+template <unsigned LIT>
+__device__ __forceinline__ unsigned and_k(unsigned a) {
+    unsigned r;
+    asm("v_and_b32_e32 %0, %2, %1" : "=v"(r) : "v"(a), "n"(LIT));
+    return r;
+}
+__device__ __forceinline__ unsigned add_v(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_add_u32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned sub_v(unsigned a, unsigned b) {  // a - b
+    unsigned r;
+    asm("v_sub_u32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned or_v(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_or_b32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ unsigned shr_k(unsigned a) {
+    unsigned r;
+    asm("v_lshrrev_b32_e32 %0, %2, %1" : "=v"(r) : "v"(a), "n"(N));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_shr(unsigned v, unsigned by) {  // each half of v shifted right by the same half of `by`
+    unsigned r;
+    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(by), "v"(v));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_sign_mask(unsigned v, unsigned fifteen) {  // 0xFFFF in the halves whose bit 15 is set
+    unsigned r;
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(fifteen), "v"(v));
+    return r;
+}
+__device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) {  // (mask & a) | (~mask & b)
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned bfi_v(unsigned mask, unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+// a >= b for both halves: the answer in bits 15 and 31, the bits below are of no use to anyone
+__device__ __forceinline__ unsigned ge_word(unsigned a, unsigned b) { return sub_v(or_k<GUARD>(a), b); }
 
 struct Cell {
-    int h, hmoe, emex, fmex;  // H, H - (open + ext), E - ext, F - ext
-    unsigned best;            // max over the rows so far of (H << 15) | (32767 - row)
+    unsigned hs, hmoe, emex, fmex;  // H + 8; H - (open + ext) + 12, E - ext + 12, F - ext + 12 -- task X low, task Y high
 };
 
-// Direction nibble of a cell, most significant bit first: [source:2][E opened][F opened];
-// source 0 = diagonal, 1 = diagonal from a restart cell (the path starts here), 2 = E, 3 = F.
-// e / f: the gap states arriving from the left / from above, eo / fo: lane masks "the gap was opened there" (open wins
-// ties) -- computed by the caller, which also knows the band's edge lanes.
-// (Measured and rejected: one bit plane per compare, shifted in without the scalar mask arithmetic in between -- one more
-// vector instruction per cell, 14.8 ms against 13.5 ms per pass.)
-__device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned inv_r, unsigned prof, unsigned tsh, int e,
-                                        unsigned long long eo, int f, unsigned long long fo) {
-    const int s = __builtin_amdgcn_sbfe((int)prof, tsh, 6u);
-    const unsigned long long fresh = __builtin_amdgcn_ballot_w64(c.h == 0);
-    const int d = c.h + s;  // diagonal: the lane's own previous row
-    const int m = max(max(d, e), f);
-    const unsigned long long from_d = __builtin_amdgcn_ballot_w64(d == m);  // the diagonal wins ties, then E
-    const unsigned long long from_e = __builtin_amdgcn_ballot_w64(e == m);
-    const int h = max(m, 0);
-    c.h = h; c.hmoe = h - OE; c.emex = e - EX; c.fmex = f - EX;
-    c.best = max(c.best, ((unsigned)h << 15) | inv_r);
-    push_bit(acc, ~from_d);
-    push_bit(acc, (from_d & fresh) | ~(from_d | from_e));
-    push_bit(acc, eo);
-    push_bit(acc, fo);
+// Direction nibble of a cell, most significant bit first: [D][L][E opened][F opened].  D: the diagonal won (it wins
+// ties, then E).  L: with D, "the diagonal predecessor holds H > 0" (0 = the path starts in this cell); without D,
+// 1 = E, 0 = F.  e / f: the gap states arriving from the left / from above, eo / fo: comparison words "the gap was
+// opened there" (open wins ties) -- computed by the caller, which also knows the band's edge lanes.
+// The nibbles of four steps share 16 bits: the first step's ends up lowest.
+template <bool FIRST>
+__device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, unsigned tsh, unsigned e, unsigned eo, unsigned f,
+                                        unsigned fo, unsigned twelve) {
+    const unsigned s = and_k<7u * K1>(pk_shr(prof, tsh));        // score + 4
+    const unsigned nz = add_k<0u - (HB + 1u) * K1>(or_k<GUARD>(c.hs));  // H of the diagonal predecessor >= 1
+    const unsigned d = add_v(c.hs, s);                            // diagonal candidate, biased by 12
+    const unsigned m = pk_max(pk_max(d, e), f);
+    const unsigned dw = ge_word(d, m), ew = ge_word(e, m);       // == m, as neither exceeds it
+    const unsigned h = pk_max(m, twelve);                        // H + 12
+    c.hs = add_k<0u - 4u * K1>(h);
+    c.hmoe = add_k<0u - (unsigned)OE * K1>(h);
+    c.emex = add_k<0u - (unsigned)EX * K1>(e);
+    c.fmex = add_k<0u - (unsigned)EX * K1>(f);
+    const unsigned lw = bfi_v(dw, nz, ew);
+    unsigned n = bfi(0x80008000u, dw, shr_k<1>(lw));
+    n = bfi(0xC000C000u, n, shr_k<2>(eo));
+    n = bfi(0xE000E000u, n, shr_k<3>(fo));
+    n = and_k<0xF000F000u>(n);
+    acc = FIRST ? n : or_v(shr_k<4>(acc), n);
 }
 
 struct State {
     Cell A, B, C, D;
     unsigned qb, t0, t1, t2, t3;
+    unsigned best, brow, sA, sB, sC, sD;  // running maximum of the lane's cells (H + 8), step of its last rise, the cells then
 };
 
-template <int P>
-__device__ __forceinline__ void dp_step(State &s, unsigned &acc, int m, int l, unsigned prof_in, unsigned t_in,
-                                        unsigned long long first_lanes, unsigned long long last_lanes) {
+template <int P, bool FIRST>
+__device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned step_k, int l, unsigned prof_in, unsigned t_in,
+                                        unsigned first_all, unsigned last_all, unsigned edge, unsigned twelve, unsigned fifteen) {
     constexpr bool ROW = P <= 16;
-    const unsigned q_shift = (unsigned)from_lower<ROW>((int)s.qb);
-    s.qb = (l == 0) ? prof_in : q_shift;  // profile of row m enters at lane 0
-    const unsigned inv_r = (unsigned)(32767 - (m - l)) & 32767u;
+    const unsigned q_shift = from_lower<ROW>(s.qb);
+    s.qb = (l == 0) ? prof_in : q_shift;  // profiles of row m enter at lane 0
 
     // A: the left neighbour is lane l-1's D of the previous step; left of the band's first diagonal H = 0, E = -inf, so
     // the band's first lane takes E = -(open + ext), "opened" (one select on the result instead of one per operand)
-    const int l_hmoe = from_lower<ROW>(s.D.hmoe), l_gmex = from_lower<ROW>(s.D.emex);
-    const int eA = (l == 0) ? -OE : max(l_hmoe, l_gmex);
-    const unsigned long long eoA = __builtin_amdgcn_ballot_w64(l_hmoe >= l_gmex) | first_lanes;
-    dp_cell(s.A, acc, inv_r, s.qb, s.t0, eA, eoA, max(s.B.hmoe, s.B.fmex), __builtin_amdgcn_ballot_w64(s.B.hmoe >= s.B.fmex));
-    dp_cell(s.B, acc, inv_r, s.qb, s.t1, max(s.A.hmoe, s.A.emex), __builtin_amdgcn_ballot_w64(s.A.hmoe >= s.A.emex),
-            max(s.C.hmoe, s.C.fmex), __builtin_amdgcn_ballot_w64(s.C.hmoe >= s.C.fmex));
-    dp_cell(s.C, acc, inv_r, s.qb, s.t2, max(s.B.hmoe, s.B.emex), __builtin_amdgcn_ballot_w64(s.B.hmoe >= s.B.emex),
-            max(s.D.hmoe, s.D.fmex), __builtin_amdgcn_ballot_w64(s.D.hmoe >= s.D.fmex));
+    const unsigned l_hmoe = from_lower<ROW>(s.D.hmoe), l_emex = from_lower<ROW>(s.D.emex);
+    const unsigned eA = bfi_v(first_all, edge, pk_max(l_hmoe, l_emex));
+    const unsigned eoA = or_v(ge_word(l_hmoe, l_emex), first_all);  // (only bits 15 and 31 are looked at)
+    dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), ge_word(s.B.hmoe, s.B.fmex), twelve);
+    dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max(s.A.hmoe, s.A.emex), ge_word(s.A.hmoe, s.A.emex),
+                   pk_max(s.C.hmoe, s.C.fmex), ge_word(s.C.hmoe, s.C.fmex), twelve);
+    dp_cell<FIRST>(s.C, acc[2], s.qb, s.t2, pk_max(s.B.hmoe, s.B.emex), ge_word(s.B.hmoe, s.B.emex),
+                   pk_max(s.D.hmoe, s.D.fmex), ge_word(s.D.hmoe, s.D.fmex), twelve);
     // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal the same boundary applies
-    const int u_hmoe = from_upper<ROW>(s.A.hmoe), u_gmex = from_upper<ROW>(s.A.fmex);
-    const int fD = (l == P - 1) ? -OE : max(u_hmoe, u_gmex);
-    const unsigned long long foD = __builtin_amdgcn_ballot_w64(u_hmoe >= u_gmex) | last_lanes;
-    dp_cell(s.D, acc, inv_r, s.qb, s.t3, max(s.C.hmoe, s.C.emex), __builtin_amdgcn_ballot_w64(s.C.hmoe >= s.C.emex), fD, foD);
+    const unsigned u_hmoe = from_upper<ROW>(s.A.hmoe), u_fmex = from_upper<ROW>(s.A.fmex);
+    const unsigned fD = bfi_v(last_all, edge, pk_max(u_hmoe, u_fmex));
+    const unsigned foD = or_v(ge_word(u_hmoe, u_fmex), last_all);
+    dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), ge_word(s.C.hmoe, s.C.emex), fD, foD, twelve);
 
-    const unsigned t_shift = (unsigned)from_upper<ROW>((int)s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
+    // best cell of the lane so far: a strict rise keeps the first row; the cells of that step tell the column later
+    const unsigned top = pk_max(pk_max(s.A.hs, s.B.hs), pk_max(s.C.hs, s.D.hs));
+    const unsigned keep = pk_sign_mask(ge_word(s.best, top), fifteen);  // halves that did not rise
+    s.best = pk_max(s.best, top);
+    s.brow = bfi_v(keep, s.brow, step_k);
+    s.sA = bfi_v(keep, s.sA, s.A.hs); s.sB = bfi_v(keep, s.sB, s.B.hs);
+    s.sC = bfi_v(keep, s.sC, s.C.hs); s.sD = bfi_v(keep, s.sD, s.D.hs);
+
+    const unsigned t_shift = from_upper<ROW>(s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
     s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
-    s.t3 = (l == P - 1) ? t_in : t_shift;  // target code x = m + 1 + 3P enters at lane P-1
+    s.t3 = (l == P - 1) ? t_in : t_shift;  // target codes x = m + 1 + 3P enter at lane P-1
 }
 
-constexpr int PROF_WORDS = 16 * CH;                      // LDS of one block: profiles of 64/P groups x CH rows (P >= 4)
-constexpr int TCODE_BYTES = 16 * (CH + 3 * 4 + 4 + 4);   // ... and their target codes (largest for P = 4), rows padded
-constexpr int TWORD_WORDS = 128;                         // ... and the packed words those codes are cut from
+constexpr int PROF_WORDS = 16 * CH;                      // LDS of one block: profile pairs of 64/P groups x CH rows (P >= 4)
+constexpr int TCODE_HALVES = 16 * (CH + 3 * 4 + 4 + 4);  // ... their target shift amounts, a byte per task (largest for P = 4)
+constexpr int TWORD_WORDS = 2 * 128;                     // ... and the packed words those are cut from
 
 // all tasks of one band class, seen from block `block` of `n_blocks` that work on the class
 template <int P>
@@ -144,81 +239,101 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                                          uint32_t n_tasks, const uint32_t *__restrict__ order,
                                          KpSwEnd *__restrict__ ends, uint4 *__restrict__ trace,
                                          unsigned long long *__restrict__ trace_top, uint64_t trace_cap, uint32_t block,
-                                         uint32_t n_blocks, uint32_t *s_prof_raw, uint8_t *s_t_raw, uint32_t *s_tw_raw) {
+                                         uint32_t n_blocks, uint32_t *s_prof_raw, uint16_t *s_t_raw, uint32_t *s_tw_raw) {
     constexpr int G = 64 / P;
     constexpr int TW = CH + 3 * P + 4;  // staged target codes per chunk: window x in [m0, m0 + CH + 3P]
     // the codes a step pulls in start at x = step + 3P + 1: the row is shifted by PAD so that every fourth step's lies
-    // on a 4-byte boundary (one ds_read_b32 feeds four steps)
+    // on an 8-byte boundary (one ds_read_b64 feeds four steps)
     constexpr int PAD = (4 - (3 * P + 1) % 4) % 4;
     constexpr int TROW = (TW + PAD + 3) & ~3;
-    static_assert(G * CH <= PROF_WORDS && G * TROW <= TCODE_BYTES, "LDS carve-up");
+    static_assert(G * CH <= PROF_WORDS && G * TROW <= TCODE_HALVES, "LDS carve-up");
     uint32_t(*s_prof)[CH] = reinterpret_cast<uint32_t(*)[CH]>(s_prof_raw);
-    uint8_t(*s_t)[TROW] = reinterpret_cast<uint8_t(*)[TROW]>(s_t_raw);
+    uint16_t(*s_t)[TROW] = reinterpret_cast<uint16_t(*)[TROW]>(s_t_raw);  // byte 0: task X, byte 1: task Y
 
     const int lane = threadIdx.x;
     const int g = lane / P, l = lane % P;
-    const unsigned long long first_lanes = __builtin_amdgcn_ballot_w64(l == 0), last_lanes = __builtin_amdgcn_ballot_w64(l == P - 1);
+    // all ones in the band's first / last lane: the selects of the band edges are bitwise (a ternary around the asm
+    // statements becomes a branch)
+    unsigned first_all = l == 0 ? ~0u : 0u, last_all = l == P - 1 ? ~0u : 0u;
+    // (VGPR copies of constants that VOP3 / VOP3P instructions cannot take as literals)
+    unsigned twelve = CB * K1, fifteen = 15u * K1, edge = GAP_EDGE;
+    asm volatile("" : "+v"(twelve), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
 
-    for (uint32_t quad = block; (uint64_t)quad * G < n_tasks; quad += n_blocks) {
-        const uint32_t slot = quad * G + g;
-        const bool have = slot < n_tasks;
-        const uint32_t ti = have ? order[slot] : 0u;  // tasks of similar length share a wave (kp_chain.hip)
-        KpTask tk;
-        tk.asm_id = 0; tk.gs = 0; tk.contig = 0; tk.lo = 0;
-        if (have) tk = tasks[ti];
-        const int gene = tk.gs >> 1;
-        const int qlen = have ? genes.len[gene] : 0;
-        const uint32_t *qnib = genes.nib + genes.word_off[(tk.gs & 1) ? genes.n_genes + gene : gene];
-        const uint32_t *asm_words = b.words + b.asm_word_off[tk.asm_id];
-        const int c_abs = b.asm_first_ctg[tk.asm_id] + tk.contig;
-        const int32_t cstart = b.ctg_start[c_abs], cend = cstart + b.ctg_len[c_abs];
-        const int r0 = b.asm_first_nrun[tk.asm_id];
-        const int n_runs = b.asm_first_nrun[tk.asm_id + 1] - r0;
-        const int32_t *runs = b.n_runs + 2 * (size_t)r0;
-        const int lo = tk.lo;
-
-        const int steps = have ? qlen + P - 1 : 0;  // steps this group needs
-        // 8-step trace pieces per lane (an even number: task blocks then start on 128-byte lines)
-        const int n_chunks = (((steps + 7) >> 3) + 1) & ~1;
-        int max_steps = steps;
+    for (uint32_t quad = block; (uint64_t)quad * (2 * G) < n_tasks; quad += n_blocks) {
+        // the pair of this group: two neighbours in the length-ordered list (kp_chain.hip)
+        bool have[2];
+        uint32_t ti[2];
+        KpTask tk[2];
+        int qlen[2], lo[2], n_runs[2], steps[2], n_chunks[2];
+        int32_t cstart[2], cend[2];
+        // (32-bit offsets from the batch's and the genes' arrays rather than pointers: registers)
+        uint32_t asm_n_words[2], q_off[2], w_off[2], run_off[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t slot = (quad * G + g) * 2 + h;
+            have[h] = slot < n_tasks;
+            ti[h] = have[h] ? order[slot] : 0u;
+            tk[h].asm_id = 0; tk[h].gs = 0; tk[h].contig = 0; tk[h].lo = 0;
+            if (have[h]) tk[h] = tasks[ti[h]];
+            const int gene = tk[h].gs >> 1;
+            qlen[h] = have[h] ? genes.len[gene] : 0;
+            q_off[h] = (uint32_t)genes.word_off[(tk[h].gs & 1) ? genes.n_genes + gene : gene];
+            w_off[h] = (uint32_t)b.asm_word_off[tk[h].asm_id];
+            asm_n_words[h] = (uint32_t)(b.asm_word_off[tk[h].asm_id + 1] - b.asm_word_off[tk[h].asm_id]);
+            const int c_abs = b.asm_first_ctg[tk[h].asm_id] + tk[h].contig;
+            cstart[h] = b.ctg_start[c_abs]; cend[h] = cstart[h] + b.ctg_len[c_abs];
+            const int r0 = b.asm_first_nrun[tk[h].asm_id];
+            n_runs[h] = b.asm_first_nrun[tk[h].asm_id + 1] - r0;
+            run_off[h] = 2u * (uint32_t)r0;
+            lo[h] = tk[h].lo;
+            steps[h] = have[h] ? qlen[h] + P - 1 : 0;  // steps the task needs
+            // 8-step trace pieces per lane (an even number: task blocks then start on 128-byte lines)
+            n_chunks[h] = (((steps[h] + 7) >> 3) + 1) & ~1;
+        }
+        int max_steps = max(steps[0], steps[1]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, o));
-        // the task's trace block: P lane streams of n_chunks 16-byte pieces each
+        // the pair's trace blocks, X's then Y's: P lane streams of n_chunks 16-byte pieces each
+        const unsigned long long want = (unsigned long long)P * (unsigned)((have[0] ? n_chunks[0] : 0) + (have[1] ? n_chunks[1] : 0));
         unsigned long long toff = 0;
-        if (have && l == 0) toff = atomicAdd(trace_top, (unsigned long long)(P * n_chunks));
+        if (have[0] && l == 0) toff = atomicAdd(trace_top, want);
         toff = ((unsigned long long)__shfl((unsigned)(toff >> 32), g * P) << 32) | __shfl((unsigned)toff, g * P);
-        const bool fits = have && toff + (unsigned long long)(P * n_chunks) <= trace_cap;  // else: counted, host reruns
+        const bool fits = have[0] && toff + want <= trace_cap;  // else: counted, host reruns
         // piece j of lane l at [j][l]: the P lanes of a task write P * 16 contiguous bytes per store, and a 128-byte line
         // is complete after 8 * 8 / P steps -- with a stream per lane a line stayed open for 64 steps, more open lines
         // than the L2 holds, and HBM saw three times the bytes (WRITE_SIZE, profiles/)
-        uint4 *my_trace = trace + toff + l;
+        const unsigned long long toff_y = toff + (unsigned long long)P * (unsigned)n_chunks[0];
+        uint4 *trace_x = trace + toff + l, *trace_y = trace + toff_y + l;
 
         State st;
-        st.A.h = 0; st.A.hmoe = -OE; st.A.emex = NEG; st.A.fmex = NEG; st.A.best = 0;
+        st.A.hs = H_ZERO; st.A.hmoe = GAP_EDGE; st.A.emex = GAP_NONE; st.A.fmex = GAP_NONE;
         st.B = st.A; st.C = st.A; st.D = st.A;
-        st.qb = PROF_OUT; st.t0 = st.t1 = st.t2 = st.t3 = T_OUT;
-        unsigned acc[4] = {0, 0, 0, 0};
-        bool saw_n = false;  // an N in the gene or in the target window: the traceback then compares bases itself
+        st.qb = PROF_OUT; st.t0 = st.t1 = st.t2 = st.t3 = T_OUT * K1;
+        st.best = H_ZERO; st.brow = 0; st.sA = st.sB = st.sC = st.sD = H_ZERO;
+        unsigned acc[4] = {0, 0, 0, 0}, held[4] = {0, 0, 0, 0};
+        bool saw_n[2] = {false, false};  // an N in the gene or in the target window: the traceback then compares bases itself
 
         const int steps8 = (max_steps + 7) & ~7;
         // Staging of a chunk (profiles of its query rows, codes of its target window) works from packed words that were
-        // requested one chunk earlier: NQ gene words (8 rows each) and NT assembly words (16 bases each) per lane.
+        // requested one chunk earlier: NQ gene words (8 rows each) and NT assembly words (16 bases each) per lane and task.
         constexpr int NQ = (CH / 8 + P - 1) / P, NTW = (TW + 15) / 16 + 1, NT = (NTW + P - 1) / P;
-        static_assert(G * NTW <= TWORD_WORDS, "LDS carve-up");
-        uint32_t(*s_tw)[NTW] = reinterpret_cast<uint32_t(*)[NTW]>(s_tw_raw);
-        const int64_t asm_n_words = b.asm_word_off[tk.asm_id + 1] - b.asm_word_off[tk.asm_id];
-        uint32_t qreg[NQ], treg[NT];
+        static_assert(2 * G * NTW <= TWORD_WORDS, "LDS carve-up");
+        uint32_t(*s_tw)[G][NTW] = reinterpret_cast<uint32_t(*)[G][NTW]>(s_tw_raw);
+        uint32_t qreg[2][NQ], treg[2][NT];
         auto request = [&](int m0) {  // global loads only; nothing waits for them here
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int w = l + i * P, r = m0 + 8 * w;
-                qreg[i] = (have && w < CH / 8 && r < qlen) ? qnib[r >> 3] : 0u;
-            }
-            const int w0 = (lo + m0) >> 4;
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int64_t wi = (int64_t)w0 + l + i * P;
-                treg[i] = (have && l + i * P < NTW && wi >= 0 && wi < asm_n_words) ? asm_words[wi] : 0u;
+                for (int i = 0; i < NQ; ++i) {
+                    const int w = l + i * P, r = m0 + 8 * w;
+                    qreg[h][i] = (have[h] && w < CH / 8 && r < qlen[h]) ? genes.nib[q_off[h] + (uint32_t)(r >> 3)] : 0u;
+                }
+                const int w0 = (lo[h] + m0) >> 4;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int wi = w0 + l + i * P;
+                    treg[h][i] = (have[h] && l + i * P < NTW && wi >= 0 && (uint32_t)wi < asm_n_words[h]) ? b.words[w_off[h] + (uint32_t)wi] : 0u;
+                }
             }
         };
         request(0);
@@ -231,57 +346,72 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                 if (w < CH / 8) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const bool live = have && r + j < qlen;
-                        s_prof[g][8 * w + j] = live ? row_profile(nibble(qreg[i], j)) : PROF_OUT;
-                        saw_n |= live && nibble(qreg[i], j) >= 4u;
+                        unsigned pair = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const bool live = have[h] && r + j < qlen[h];
+                            pair |= (live ? row_profile(nibble(qreg[h][i], j)) : PROF_OUT) << (16 * h);
+                            saw_n[h] |= live && nibble(qreg[h][i], j) >= 4u;
+                        }
+                        s_prof[g][8 * w + j] = pair;
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
-                if (l + i * P < NTW) s_tw[g][l + i * P] = treg[i];
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (l + i * P < NTW) s_tw[h][g][l + i * P] = treg[h][i];
             __syncthreads();
             {
-                // codes of the window, four at a time (one 32-bit LDS store): byte y of the padded row = position
-                // p0 + y - PAD.  Whole groups inside the contig of an assembly without N runs -- nearly all -- are cut
-                // out of the packed words with one funnel shift and spread to bytes; the rest go base by base.
-                const int p0 = lo + m0, w0 = p0 >> 4;
+                // shift amounts (3 * code) of the window, four positions at a time: byte pair y of the padded row =
+                // position p0 + y - PAD.  Whole groups inside the contig of an assembly without N runs -- nearly all -- are
+                // cut out of the packed words with one funnel shift and spread to bytes; the rest go base by base.
                 for (int y = 4 * l; y < TROW; y += 4 * P) {
-                    const int t0 = p0 + y - PAD;
-                    uint32_t four;
-                    if (have && n_runs == 0 && y >= PAD && t0 >= cstart && t0 + 3 < cend) {
-                        const int wi = (t0 >> 4) - w0;
-                        const uint32_t lo_w = s_tw[g][wi], hi_w = wi + 1 < NTW ? s_tw[g][wi + 1] : 0u;
-                        const uint32_t v = __builtin_amdgcn_alignbit(hi_w, lo_w, 2 * (t0 & 15)) & 255u;
-                        four = ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18)) * 6u;
-                    } else {
-                        four = 0;
-                        for (int i = 0; i < 4; ++i) {
-                            const int t = t0 + i;
-                            unsigned code = 5u;
-                            if (have && t >= p0 && t >= cstart && t < cend) {  // (bytes before the window are never read)
-                                code = (s_tw[g][(t >> 4) - w0] >> (2 * (t & 15))) & 3u;
-                                if (n_runs > 0) {  // rare: assemblies with scaffold gaps
-                                    int a = 0, z = n_runs;
-                                    while (a < z) {
-                                        const int mid = (a + z) >> 1;
-                                        if (runs[2 * mid + 1] <= t) a = mid + 1; else z = mid;
+                    uint32_t four[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p0 = lo[h] + m0, w0 = p0 >> 4;
+                        const int t0 = p0 + y - PAD;
+                        if (have[h] && n_runs[h] == 0 && y >= PAD && t0 >= cstart[h] && t0 + 3 < cend[h]) {
+                            const int wi = (t0 >> 4) - w0;
+                            const uint32_t lo_w = s_tw[h][g][wi], hi_w = wi + 1 < NTW ? s_tw[h][g][wi + 1] : 0u;
+                            const uint32_t v = __builtin_amdgcn_alignbit(hi_w, lo_w, 2 * (t0 & 15)) & 255u;
+                            four[h] = ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18)) * 3u;
+                        } else {
+                            four[h] = 0;
+                            for (int i = 0; i < 4; ++i) {
+                                const int t = t0 + i;
+                                unsigned code = 5u;
+                                if (have[h] && t >= p0 && t >= cstart[h] && t < cend[h]) {  // (bytes before the window are never read)
+                                    code = (s_tw[h][g][(t >> 4) - w0] >> (2 * (t & 15))) & 3u;
+                                    if (n_runs[h] > 0) {  // rare: assemblies with scaffold gaps
+                                        int a = 0, z = n_runs[h];
+                                        while (a < z) {
+                                            const int mid = (a + z) >> 1;
+                                            if (b.n_runs[run_off[h] + 2 * mid + 1] <= t) a = mid + 1; else z = mid;
+                                        }
+                                        if (a < n_runs[h] && b.n_runs[run_off[h] + 2 * a] <= t) code = 4u;
                                     }
-                                    if (a < n_runs && runs[2 * a] <= t) code = 4u;
                                 }
+                                four[h] |= (code < 5u ? 3u * code : T_OUT) << (8 * i);
+                                saw_n[h] |= code == 4u;
                             }
-                            four |= (code < 5u ? 6u * code : T_OUT) << (8 * i);
-                            saw_n |= code == 4u;
                         }
                     }
-                    *reinterpret_cast<uint32_t *>(&s_t[g][y]) = four;
+                    // bytes X0 Y0 X1 Y1 | X2 Y2 X3 Y3 (v_perm_b32 selects: bytes 0-3 = second operand, 4-7 = first)
+                    const uint32_t lo2 = __builtin_amdgcn_perm(four[1], four[0], 0x05010400u);
+                    const uint32_t hi2 = __builtin_amdgcn_perm(four[1], four[0], 0x07030602u);
+                    *reinterpret_cast<uint2 *>(&s_t[g][y]) = make_uint2(lo2, hi2);
                 }
             }
             __syncthreads();
             if (m0 + CH < steps8) request(m0 + CH);  // the next chunk's words arrive while this chunk is computed
             if (m0 == 0) {  // initial window: cell k of lane l sits on x = 3l + k
-                st.t0 = s_t[g][PAD + 3 * l]; st.t1 = s_t[g][PAD + 3 * l + 1]; st.t2 = s_t[g][PAD + 3 * l + 2];
-                st.t3 = s_t[g][PAD + 3 * l + 3];
+                const unsigned a0 = s_t[g][PAD + 3 * l], a1 = s_t[g][PAD + 3 * l + 1], a2 = s_t[g][PAD + 3 * l + 2],
+                               a3 = s_t[g][PAD + 3 * l + 3];
+                st.t0 = (a0 & 255u) | ((a0 >> 8) << 16); st.t1 = (a1 & 255u) | ((a1 >> 8) << 16);
+                st.t2 = (a2 & 255u) | ((a2 >> 8) << 16); st.t3 = (a3 & 255u) | ((a3 >> 8) << 16);
             }
             const int m_end = min(m0 + CH, steps8);
             for (int m = m0; m < m_end; m += 8) {
@@ -289,37 +419,55 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                 for (int half = 0; half < 2; ++half) {
                     const int mm = m + 4 * half;
                     const uint4 pr = *reinterpret_cast<const uint4 *>(&s_prof[g][mm - m0]);
-                    const uint32_t tc = *reinterpret_cast<const uint32_t *>(&s_t[g][mm - m0 + 3 * P + 1 + PAD]);
-                    dp_step<P>(st, acc[2 * half], mm, l, pr.x, tc & 255u, first_lanes, last_lanes);
-                    dp_step<P>(st, acc[2 * half], mm + 1, l, pr.y, (tc >> 8) & 255u, first_lanes, last_lanes);
-                    dp_step<P>(st, acc[2 * half + 1], mm + 2, l, pr.z, (tc >> 16) & 255u, first_lanes, last_lanes);
-                    dp_step<P>(st, acc[2 * half + 1], mm + 3, l, pr.w, tc >> 24, first_lanes, last_lanes);
+                    const uint2 tc = *reinterpret_cast<const uint2 *>(&s_t[g][mm - m0 + 3 * P + 1 + PAD]);
+                    // byte pairs -> (X | Y << 16): selector bytes 0x0c are zeros
+                    const unsigned ta = __builtin_amdgcn_perm(0u, tc.x, 0x0c010c00u), tb = __builtin_amdgcn_perm(0u, tc.x, 0x0c030c02u);
+                    const unsigned tcw = __builtin_amdgcn_perm(0u, tc.y, 0x0c010c00u), td = __builtin_amdgcn_perm(0u, tc.y, 0x0c030c02u);
+                    dp_step<P, true>(st, acc, (unsigned)mm * K1, l, pr.x, ta, first_all, last_all, edge, twelve, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, l, pr.y, tb, first_all, last_all, edge, twelve, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, l, pr.z, tcw, first_all, last_all, edge, twelve, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, l, pr.w, td, first_all, last_all, edge, twelve, fifteen);
+                    if (half == 0) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) held[c] = acc[c];
+                    }
                 }
+                // eight steps of both tasks per cell: X = low halves, Y = high halves (steps 0-3 low, 4-7 high)
                 const int j = m >> 3;
-                if (fits && j < n_chunks) my_trace[(size_t)j * P] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                if (fits && j < n_chunks[0])
+                    trace_x[(size_t)j * P] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x05040100u), __builtin_amdgcn_perm(acc[1], held[1], 0x05040100u),
+                                                        __builtin_amdgcn_perm(acc[2], held[2], 0x05040100u), __builtin_amdgcn_perm(acc[3], held[3], 0x05040100u));
+                if (fits && have[1] && j < n_chunks[1])
+                    trace_y[(size_t)j * P] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x07060302u), __builtin_amdgcn_perm(acc[1], held[1], 0x07060302u),
+                                                        __builtin_amdgcn_perm(acc[2], held[2], 0x07060302u), __builtin_amdgcn_perm(acc[3], held[3], 0x07060302u));
             }
         }
 
-        // ---- best cell of the task: max score, then first row, then first column ---------------------------------
-        unsigned key = st.A.best;
-        int eb = 4 * l;
-        if (st.B.best > key) { key = st.B.best; eb = 4 * l + 1; }
-        if (st.C.best > key) { key = st.C.best; eb = 4 * l + 2; }
-        if (st.D.best > key) { key = st.D.best; eb = 4 * l + 3; }
+        // ---- best cell of each task: max score, then first row, then first column -------------------------------------
 #pragma unroll
-        for (int o = 1; o < P; o <<= 1) {
-            const unsigned key2 = (unsigned)__shfl_xor((int)key, o);
-            const int eb2 = __shfl_xor(eb, o);
-            if (key2 > key || (key2 == key && eb2 < eb)) { key = key2; eb = eb2; }
-            saw_n |= __shfl_xor((int)saw_n, o) != 0;
-        }
-        if (have && l == 0) {
-            KpSwEnd out;
-            out.score = fits ? (int)(key >> 15) : 0;
-            out.er = 32767 - (int)(key & 32767u);
-            out.eb = eb | (saw_n ? KP_SWEND_HAS_N : 0);
-            out.trace_off = (uint32_t)toff;
-            ends[ti] = out;
+        for (int h = 0; h < 2; ++h) {
+            const unsigned v = (st.best >> (16 * h)) & 0xFFFFu;  // H + 8
+            const int mstar = (int)((st.brow >> (16 * h)) & 0xFFFFu);
+            const unsigned a = (st.sA >> (16 * h)) & 0xFFFFu, bq = (st.sB >> (16 * h)) & 0xFFFFu, cq = (st.sC >> (16 * h)) & 0xFFFFu;
+            int eb = 4 * l + (a == v ? 0 : bq == v ? 1 : cq == v ? 2 : 3);
+            unsigned key = v > HB ? ((v - HB) << 15) | (unsigned)(32767 - (mstar - l)) : 0u;
+            if (key == 0u) eb = 4 * l;
+            bool sn = saw_n[h];
+#pragma unroll
+            for (int o = 1; o < P; o <<= 1) {
+                const unsigned key2 = (unsigned)__shfl_xor((int)key, o);
+                const int eb2 = __shfl_xor(eb, o);
+                if (key2 > key || (key2 == key && eb2 < eb)) { key = key2; eb = eb2; }
+                sn |= __shfl_xor((int)sn, o) != 0;
+            }
+            if (have[h] && l == 0) {
+                KpSwEnd out;
+                out.score = fits ? (int)(key >> 15) : 0;
+                out.er = 32767 - (int)(key & 32767u);
+                out.eb = eb | (sn ? KP_SWEND_HAS_N : 0);
+                out.trace_off = (uint32_t)(h ? toff_y : toff);
+                ends[ti[h]] = out;
+            }
         }
     }
 }
@@ -330,7 +478,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
 
 #ifndef KP_SW_WAVES
-#define KP_SW_WAVES 5  // waves per SIMD the register budget is set for (96 VGPRs; measured against 4, 6 and 8: profiles/)
+#define KP_SW_WAVES 4  // waves per SIMD the register budget is set for (two tasks per register: 128 VGPRs)
 #endif
 __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
@@ -338,7 +486,7 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
                                                    uint4 *__restrict__ trace, unsigned long long *__restrict__ trace_top,
                                                    uint64_t trace_cap) {
     __shared__ __attribute__((aligned(16))) uint32_t s_prof[PROF_WORDS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_t[TCODE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[TCODE_HALVES];
     __shared__ uint32_t s_tw[TWORD_WORDS];
     // class c (0..3 = 16/32/64/128 diagonals): tasks, order and results at c * task_cap, count at task_count[c]
     const uint32_t blk = blockIdx.x;
@@ -355,7 +503,7 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
 // Cell (row r, band index bi) sits on target position lo + r + bi; a diagonal step keeps bi, a step to the left (E, gap
 // in the query) lowers it, a step up (F, gap in the target) raises it.  The nibble of (r, bi) is in lane stream bi / 4,
-// step r + bi / 4: piece (step / 8), word (step % 8) / 2, upper half for even steps, cell A first.
+// step r + bi / 4: piece (step / 8), word bi % 4 (the cell), bits [4 (step % 8) + 3 : 4 (step % 8)].
 //
 // A path runs along a diagonal most of the time: it stays in one lane stream and walks it backwards.  The walk therefore
 // works on whole 16-byte pieces (8 steps x 4 cells) held in registers: when it stands on the last step of a piece and
@@ -368,9 +516,9 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
 // the fill kernel) compare the bases of every diagonal step instead.
 constexpr int TB_THREADS = 256;
 
-__device__ __forceinline__ uint32_t piece_word(const uint4 &v, int w) {  // word w of a piece, w in registers' terms
-    const uint32_t lo = (w & 1) ? v.y : v.x, hi = (w & 1) ? v.w : v.z;
-    return (w & 2) ? hi : lo;
+__device__ __forceinline__ uint32_t piece_word(const uint4 &v, int k) {  // cell k's word of a piece, in registers' terms
+    const uint32_t lo = (k & 1) ? v.y : v.x, hi = (k & 1) ? v.w : v.z;
+    return (k & 2) ? hi : lo;
 }
 
 __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
@@ -423,17 +571,14 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
                 cur_tag = tag;
                 if (pc > 0) { nxt = stream[(size_t)(pc - 1) * P]; nxt_tag = tag - 1; }  // used one piece from now at the earliest
             }
-            if (state == 0 && !has_n && (step & 7) == 7) {
-                // src bits (the nibble's upper two) of cell k in both steps of a word
-                const uint32_t pure = (0xC000C000u >> (4 * k));
-                if (((cur.x | cur.y | cur.z | cur.w) & pure) == 0u) {  // eight plain diagonal steps
-                    cols += 8; diag += 8; r -= 8;
-                    continue;
-                }
+            const uint32_t word = piece_word(cur, k);
+            if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xCCCCCCCCu) == 0xCCCCCCCCu) {  // eight plain diagonal steps
+                cols += 8; diag += 8; r -= 8;
+                continue;
             }
-            const uint32_t word = piece_word(cur, (step & 7) >> 1);
-            const uint32_t nib = (word >> ((step & 1 ? 0 : 16) + 12 - 4 * k)) & 15u;
-            const uint32_t src = nib >> 2;
+            const uint32_t nib = (word >> (4 * (step & 7))) & 15u;
+            // [D][L][E opened][F opened] -> source 0 = diagonal, 1 = diagonal and the path starts here, 2 = E, 3 = F
+            const uint32_t src = (nib & 8u) ? ((nib & 4u) ? 0u : 1u) : ((nib & 4u) ? 2u : 3u);
             if (state == 0) {
                 if (src <= 1u) {  // diagonal: one column
                     ++cols; ++diag;

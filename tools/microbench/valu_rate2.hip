@@ -105,6 +105,32 @@ K3(k_pk_fma_f16, "v_pk_fma_f16")
 K3(k_max3_i16, "v_max3_i16")
 K3(k_pk_max3_f16, "v_pk_maximum3_f16")
 K3(k_maximum3_f32, "v_maximum3_f32")
+K2(k_ashr, "v_ashrrev_i32_e32")
+K2(k_max_u16, "v_max_u16_e32")
+K2(k_min_i16, "v_min_i16_e32")
+K2(k_sub_u16, "v_sub_u16_e32")
+K2(k_lshl_b16, "v_lshlrev_b16_e32")
+K2(k_lshr_b16, "v_lshrrev_b16_e32")
+K2(k_mul_lo_u16, "v_mul_lo_u16_e32")
+K2(k_pk_lshr_b16, "v_pk_lshrrev_b16")
+K2(k_pk_ashr_i16, "v_pk_ashrrev_i16")
+K2(k_pk_max_u16, "v_pk_max_u16")
+K2(k_pk_sub_u16, "v_pk_sub_u16")
+K2(k_pk_sub_i16, "v_pk_sub_i16")
+K2(k_add_dpp, "v_add_u32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1 ;")
+K2(k_add_lit, "v_add_u32_e32 %0, 0x12345, %0 ;")
+K2(k_add_sgpr, "v_add_u32_e32 %0, s4, %0 ;")
+K2(k_and_lit, "v_and_b32_e32 %0, 0x80008000, %0 ;")
+K2(k_not, "v_not_b32_e32 %0, %4 ;")
+K2(k_add_co, "v_add_co_u32_e32 %0, vcc, %0, %4 ;")
+K2(k_addc, "v_addc_co_u32_e32 %0, vcc, %0, %4, vcc ;")
+K2(k_cndmask_vcc, "v_cndmask_b32_e32 %0, %0, %4, vcc ;")
+K2(k_mov_sdwa, "v_mov_b32_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 ;")
+K2(k_add_sdwa, "v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1 ;")
+K3(k_bfi, "v_bfi_b32")
+K3(k_sad_u16, "v_sad_u16")
+K3(k_add3, "v_add3_u32")
+K3(k_fmac, "v_fma_f32")
 K2W(k_pk_add_f32, "v_pk_add_f32")
 K2W(k_pk_mul_f32, "v_pk_mul_f32")
 K3W(k_pk_fma_f32, "v_pk_fma_f32")
@@ -142,5 +168,9 @@ int main() {
     RUN(k_pk_mad_i16); RUN(k_pk_fma_f16); RUN(k_max3_i16); RUN(k_pk_max3_f16); RUN(k_maximum3_f32);
     RUN(k_pk_add_f32); RUN(k_pk_mul_f32); RUN(k_pk_fma_f32); RUN(k_lshl_b64);
     RUN(k_cmp_gt_i32); RUN(k_cmp_gt_f32); RUN(k_cmp_eq_u32); RUN(k_cmp_gt_i16);
+    RUN(k_ashr); RUN(k_max_u16); RUN(k_min_i16); RUN(k_sub_u16); RUN(k_lshl_b16); RUN(k_lshr_b16); RUN(k_mul_lo_u16);
+    RUN(k_pk_lshr_b16); RUN(k_pk_ashr_i16); RUN(k_pk_max_u16); RUN(k_pk_sub_u16); RUN(k_pk_sub_i16); RUN(k_add_dpp); RUN(k_add_lit);
+    RUN(k_add_sgpr); RUN(k_and_lit); RUN(k_not); RUN(k_add_co); RUN(k_addc); RUN(k_cndmask_vcc); RUN(k_mov_sdwa); RUN(k_add_sdwa);
+    RUN(k_bfi); RUN(k_sad_u16); RUN(k_add3);
     return 0;
 }
