@@ -160,6 +160,11 @@ def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
     return 200 + rank * assemblies_per_rank
 
 
+L2_GATHER_ROOF_G = 269.0  # G independent 8-byte reads per second out of a 2 MB table (profiles/l2_gather_r2.txt)
+FILL_CYCLES_PER_WAVE_STEP = 3626 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r2.txt)
+FILL_CLOCK_HZ = 2.28e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/fill_pmc_r2.txt)
+
+
 def offline_pmc(args) -> dict | None:
     """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
     collection of this same command (profiles/scan_pmc_r2.json) and are reported only for the workload it ran."""
@@ -191,6 +196,10 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true",
                     help="ranks take device LOCAL_RANK modulo the visible devices (tests of the multi-process path on a "
                          "one-GPU box; use with --dist-backend gloo, RCCL refuses two ranks on one device)")
+    ap.add_argument("--ahead", type=int, default=2, choices=(1, 2),
+                    help="alignment passes in flight beside the shard being reduced (a context has KP_WORK_SLOTS = 3 work sets)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning knob of every context (kp_ctx_set_option), e.g. sw_blocks_per_cu=128")
     ap.add_argument("--separate-passes", action="store_true",
                     help="one context and one alignment pass per database, as the reference runs them (default: the genes "
                          "of both databases share one seed index, so every assembly is scanned, chained and aligned once; "
@@ -259,6 +268,10 @@ def main() -> None:
         engines = [both.view(k) for k in range(len(dbs))]
     else:
         engines = [Engine(db, device=local_rank) for db in dbs]
+    for ctx in {id(e.ctx): e.ctx for e in engines}.values():
+        for opt in args.ctx_option:
+            name, _, value = opt.partition("=")
+            ctx.set_option(name, int(value))
     typers = [Serotyper(db, device=local_rank) for db in dbs]
     for eng, typer in zip(engines, typers):
         typer._engine = eng
@@ -291,18 +304,23 @@ def main() -> None:
             t_ref[0] = now
 
     def run_pass(get_batches, release=None, rows_sink=None, record=False):
-        """One step: every shard through every database.  Alignment passes run one shard ahead of the reductions."""
+        """One step: every shard through every database.  The alignment passes of the next --ahead shards are on the device
+        (each on its work set's own stream) while this shard's reductions run and its results are collected."""
         out = []
         mark("step begins")
-        live = {0: get_batches(0)}
-        for b in distinct(live[0]):
-            b.align_async()
+        live = {}
+
+        def enqueue(j):
+            live[j] = get_batches(j)
+            for b in distinct(live[j]):
+                b.align_async()
+
+        for j in range(min(args.ahead, n_batches)):
+            enqueue(j)
         for i in range(n_batches):
-            if i + 1 < n_batches:
-                live[i + 1] = get_batches(i + 1)
-                for b in distinct(live[i + 1]):
-                    b.align_async()
-                mark(f"align {i + 1} enqueued")
+            if i + args.ahead < n_batches:
+                enqueue(i + args.ahead)
+                mark(f"align {i + args.ahead} enqueued")
             bs = live[i]
             if shared:  # all scores first (cheap), so that none queues up behind another database's reduction kernels
                 scored = {k: engines[k].score_batches(typers[k], [bs[k]]) for k in reversed(collect_order)}
@@ -329,8 +347,13 @@ def main() -> None:
             b.close()
 
     resident = [make_batches(i) for i in range(n_batches)]
+    # (untimed) buffer sizing: the first pass of a context learns its work-buffer sizes and reruns until they fit; it also
+    # takes every first-call cost of the measurement itself (event timing, statistics) out of the warm-up steps
+    run_pass(lambda i: resident[i], record=True)
     for _ in range(args.warmup):
-        run_pass(lambda i: resident[i])
+        run_pass(lambda i: resident[i], record=True)
+    for lst in (*prof, *stats):
+        lst.clear()
     sync_all()
     t0 = time.perf_counter()
     step_ms = []
@@ -340,6 +363,15 @@ def main() -> None:
         step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))  # host view, no synchronisation added
     sync_all()
     elapsed = time.perf_counter() - t0
+    # (untimed) the alignment kernels of one batch with nothing else on the device: what a launch takes on its own; in
+    # the timed steps the passes of consecutive batches overlap and stretch each other's kernels
+    alone = []
+    for bs in resident[: min(2, n_batches)]:
+        for b in distinct(bs)[:1]:
+            b.align_async()
+            b.wait()
+            alone.append(b.profile())
+    sync_all()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -368,7 +400,7 @@ def main() -> None:
             ahead = {}
 
             def get(i):  # uploads run two shards ahead of the alignment pass that reads them
-                for j in (i, i + 1, i + 2):
+                for j in range(i, i + args.ahead + 2):
                     if j < n_batches and j not in ahead:
                         ahead[j] = make_batches(j, pins[j].array)
                 return ahead.pop(i)
@@ -399,6 +431,8 @@ def main() -> None:
         scan_bytes = float(np.mean([p["bytes_scanned"] for p in prof[0]]))
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
         pmc = offline_pmc(args)
+        scan_alone_ms = float(np.mean([p["scan"] for p in alone]))
+        fill_alone_ms = float(np.mean([p["sw16"] for p in alone]))
         # per database: kernel milliseconds per step (sum over the step's batches, mean over steps)
         mean_ms = [{k: float(np.sum([p[k] for p in plist])) / args.steps for k in plist[0] if k != "bytes_scanned"}
                    for plist in prof]
@@ -406,6 +440,13 @@ def main() -> None:
         per_step = [{k: sum(s[k] for s in slist) // args.steps for k in slist[0]} for slist in stats]
         cells = sum(s["dp_cells"] for s in per_step)
         typed = int(sum(bt.typeable.sum() for bt in res))
+        # a wave steps 2 x 64/P tasks of 4P diagonals each: 512 cells per wave-step whatever P
+        wave_steps = cells / args.steps / n_batches / 512.0
+        need = wave_steps * FILL_CYCLES_PER_WAVE_STEP / (256 * 4)
+        have_cycles = fill_alone_ms * 1e-3 * FILL_CLOCK_HZ
+        fill_model = {"cycles_per_wave_step": FILL_CYCLES_PER_WAVE_STEP, "wave_steps_per_launch": wave_steps,
+                      "ms_per_launch_alone": fill_alone_ms, "clock_hz": FILL_CLOCK_HZ,
+                      "simd_cycles_needed": need, "simd_cycles_available": have_cycles, "frac": need / have_cycles}
         t_rows = time.perf_counter()
         blobs = [bt.tsv() for bt in res]  # TSV bytes of the last step
         t_rows = time.perf_counter() - t_rows
@@ -452,11 +493,24 @@ def main() -> None:
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "traffic_source": f"offline: {pmc['source']}" if pmc else None,
                 "bytes_per_launch": scan_bytes, "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
+                "note": "timed-region launches share the device with the other kernels of up to --ahead overlapping "
+                        "passes; `alone` = the same launch with nothing else running (untimed, after the steps)",
+                "alone": {"ms_per_launch": scan_alone_ms, "achieved": scan_bytes / (scan_alone_ms * 1e-3) / 1e9,
+                          "frac": scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                # one 8-byte presence-filter probe per selected position (a quarter of the bases): the kernel's real
+                # roof is the rate at which the L2s serve independent requests (tools/microbench/l2_gather.hip)
+                "l2_requests": {"per_launch": scan_bytes, "rate_alone_G_per_s": scan_bytes / (scan_alone_ms * 1e-3) / 1e9,
+                                "measured_roof_G_per_s": L2_GATHER_ROOF_G, "frac_alone": scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / L2_GATHER_ROOF_G,
+                                "roof_source": "profiles/l2_gather_r2.txt (2 MB table, 8 loads in flight per lane)"},
             },
             "dp": {
                 "kernel": "kp_sw_kernel", "cells_per_step": [s["dp_cells"] for s in per_step],
                 "ms_per_step": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
                 "tasks_per_step": [s["tasks"] for s in per_step], "anchors_per_step": [s["anchors"] for s in per_step],
+                # fill kernel against its own roof, VALU issue: cycles the instruction mix of its 8-step body needs (tools/
+                # isa_cost.py with the per-opcode costs measured by tools/microbench/valu_rate*.hip) over the SIMD cycles
+                # the launch had, at the shader clock the PMC run saw (GRBM_GUI_ACTIVE / duration, profiles/)
+                "fill_issue_model": fill_model,
             },
             "kernel_ms_per_step": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16", "sw32")},
         }  # fmt: skip

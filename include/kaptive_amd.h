@@ -54,7 +54,7 @@ KP_API void *kp_ctx_stream(kp_ctx *ctx);
  * filter even for small databases), scan_mode (ablation modes of the scan kernel, tools/scan_ablate.py),
  * sw_blocks_per_cu (grid of the banded Smith-Waterman launch). */
 KP_API int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value);
-#define KP_WORK_SLOTS 2
+#define KP_WORK_SLOTS 3
 
 /* ---- pinned host memory ---------------------------------------------------------------------------------------------------
  * For callers that stream shards: kp_batch_create_async only overlaps with device work when `words` is page-locked. */

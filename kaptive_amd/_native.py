@@ -12,6 +12,7 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
+WORK_SLOTS = 3  # KP_WORK_SLOTS of include/kaptive_amd.h: alignment results a context keeps resident
 
 HIT_DTYPE = np.dtype(
     [("gene", "<i4"), ("contig", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"), ("t_start", "<i4"), ("t_end", "<i4"),

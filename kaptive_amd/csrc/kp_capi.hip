@@ -117,7 +117,7 @@ struct KpOptions {
     uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
     int no_lds_filter = 0;       // tests compare the two filter tiers
-    int sw_blocks_per_cu = 256;
+    int sw_blocks_per_cu = 32;
 };
 
 // Device copy of one batch's input (packed words + tables).  Recycled through the context (hipFree synchronises the
@@ -158,6 +158,13 @@ struct KpWork {
     DevBuf<KpSwEnd> d_ends;
     DevBuf<unsigned long long> d_trace_top;
     uint64_t trace_cap = 0;  // 16-byte units the trace buffer was sized for in the most recent pass
+    // A work set's alignment pass runs on the set's own stream with its own trace buffer and sort scratch: the passes of
+    // consecutive batches overlap on the device (the seed scan and the sort of one wait on the L2 and on HBM while the
+    // fill kernel of the other keeps the vector ALUs busy)
+    hipStream_t astream = nullptr;
+    DevBuf<uint4> d_trace;  // direction bits of the banded Smith-Waterman: written by the fill kernel, read by the traceback
+    void *sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
     // device-side hit tables (per-assembly regions of hit_cap rows)
     DevBuf<kp_hit> d_hits_raw, d_hits;
@@ -177,7 +184,9 @@ struct KpWork {
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
         d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_order.release();
-        d_ends.release(); d_trace_top.release();
+        d_ends.release(); d_trace_top.release(); d_trace.release();
+        if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
+        if (astream) { (void)hipStreamSynchronize(astream); (void)hipStreamDestroy(astream); astream = nullptr; }
         d_hits_raw.release(); d_hits.release(); d_hit_counts.release(); d_keys.release(); d_cells.release();
         for (auto &r : runs)
             if (r) r->release();
@@ -194,7 +203,7 @@ struct kp_ctx {
     int device = 0;
     int gs_bits = 18;              // bits of the gene/strand field of an anchor key this database can set
     int max_gene_len = 0;
-    hipStream_t stream = nullptr;  // alignment passes (scan .. SW), in submission order
+    hipStream_t stream = nullptr;  // database uploads, stand-alone protein alignments (alignment passes: KpWork::astream)
     hipStream_t post = nullptr;    // everything after a batch's alignment pass (waits on that batch's event)
     hipStream_t aux = nullptr;     // forked off `post` for kernels that only fill a few CUs (wide-band proteins)
     hipStream_t copy = nullptr;    // H2D copies of batch inputs (overlap with the passes of earlier batches)
@@ -206,9 +215,6 @@ struct kp_ctx {
     uint32_t tasks_per_asm = 0;  // task_cap of a pass = n_asm * tasks_per_asm
     double cand_frac = 0.0;      // cand_cap of a pass = total selected positions * cand_frac
     uint64_t trace_units_per_asm = 0;  // trace buffer of a pass = n_asm * this many 16-byte units
-    // direction bits of the banded Smith-Waterman: written by the fill kernel, read by the traceback that follows it on
-    // the same stream, so one buffer serves every work set
-    DevBuf<uint4> d_trace;
     // resident database
     bool has_db = false;
     int32_t n_genes = 0;
@@ -226,9 +232,6 @@ struct kp_ctx {
     DevBuf<float> d_ln;  // logarithm tables of the mapping quality (kp_mapq.h): ln(i / 2), then ln(i), from the host's logf
     DevBuf<uint8_t> d_pq, d_pt;
     DevBuf<int32_t> d_pmeta, d_pout, d_pscratch;
-    // sort scratch
-    void *sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
     // typing tables (kp_db_load_typing / kp_db_load_typing_group): one set per database whose genes are in the index
     std::vector<std::unique_ptr<KpTypingGroup>> groups;
     // per typing group: learnt sizes of the reduction buffers
@@ -528,11 +531,10 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (auto &w : ctx->work) w.release();
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
-    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_trace.release(); ctx->d_ln.release();
+    ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_ln.release();
     for (auto &g : ctx->groups)
         if (g) g->release();
     ctx->groups.clear();
-    if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->post) (void)hipStreamDestroy(ctx->post);
@@ -765,6 +767,8 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         for (auto &e : w->ev) KP_HIP_CHECK(ctx, hipEventCreate(&e));
         w->have_events = true;
     }
+    if (!w->astream) KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->astream, hipStreamNonBlocking));
+    hipStream_t stream = w->astream;
     hipEvent_t *ev = w->ev;
     if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
@@ -781,43 +785,43 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(1));
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
-    KP_HIP_CHECK(ctx, w->d_trace_top.reserve(1));
-    KP_HIP_CHECK(ctx, ctx->d_trace.reserve(w->trace_cap));
-    KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->in->ready, 0));  // the batch's H2D copies
-    if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->after->in->ready, 0));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), ctx->stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, sizeof(unsigned long long), ctx->stream));
+    KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
+    KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
+    KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->in->ready, 0));  // the batch's H2D copies
+    if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->after->in->ready, 0));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
     auto bits_for = [](uint64_t max_value) { uint32_t n = 1; while (n < 63 && (max_value >> n)) ++n; return n; };
     w->key_bits.qb = std::min<uint32_t>(16, bits_for((uint64_t)std::max(ctx->max_gene_len, 1)));
     w->key_bits.db = std::min<uint32_t>(30, bits_for((uint64_t)b->max_asm_bases + KP_DIAG_BIAS));
-    KP_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
     kp_launch_scan(b->view, ctx->index, w->d_cand.p, w->d_cand_count.p, w->cand_cap, w->d_anchors_a.p, w->d_sub_counts.p,
-                   sub_cap, w->key_bits, ctx->opt.scan_mode, ctx->opt.no_lds_filter != 0, ctx->stream, ev[1]);
+                   sub_cap, w->key_bits, ctx->opt.scan_mode, ctx->opt.no_lds_filter != 0, stream, ev[1]);
     kp_launch_anchor_compact(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_counts.p,
-                             w->d_counts.p + n_asm + KP_N_CLASSES, ctx->stream);
+                             w->d_counts.p + n_asm + KP_N_CLASSES, stream);
     int rc = kp_sort_anchors(ctx, w->d_anchors_b.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, b->n_asm,
-                             &ctx->sort_temp, &ctx->sort_temp_bytes, w->d_seg.p, w->d_seg.p + n_asm,
+                             &w->sort_temp, &w->sort_temp_bytes, w->d_seg.p, w->d_seg.p + n_asm,
                              (int)(w->key_bits.qb + w->key_bits.db) + ctx->gs_bits,
-                             ctx->stream);
+                             stream);
     if (rc) return rc;
-    KP_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
-                    d_task_count, w->task_cap, ctx->stream);
+                    d_task_count, w->task_cap, stream);
     kp_launch_task_order(ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
-                         ctx->stream);
-    KP_HIP_CHECK(ctx, hipEventRecord(ev[3], ctx->stream));
+                         stream);
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p + ORDER_HEAD,
-                 w->d_ends.p, ctx->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->opt.sw_blocks_per_cu,
-                 ctx->stream, ev[4]);
-    for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], ctx->stream));
+                 w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->opt.sw_blocks_per_cu,
+                 stream, ev[4]);
+    for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }

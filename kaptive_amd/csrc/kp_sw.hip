@@ -239,7 +239,8 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                                          uint32_t n_tasks, const uint32_t *__restrict__ order,
                                          KpSwEnd *__restrict__ ends, uint4 *__restrict__ trace,
                                          unsigned long long *__restrict__ trace_top, uint64_t trace_cap, uint32_t block,
-                                         uint32_t n_blocks, uint32_t *s_prof_raw, uint16_t *s_t_raw, uint32_t *s_tw_raw) {
+                                         uint32_t n_blocks, unsigned int *__restrict__ next_quad, uint32_t *s_prof_raw,
+                                         uint16_t *s_t_raw, uint32_t *s_tw_raw) {
     constexpr int G = 64 / P;
     constexpr int TW = CH + 3 * P + 4;  // staged target codes per chunk: window x in [m0, m0 + CH + 3P]
     // the codes a step pulls in start at x = step + 3P + 1: the row is shifted by PAD so that every fourth step's lies
@@ -259,7 +260,16 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     unsigned twelve = CB * K1, fifteen = 15u * K1, edge = GAP_EDGE;
     asm volatile("" : "+v"(twelve), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
 
-    for (uint32_t quad = block; (uint64_t)quad * (2 * G) < n_tasks; quad += n_blocks) {
+    // Quads are handed out by a counter when the class has one (the narrow class: a few resident waves per SIMD keep the
+    // vector ALUs busy, so the launch is kept small and leaves registers and LDS to the kernels of other passes), else
+    // the block strides over them.
+    auto take = [&](uint32_t prev) -> uint32_t {
+        if (!next_quad) return prev + n_blocks;
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(next_quad, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    };
+    for (uint32_t quad = next_quad ? take(0) : block; (uint64_t)quad * (2 * G) < n_tasks; quad = take(quad)) {
         // the pair of this group: two neighbours in the length-ordered list (kp_chain.hip)
         bool have[2];
         uint32_t ti[2];
@@ -494,10 +504,11 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     const size_t off = (size_t)c * task_cap;
     uint32_t n = task_count[c];
     if (n > task_cap) n = task_cap;
-    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk, WIDE_BLOCKS, s_prof, s_t, s_tw);
-    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - WIDE_BLOCKS, WIDE_BLOCKS, s_prof, s_t, s_tw);
-    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, s_prof, s_t, s_tw);
-    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, s_prof, s_t, s_tw);
+    unsigned int *next_quad = reinterpret_cast<unsigned int *>(trace_top + 1);  // zeroed with trace_top before the launch
+    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
+    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
+    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
+    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, next_quad, s_prof, s_t, s_tw);
 }
 
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
@@ -628,9 +639,10 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
                   uint64_t trace_cap_units, KpSwResult *results, int blocks_per_cu, hipStream_t stream,
                   hipEvent_t after_fill) {
-    // many short-lived single-wave blocks (each strides over a quad or two): CU slots turn over every few hundred
-    // microseconds, so the tail is even and the high-priority streams of other batches' reductions get their turn
-    const dim3 grid(3 * WIDE_BLOCKS + 256 * (unsigned)(blocks_per_cu > 0 ? blocks_per_cu : 256)), block(64);
+    // single-wave blocks that take the narrow class's quads off a counter: 32 per CU (a first wave of 16 resident per CU,
+    // the rest follow as those retire) balance the tail without flooding the dispatcher, and the kernels other passes
+    // have in flight on their own streams get their share of the CUs
+    const dim3 grid(3 * WIDE_BLOCKS + 256 * (unsigned)(blocks_per_cu > 0 ? blocks_per_cu : 32)), block(64);
     hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, ends,
                        reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
     if (after_fill) (void)hipEventRecord(after_fill, stream);

@@ -595,10 +595,11 @@ def _reload_small(ctx, oracle, small_db):
 
 def test_work_slots_rotate_and_displaced_results_raise(ctx, oracle, small_db):
     odb = _reload_small(ctx, oracle, small_db)
-    asms = [make_assembly(small_db, seed=600 + i, length=60_000, median_contigs=4, min_contig=200) for i in range(3)]
+    asms = [make_assembly(small_db, seed=600 + i, length=60_000, median_contigs=4, min_contig=200)
+            for i in range(_native.WORK_SLOTS + 1)]
     batches = [ctx.batch([a.packed()]) for a in asms]
     for b in batches:
-        b.align_async()  # three passes through two work sets: the first batch's results are displaced
+        b.align_async()  # one pass more than the context has work sets: the first batch's results are displaced
     for b, a in zip(batches[1:], asms[1:]):
         b.wait()
         hits, _ = b.hits()

@@ -31,6 +31,11 @@ def test_hit_record_layout_matches_header():
     assert _native.HIT_DTYPE.fields["strand"][1] == 36 and _native.HIT_DTYPE.fields["mapq"][1] == 37
 
 
+def test_binding_constants_match_header():
+    text = (ROOT / "include" / "kaptive_amd.h").read_text()
+    assert int(re.search(r"#define\s+KP_WORK_SLOTS\s+(\d+)", text).group(1)) == _native.WORK_SLOTS
+
+
 def test_no_gpu_means_loud_failure():
     import torch
 

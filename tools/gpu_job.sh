@@ -19,6 +19,9 @@ for what in "$@"; do
     trace)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_trace.log 2>&1)
       tail -c 1500 $OUT/${TAG}_trace.log | head -c 1200; f=$(ls $OUT/${TAG}_trace/*/*kernel_stats.csv | head -1); head -25 $f;;
+    trace_full)  # the default bench command itself under the kernel trace (the summary profiles/ holds for the bench line)
+      (cd /tmp && timeout 1700 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_full -- python $GRAFT_REPO_ROOT/bench.py > $OUT/${TAG}_trace_full.log 2>&1)
+      grep '^{' $OUT/${TAG}_trace_full.log | cut -c1-400; f=$(ls $OUT/${TAG}_trace_full/*/*kernel_stats.csv | head -1); head -12 $f | cut -c1-200;;
     pmc_sq)
       (cd /tmp && timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
         --output-format csv -d $OUT/${TAG}_pmc_sq -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_pmc_sq.log 2>&1); tail -2 $OUT/${TAG}_pmc_sq.log;;
