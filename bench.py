@@ -441,7 +441,7 @@ def main() -> None:
         cells = sum(s["dp_cells"] for s in per_step)
         typed = int(sum(bt.typeable.sum() for bt in res))
         # a wave steps 2 x 64/P tasks of 4P diagonals each: 512 cells per wave-step whatever P
-        wave_steps = cells / args.steps / n_batches / 512.0
+        wave_steps = cells / n_batches / 512.0  # (cells: per step, all batches)
         need = wave_steps * FILL_CYCLES_PER_WAVE_STEP / (256 * 4)
         have_cycles = fill_alone_ms * 1e-3 * FILL_CLOCK_HZ
         fill_model = {"cycles_per_wave_step": FILL_CYCLES_PER_WAVE_STEP, "wave_steps_per_launch": wave_steps,

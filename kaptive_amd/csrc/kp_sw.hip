@@ -53,6 +53,10 @@
 namespace {
 
 constexpr int CH = 64;  // steps staged per chunk (multiple of 8)
+#ifndef KP_TRACE_GROUP
+#define KP_TRACE_GROUP 2
+#endif
+constexpr int TG = KP_TRACE_GROUP;  // consecutive 8-step trace pieces of a lane that are contiguous in memory (2 or 4)
 constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
 static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1 && OE == 6 && EX == 2,
@@ -297,8 +301,8 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             run_off[h] = 2u * (uint32_t)r0;
             lo[h] = tk[h].lo;
             steps[h] = have[h] ? qlen[h] + P - 1 : 0;  // steps the task needs
-            // 8-step trace pieces per lane (an even number: task blocks then start on 128-byte lines)
-            n_chunks[h] = (((steps[h] + 7) >> 3) + 1) & ~1;
+            // 8-step trace pieces per lane, in whole groups of four
+            n_chunks[h] = (((steps[h] + 7) >> 3) + 3) & ~3;  // (a multiple of four whatever TG: task blocks start on 128-byte lines)
         }
         int max_steps = max(steps[0], steps[1]);
 #pragma unroll
@@ -309,11 +313,14 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         if (have[0] && l == 0) toff = atomicAdd(trace_top, want);
         toff = ((unsigned long long)__shfl((unsigned)(toff >> 32), g * P) << 32) | __shfl((unsigned)toff, g * P);
         const bool fits = have[0] && toff + want <= trace_cap;  // else: counted, host reruns
-        // piece j of lane l at [j][l]: the P lanes of a task write P * 16 contiguous bytes per store, and a 128-byte line
-        // is complete after 8 * 8 / P steps -- with a stream per lane a line stayed open for 64 steps, more open lines
-        // than the L2 holds, and HBM saw three times the bytes (WRITE_SIZE, profiles/)
+        // piece j of lane l at [j / TG][l][j % TG]: TG consecutive pieces of a lane are contiguous, so the traceback -- it
+        // follows one lane's pieces backwards -- fetches them in one go.  With TG = 2 a 128-byte line (four lanes) is
+        // complete after 16 steps; TG = 4 halves the traceback's fetches again (1.75 ms against 2.75 ms with a fetch per
+        // piece) but keeps lines open for 32 steps, and the fill kernel pays more for the partial write-backs than the
+        // traceback gains (11.9 ms against 11.0 ms); with a whole stream per lane a line stayed open for 64 steps, more open
+        // lines than the L2 holds, and HBM saw three times the bytes (WRITE_SIZE, profiles/).
         const unsigned long long toff_y = toff + (unsigned long long)P * (unsigned)n_chunks[0];
-        uint4 *trace_x = trace + toff + l, *trace_y = trace + toff_y + l;
+        uint4 *trace_x = trace + toff + TG * l, *trace_y = trace + toff_y + TG * l;
 
         State st;
         st.A.hs = H_ZERO; st.A.hmoe = GAP_EDGE; st.A.emex = GAP_NONE; st.A.fmex = GAP_NONE;
@@ -445,10 +452,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                 // eight steps of both tasks per cell: X = low halves, Y = high halves (steps 0-3 low, 4-7 high)
                 const int j = m >> 3;
                 if (fits && j < n_chunks[0])
-                    trace_x[(size_t)j * P] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x05040100u), __builtin_amdgcn_perm(acc[1], held[1], 0x05040100u),
+                    trace_x[(size_t)(j / TG) * (TG * P) + (j % TG)] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x05040100u), __builtin_amdgcn_perm(acc[1], held[1], 0x05040100u),
                                                         __builtin_amdgcn_perm(acc[2], held[2], 0x05040100u), __builtin_amdgcn_perm(acc[3], held[3], 0x05040100u));
                 if (fits && have[1] && j < n_chunks[1])
-                    trace_y[(size_t)j * P] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x07060302u), __builtin_amdgcn_perm(acc[1], held[1], 0x07060302u),
+                    trace_y[(size_t)(j / TG) * (TG * P) + (j % TG)] = make_uint4(__builtin_amdgcn_perm(acc[0], held[0], 0x07060302u), __builtin_amdgcn_perm(acc[1], held[1], 0x07060302u),
                                                         __builtin_amdgcn_perm(acc[2], held[2], 0x07060302u), __builtin_amdgcn_perm(acc[3], held[3], 0x07060302u));
             }
         }
@@ -514,14 +521,15 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
 // Cell (row r, band index bi) sits on target position lo + r + bi; a diagonal step keeps bi, a step to the left (E, gap
 // in the query) lowers it, a step up (F, gap in the target) raises it.  The nibble of (r, bi) is in lane stream bi / 4,
-// step r + bi / 4: piece (step / 8), word bi % 4 (the cell), bits [4 (step % 8) + 3 : 4 (step % 8)].
+// step r + bi / 4: piece j = step / 8 (at [j / TG][lane][j % TG] of the task's block), word bi % 4 (the cell), bits [4 (step % 8) + 3 : 4 (step % 8)].
 //
 // A path runs along a diagonal most of the time: it stays in one lane stream and walks it backwards.  The walk therefore
 // works on whole 16-byte pieces (8 steps x 4 cells) held in registers: when it stands on the last step of a piece and
 // all eight nibbles of its cell say "diagonal, not the start", it takes the eight steps at once; everything else (gaps,
 // the first and last steps of a path, tasks with an N, whose matches are counted base by base) goes step by step from
-// the same registers.  The piece after the current one is requested a whole piece ahead, so the 160 or so dependent loads
-// of a path overlap with other waves' work; the direction bits are read about once (a quarter of what the fill wrote).
+// the same registers.  Pieces are fetched TG at a time (contiguous bytes) and the group
+// after the current one is requested a whole group ahead, so the dependent fetches of a path overlap with other
+// waves' work; the direction bits are read about once (a quarter of what the fill wrote).
 // Matches: without an N in the gene or the window every diagonal step scores +2 or -4, so
 // score = 6 * matches - 4 * diagonal_steps - gap_costs gives the matches in closed form; tasks that saw an N (flagged by
 // the fill kernel) compare the bases of every diagonal step instead.
@@ -565,22 +573,41 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
         const int r0 = b.asm_first_nrun[tk.asm_id];
         const int n_runs = b.asm_first_nrun[tk.asm_id + 1] - r0;
         const int32_t *runs = b.n_runs + 2 * (size_t)r0;
-        const uint4 *tw = reinterpret_cast<const uint4 *>(trace) + e.trace_off;  // piece j of lane l at [j * P + l]
+        const uint4 *tw = reinterpret_cast<const uint4 *>(trace) + e.trace_off;  // piece j of lane l at [(j / TG) * TG * P + TG * l + j % TG]
         int r = e.er, bi = eb, state = 0, cols = 0, matches = 0, diag = 0, gap_cost = 0, gap = 0, credit = 0;
         int sr = r, sb = bi;
-        // cur = the piece the walk stands in, nxt = the one before it in the same lane stream (requested ahead)
-        uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
-        int cur_tag = -1, nxt_tag = -1;  // (stream << 20) | piece index
+        // curq = the TG pieces (contiguous bytes) of the lane stream the walk stands in, nxtq = the TG before them
+        // (requested a whole group ahead).  A group is fetched with loads in a row: one trip to memory --
+        // with a load per piece the line had left the L2 by the time the walk came back for the next one (75 % misses,
+        // one random 64-byte fetch per piece: the kernel ran at the rate HBM serves those, tools/microbench/l2_gather.hip)
+        uint4 curq[TG], nxtq[TG];
+#pragma unroll
+        for (int i = 0; i < TG; ++i) curq[i] = nxtq[i] = make_uint4(0, 0, 0, 0);
+        int cur_tag = -1, nxt_tag = -1;  // (stream << 20) | group index
         while (__any(walking)) {
             if (!walking) continue;
             const int l = bi >> 2, k = bi & 3, step = r + l;
-            const int pc = step >> 3, tag = (l << 20) | pc;
+            const int pc = step >> 3, grp = pc / TG, tag = (l << 20) | grp;
             if (tag != cur_tag) {
-                const uint4 *stream = tw + l;
-                if (tag == nxt_tag) cur = nxt;
-                else cur = stream[(size_t)pc * P];
+                const uint4 *stream = tw + TG * l;
+                if (tag == nxt_tag) {
+#pragma unroll
+                    for (int i = 0; i < TG; ++i) curq[i] = nxtq[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TG; ++i) curq[i] = stream[(size_t)grp * (TG * P) + i];
+                }
                 cur_tag = tag;
-                if (pc > 0) { nxt = stream[(size_t)(pc - 1) * P]; nxt_tag = tag - 1; }  // used one piece from now at the earliest
+                if (grp > 0) {
+#pragma unroll
+                    for (int i = 0; i < TG; ++i) nxtq[i] = stream[(size_t)(grp - 1) * (TG * P) + i];
+                    nxt_tag = tag - 1;
+                }
+            }
+            uint4 cur = (pc & 1) ? curq[1] : curq[0];
+            if (TG == 4) {
+                const uint4 hi2 = (pc & 1) ? curq[TG - 1] : curq[TG - 2];
+                cur = (pc & 2) ? hi2 : cur;
             }
             const uint32_t word = piece_word(cur, k);
             if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xCCCCCCCCu) == 0xCCCCCCCCu) {  // eight plain diagonal steps
