@@ -45,7 +45,8 @@ KP_API int kp_ctx_create(int device_id, kp_ctx **out);
 KP_API void kp_ctx_destroy(kp_ctx *ctx);
 /* Message of the last failed call on ctx (ctx may be NULL for a failed kp_ctx_create). Never NULL. */
 KP_API const char *kp_last_error(const kp_ctx *ctx);
-/* The hipStream_t the alignment passes of this context are enqueued on (for event timing by the caller). */
+/* The context's own hipStream_t: database uploads and stand-alone protein alignments.  (Alignment passes run on the
+ * stream of the work set they take, so that the passes of consecutive batches overlap; their stage times: kp_batch_profile.) */
 KP_API void *kp_ctx_stream(kp_ctx *ctx);
 /* Tuning knobs.  Defaults are read from the environment once, in kp_ctx_create (KAPTIVE_AMD_<NAME in upper case>);
  * names: anchor_cap, tasks_per_asm, hit_cap, trace_kb_per_asm, kept_cap, piece_cap, prot_cap (initial sizes of the work

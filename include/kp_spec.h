@@ -60,7 +60,7 @@
 #define KP_MIN_ANCHORS 3
 #define KP_MIN_SEED_SPAN 40
 
-/* ---- banded local alignment (Smith-Waterman-Gotoh, int32) ----------------------------------------------------------
+/* ---- banded local alignment (Smith-Waterman-Gotoh; scores <= 2 * KP_MAX_GENE_LEN) ----------------------------------------------------------
  * H = max(0, Hdiag + s, E, F);  E (gap in query, moves along the target) = max(Hleft - (O+X), Eleft - X);
  * F (gap in target, moves along the query) = max(Hup - (O+X), Fup - X).  Opening wins ties against extending; the
  * diagonal wins ties against E, E against F; a cell whose best is <= 0 is a restart cell.  The reported cell is the
