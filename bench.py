@@ -43,6 +43,8 @@ from pathlib import Path
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch / HIP initialise: see kaptive_amd/__init__.py
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -189,7 +191,7 @@ def main() -> None:
     ap.add_argument("--length", type=float, default=0.0, help="mean assembly length (0 = the workload's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
-    ap.add_argument("--e2e-steps", type=int, default=1)
+    ap.add_argument("--e2e-steps", type=int, default=3, help="steps per end-to-end leg (back to back: the pipeline fills and drains once per leg)")
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="torch.distributed backend of the barrier and the max-over-ranks of the elapsed time (nccl = RCCL)")
@@ -199,7 +201,7 @@ def main() -> None:
     ap.add_argument("--ahead", type=int, default=2, choices=(1, 2),
                     help="alignment passes in flight beside the shard being reduced (a context has KP_WORK_SLOTS = 3 work sets)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
-                    help="tuning knob of every context (kp_ctx_set_option), e.g. sw_blocks_per_cu=128")
+                    help="tuning knob of every context (kp_ctx_set_option), e.g. trace_kb_per_asm=16384")
     ap.add_argument("--separate-passes", action="store_true",
                     help="one context and one alignment pass per database, as the reference runs them (default: the genes "
                          "of both databases share one seed index, so every assembly is scanned, chained and aligned once; "
@@ -303,9 +305,11 @@ def main() -> None:
             print(f"[bench] {what}: +{(now - t_ref[0]) * 1e3:.1f} ms", file=sys.stderr)
             t_ref[0] = now
 
-    def run_pass(get_batches, release=None, rows_sink=None, record=False):
-        """One step: every shard through every database.  The alignment passes of the next --ahead shards are on the device
-        (each on its work set's own stream) while this shard's reductions run and its results are collected."""
+    def run_pass(get_batches, release=None, rows_sink=None, record=False, count=None):
+        """One step (or `count` shards in a row, numbered on through the steps): every shard through every database.  The
+        alignment passes of the next --ahead shards are on the device (each on its work set's own stream) while this
+        shard's reductions run and its results are collected."""
+        n_batches = count or len(spans)
         out = []
         mark("step begins")
         live = {}
@@ -329,7 +333,7 @@ def main() -> None:
                 staged = {k: engines[k].reduce_batches(typers[k], [bs[k]], aligned=True) for k in collect_order}
             mark(f"reductions of {i} enqueued")
             for k in collect_order:
-                bt = engines[k].collect_batches(typers[k], [bs[k]], [batch_ids[i]], staged[k])[0]
+                bt = engines[k].collect_batches(typers[k], [bs[k]], [batch_ids[i % len(spans)]], staged[k])[0]
                 if rows_sink is not None:
                     rows_sink.append(bt.tsv())
                 out.append(bt)
@@ -396,31 +400,59 @@ def main() -> None:
             pins.append(pb)
         t_pin = time.perf_counter() - t_pin
 
+        host_create = [0.0]
+
         def timed(with_rows: bool):
             ahead = {}
+            host_create[0] = 0.0
 
-            def get(i):  # uploads run two shards ahead of the alignment pass that reads them
+            total = n_batches * args.e2e_steps  # the leg is one stream of shards: step s re-sends shard i as number s * n + i
+
+            def get(i):  # uploads run two shards ahead of the alignment pass that reads them: a pass enqueued behind an
+                # upload that is still running holds up whatever shares its hardware queue
+                t_c = time.perf_counter()
                 for j in range(i, i + args.ahead + 2):
-                    if j < n_batches and j not in ahead:
-                        ahead[j] = make_batches(j, pins[j].array)
+                    if j < total and j not in ahead:
+                        ahead[j] = make_batches(j % n_batches, pins[j % n_batches].array)
+                host_create[0] += time.perf_counter() - t_c
                 return ahead.pop(i)
 
             sink = [] if with_rows else None
+            for j in range(min(args.ahead + 2, total)):  # (untimed) the first shards of the stream are on the device
+                ahead[j] = make_batches(j % n_batches, pins[j % n_batches].array)
+            for j in list(ahead):
+                for b in distinct(ahead[j])[:1]:
+                    b.upload_wait()
             sync_all()
             t1 = time.perf_counter()
-            for _ in range(args.e2e_steps):
-                run_pass(get, release=close_all, rows_sink=sink)
+            run_pass(get, release=close_all, rows_sink=sink, count=total)
             sync_all()
             dt = time.perf_counter() - t1
+            if debug:
+                print(f"[bench] e2e leg: {dt * 1e3:.1f} ms, of which {host_create[0] * 1e3:.1f} ms in batch creation calls", file=sys.stderr)
             return args.assemblies * args.e2e_steps / dt, sum(len(x) for x in sink) if with_rows else 0
 
         timed(False)  # warm-up of the upload path (input buffers, pinned staging)
         v_shards, _ = timed(False)
         v_tsv, tsv_bytes = timed(True)
+        # the copy alone: every shard uploaded (asynchronously, from the pinned buffers) and waited for, nothing typed
+        sync_all()
+        t_up = time.perf_counter()
+        ups = [make_batches(j, pins[j].array) for j in range(n_batches)]
+        for bs in ups:
+            for b in distinct(bs)[:1]:
+                b.upload_wait()
+        t_up = time.perf_counter() - t_up
+        up_bytes = sum(int(pb.array.nbytes) for pb in pins)
+        for bs in ups:
+            close_all(bs)
         e2e = {"from_host_shards": v_shards, "with_tsv": v_tsv, "unit": "assemblies/s", "steps": args.e2e_steps,
+               "h2d_alone": {"GB_per_s": up_bytes / t_up / 1e9, "assemblies_per_s": args.assemblies / t_up,
+                             "bytes": up_bytes, "note": "upper bound of any leg that starts from host memory"},
                "tsv_bytes_per_step": tsv_bytes // max(args.e2e_steps, 1), "pinning_s": round(t_pin, 1),
-               "note": "shards of --batch pre-packed assemblies in pinned host memory; H2D on a copy stream two shards "
-                       "ahead; with_tsv adds the KaptiveRow bytes of every assembly and database"}  # fmt: skip
+               "note": "a stream of steps x shards of --batch pre-packed assemblies in pinned host memory; H2D on a copy "
+                       "stream two shards ahead of the alignment passes (the first ones resident when the clock starts); "
+                       "with_tsv adds the KaptiveRow bytes of every assembly and database"}  # fmt: skip
         for pb in pins:
             pb.close()
 

@@ -117,7 +117,6 @@ struct KpOptions {
     uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
     int no_lds_filter = 0;       // tests compare the two filter tiers
-    int sw_blocks_per_cu = 32;
 };
 
 // Device copy of one batch's input (packed words + tables).  Recycled through the context (hipFree synchronises the
@@ -295,7 +294,6 @@ void options_from_env(KpOptions &o) {
     o.prot_cap = env_u32("KAPTIVE_AMD_PROT_CAP", o.prot_cap);
     o.scan_mode = (int)env_u32("KAPTIVE_AMD_SCAN_ABLATE", 0);
     o.no_lds_filter = (int)env_u32("KAPTIVE_AMD_NO_LDS_FILTER", 0);
-    o.sw_blocks_per_cu = (int)env_u32("KAPTIVE_AMD_SW_BLOCKS_PER_CU", (uint32_t)o.sw_blocks_per_cu);
 }
 
 // BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
@@ -569,7 +567,6 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
     else if (n == "prot_cap") { o.prot_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.prot_cap = 0; }
     else if (n == "scan_mode") o.scan_mode = (int)value;
     else if (n == "no_lds_filter") o.no_lds_filter = value != 0;
-    else if (n == "sw_blocks_per_cu") o.sw_blocks_per_cu = (int)std::max<int64_t>(value, 1);
     else return kp_fail(ctx, KP_EINVAL, "unknown option: " + n);
     return KP_OK;
 }
@@ -819,7 +816,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p + ORDER_HEAD,
-                 w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->opt.sw_blocks_per_cu,
+                 w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p,
                  stream, ev[4]);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());

@@ -161,7 +161,7 @@ void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const
 // `trace` holds trace_cap_units 16-byte units; *trace_top (zeroed by the caller) ends up as the units the pass needs.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
-                  uint64_t trace_cap_units, KpSwResult *results, int blocks_per_cu, hipStream_t stream,
+                  uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
                   hipEvent_t after_fill);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
 void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,

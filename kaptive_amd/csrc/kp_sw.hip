@@ -264,16 +264,17 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     unsigned twelve = CB * K1, fifteen = 15u * K1, edge = GAP_EDGE;
     asm volatile("" : "+v"(twelve), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
 
-    // Quads are handed out by a counter when the class has one (the narrow class: a few resident waves per SIMD keep the
-    // vector ALUs busy, so the launch is kept small and leaves registers and LDS to the kernels of other passes), else
-    // the block strides over them.
-    auto take = [&](uint32_t prev) -> uint32_t {
-        if (!next_quad) return prev + n_blocks;
+    // The narrow class hands its quads out by a counter, ONE per block: the launch has at least as many single-wave blocks
+    // as quads, a block lives for one quad (about a millisecond) and its CU slot then goes to whoever is next in line --
+    // the reductions, copies and scans other passes have in flight on their own streams wait a millisecond for a slot,
+    // not for the end of this kernel, which persistent blocks would hold the chip for.  Blocks of the wide classes stride.
+    auto take = [&]() -> uint32_t {
         uint32_t q = 0;
         if (lane == 0) q = atomicAdd(next_quad, 1u);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     };
-    for (uint32_t quad = next_quad ? take(0) : block; (uint64_t)quad * (2 * G) < n_tasks; quad = take(quad)) {
+    for (uint32_t quad = next_quad ? take() : block; (uint64_t)quad * (2 * G) < n_tasks;
+         quad = next_quad ? 0xFFFFFFFFu : quad + n_blocks) {
         // the pair of this group: two neighbours in the length-ordered list (kp_chain.hip)
         bool have[2];
         uint32_t ti[2];
@@ -664,12 +665,11 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
-                  uint64_t trace_cap_units, KpSwResult *results, int blocks_per_cu, hipStream_t stream,
+                  uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
                   hipEvent_t after_fill) {
-    // single-wave blocks that take the narrow class's quads off a counter: 32 per CU (a first wave of 16 resident per CU,
-    // the rest follow as those retire) balance the tail without flooding the dispatcher, and the kernels other passes
-    // have in flight on their own streams get their share of the CUs
-    const dim3 grid(3 * WIDE_BLOCKS + 256 * (unsigned)(blocks_per_cu > 0 ? blocks_per_cu : 32)), block(64);
+    // one single-wave block per quad of the narrow class (they take them off a counter, longest tasks first): the grid
+    // covers what the task list can hold (32 tasks per quad); surplus blocks find the counter exhausted and leave
+    const dim3 grid(3 * WIDE_BLOCKS + (task_cap + 31u) / 32u), block(64);
     hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, ends,
                        reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
     if (after_fill) (void)hipEventRecord(after_fill, stream);
