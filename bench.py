@@ -163,7 +163,7 @@ def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
 
 
 L2_GATHER_ROOF_G = 269.0  # G independent 8-byte reads per second out of a 2 MB table (profiles/l2_gather_r2.txt)
-FILL_CYCLES_PER_WAVE_STEP = 3626 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r2.txt)
+FILL_CYCLES_PER_WAVE_STEP = 3320 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r2.txt)
 FILL_CLOCK_HZ = 2.28e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/fill_pmc_r2.txt)
 
 
@@ -305,6 +305,10 @@ def main() -> None:
             print(f"[bench] {what}: +{(now - t_ref[0]) * 1e3:.1f} ms", file=sys.stderr)
             t_ref[0] = now
 
+    from concurrent.futures import ThreadPoolExecutor
+
+    row_pool = ThreadPoolExecutor(max_workers=1)
+
     def run_pass(get_batches, release=None, rows_sink=None, record=False, count=None):
         """One step (or `count` shards in a row, numbered on through the steps): every shard through every database.  The
         alignment passes of the next --ahead shards are on the device (each on its work set's own stream) while this
@@ -334,8 +338,8 @@ def main() -> None:
             mark(f"reductions of {i} enqueued")
             for k in collect_order:
                 bt = engines[k].collect_batches(typers[k], [bs[k]], [batch_ids[i % len(spans)]], staged[k])[0]
-                if rows_sink is not None:
-                    rows_sink.append(bt.tsv())
+                if rows_sink is not None:  # formatted beside the main thread (the native formatter releases the GIL)
+                    rows_sink.append(row_pool.submit(bt.tsv))
                 out.append(bt)
                 if record and (not shared or k == collect_order[-1]):
                     prof[k if not shared else 0].append(bs[k].profile())
@@ -426,6 +430,8 @@ def main() -> None:
             sync_all()
             t1 = time.perf_counter()
             run_pass(get, release=close_all, rows_sink=sink, count=total)
+            if with_rows:
+                sink = [f.result() for f in sink]  # every row is in memory before the clock stops
             sync_all()
             dt = time.perf_counter() - t1
             if debug:

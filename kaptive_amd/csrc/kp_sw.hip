@@ -18,9 +18,9 @@
 //   * maxima are one v_pk_max_u16 for two cells,
 //   * a comparison a >= b is (a | 0x80008000) - b: two 2-cycle instructions leave the answer for both cells in bits 15
 //     and 31 (the guard bit survives exactly when no borrow reaches it) -- no v_cmp, no lane mask, no carry push,
-//   * the four direction bits of a cell are merged from those words with shifts and v_bfi,
+//   * the four direction bits of a cell are gathered from those words byte-wise (v_perm_b32, one v_bfi),
 //   * every cross-lane move (DPP) and every band-edge select serves two cells.
-// ~55 issue cycles per cell instead of 82.
+// 6.5 issue cycles per cell (3320 per 8 steps of 512 cells, tools/isa_cost.py) instead of 82.
 //
 // Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
 //   * a task's band has W = 4P diagonals; P lanes own a PAIR of tasks of that width (neighbours in the length-ordered task
@@ -39,14 +39,15 @@
 //     gives the same E, F and diagonal there); cells past the contig's end or below the gene only ever feed further such
 //     cells, hold values strictly below the inside cell they derive from, so none becomes the best cell, and the
 //     traceback, which only moves up and left, cannot reach them.
-//   * biases: H is kept as H + 8; the candidates of a cell (diagonal, E, F) and the pre-charged gap states (H - open - ext,
-//     E - ext, F - ext) as value + 12.  The smallest value the recurrence can produce is -(open + 2 ext) = -8, and "no
-//     gap yet" is represented by exactly that (it loses every maximum it takes part in, like -inf), so everything is >= 0;
-//     the largest is 2 * length + 14 < 32768 (KP_MAX_GENE_LEN).
+//   * biases: the pre-charged gap states (H - open - ext, E - ext, F - ext) are kept as value + 12 and a cell's three
+//     candidates are compared two below their value (d - 2 is the predecessor's H - open - ext plus the score + 4; e - 2
+//     and f - 2 are the cell's own E - ext and F - ext), so H itself is never formed.  The smallest value the recurrence can
+//     produce is -(open + 2 ext) = -8, and "no gap yet" is represented by exactly that (it loses every maximum it takes
+//     part in, like -inf), so everything is >= 0; the largest is 2 * length + 12 < 32768 (KP_MAX_GENE_LEN).
 //   * best cell: per lane and task the running maximum of its four cells, the step at which it last rose and the four H
 //     of that step (packed max, guard compare, v_pk_ashrrev_i16 to a half-word mask, v_bfi selects): first maximum in
 //     row order, then the first of the lane's cells that holds it.
-//   * direction nibbles, four steps per 16 bits, eight steps per 32-bit word and cell: the two tasks' halves are
+//   * direction bits, four steps per 16 bits, eight steps per 32-bit word and cell: the two tasks' halves are
 //     separated with v_perm_b32 every eight steps and each task's 16 bytes go to its own trace block.
 #include "kp_internal.h"
 
@@ -65,8 +66,8 @@ static_assert(2 * KP_MAX_GENE_LEN + 14 < 32768, "biased scores must leave bit 15
 
 constexpr unsigned K1 = 0x00010001u;                        // a value in both halves: x * K1
 constexpr unsigned GUARD = 0x80008000u;
-constexpr unsigned HB = 8, CB = 12;                         // bias of H, bias of candidates and gap states
-constexpr unsigned H_ZERO = HB * K1;                        // H = 0
+constexpr unsigned CB = 12;                                 // bias of the gap states and of H - (open + ext)
+constexpr unsigned ZB = CB - OE;                            // H = 0 as the kernel holds it: H - (open + ext) + 12
 constexpr unsigned GAP_NONE = (CB - OE - EX) * K1;          // "no gap": -(open + 2 ext), biased
 constexpr unsigned GAP_EDGE = (CB - OE) * K1;               // the gap state a band-edge cell sees: opened from H = 0
 constexpr unsigned T_OUT = 12u;                             // shift amount of the N field: columns outside the contig
@@ -162,44 +163,49 @@ __device__ __forceinline__ unsigned bfi_v(unsigned mask, unsigned a, unsigned b)
 __device__ __forceinline__ unsigned ge_word(unsigned a, unsigned b) { return sub_v(or_k<GUARD>(a), b); }
 
 struct Cell {
-    unsigned hs, hmoe, emex, fmex;  // H + 8; H - (open + ext) + 12, E - ext + 12, F - ext + 12 -- task X low, task Y high
+    // H - (open + ext) + 12 (= H + 6), the same with the guard bits set, E - ext + 12, F - ext + 12 -- task X low, task Y high
+    unsigned hmoe, hg, emex, fmex;
 };
 
 // Direction nibble of a cell, most significant bit first: [D][L][E opened][F opened].  D: the diagonal won (it wins
 // ties, then E).  L: with D, "the diagonal predecessor holds H > 0" (0 = the path starts in this cell); without D,
 // 1 = E, 0 = F.  e / f: the gap states arriving from the left / from above, eo / fo: comparison words "the gap was
 // opened there" (open wins ties) -- computed by the caller, which also knows the band's edge lanes.
-// The nibbles of four steps share 16 bits: the first step's ends up lowest.
+// The three candidates are compared two below their value (d - 2, e - 2, f - 2: the last two are the cell's own
+// pre-charged gap states, and d - 2 is the predecessor's H - (open + ext) plus the biased score), so H itself is never
+// formed.  Four steps share 16 bits per task: a byte of [D, E opened] pairs above a byte of [L, F opened] pairs, the first
+// step's pair lowest in each.
 template <bool FIRST>
 __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, unsigned tsh, unsigned e, unsigned eo, unsigned f,
-                                        unsigned fo, unsigned twelve) {
+                                        unsigned fo, unsigned ten) {
     const unsigned s = and_k<7u * K1>(pk_shr(prof, tsh));        // score + 4
-    const unsigned nz = add_k<0u - (HB + 1u) * K1>(or_k<GUARD>(c.hs));  // H of the diagonal predecessor >= 1
-    const unsigned d = add_v(c.hs, s);                            // diagonal candidate, biased by 12
-    const unsigned m = pk_max(pk_max(d, e), f);
-    const unsigned dw = ge_word(d, m), ew = ge_word(e, m);       // == m, as neither exceeds it
-    const unsigned h = pk_max(m, twelve);                        // H + 12
-    c.hs = add_k<0u - 4u * K1>(h);
-    c.hmoe = add_k<0u - (unsigned)OE * K1>(h);
-    c.emex = add_k<0u - (unsigned)EX * K1>(e);
-    c.fmex = add_k<0u - (unsigned)EX * K1>(f);
+    const unsigned nz = add_k<0u - (CB - OE + 1u) * K1>(c.hg);   // H of the diagonal predecessor >= 1
+    const unsigned d = add_v(c.hmoe, s);                         // diagonal candidate - 2, biased by 12
+    const unsigned en = add_k<0u - (unsigned)EX * K1>(e), fn = add_k<0u - (unsigned)EX * K1>(f);
+    const unsigned m = pk_max(pk_max(d, en), fn);
+    const unsigned dw = ge_word(d, m), ew = ge_word(en, m);      // == m, as neither exceeds it
+    const unsigned h = pk_max(m, ten);                           // H + 10
+    c.hmoe = add_k<0u - 4u * K1>(h);
+    c.hg = or_k<GUARD>(c.hmoe);
+    c.emex = en;
+    c.fmex = fn;
     const unsigned lw = bfi_v(dw, nz, ew);
-    unsigned n = bfi(0x80008000u, dw, shr_k<1>(lw));
-    n = bfi(0xC000C000u, n, shr_k<2>(eo));
-    n = bfi(0xE000E000u, n, shr_k<3>(fo));
-    n = and_k<0xF000F000u>(n);
-    acc = FIRST ? n : or_v(shr_k<4>(acc), n);
+    // the bytes that hold the four answers of both tasks, side by side: [D_Y L_Y D_X L_X] and [EO_Y FO_Y EO_X FO_X], each
+    // answer in bit 7 of its byte; the second set goes to bit 6, and a step's two bits per byte move down as steps follow
+    const unsigned p1 = (unsigned)__builtin_amdgcn_perm(dw, lw, 0x07030501u), p2 = (unsigned)__builtin_amdgcn_perm(eo, fo, 0x07030501u);
+    const unsigned n = and_k<0xC0C0C0C0u>(bfi(0x80808080u, p1, shr_k<1>(p2)));
+    acc = FIRST ? n : or_v(shr_k<2>(acc), n);
 }
 
 struct State {
     Cell A, B, C, D;
     unsigned qb, t0, t1, t2, t3;
-    unsigned best, brow, sA, sB, sC, sD;  // running maximum of the lane's cells (H + 8), step of its last rise, the cells then
+    unsigned best, brow, sA, sB, sC, sD;  // running maximum of the lane's cells (H + 6), step of its last rise, the cells then
 };
 
 template <int P, bool FIRST>
 __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned step_k, int l, unsigned prof_in, unsigned t_in,
-                                        unsigned first_all, unsigned last_all, unsigned edge, unsigned twelve, unsigned fifteen) {
+                                        unsigned first_all, unsigned last_all, unsigned edge, unsigned ten, unsigned fifteen) {
     constexpr bool ROW = P <= 16;
     const unsigned q_shift = from_lower<ROW>(s.qb);
     s.qb = (l == 0) ? prof_in : q_shift;  // profiles of row m enter at lane 0
@@ -209,24 +215,24 @@ __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned s
     const unsigned l_hmoe = from_lower<ROW>(s.D.hmoe), l_emex = from_lower<ROW>(s.D.emex);
     const unsigned eA = bfi_v(first_all, edge, pk_max(l_hmoe, l_emex));
     const unsigned eoA = or_v(ge_word(l_hmoe, l_emex), first_all);  // (only bits 15 and 31 are looked at)
-    dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), ge_word(s.B.hmoe, s.B.fmex), twelve);
-    dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max(s.A.hmoe, s.A.emex), ge_word(s.A.hmoe, s.A.emex),
-                   pk_max(s.C.hmoe, s.C.fmex), ge_word(s.C.hmoe, s.C.fmex), twelve);
-    dp_cell<FIRST>(s.C, acc[2], s.qb, s.t2, pk_max(s.B.hmoe, s.B.emex), ge_word(s.B.hmoe, s.B.emex),
-                   pk_max(s.D.hmoe, s.D.fmex), ge_word(s.D.hmoe, s.D.fmex), twelve);
+    dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), sub_v(s.B.hg, s.B.fmex), ten);
+    dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max(s.A.hmoe, s.A.emex), sub_v(s.A.hg, s.A.emex),
+                   pk_max(s.C.hmoe, s.C.fmex), sub_v(s.C.hg, s.C.fmex), ten);
+    dp_cell<FIRST>(s.C, acc[2], s.qb, s.t2, pk_max(s.B.hmoe, s.B.emex), sub_v(s.B.hg, s.B.emex),
+                   pk_max(s.D.hmoe, s.D.fmex), sub_v(s.D.hg, s.D.fmex), ten);
     // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal the same boundary applies
     const unsigned u_hmoe = from_upper<ROW>(s.A.hmoe), u_fmex = from_upper<ROW>(s.A.fmex);
     const unsigned fD = bfi_v(last_all, edge, pk_max(u_hmoe, u_fmex));
     const unsigned foD = or_v(ge_word(u_hmoe, u_fmex), last_all);
-    dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), ge_word(s.C.hmoe, s.C.emex), fD, foD, twelve);
+    dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), sub_v(s.C.hg, s.C.emex), fD, foD, ten);
 
     // best cell of the lane so far: a strict rise keeps the first row; the cells of that step tell the column later
-    const unsigned top = pk_max(pk_max(s.A.hs, s.B.hs), pk_max(s.C.hs, s.D.hs));
+    const unsigned top = pk_max(pk_max(s.A.hmoe, s.B.hmoe), pk_max(s.C.hmoe, s.D.hmoe));
     const unsigned keep = pk_sign_mask(ge_word(s.best, top), fifteen);  // halves that did not rise
     s.best = pk_max(s.best, top);
     s.brow = bfi_v(keep, s.brow, step_k);
-    s.sA = bfi_v(keep, s.sA, s.A.hs); s.sB = bfi_v(keep, s.sB, s.B.hs);
-    s.sC = bfi_v(keep, s.sC, s.C.hs); s.sD = bfi_v(keep, s.sD, s.D.hs);
+    s.sA = bfi_v(keep, s.sA, s.A.hmoe); s.sB = bfi_v(keep, s.sB, s.B.hmoe);
+    s.sC = bfi_v(keep, s.sC, s.C.hmoe); s.sD = bfi_v(keep, s.sD, s.D.hmoe);
 
     const unsigned t_shift = from_upper<ROW>(s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
     s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
@@ -261,8 +267,8 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     // statements becomes a branch)
     unsigned first_all = l == 0 ? ~0u : 0u, last_all = l == P - 1 ? ~0u : 0u;
     // (VGPR copies of constants that VOP3 / VOP3P instructions cannot take as literals)
-    unsigned twelve = CB * K1, fifteen = 15u * K1, edge = GAP_EDGE;
-    asm volatile("" : "+v"(twelve), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
+    unsigned ten = (CB - 2u) * K1, fifteen = 15u * K1, edge = GAP_EDGE;
+    asm volatile("" : "+v"(ten), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
 
     // The narrow class hands its quads out by a counter, ONE per block: the launch has at least as many single-wave blocks
     // as quads, a block lives for one quad (about a millisecond) and its CU slot then goes to whoever is next in line --
@@ -324,10 +330,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         uint4 *trace_x = trace + toff + TG * l, *trace_y = trace + toff_y + TG * l;
 
         State st;
-        st.A.hs = H_ZERO; st.A.hmoe = GAP_EDGE; st.A.emex = GAP_NONE; st.A.fmex = GAP_NONE;
+        st.A.hmoe = GAP_EDGE; st.A.hg = GAP_EDGE | GUARD; st.A.emex = GAP_NONE; st.A.fmex = GAP_NONE;
         st.B = st.A; st.C = st.A; st.D = st.A;
         st.qb = PROF_OUT; st.t0 = st.t1 = st.t2 = st.t3 = T_OUT * K1;
-        st.best = H_ZERO; st.brow = 0; st.sA = st.sB = st.sC = st.sD = H_ZERO;
+        st.best = GAP_EDGE; st.brow = 0; st.sA = st.sB = st.sC = st.sD = GAP_EDGE;  // H = 0
         unsigned acc[4] = {0, 0, 0, 0}, held[4] = {0, 0, 0, 0};
         bool saw_n[2] = {false, false};  // an N in the gene or in the target window: the traceback then compares bases itself
 
@@ -441,10 +447,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                     // byte pairs -> (X | Y << 16): selector bytes 0x0c are zeros
                     const unsigned ta = __builtin_amdgcn_perm(0u, tc.x, 0x0c010c00u), tb = __builtin_amdgcn_perm(0u, tc.x, 0x0c030c02u);
                     const unsigned tcw = __builtin_amdgcn_perm(0u, tc.y, 0x0c010c00u), td = __builtin_amdgcn_perm(0u, tc.y, 0x0c030c02u);
-                    dp_step<P, true>(st, acc, (unsigned)mm * K1, l, pr.x, ta, first_all, last_all, edge, twelve, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, l, pr.y, tb, first_all, last_all, edge, twelve, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, l, pr.z, tcw, first_all, last_all, edge, twelve, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, l, pr.w, td, first_all, last_all, edge, twelve, fifteen);
+                    dp_step<P, true>(st, acc, (unsigned)mm * K1, l, pr.x, ta, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, l, pr.y, tb, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, l, pr.z, tcw, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, l, pr.w, td, first_all, last_all, edge, ten, fifteen);
                     if (half == 0) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) held[c] = acc[c];
@@ -464,11 +470,11 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         // ---- best cell of each task: max score, then first row, then first column -------------------------------------
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const unsigned v = (st.best >> (16 * h)) & 0xFFFFu;  // H + 8
+            const unsigned v = (st.best >> (16 * h)) & 0xFFFFu;  // H + 6
             const int mstar = (int)((st.brow >> (16 * h)) & 0xFFFFu);
             const unsigned a = (st.sA >> (16 * h)) & 0xFFFFu, bq = (st.sB >> (16 * h)) & 0xFFFFu, cq = (st.sC >> (16 * h)) & 0xFFFFu;
             int eb = 4 * l + (a == v ? 0 : bq == v ? 1 : cq == v ? 2 : 3);
-            unsigned key = v > HB ? ((v - HB) << 15) | (unsigned)(32767 - (mstar - l)) : 0u;
+            unsigned key = v > ZB ? ((v - ZB) << 15) | (unsigned)(32767 - (mstar - l)) : 0u;
             if (key == 0u) eb = 4 * l;
             bool sn = saw_n[h];
 #pragma unroll
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
 // Cell (row r, band index bi) sits on target position lo + r + bi; a diagonal step keeps bi, a step to the left (E, gap
 // in the query) lowers it, a step up (F, gap in the target) raises it.  The nibble of (r, bi) is in lane stream bi / 4,
-// step r + bi / 4: piece j = step / 8 (at [j / TG][lane][j % TG] of the task's block), word bi % 4 (the cell), bits [4 (step % 8) + 3 : 4 (step % 8)].
+// step r + bi / 4: piece j = step / 8 (at [j / TG][lane][j % TG] of the task's block), word bi % 4 (the cell); bit layout of a word: below.
 //
 // A path runs along a diagonal most of the time: it stays in one lane stream and walks it backwards.  The walk therefore
 // works on whole 16-byte pieces (8 steps x 4 cells) held in registers: when it stands on the last step of a piece and
@@ -611,12 +617,16 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
                 cur = (pc & 2) ? hi2 : cur;
             }
             const uint32_t word = piece_word(cur, k);
-            if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xCCCCCCCCu) == 0xCCCCCCCCu) {  // eight plain diagonal steps
+            if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xAAAAAAAAu) == 0xAAAAAAAAu) {  // eight plain diagonal steps
                 cols += 8; diag += 8; r -= 8;
                 continue;
             }
-            const uint32_t nib = (word >> (4 * (step & 7))) & 15u;
-            // [D][L][E opened][F opened] -> source 0 = diagonal, 1 = diagonal and the path starts here, 2 = E, 3 = F
+            // a cell's word: steps 0-3 in the low half, 4-7 in the high half; per half a byte of [L, F opened] pairs below
+            // a byte of [D, E opened] pairs, step j's pair at bits 2j+1, 2j
+            const uint32_t half = word >> (16 * ((step >> 2) & 1)), sh = 2 * (step & 3);
+            const uint32_t de = (half >> (8 + sh)) & 3u, lf = (half >> sh) & 3u;
+            const uint32_t nib = ((de & 2u) << 2) | ((lf & 2u) << 1) | ((de & 1u) << 1) | (lf & 1u);  // [D][L][EO][FO]
+            // -> source 0 = diagonal, 1 = diagonal and the path starts here, 2 = E, 3 = F
             const uint32_t src = (nib & 8u) ? ((nib & 4u) ? 0u : 1u) : ((nib & 4u) ? 2u : 3u);
             if (state == 0) {
                 if (src <= 1u) {  // diagonal: one column
