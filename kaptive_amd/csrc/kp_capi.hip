@@ -923,7 +923,22 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);
         const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
-        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap) break;
+        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap) {
+            // Everything fitted.  What came close makes room for the passes after this one: the sub-slice an anchor
+            // lands in depends on the order in which the scan's waves flushed, so the fullest slice varies from pass to
+            // pass on the same input, and a rerun costs a whole pass.
+            if (max_slice + max_slice / 4 > sub_cap)
+                ctx->anchor_cap = std::max(ctx->anchor_cap, ((max_slice + max_slice / 2 + 15u) & ~15u) * KP_ANCHOR_SUBS);
+            if (trace_need + trace_need / 16 > w->trace_cap && trace_need + trace_need / 4 <= (1ull << 32))
+                ctx->trace_units_per_asm = std::max<uint64_t>(ctx->trace_units_per_asm,
+                                                              (trace_need + trace_need / 4 + n_asm - 1) / std::max<size_t>(n_asm, 1));
+            if ((uint64_t)max_task + max_task / 16 > w->task_cap)
+                ctx->tasks_per_asm = std::max<uint32_t>(ctx->tasks_per_asm,
+                                                        (uint32_t)(((uint64_t)max_task + max_task / 4 + n_asm - 1) / std::max<size_t>(n_asm, 1)));
+            if (n_cand + n_cand / 16 > w->cand_cap)
+                ctx->cand_frac = std::max(ctx->cand_frac, (double)(n_cand + n_cand / 4) / ((double)b->view.total_words * 4.0));
+            break;
+        }
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
         // a region overflowed: counts kept counting, so they say how much room a clean rerun needs.  The context
         // remembers it (with some headroom, later batches differ a little) for every later pass.
@@ -932,7 +947,7 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
             ctx->cand_frac = std::max(ctx->cand_frac, (double)w->cand_cap / ((double)b->view.total_words * 4.0) * 1.0001);
         }
         if (max_slice > sub_cap) {
-            w->anchor_cap = ((max_slice + max_slice / 4 + 15u) & ~15u) * KP_ANCHOR_SUBS;
+            w->anchor_cap = ((max_slice + max_slice / 2 + 15u) & ~15u) * KP_ANCHOR_SUBS;
             ctx->anchor_cap = std::max(ctx->anchor_cap, w->anchor_cap);
         }
         if (trace_need > w->trace_cap) {  // (a pass cut short by another overflow reports less than it will need)
