@@ -164,7 +164,7 @@ def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
 
 L2_GATHER_ROOF_G = 269.0  # G independent 8-byte reads per second out of a 2 MB table (profiles/l2_gather_r2.txt)
 FILL_CYCLES_PER_WAVE_STEP = 3320 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r2.txt)
-FILL_CLOCK_HZ = 2.28e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/fill_pmc_r2.txt)
+FILL_CLOCK_HZ = 2.26e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/r2_pmc.txt)
 
 
 def offline_pmc(args) -> dict | None:
@@ -364,6 +364,7 @@ def main() -> None:
         lst.clear()
     sync_all()
     t0 = time.perf_counter()
+    cpu0 = time.thread_time()  # CPU seconds of this (the driving) thread: what a rank needs of a host core
     step_ms = []
     for _ in range(args.steps):
         t_step = time.perf_counter()
@@ -371,6 +372,7 @@ def main() -> None:
         step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))  # host view, no synchronisation added
     sync_all()
     elapsed = time.perf_counter() - t0
+    host_busy = (time.thread_time() - cpu0) / max(elapsed, 1e-9)
     # (untimed) the alignment kernels of one batch with nothing else on the device: what a launch takes on its own; in
     # the timed steps the passes of consecutive batches overlap and stretch each other's kernels
     alone = []
@@ -521,6 +523,7 @@ def main() -> None:
                 "tsv_rows_per_s_host": round(len(rows) / max(t_rows, 1e-9), 1),
                 "tsv_rows_sha1": rows_digest,
                 "tsv_rows_sha1_per_rank": digests if world > 1 else None,
+                "host_thread_busy_frac": round(host_busy, 3),
                 "buffer_growth_reruns_in_timed_steps": [sum(s["retries"] for s in slist) for slist in stats],
                 "workload_generation_s": round(t_gen, 1),
             },
