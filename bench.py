@@ -125,6 +125,35 @@ def _cpu_worker(job):
     return len(genomes), time.perf_counter() - t0
 
 
+def ingest_rate(seed0: int, length: float) -> dict:
+    """FASTA text -> contig table + 2-bit words + N runs (kp_fasta_ingest, what GenomeAssembly.from_file calls): MB/s of
+    plain FASTA on one host core, and on all of them at once (a thread per core; the native call releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from kaptive_amd import _native
+    from kaptive_amd.synth import make_assembly
+
+    also = (_DBS["also"],) if _DBS["also"] is not None else ()
+    texts = [make_assembly(_DBS["main"], seed=seed0 + i, length=length, also=also, **_WL["asm_kw"]).contigs.to_fasta()
+             for i in range(4)]
+    nbytes = sum(len(t) for t in texts)
+    _native.fasta_ingest(texts[0])  # first call: library load
+    t = time.perf_counter()
+    for x in texts:
+        _native.fasta_ingest(x)
+    one = nbytes / (time.perf_counter() - t) / 1e6
+    cores = os.cpu_count() or 1
+    jobs = [texts[i % len(texts)] for i in range(4 * cores)]
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        t = time.perf_counter()
+        list(pool.map(_native.fasta_ingest, jobs))
+        box = sum(len(x) for x in jobs) / (time.perf_counter() - t) / 1e6
+    return {"MBps_per_core": round(one, 1), "MBps_per_box": round(box, 1), "cores": cores,
+            "assemblies_per_s_per_box": round(box * 1e6 / (nbytes / len(texts)), 1),
+            "note": "plain FASTA bytes through kp_fasta_ingest (sequence text kept, as GenomeAssembly.from_file needs it); "
+                    "outside every timed leg above"}
+
+
 def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
     """The CPU oracle (C aligner + C protein DP + numpy reduction) typing the first assemblies of the workload against
     every database: all host cores at once (one assembly per process at a time), then one core alone."""
@@ -225,9 +254,10 @@ def main() -> None:
     t_gen = time.perf_counter()
     ids, packed = build_workload(args.assemblies, seed0, length, workers)
     t_gen = time.perf_counter() - t_gen
-    cpu = None
+    cpu = ingest = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(seed0, length)
+        ingest = ingest_rate(seed0, length)
 
     import torch
     import torch.distributed as dist
@@ -557,6 +587,7 @@ def main() -> None:
         }  # fmt: skip
         if cpu is not None:
             line["cpu_baseline"] = cpu
+            line["ingest"] = ingest
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

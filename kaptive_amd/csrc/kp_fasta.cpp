@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,6 +30,53 @@ struct Tables {
     }
 };
 const Tables T;
+
+// The two large arrays of a result (packed words, sequence text) come from a small pool of recycled blocks: a thread pool
+// that ingests file after file would otherwise map, fault in and unmap ~12 MB per 5 Mbp assembly, and with many threads
+// those page faults serialise in the kernel (measured: 8 threads together slower than one).
+struct BlockPool {
+    struct Block { void *p; size_t cap; };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    size_t held = 0;
+    static constexpr size_t MAX_HELD = (size_t)2 << 30, MAX_BLOCKS = 512;
+    void *take(size_t bytes, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].cap >= bytes && (best == free_blocks.size() || free_blocks[i].cap < free_blocks[best].cap)) best = i;
+            if (best < free_blocks.size() && free_blocks[best].cap <= 2 * bytes + (1 << 20)) {
+                Block b = free_blocks[best];
+                free_blocks[best] = free_blocks.back();
+                free_blocks.pop_back();
+                held -= b.cap;
+                *cap = b.cap;
+                return b.p;
+            }
+        }
+        const size_t want = bytes + bytes / 8 + 4096;  // the next file is a little longer or shorter
+        *cap = want;
+        return std::malloc(want);
+    }
+    void give(void *p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cap && held + cap <= MAX_HELD && free_blocks.size() < MAX_BLOCKS) {
+                free_blocks.push_back({p, cap});
+                held += cap;
+                return;
+            }
+        }
+        std::free(p);
+    }
+};
+BlockPool g_pool;
+
+struct Owned : kp_packed_fasta {  // what kp_fasta_free gets back: the public record plus the capacities of its pooled blocks
+    size_t words_cap = 0, seqs_cap = 0;
+};
 
 // 2-bit writer: bases go through a 64-bit accumulator, whole words leave it
 struct Packer {
@@ -116,12 +164,20 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
     // every '>' may open a contig (32-base alignment: at most two more words each); sequence bytes give <= n bases
     size_t marks = 0;
     for (const uint8_t *p = data, *e = data + n; p < e && (p = (const uint8_t *)std::memchr(p, '>', (size_t)(e - p))); ++p) ++marks;
-    std::vector<uint32_t> words((size_t)n / 16 + 2 * marks + 8, 0u);
+    const size_t n_words_max = (size_t)n / 16 + 2 * marks + 8;
+    size_t words_cap = 0, seqs_cap = 0;
+    uint32_t *words = (uint32_t *)g_pool.take(n_words_max * 4, &words_cap);
+    uint8_t *dense = keep_text ? (uint8_t *)g_pool.take((size_t)n + 16, &seqs_cap) : nullptr;  // the contigs' symbols as written
+    uint8_t *dp = dense;                                                                          // (whitespace removed), back to back
+    struct Guard {  // blocks go back to the pool on every early return
+        uint32_t *&w; size_t &wc; uint8_t *&d; size_t &dc; bool armed = true;
+        ~Guard() { if (armed) { g_pool.give(w, wc); g_pool.give(d, dc); } }
+    } guard{words, words_cap, dense, seqs_cap};
+    if (!words || (keep_text && !dense)) return KP_ENOMEM;
+    std::memset(words, 0, n_words_max * 4);
     std::vector<int32_t> ctg_start, ctg_len, runs, name_off;
     std::string names;
-    std::vector<uint8_t> dense;  // keep_text: the contigs' symbols as written (whitespace removed), back to back
-    if (keep_text) dense.reserve((size_t)n);
-    Packer pk(words.data());
+    Packer pk(words);
     int64_t i = 0;
     while (i < n && data[i] != '>') {  // text before the first header is ignored
         const uint8_t *nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
@@ -132,7 +188,7 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
         for (; p < e; ++p) {
             const uint8_t c = T.code[*p];
             if (c == 8) continue;
-            if (keep_text) dense.push_back(*p);
+            if (keep_text) *dp++ = *p;
             if (c == 4) {
                 if (!in_run) { runs.push_back((int32_t)pk.pos); runs.push_back((int32_t)pk.pos); in_run = true; }
                 runs.back() = (int32_t)pk.pos + 1;
@@ -172,7 +228,7 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
                 else {
                     in_run = false;
                     pk.put16(w);
-                    if (keep_text) dense.insert(dense.end(), p, p + 16);
+                    if (keep_text) { std::memcpy(dp, p, 16); dp += 16; }
                 }
             }
             slow(p, e);
@@ -184,9 +240,8 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
     name_off.push_back((int32_t)names.size());
     pk.pad_to(KP_ASM_ALIGN);
     const int64_t pos = pk.pos;
-    words.resize((size_t)(pos / 16));
 
-    kp_packed_fasta *r = new (std::nothrow) kp_packed_fasta();
+    Owned *r = new (std::nothrow) Owned();
     if (!r) return KP_ENOMEM;
     auto dup = [](const void *src, size_t bytes) -> void * {
         void *p = std::malloc(bytes ? bytes : 1);
@@ -196,15 +251,16 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
     r->padded_len = pos;
     r->n_contigs = (int32_t)ctg_start.size();
     r->n_runs = (int32_t)(runs.size() / 2);
-    r->words = (uint32_t *)dup(words.data(), words.size() * 4);
+    r->words = words; r->words_cap = words_cap;
+    r->seqs = dense; r->seqs_cap = seqs_cap;
+    r->n_seq_bytes = keep_text ? (int64_t)(dp - dense) : 0;
+    guard.armed = false;  // the record owns the blocks now
     r->ctg_start = (int32_t *)dup(ctg_start.data(), ctg_start.size() * 4);
     r->ctg_len = (int32_t *)dup(ctg_len.data(), ctg_len.size() * 4);
     r->n_run_pairs = (int32_t *)dup(runs.data(), runs.size() * 4);
     r->names = (char *)dup(names.data(), names.size());
     r->name_off = (int32_t *)dup(name_off.data(), name_off.size() * 4);
-    r->seqs = keep_text ? (uint8_t *)dup(dense.data(), dense.size()) : nullptr;
-    r->n_seq_bytes = keep_text ? (int64_t)dense.size() : 0;
-    if (!r->words || !r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off || (keep_text && !r->seqs)) {
+    if (!r->ctg_start || !r->ctg_len || !r->n_run_pairs || !r->names || !r->name_off) {
         kp_fasta_free(r);
         return KP_ENOMEM;
     }
@@ -265,7 +321,7 @@ int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *
     }
     pk.pad_to(KP_ASM_ALIGN);
     words.resize((size_t)(pk.pos / 16));
-    kp_packed_fasta *r = new (std::nothrow) kp_packed_fasta();
+    Owned *r = new (std::nothrow) Owned();
     if (!r) return KP_ENOMEM;
     auto dup = [](const void *src, size_t bytes) -> void * {
         void *q = std::malloc(bytes ? bytes : 1);
@@ -294,9 +350,12 @@ int kp_pack_contigs(const uint8_t *seqs, const int64_t *offsets, const int32_t *
 
 void kp_fasta_free(kp_packed_fasta *p) {
     if (!p) return;
-    std::free(p->words); std::free(p->ctg_start); std::free(p->ctg_len); std::free(p->n_run_pairs);
-    std::free(p->names); std::free(p->name_off); std::free(p->seqs);
-    delete p;
+    Owned *o = static_cast<Owned *>(p);  // every record this library hands out is one
+    g_pool.give(o->words, o->words_cap);  // (capacity 0: a plain malloc, freed)
+    g_pool.give(o->seqs, o->seqs_cap);
+    std::free(p->ctg_start); std::free(p->ctg_len); std::free(p->n_run_pairs);
+    std::free(p->names); std::free(p->name_off);
+    delete o;
 }
 
 }  // extern "C"
