@@ -41,13 +41,43 @@ class PackedFasta(C.Structure):  # kp_packed_fasta
                 ("seqs", C.POINTER(C.c_uint8)), ("n_seq_bytes", C.c_int64)]  # fmt: skip
 
 
-def _packed_from(out, want_names: bool):
+class _FastaRecord:
+    """Keeps a kp_packed_fasta alive for as long as an array that views its large buffers (packed words, sequence text)
+    is: the arrays are handed out without a copy -- a copy is a few milliseconds with the GIL held per 5 Mbp assembly,
+    which is what stopped a thread pool of readers from scaling -- and the buffers return to the library's block pool
+    when the last view dies."""
+
+    def __init__(self, out) -> None:
+        self.out = out
+
+    def __del__(self) -> None:
+        try:
+            h = lib()
+            h.kp_fasta_free.restype = None
+            h.kp_fasta_free(self.out)
+        except Exception:  # interpreter shutdown
+            pass
+
+    def view(self, ptr, n: int, ctype, dtype) -> np.ndarray:
+        if not n:
+            return np.empty(0, dtype)
+        buf = (ctype * n).from_address(C.addressof(ptr.contents))
+        buf._record = self  # numpy keeps `buf` as the array's base, `buf` keeps the record
+        return np.frombuffer(buf, dtype=dtype)
+
+
+def _packed_from(out, want_names: bool, record: "_FastaRecord | None" = None):
+    """kp_packed_fasta -> (PackedAssembly, names).  With ``record`` the packed words are a view of the library's buffer
+    (the record frees it when the views are gone); without, everything is copied and the caller frees."""
     from kaptive_amd.pack import PackedAssembly
 
     p = out.contents
     nc, nr = p.n_contigs, p.n_runs
     arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.empty(0, dt)  # noqa: E731
-    words = arr(p.words, p.padded_len // 16, np.uint32)
+    if record is not None:
+        words = record.view(p.words, p.padded_len // 16, C.c_uint32, np.uint32)
+    else:
+        words = arr(p.words, p.padded_len // 16, np.uint32)
     names = ()
     if want_names:
         off = arr(p.name_off, nc + 1, np.int32)
@@ -83,14 +113,11 @@ def fasta_ingest(data: bytes, gzipped: bool = False):
     rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32((1 if gzipped else 0) | 2), C.byref(out))
     if rc != 0:
         raise ValueError(f"kp_fasta_ingest failed ({rc}): not a readable FASTA / gzip stream, or longer than KP_MAX_ASM_LEN")
-    try:
-        pa, names = _packed_from(out, True)
-        p = out.contents
-        n = int(p.n_seq_bytes)
-        seqs = np.ctypeslib.as_array(p.seqs, shape=(n,)).copy() if n else np.empty(0, np.uint8)
-        return pa, names, seqs, pa.ctg_len.copy()
-    finally:
-        h.kp_fasta_free(out)
+    record = _FastaRecord(out)  # frees the native record when the arrays below are gone
+    pa, names = _packed_from(out, True, record)
+    p = out.contents
+    seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)
+    return pa, names, seqs, pa.ctg_len.copy()
 
 
 def fasta_pack(data: bytes):
