@@ -72,7 +72,8 @@ struct KpTypingGroup {
 // rebased) and everything score / reduce / typing produce for it.
 struct KpTypingRun {
     // every group works on streams of its own (highest priority), so the reductions of several databases over one
-    // batch overlap: they are chains of short, low-occupancy kernels
+    // batch overlap: they are chains of short, low-occupancy kernels.  The streams belong to the context (one pair per
+    // group, shared by the work sets: a context's streams should not outnumber the runtime's hardware queues)
     hipStream_t stream = nullptr, aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool split = false;  // hits / hit_n belong to the work set's most recent alignment pass
@@ -98,8 +99,8 @@ struct KpTypingRun {
     std::vector<KpAsmSummary> h_sums;
     int32_t max_kept = 1, max_pieces = 1;
     void release() {
-        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
-        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
+        if (stream) { (void)hipStreamSynchronize(stream); stream = nullptr; }
+        if (aux) { (void)hipStreamSynchronize(aux); aux = nullptr; }
         if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
         if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
         d_keys.release(); d_order.release(); d_flag.release(); d_dp_scratch.release();
@@ -236,6 +237,8 @@ struct kp_ctx {
     // per typing group: learnt sizes of the reduction buffers
     struct RunCaps { int kept_cap = 0, piece_cap = 0, prot_cap = 0; };
     std::vector<RunCaps> run_caps;
+    struct GroupStreams { hipStream_t stream = nullptr, aux = nullptr; };
+    std::vector<GroupStreams> group_streams;  // reduction streams, per typing group
     // work sets and recycled inputs
     KpWork work[KP_WORK_SLOTS];
     uint32_t next_slot = 0;
@@ -535,6 +538,10 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->groups.clear();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+    for (auto &gs : ctx->group_streams) {
+        if (gs.stream) (void)hipStreamDestroy(gs.stream);
+        if (gs.aux) (void)hipStreamDestroy(gs.aux);
+    }
     if (ctx->post) (void)hipStreamDestroy(ctx->post);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1139,11 +1146,16 @@ static kp_ctx::RunCaps &run_caps(kp_ctx *ctx, int32_t group) {
     if (c.prot_cap == 0) c.prot_cap = (int)ctx->opt.prot_cap;
     return c;
 }
-static int ensure_run_streams(kp_ctx *ctx, KpTypingRun &R) {
+static int ensure_run_streams(kp_ctx *ctx, KpTypingRun &R, int32_t group) {
     if (R.stream) return KP_OK;
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    KP_HIP_CHECK(ctx, create_priority_stream(&R.stream));
-    KP_HIP_CHECK(ctx, create_priority_stream(&R.aux));
+    if (ctx->group_streams.size() <= (size_t)group) ctx->group_streams.resize((size_t)group + 1);
+    kp_ctx::GroupStreams &gs = ctx->group_streams[(size_t)group];
+    if (!gs.stream) {
+        KP_HIP_CHECK(ctx, create_priority_stream(&gs.stream));
+        KP_HIP_CHECK(ctx, create_priority_stream(&gs.aux));
+    }
+    R.stream = gs.stream; R.aux = gs.aux;
     KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&R.ev_fork, hipEventDisableTiming));
     KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&R.ev_join, hipEventDisableTiming));
     return KP_OK;
@@ -1187,7 +1199,7 @@ int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *l
     if (rc) return rc;
     KpWork *w = work_of(ctx, b);
     KpTypingRun &R = typing_run(w, b->group);
-    if ((rc = ensure_run_streams(ctx, R))) return rc;
+    if ((rc = ensure_run_streams(ctx, R, b->group))) return rc;
     if ((rc = split_hits(ctx, b, w, T, R))) return rc;
     const size_t n = (size_t)b->n_asm * (size_t)T.typing.n_loci;
     KP_HIP_CHECK(ctx, R.d_scores.reserve(n));
