@@ -277,6 +277,19 @@ def main() -> None:
     torch.cuda.init()
     torch.zeros(1, device="cuda")
     torch.cuda.synchronize()
+    # the box's own device-copy rate (read + write), quoted beside the 8 TB/s of the data sheet
+    src_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    dst_t = torch.empty_like(src_t)
+    dst_t.copy_(src_t)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        dst_t.copy_(src_t)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 8 * 2 * src_t.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src_t, dst_t
+    torch.cuda.empty_cache()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -561,6 +574,7 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "kernel": "kp_scan_kernel (" + ("pass over K and O genes" if shared else "K database pass") + ")", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "device_copy_GBps_measured": round(copy_gbps, 1),  # torch copy of 1 GiB, read + write bytes
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "traffic_source": f"offline: {pmc['source']}" if pmc else None,
                 "bytes_per_launch": scan_bytes, "ms_per_launch": scan_ms, "launches_timed": len(scan_all),
