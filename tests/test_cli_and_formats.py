@@ -206,3 +206,32 @@ def test_from_file_goes_through_the_native_ingest(tmp_path):
         GenomeAssembly.from_file(cut)
     with pytest.raises(NotImplementedError):
         GenomeAssembly.from_file(tmp_path / "x.txt")
+
+
+def test_ingest_views_outlive_the_call_and_buffers_are_recycled():
+    """fasta_ingest hands out views of the native buffers (no copy with the GIL held); the record behind them lives as
+    long as any view does, its blocks go back to the library's pool afterwards, and a pool of reader threads gives the
+    same bytes as one."""
+    import gc
+    from concurrent.futures import ThreadPoolExecutor
+
+    db = make_db("kpsc_k", seed=7, n_loci=3)
+    texts = [make_assembly(db, seed=40 + i, length=120_000 + 7_000 * i, median_contigs=5, n_run=10).contigs.to_fasta()
+             for i in range(6)]
+    want = []
+    for t in texts:
+        pa, names, seqs, lengths = _native.fasta_ingest(t)
+        want.append((pa.words.copy(), seqs.copy(), names))
+        words_view, seqs_view = pa.words, seqs
+        del pa, seqs
+        gc.collect()  # the views alone keep the native record alive
+        assert np.array_equal(words_view, want[-1][0]) and np.array_equal(seqs_view, want[-1][1])
+        assert words_view.flags.writeable is not None and not words_view.flags.owndata
+    del words_view, seqs_view
+    gc.collect()
+    with ThreadPoolExecutor(4) as pool:  # blocks of freed records are reused by whichever thread asks next
+        for rnd in range(3):
+            got = list(pool.map(_native.fasta_ingest, texts))
+            for (pa, names, seqs, _), (w, s, n) in zip(got, want):
+                assert np.array_equal(pa.words, w) and np.array_equal(seqs, s) and names == n
+            del got
