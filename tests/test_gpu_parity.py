@@ -633,3 +633,44 @@ def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, oracle, sm
     other.close()
     up.close()
     pin.close()
+
+
+def test_longest_genes_reach_the_packed_score_range(oracle):
+    """Genes at KP_MAX_GENE_LEN: the fill kernel's biased 16-bit scores (2 * length + 12) come within a few hundred of the
+    guard bit.  Exact copies, copies with substitutions, with an insertion and a deletion (wide bands), with an N run,
+    on both strands, and a gene one base too long (rejected at load)."""
+    from kaptive_amd.synth import revcomp
+
+    rng = np.random.default_rng(4242)
+    max_len = 16000
+    g1, g2, g3 = (random_dna(rng, n, 0.5) for n in (max_len, max_len - 1, 15000))
+    genes = Sequences.from_records([SeqRecord("g1", g1.tobytes()), SeqRecord("g2", g2.tobytes()), SeqRecord("g3", g3.tobytes())])
+    codes, off = pack_sequences_flat(genes)
+    ctx = _native.Context(0)
+    ctx.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    sub = g2.copy()
+    at = rng.choice(len(sub), 900, replace=False)
+    sub[at] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, len(at))]
+    indel = np.concatenate([g3[:5000], random_dna(rng, 9, 0.5), g3[5000:11000], g3[11006:]])
+    with_n = g1.copy()
+    with_n[7000:7030] = ord("N")
+    pad = lambda n: random_dna(rng, n, 0.5)  # noqa: E731
+    recs = [SeqRecord("exact", np.concatenate([pad(300), g1, pad(200)]).tobytes()),
+            SeqRecord("rc_sub", np.concatenate([pad(100), revcomp(sub), pad(50)]).tobytes()),
+            SeqRecord("indel", np.concatenate([pad(64), indel, pad(64)]).tobytes()),
+            SeqRecord("n_run", np.concatenate([pad(10), with_n, pad(10)]).tobytes()),
+            SeqRecord("tail_only", g1[9000:].tobytes())]  # fmt: skip
+    asm = GenomeAssembly("long_genes", Sequences.from_records(recs))
+    pa = asm.packed()
+    batch = ctx.batch([pa])
+    hits, _ = batch.align()
+    want = odb.align(pa)
+    _same_records(hits, want, "hits of 16 kb genes")
+    assert hits["score"].max() == 2 * max_len and len(hits) >= 5
+    batch.close()
+    too_long = Sequences.from_records([SeqRecord("g", random_dna(rng, max_len + 1, 0.5).tobytes())])
+    c2, o2 = pack_sequences_flat(too_long)
+    with pytest.raises(ValueError):
+        ctx.load_genes(c2, o2)
+    ctx.close()
