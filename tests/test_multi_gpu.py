@@ -56,6 +56,24 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert two["config"]["typeable_in_last_step"] > 0
 
 
+def test_schedule_does_not_change_the_rows():
+    """One or two alignment passes ahead, resident batches or shards streamed from pinned host memory (with the TSV bytes
+    formatted beside the main thread): the same rows, no buffer-growth rerun inside the timed steps, every leg reported."""
+    def run(extra):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--assemblies", "60", "--batch", "12", "--length", "400000",
+                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-steps", "2", "--workers", "1", *extra],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)  # fmt: skip
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    a, b = run(["--ahead", "1"]), run(["--ahead", "2"])
+    assert a["config"]["tsv_rows_sha1"] == b["config"]["tsv_rows_sha1"]
+    for line in (a, b):
+        assert line["config"]["buffer_growth_reruns_in_timed_steps"] == [0]
+        assert line["e2e"]["from_host_shards"] > 0 and line["e2e"]["with_tsv"] > 0 and line["e2e"]["tsv_bytes_per_step"] > 0
+        assert line["roofline"]["alone"]["ms_per_launch"] > 0 and 0 < line["dp"]["fill_issue_model"]["frac"] < 1.5
+
+
 @pytest.mark.skipif("_device_count() < 2")
 def test_two_ranks_two_gpus_over_rccl():
     two = _run_bench(2, [])
