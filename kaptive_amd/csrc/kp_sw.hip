@@ -9,18 +9,19 @@
 //
 // What the fill kernel is built around (measured on the MI355X, tools/microbench/valu_rate*.hip, profiles/valu_rate*_r2.txt):
 // a gfx950 SIMD issues a wave64 v_add_u32 / v_sub_u32 / v_and / v_or / v_xor / v_lshrrev / v_mov (VGPR or constant
-// operands) in 2 cycles, but v_max / v_min, every compare, v_addc, v_cndmask, v_bfe, every VOP3 and VOP3P (packed 16-bit)
-// instruction, DPP and SDWA forms, and anything with an SGPR operand in 4.  The round's first fill kernel (int32 scores, one
-// compare plus one carry push per direction bit) priced at 82 cycles per cell by that table and ran at exactly that.
+// operands) every 2.35 cycles, but v_max / v_min, every compare, v_addc, v_cndmask, v_bfe, every VOP3 and VOP3P (packed
+// 16-bit) instruction, DPP and SDWA forms, and anything with an SGPR operand every 4.  The round's first fill kernel (int32
+// scores, one compare plus one carry push per direction bit) priced at 82 cycles per cell of a lane by that table and ran
+// at exactly that.
 // This one keeps TWO tasks in every register -- task X in the low 16 bits, task Y in the high 16 -- so that
-//   * additions and subtractions of scores are one 2-cycle v_add_u32 for two cells (all values are kept biased into
+//   * additions and subtractions of scores are one cheap v_add_u32 for two cells (all values are kept biased into
 //     [0, 32767], so no carry or borrow ever crosses bit 16),
 //   * maxima are one v_pk_max_u16 for two cells,
-//   * a comparison a >= b is (a | 0x80008000) - b: two 2-cycle instructions leave the answer for both cells in bits 15
+//   * a comparison a >= b is (a | 0x80008000) - b: two cheap instructions leave the answer for both cells in bits 15
 //     and 31 (the guard bit survives exactly when no borrow reaches it) -- no v_cmp, no lane mask, no carry push,
 //   * the four direction bits of a cell are gathered from those words byte-wise (v_perm_b32, one v_bfi),
 //   * every cross-lane move (DPP) and every band-edge select serves two cells.
-// 6.5 issue cycles per cell (3320 per 8 steps of 512 cells, tools/isa_cost.py) instead of 82.
+// 52 issue cycles per cell of a lane (3320 per 8 steps of 8 cells, tools/isa_cost.py) instead of 82.
 //
 // Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
 //   * a task's band has W = 4P diagonals; P lanes own a PAIR of tasks of that width (neighbours in the length-ordered task
