@@ -94,6 +94,12 @@ KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
 #define KP_FASTA_GZIP 1
 #define KP_FASTA_KEEP_TEXT 2
 KP_API int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out);
+/* Many files in one call, on `threads` host threads of the library's own (0 = one per core, at most n_files): file i is
+ * data[i][0 .. n[i]) with flags[i]; out[i] and rc[i] are what kp_fasta_ingest would have returned for it.  A reader that
+ * feeds a GPU has to turn tens of GB/s of text into packed words; a Python thread per file spends too much of each call
+ * holding the interpreter lock.  Returns KP_OK when the arguments were usable (look at rc[] for the files). */
+KP_API int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int32_t *flags, int32_t n_files,
+                                int32_t threads, kp_packed_fasta **out, int32_t *rc);
 /* The same layout from contigs already in memory (Sequences.seqs / offsets / lengths of the reference's containers,
  * src/kaptive/core/seq.py:307-325): contig c is seqs[offsets[c] .. offsets[c] + lengths[c]).  names / name_off of the
  * result are empty. */

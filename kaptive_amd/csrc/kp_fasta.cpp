@@ -8,11 +8,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kaptive_amd.h"
@@ -154,6 +156,23 @@ int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fas
         return pack_text(text.data(), (int64_t)text.size(), (flags & KP_FASTA_KEEP_TEXT) != 0, out);
     }
     return pack_text(data, n, (flags & KP_FASTA_KEEP_TEXT) != 0, out);
+}
+
+int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int32_t *flags, int32_t n_files, int32_t threads,
+                         kp_packed_fasta **out, int32_t *rc) {
+    if (n_files < 0 || (n_files > 0 && (!data || !n || !flags || !out || !rc))) return KP_EINVAL;
+    int t = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    t = std::max(1, std::min(t, (int)n_files));
+    std::atomic<int32_t> next{0};
+    auto work = [&]() {
+        for (int32_t i = next.fetch_add(1); i < n_files; i = next.fetch_add(1)) rc[i] = kp_fasta_ingest(data[i], n[i], flags[i], &out[i]);
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)t - 1);
+    for (int k = 1; k < t; ++k) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    return KP_OK;
 }
 
 }  // extern "C"

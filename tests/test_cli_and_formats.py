@@ -235,3 +235,32 @@ def test_ingest_views_outlive_the_call_and_buffers_are_recycled():
             for (pa, names, seqs, _), (w, s, n) in zip(got, want):
                 assert np.array_equal(pa.words, w) and np.array_equal(seqs, s) and names == n
             del got
+
+
+def test_from_files_equals_from_file(tmp_path):
+    """GenomeAssembly.from_files (one native call, the library's own threads) gives what from_file gives file by file,
+    for plain, gzip, bz2 and xz files in one list; an unreadable file raises."""
+    import bz2
+    import gzip
+    import lzma
+
+    db = make_db("kpsc_k", seed=7, n_loci=3)
+    paths = []
+    for i, (ext, squeeze) in enumerate((("", None), (".gz", gzip.compress), (".bz2", bz2.compress), (".xz", lzma.compress),
+                                        ("", None), (".gz", gzip.compress))):
+        g = make_assembly(db, seed=60 + i, length=90_000 + 5_000 * i, median_contigs=4 + i, n_run=5 * i)
+        data = g.contigs.to_fasta()
+        p = tmp_path / f"asm{i}.fasta{ext}"
+        p.write_bytes(squeeze(data) if squeeze else data)
+        paths.append(p)
+    many = GenomeAssembly.from_files(paths, threads=3)
+    for p, got in zip(paths, many):
+        want = GenomeAssembly.from_file(p)
+        assert got.id == want.id and got.contigs.ids == want.contigs.ids
+        assert np.array_equal(got.contigs.seqs, want.contigs.seqs) and np.array_equal(got.contigs.lengths, want.contigs.lengths)
+        assert np.array_equal(got.packed().words, want.packed().words) and np.array_equal(got.packed().n_runs, want.packed().n_runs)
+    assert GenomeAssembly.from_files([]) == []
+    bad = tmp_path / "cut.fasta.gz"
+    bad.write_bytes(gzip.compress(b">x\nACGT\n")[:12])
+    with pytest.raises(ValueError):
+        GenomeAssembly.from_files([paths[0], bad])
