@@ -156,9 +156,10 @@ def ingest_rate(seed0: int, length: float) -> dict:
     for _ in range(rounds):
         _native.fasta_ingest_many(chunk)  # one call, the library's own thread per core (GenomeAssembly.from_files)
     box = rounds * sum(len(x) for x in chunk) / (time.perf_counter() - t) / 1e6
-    return {"MBps_per_core": round(one, 1), "MBps_per_box": round(box, 1), "MBps_per_box_python_threads": round(box_py, 1),
-            "cores": cores,
-            "assemblies_per_s_per_box": round(box * 1e6 / (nbytes / len(texts)), 1),
+    best = max(box, box_py)
+    return {"MBps_per_core": round(one, 1), "MBps_per_box": round(best, 1),
+            "MBps_per_box_python_thread_per_file": round(box_py, 1), "MBps_per_box_one_native_call": round(box, 1), "cores": cores,
+            "assemblies_per_s_per_box": round(best * 1e6 / (nbytes / len(texts)), 1),
             "note": "plain FASTA bytes through kp_fasta_ingest (sequence text kept, as GenomeAssembly.from_file needs it); "
                     "outside every timed leg above"}
 
