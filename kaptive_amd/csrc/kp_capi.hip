@@ -817,7 +817,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, stream);
-    kp_launch_task_order(ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
+    kp_launch_task_order(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
                          stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]

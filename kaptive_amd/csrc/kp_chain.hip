@@ -199,15 +199,23 @@ __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t 
     seg_end[a] = (uint32_t)a * cap + n;
 }
 
-// ---- task order: counting sort of each width class by query length, longest first ------------------------------------------
+// ---- task order: counting sort of each width class by the rows the fill kernel will compute, most first ---------------------
 // Tasks of one wave run in lock step for as many steps as the longest of them needs, so neighbours in the processing
 // order should have similar lengths; starting with the long ones also keeps the tail of the launch short.
-__device__ __forceinline__ int length_bucket(int qlen) {
-    const int b = qlen >> 5;
+__device__ __forceinline__ int length_bucket(int rows) {
+    const int b = rows >> 5;
     return 63 - (b > 63 ? 63 : b);
 }
+// rows of the gene the task's band can reach inside its contig (kp_task_rows: a gene at a contig end is not filled beyond it)
+__device__ __forceinline__ int task_rows(const KpBatchView &b, const KpGenes &genes, const KpTask &t) {
+    const int c_abs = b.asm_first_ctg[t.asm_id] + t.contig;
+    const int cstart = b.ctg_start[c_abs];
+    int r_lo, r_hi;
+    kp_task_rows(t.lo, t.width, cstart, cstart + b.ctg_len[c_abs], genes.len[t.gs >> 1], &r_lo, &r_hi);
+    return r_hi - r_lo;
+}
 
-__global__ __launch_bounds__(256) void kp_task_hist_kernel(KpGenes genes, const KpTask *__restrict__ tasks,
+__global__ __launch_bounds__(256) void kp_task_hist_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                            const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                            uint32_t *__restrict__ hist) {
     __shared__ uint32_t s_h[64];
@@ -217,12 +225,12 @@ __global__ __launch_bounds__(256) void kp_task_hist_kernel(KpGenes genes, const 
     if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&s_h[length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1])], 1u);
+        atomicAdd(&s_h[length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]))], 1u);
     __syncthreads();
     if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[cls * 64 + threadIdx.x], s_h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, const KpTask *__restrict__ tasks,
+__global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                               const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                               uint32_t *__restrict__ hist, uint32_t *__restrict__ order) {
     __shared__ uint32_t s_start[64], s_h[64], s_base[64];
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, con
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-        atomicAdd(&s_h[length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1])], 1u);
+        atomicAdd(&s_h[length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]))], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {
         s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[KP_N_CLASSES * 64 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
@@ -247,18 +255,18 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpGenes genes, con
     }
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int k = length_bucket(genes.len[tasks[(size_t)cls * task_cap + i].gs >> 1]);
+        const int k = length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]));
         order[(size_t)cls * task_cap + s_start[k] + s_base[k] + atomicAdd(&s_h[k], 1u)] = i;
     }
 }
 
 }  // namespace
 
-void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
+void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist, uint32_t *order, hipStream_t stream) {
     const dim3 grid(128, KP_N_CLASSES), block(256);
-    hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist);
-    hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, genes, tasks, task_count, task_cap, hist, order);
+    hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist);
+    hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist, order);
 }
 
 void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,

@@ -122,6 +122,23 @@ struct KpSwResult {
     int32_t score, q_start, q_end, t_start, t_end, matches, block_len;
 };
 
+// Rows of a band task that can touch its contig.  Cell (row r, band index bi) sits on column lo + r + bi, bi in [0, width):
+// above r_lo every cell of a row lies before the contig, from r_hi on every cell lies behind it (or the gene has ended).
+// Such cells hold H = 0 and gap states of -(open + ext) whatever happened before them (kp_spec.h: cells outside the contig
+// read as H = 0, E = F = -inf), so a fill that starts at r_lo from the all-zero state and stops at r_hi computes the same
+// values, the same best cell and the same direction bits for every cell a path can visit.  r_lo is a multiple of 8 (a
+// word of the packed gene holds eight rows).
+__host__ __device__ inline void kp_task_rows(int lo, int width, int cstart, int cend, int qlen, int *r_lo, int *r_hi) {
+    int a = cstart - lo - (width - 1);
+    if (a < 0) a = 0;
+    a &= ~7;
+    int z = cend - lo;
+    if (z > qlen) z = qlen;
+    if (z < a) z = a;
+    *r_lo = a;
+    *r_hi = z;
+}
+
 // What the fill kernel leaves per task: the best cell and where the task's direction bits are (16-byte units).
 struct KpSwEnd {
     int32_t score;  // 0 when the trace buffer had no room for the task (the host grows it and reruns the pass)
@@ -164,7 +181,7 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
                   uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
                   hipEvent_t after_fill);
 // kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
-void kp_launch_task_order(const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
+void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
                           uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);
 // kp_prot.hip
 // kp_reduce.hip: assembly a's hits with gene in [gene_lo, gene_hi) (one run: hits are sorted by gene) -> out rows, gene

@@ -287,7 +287,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         bool have[2];
         uint32_t ti[2];
         KpTask tk[2];
-        int qlen[2], lo[2], n_runs[2], steps[2], n_chunks[2];
+        int qlen[2], lo[2], q0[2], n_runs[2], steps[2], n_chunks[2];  // lo: column of (row q0, band index 0); q0: first row filled
         int32_t cstart[2], cend[2];
         // (32-bit offsets from the batch's and the genes' arrays rather than pointers: registers)
         uint32_t asm_n_words[2], q_off[2], w_off[2], run_off[2];
@@ -308,8 +308,12 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             const int r0 = b.asm_first_nrun[tk[h].asm_id];
             n_runs[h] = b.asm_first_nrun[tk[h].asm_id + 1] - r0;
             run_off[h] = 2u * (uint32_t)r0;
-            lo[h] = tk[h].lo;
-            steps[h] = have[h] ? qlen[h] + P - 1 : 0;  // steps the task needs
+            // only the rows whose band cells can lie inside the contig are filled (kp_task_rows): step m of lane l is row
+            // q0 + m - l, and everything below works in that shifted frame
+            int r_hi;
+            kp_task_rows(tk[h].lo, 4 * P, cstart[h], cend[h], qlen[h], &q0[h], &r_hi);
+            lo[h] = tk[h].lo + q0[h];
+            steps[h] = have[h] ? (r_hi - q0[h]) + P - 1 : 0;  // steps the task needs
             // 8-step trace pieces per lane, in whole groups of four
             n_chunks[h] = (((steps[h] + 7) >> 3) + 3) & ~3;  // (a multiple of four whatever TG: task blocks start on 128-byte lines)
         }
@@ -351,7 +355,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
-                    const int w = l + i * P, r = m0 + 8 * w;
+                    const int w = l + i * P, r = q0[h] + m0 + 8 * w;
                     qreg[h][i] = (have[h] && w < CH / 8 && r < qlen[h]) ? genes.nib[q_off[h] + (uint32_t)(r >> 3)] : 0u;
                 }
                 const int w0 = (lo[h] + m0) >> 4;
@@ -375,7 +379,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                         unsigned pair = 0;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const bool live = have[h] && r + j < qlen[h];
+                            const bool live = have[h] && q0[h] + r + j < qlen[h];
                             pair |= (live ? row_profile(nibble(qreg[h][i], j)) : PROF_OUT) << (16 * h);
                             saw_n[h] |= live && nibble(qreg[h][i], j) >= 4u;
                         }
@@ -476,7 +480,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             const int mstar = (int)((st.brow >> (16 * h)) & 0xFFFFu);
             const unsigned a = (st.sA >> (16 * h)) & 0xFFFFu, bq = (st.sB >> (16 * h)) & 0xFFFFu, cq = (st.sC >> (16 * h)) & 0xFFFFu;
             int eb = 4 * l + (a == v ? 0 : bq == v ? 1 : cq == v ? 2 : 3);
-            unsigned key = v > ZB ? ((v - ZB) << 15) | (unsigned)(32767 - (mstar - l)) : 0u;
+            unsigned key = v > ZB ? ((v - ZB) << 15) | (unsigned)(32767 - (q0[h] + mstar - l)) : 0u;
             if (key == 0u) eb = 4 * l;
             bool sn = saw_n[h];
 #pragma unroll
@@ -583,6 +587,13 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
         const int r0 = b.asm_first_nrun[tk.asm_id];
         const int n_runs = b.asm_first_nrun[tk.asm_id + 1] - r0;
         const int32_t *runs = b.n_runs + 2 * (size_t)r0;
+        int q0 = 0;  // first row the fill kernel computed for the task: its steps count from there
+        if (walking) {
+            const int c_abs = b.asm_first_ctg[tk.asm_id] + tk.contig;
+            const int cstart = b.ctg_start[c_abs];
+            int r_hi;
+            kp_task_rows(tk.lo, 4 * P, cstart, cstart + b.ctg_len[c_abs], qlen, &q0, &r_hi);
+        }
         const uint4 *tw = reinterpret_cast<const uint4 *>(trace) + e.trace_off;  // piece j of lane l at [(j / TG) * TG * P + TG * l + j % TG]
         int r = e.er, bi = eb, state = 0, cols = 0, matches = 0, diag = 0, gap_cost = 0, gap = 0, credit = 0;
         int sr = r, sb = bi;
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
         int cur_tag = -1, nxt_tag = -1;  // (stream << 20) | group index
         while (__any(walking)) {
             if (!walking) continue;
-            const int l = bi >> 2, k = bi & 3, step = r + l;
+            const int l = bi >> 2, k = bi & 3, step = r - q0 + l;
             const int pc = step >> 3, grp = pc / TG, tag = (l << 20) | grp;
             if (tag != cur_tag) {
                 const uint4 *stream = tw + TG * l;
