@@ -40,6 +40,8 @@
 //     gives the same E, F and diagonal there); cells past the contig's end or below the gene only ever feed further such
 //     cells, hold values strictly below the inside cell they derive from, so none becomes the best cell, and the
 //     traceback, which only moves up and left, cannot reach them.
+//   * only the rows of a band that can touch the contig are filled (kp_task_rows, kp_internal.h): a gene that runs off
+//     a contig end costs the rows that are on the contig; steps, trace pieces and the traceback count from that first row.
 //   * biases: the pre-charged gap states (H - open - ext, E - ext, F - ext) are kept as value + 12 and a cell's three
 //     candidates are compared two below their value (d - 2 is the predecessor's H - open - ext plus the score + 4; e - 2
 //     and f - 2 are the cell's own E - ext and F - ext), so H itself is never formed.  The smallest value the recurrence can
