@@ -128,6 +128,10 @@ K2(k_cndmask_vcc, "v_cndmask_b32_e32 %0, %0, %4, vcc ;")
 K2(k_mov_sdwa, "v_mov_b32_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 ;")
 K2(k_add_sdwa, "v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1 ;")
 K3(k_bfi, "v_bfi_b32")
+K2(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %4 ;")
+K2(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %4 ;")
+K2(k_ffbl, "v_ffbl_b32_e32 %0, %4 ;")
+K2(k_bcnt, "v_bcnt_u32_b32 %0, %0, %4 ;")
 K3(k_sad_u16, "v_sad_u16")
 K3(k_add3, "v_add3_u32")
 K3(k_fmac, "v_fma_f32")
@@ -171,6 +175,6 @@ int main() {
     RUN(k_ashr); RUN(k_max_u16); RUN(k_min_i16); RUN(k_sub_u16); RUN(k_lshl_b16); RUN(k_lshr_b16); RUN(k_mul_lo_u16);
     RUN(k_pk_lshr_b16); RUN(k_pk_ashr_i16); RUN(k_pk_max_u16); RUN(k_pk_sub_u16); RUN(k_pk_sub_i16); RUN(k_add_dpp); RUN(k_add_lit);
     RUN(k_add_sgpr); RUN(k_and_lit); RUN(k_not); RUN(k_add_co); RUN(k_addc); RUN(k_cndmask_vcc); RUN(k_mov_sdwa); RUN(k_add_sdwa);
-    RUN(k_bfi); RUN(k_sad_u16); RUN(k_add3);
+    RUN(k_bfi); RUN(k_mul_lo_u32); RUN(k_mul_hi_u32); RUN(k_ffbl); RUN(k_bcnt); RUN(k_sad_u16); RUN(k_add3);
     return 0;
 }
