@@ -95,14 +95,16 @@ def build_workload(n_asm: int, seed0: int, length: float, workers: int):
 
 
 # ---- CPU baseline (runs before any GPU state exists; workers are forked) ------------------------------------------------
-def _cpu_worker(job):
-    seeds, length, native_so = job
+_CPU: dict = {}
+
+
+def _cpu_prepare(native_so) -> None:
+    """Parent side, before the fork: the oracle library and one seed index per database, so that every worker shares
+    the same pages instead of building (and thrashing the caches with) a private copy."""
     from kaptive_amd.core.pairwise import PairwiseAlignments
     from kaptive_amd.pack import pack_sequences_flat
     from kaptive_amd.serotyping.core import Serotyper
-    from kaptive_amd.synth import make_assembly
     from oracle import oracle as O
-    from tests.golden_util import hits_to_alignments
 
     if native_so:
         O.use_library(native_so)
@@ -110,19 +112,52 @@ def _cpu_worker(job):
     def oracle_proteins(q, t):
         return PairwiseAlignments.from_table(O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths))
 
-    dbs = [d for d in (_DBS["main"], _DBS["also"]) if d is not None]
     stages = []
-    for db in dbs:
+    for db in (d for d in (_DBS["main"], _DBS["also"]) if d is not None):
         odb = O.OracleDB(*pack_sequences_flat(db.genes))
         stages.append((db, odb, Serotyper(db, aligner=lambda g: None, protein_aligner=oracle_proteins)))
+    _CPU["stages"] = stages
+
+
+def _cpu_init(barrier) -> None:
+    _CPU["barrier"] = barrier
+    try:  # one thread per process: the numpy reduction must not start a BLAS/OpenMP pool per worker
+        from threadpoolctl import threadpool_limits
+
+        _CPU["limit"] = threadpool_limits(1)
+    except Exception:
+        pass
+    try:
+        import torch
+
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+
+
+def _cpu_worker(job):
+    """Types `seeds` on this core.  Inputs are generated first; the clock starts when every worker has its inputs
+    (barrier), so nothing but typing runs on any core while any worker is being timed."""
+    seeds, length = job
+    from kaptive_amd.synth import make_assembly
+    from tests.golden_util import hits_to_alignments
+
     also = (_DBS["also"],) if _DBS["also"] is not None else ()
     genomes = [make_assembly(_DBS["main"], seed=s, length=length, also=also, **_WL["asm_kw"]) for s in seeds]
     packed = [g.packed() for g in genomes]
-    t0 = time.perf_counter()
+    barrier = _CPU.get("barrier")
+    if barrier is not None:
+        barrier.wait(timeout=900)  # a dead worker must not hang the bench
+    t0 = time.time()
+    c0 = time.process_time()
+    t_align = 0.0
     for g, pa in zip(genomes, packed):
-        for db, odb, typer in stages:
-            typer.reduce(g, hits_to_alignments(db, g, odb.align(pa)))
-    return len(genomes), time.perf_counter() - t0
+        for db, odb, typer in _CPU["stages"]:
+            ta = time.perf_counter()
+            hits = odb.align(pa)
+            t_align += time.perf_counter() - ta
+            typer.reduce(g, hits_to_alignments(db, g, hits))
+    return len(genomes), t0, time.time(), time.process_time() - c0, t_align
 
 
 def ingest_rate(seed0: int, length: float) -> dict:
@@ -166,32 +201,43 @@ def ingest_rate(seed0: int, length: float) -> dict:
 
 def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
     """The CPU oracle (C aligner + C protein DP + numpy reduction) typing the first assemblies of the workload against
-    every database: all host cores at once (one assembly per process at a time), then one core alone."""
+    every database: all host cores at once (one process per core, one thread each, one shared seed index, clock started
+    on a barrier once every process holds its inputs), then one core alone."""
     from oracle import oracle as O
 
     native = O.build_native()  # -O3 -march=native for this box; None when no compiler is here (then the portable build)
     flags = "-O3 -march=native" if native else "-O2 (prebuilt; no compiler on this box)"
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n_dbs = 2 if _DBS["also"] is not None else 1
-    jobs = [([seed0 + w * per_worker + i for i in range(per_worker)], length, native) for w in range(cores)]
-    pool = get_context("fork").Pool(cores)
+    _cpu_prepare(native)
+    ctx = get_context("fork")
+    jobs = [([seed0 + w * per_worker + i for i in range(per_worker)], length) for w in range(cores)]
+    pool = ctx.Pool(cores, initializer=_cpu_init, initargs=(ctx.Barrier(cores),))
     try:
-        t0 = time.perf_counter()
-        parts = pool.map(_cpu_worker, jobs, chunksize=1)
-        wall = time.perf_counter() - t0
+        parts = pool.map(_cpu_worker, jobs, chunksize=1)  # exactly one job per process: the barrier needs all of them
     finally:
         pool.close()
         pool.join()
-    rate_all = sum(n / dt for n, dt in parts)  # workers type concurrently; each one's rate over its own typing time
-    n1, dt1 = _cpu_worker(([seed0 + i for i in range(max(per_worker * 2, 6))], length, native))
+    n_all = sum(p[0] for p in parts)
+    wall = max(p[2] for p in parts) - min(p[1] for p in parts)
+    cpu_s = sum(p[3] for p in parts)
+    align_s = sum(p[4] for p in parts)
+    rate_all = n_all / wall  # assemblies finished by all cores together per second of the common typing window
+    _cpu_init(None)
+    n1, t0, t1, c1, a1 = _cpu_worker(([seed0 + i for i in range(max(per_worker * 2, 6))], length))
+    rate_one = n1 / (t1 - t0)
     what = "K then O" if n_dbs == 2 else "K"
     return {
         "value": rate_all, "unit": "assemblies/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} processes x {per_worker} assemblies of the same workload each ({what}), all at once: CPU oracle "
-                  f"(oracle/kp_oracle.c aligner + protein DP built {flags}, numpy reduction), {wall:.1f} s wall including "
-                  "input generation; the rate is the sum of the processes' typing rates",
-        "single_core": {"value": n1 / dt1, "unit": "assemblies/s", "cores": 1,
-                        "sample": f"first {n1} assemblies, {dt1:.1f} s on one of {cores} host cores"},
+        "sample": f"{cores} single-threaded processes x {per_worker} assemblies of the same workload each ({what}), started "
+                  f"together on a barrier after input generation: CPU oracle (oracle/kp_oracle.c aligner + protein DP built "
+                  f"{flags}, one seed index shared by all processes, numpy reduction); {n_all} assemblies in {wall:.1f} s",
+        "parallel_efficiency": round(rate_all / (cores * rate_one), 3),
+        "cpu_seconds_per_assembly_all_cores": round(cpu_s / n_all, 3),
+        "aligner_share_all_cores": round(align_s / max(sum(p[2] - p[1] for p in parts), 1e-9), 3),
+        "single_core": {"value": rate_one, "unit": "assemblies/s", "cores": 1,
+                        "cpu_seconds_per_assembly": round(c1 / n1, 3), "aligner_share": round(a1 / (t1 - t0), 3),
+                        "sample": f"first {n1} assemblies, {t1 - t0:.1f} s on one of {cores} host cores"},
     }  # fmt: skip
 
 
@@ -225,6 +271,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--assemblies", type=int, default=10000, help="assemblies per GPU (one step types all of them)")
+    ap.add_argument("--assemblies-total", type=int, default=0,
+                    help="assemblies of the WHOLE job, sharded evenly over the ranks (overrides --assemblies): BASELINE.json "
+                         "config 5 is `--gpus 8 --assemblies-total 100000`, i.e. 12 500 per rank")
     ap.add_argument("--batch", type=int, default=1000, help="assemblies per device batch")
     ap.add_argument("--db", choices=sorted(WORKLOADS), default="kpsc")
     ap.add_argument("--length", type=float, default=0.0, help="mean assembly length (0 = the workload's own)")
@@ -254,6 +303,13 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if args.assemblies_total:
+        from kaptive_amd.shard import shard_bounds as _bounds
+
+        lo_r, hi_r = _bounds(args.assemblies_total, rank, world)  # the partitioning rule of the product (kaptive_amd/shard.py)
+        if hi_r - lo_r != args.assemblies_total // world:
+            raise SystemExit(f"--assemblies-total {args.assemblies_total} does not divide over {world} ranks")
+        args.assemblies = hi_r - lo_r
     workers = args.workers or max(1, min(64, (os.cpu_count() or 1) // max(world, 1)))
     # torch (and with it the HIP runtime it bundles) has to be loaded before libkaptive_amd.so, which the packer below
     # already needs: in the other order the process ends up with two HIP runtimes and sees no device
@@ -418,6 +474,7 @@ def main() -> None:
     sync_all()
     t0 = time.perf_counter()
     cpu0 = time.thread_time()  # CPU seconds of this (the driving) thread: what a rank needs of a host core
+    proc0 = time.process_time()  # ... and of the whole process (driving thread + the HIP runtime's helper threads)
     step_ms = []
     for _ in range(args.steps):
         t_step = time.perf_counter()
@@ -426,6 +483,13 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     host_busy = (time.thread_time() - cpu0) / max(elapsed, 1e-9)
+    import resource
+
+    host_rank = {"rank": rank, "driving_thread_cpu_s": round(time.thread_time() - cpu0, 3),
+                 "process_cpu_s": round(time.process_time() - proc0, 3), "elapsed_s": round(elapsed, 3),
+                 "max_rss_MB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, 1),
+                 "pinned_host_MB": round(_native.pinned_bytes() / 2**20, 1),
+                 "buffer_growth_reruns_in_timed_steps": [sum(x["retries"] for x in slist) for slist in stats]}
     # (untimed) the alignment kernels of one batch with nothing else on the device: what a launch takes on its own; in
     # the timed steps the passes of consecutive batches overlap and stretch each other's kernels
     alone = []
@@ -441,6 +505,10 @@ def main() -> None:
         elapsed = float(t.item())
         digests = [None] * world  # every rank's row digest, so that rank 0 can report what the whole job typed
         dist.all_gather_object(digests, hashlib.sha1(b"".join(sorted(r for bt in res for r in bt.tsv().splitlines(keepends=True)))).hexdigest())
+        host_ranks = [None] * world  # what every rank took of the host while the clock ran
+        dist.all_gather_object(host_ranks, host_rank)
+    else:
+        host_ranks = [host_rank]
 
     # ---- legs 2 and 3: from pinned host shards, without and with TSV bytes (one GPU only) -------------------------------------
     e2e = None
@@ -477,13 +545,8 @@ def main() -> None:
                 return ahead.pop(i)
 
             sink = [] if with_rows else None
-            for j in range(min(args.ahead + 2, total)):  # (untimed) the first shards of the stream are on the device
-                ahead[j] = make_batches(j % n_batches, pins[j % n_batches].array)
-            for j in list(ahead):
-                for b in distinct(ahead[j])[:1]:
-                    b.upload_wait()
             sync_all()
-            t1 = time.perf_counter()
+            t1 = time.perf_counter()  # nothing of the stream is on the device yet: the first uploads are inside the clock
             run_pass(get, release=close_all, rows_sink=sink, count=total)
             if with_rows:
                 sink = [f.result() for f in sink]  # every row is in memory before the clock stops
@@ -512,7 +575,7 @@ def main() -> None:
                              "bytes": up_bytes, "note": "upper bound of any leg that starts from host memory"},
                "tsv_bytes_per_step": tsv_bytes // max(args.e2e_steps, 1), "pinning_s": round(t_pin, 1),
                "note": "a stream of steps x shards of --batch pre-packed assemblies in pinned host memory; H2D on a copy "
-                       "stream two shards ahead of the alignment passes (the first ones resident when the clock starts); "
+                       "stream two shards ahead of the alignment passes (cold start: every upload, the first ones included, is inside the clock); "
                        "with_tsv adds the KaptiveRow bytes of every assembly and database"}  # fmt: skip
         for pb in pins:
             pb.close()
@@ -559,16 +622,19 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "uint16x2 (exact; int32-equivalent)",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU {what}; one step "
+                "workload": (f"{args.assemblies_total} assemblies sharded over {world} ranks (BASELINE.json config 5 shape): "
+                             if args.assemblies_total else "")
+                            + f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU {what}; one step "
                             f"= all of them, as {n_batches} batches of {args.batch} through context-owned work buffers; packed "
                             "assemblies resident in HBM before the timed region; "
                             + ("one alignment pass over the genes of both databases, one reduction per database" if shared
                                else "one context and alignment pass per database, one device copy of the assemblies"),
                 "alignment_passes_per_batch": n_passes,
                 "assemblies_per_gpu": args.assemblies,
+                "assemblies_total": args.assemblies * world,
                 "batch": args.batch,
                 "databases": [f"{d.metadata.keyword}: {len(d.loci)} loci / {len(d.genes)} genes" for d in dbs],
                 "parallelism": f"{world} x independent shard, no collective",
@@ -577,6 +643,8 @@ def main() -> None:
                 "tsv_rows_sha1": rows_digest,
                 "tsv_rows_sha1_per_rank": digests if world > 1 else None,
                 "host_thread_busy_frac": round(host_busy, 3),
+                "host_per_rank": host_ranks,
+                "host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
                 "buffer_growth_reruns_in_timed_steps": [sum(s["retries"] for s in slist) for slist in stats],
                 "workload_generation_s": round(t_gen, 1),
             },

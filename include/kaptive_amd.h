@@ -60,6 +60,9 @@ KP_API int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value);
  * For callers that stream shards: kp_batch_create_async only overlaps with device work when `words` is page-locked. */
 KP_API int kp_host_alloc(size_t bytes, void **out);
 KP_API void kp_host_free(void *p);
+/* Page-locked bytes this process currently holds through the library: kp_host_alloc blocks plus the table staging of
+ * the contexts' input buffers.  (What a rank pins matters when eight of them share one host.) */
+KP_API int64_t kp_host_pinned_bytes(void);
 
 /* ---- database ---------------------------------------------------------------------------------------------------
  * Replaces what Serotyper.__init__ prepares for the aligner -- the list of (name, gene bytes) handed to

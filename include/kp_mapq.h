@@ -15,8 +15,9 @@
  *   q -= int(4.343 * ln(n_sub + 1) + 0.499);  clamp to [0, 60];  q == 0 and score > sub -> 1
  *
  * All arithmetic is float32 in exactly this order (no fused multiply-add: the function switches contraction off for
- * clang; gcc in ISO C mode does not contract).  The two logarithms come from tables the caller fills with logf on the
- * host (ln_half[i] = logf(i / 2.0f), ln_int[i] = logf(i)), so device and host see the same values.
+ * clang; gcc in ISO C mode does not contract).  The two logarithms come from tables the caller fills on the host with
+ * kp_mapq_ln below (ln_half[i] = kp_mapq_ln(i / 2), ln_int[i] = kp_mapq_ln(i); entry 0 is 0): a fixed sequence of IEEE
+ * double operations, so the tables -- and with them every mapping quality -- are the same on every host, whatever its libm.
  */
 #ifndef KP_MAPQ_H
 #define KP_MAPQ_H
@@ -28,6 +29,31 @@
 #ifndef KP_MAPQ_FN
 #define KP_MAPQ_FN static inline
 #endif
+
+/* Natural logarithm of x > 0 as float, from IEEE double +, -, *, / only: x = m * 2^e with m in [sqrt(1/2), sqrt(2)),
+ * ln m = 2 atanh s with s = (m - 1) / (m + 1) summed as an odd series to s^21 (|s| < 0.172: the truncation is below
+ * 1e-18), ln x = e * ln 2 + ln m, rounded once to float. */
+static inline float kp_mapq_ln(double x) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    union {
+        double d;
+        uint64_t u;
+    } v;
+    v.d = x;
+    int e = (int)((v.u >> 52) & 0x7FF) - 1023;
+    v.u = (v.u & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL; /* m in [1, 2) */
+    double m = v.d;
+    if (m > 1.4142135623730951) m = m * 0.5, e += 1;
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+    double term = s, sum = 0.0;
+    for (int k = 1; k <= 21; k += 2) {
+        sum = sum + term / (double)k;
+        term = term * s2;
+    }
+    return (float)((double)e * 0.6931471805599453 + 2.0 * sum);
+}
 
 #define KP_MAPQ_LN_HALF_SIZE 131072 /* scores are at most 2 * KP_MAX_GENE_LEN plus the two-piece credit of long gaps */
 #define KP_MAPQ_LN_INT_SIZE 4096

@@ -7,11 +7,22 @@ the Python host side that mirrors the reference's operator interface for that pa
 
 import os as _os
 
-# A context drives about a dozen HIP streams (a copy stream, three alignment passes, the reductions of every typing group);
-# the runtime multiplexes them onto 4 hardware queues by default, and a queue whose head waits -- a 20 ms upload, a long
-# kernel -- then holds up unrelated streams behind it (measured: 26 k instead of 32 k assemblies/s when shards stream in
-# from the host).  Takes effect when set before the HIP runtime initialises; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+def tune_runtime(hw_queues: int = 16) -> bool:
+    """Ask the HIP runtime for `hw_queues` hardware queues (GPU_MAX_HW_QUEUES) unless the environment already says.
+
+    A context drives about a dozen HIP streams (a copy stream, three alignment passes, the reductions of every typing
+    group); the runtime multiplexes them onto 4 hardware queues by default, and a queue whose head waits -- a 20 ms
+    upload, a long kernel -- then holds up unrelated streams behind it (measured: 26 k instead of 32 k assemblies/s when
+    shards stream in from the host).  The variable is read when the HIP runtime initialises, so this is for ENTRY
+    POINTS to call first thing (`kaptive_amd.cli`, `bench.py`, `__graft_entry__` do); importing the package does not
+    touch the process environment.  Returns False when the native library (and with it HIP) is already loaded in this
+    process, i.e. when the call came too late to matter."""
+    from kaptive_amd import _native
+
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(hw_queues))
+    return not _native.is_loaded()
+
 
 __version__ = "0.1.0"
 # Version string written into TSV/JSON rows where the reference writes kaptive.__version__

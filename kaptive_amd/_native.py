@@ -12,6 +12,7 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
+MAX_GENE_LEN = 16000  # KP_MAX_GENE_LEN of include/kp_spec.h (tests/test_native_abi.py compares the two)
 WORK_SLOTS = 3  # KP_WORK_SLOTS of include/kaptive_amd.h: alignment results a context keeps resident
 
 HIT_DTYPE = np.dtype(
@@ -25,7 +26,7 @@ TASK_DTYPE = np.dtype(
 
 EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
-    "kp_host_free", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
+    "kp_host_free", "kp_host_pinned_bytes", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
@@ -260,6 +261,11 @@ def _close_all() -> None:
 
 class NativeError(RuntimeError):
     pass
+
+
+def is_loaded() -> bool:
+    """Whether the shared library (and with it the HIP runtime) has been loaded into this process."""
+    return _lib is not None
 
 
 def lib() -> C.CDLL:
@@ -579,6 +585,13 @@ def randstrobe_top_hits(q_records: np.ndarray, n_queries: int, t_records: np.nda
     if rc != 0:
         raise ValueError(f"kp_randstrobe_top_hits failed ({rc})")
     return best_t, score, off
+
+
+def pinned_bytes() -> int:
+    """Page-locked host bytes this process holds through the library (kp_host_pinned_bytes)."""
+    f = lib().kp_host_pinned_bytes
+    f.restype = C.c_int64
+    return int(f())
 
 
 class PinnedBuffer:

@@ -247,6 +247,9 @@ def run_convert(args: argparse.Namespace) -> int:
 
 
 def main(argv=None) -> int:
+    import kaptive_amd
+
+    kaptive_amd.tune_runtime()  # before the first HIP call of the process
     from kaptive_amd.db.models import DatabaseError
 
     args = build_parser().parse_args(argv)

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "kp_internal.h"
 #include "kp_reduce_core.h"
@@ -120,6 +121,29 @@ struct KpOptions {
     int no_lds_filter = 0;       // tests compare the two filter tiers
 };
 
+// Page-locked host memory the library holds (kp_host_alloc and the batches' table staging), for kp_host_pinned_bytes.
+static std::mutex g_pin_mutex;
+static std::unordered_map<void *, size_t> g_pin_sizes;
+static size_t g_pin_bytes = 0;
+static hipError_t pinned_alloc(void **out, size_t bytes) {
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pin_mutex);
+        g_pin_sizes[*out] = bytes;
+        g_pin_bytes += bytes;
+    }
+    return e;
+}
+static void pinned_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mutex);
+        auto it = g_pin_sizes.find(p);
+        if (it != g_pin_sizes.end()) { g_pin_bytes -= it->second; g_pin_sizes.erase(it); }
+    }
+    (void)hipHostFree(p);
+}
+
 // Device copy of one batch's input (packed words + tables).  Recycled through the context (hipFree synchronises the
 // device, so a stream of batches must not free anything).
 struct KpInput {
@@ -132,7 +156,7 @@ struct KpInput {
     void release() {
         d_words.release(); d_asm_word_off.release(); d_ctg_start.release(); d_ctg_len.release();
         d_asm_first_ctg.release(); d_n_runs.release(); d_asm_first_nrun.release();
-        if (h_stage) (void)hipHostFree(h_stage);
+        pinned_free(h_stage);
         h_stage = nullptr; h_stage_bytes = 0;
         if (ready) (void)hipEventDestroy(ready);
         ready = nullptr;
@@ -229,7 +253,7 @@ struct kp_ctx {
     KpGenes genes{};
     // protein stage
     DevBuf<int8_t> d_blosum;
-    DevBuf<float> d_ln;  // logarithm tables of the mapping quality (kp_mapq.h): ln(i / 2), then ln(i), from the host's logf
+    DevBuf<float> d_ln;  // logarithm tables of the mapping quality (kp_mapq.h): ln(i / 2), then ln(i), from kp_mapq_ln
     DevBuf<uint8_t> d_pq, d_pt;
     DevBuf<int32_t> d_pmeta, d_pout, d_pscratch;
     // typing tables (kp_db_load_typing / kp_db_load_typing_group): one set per database whose genes are in the index
@@ -389,10 +413,10 @@ int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_wor
     // staging layout: asm_word_off (8-byte entries first), then the int32 tables
     const size_t bytes = na1 * 8 + (2 * n_ctg + 2 * na1 + 2 * n_run) * 4;
     if (bytes > in.h_stage_bytes) {
-        if (in.h_stage) (void)hipHostFree(in.h_stage);
+        pinned_free(in.h_stage);
         in.h_stage = nullptr; in.h_stage_bytes = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        KP_HIP_CHECK(ctx, hipHostMalloc((void **)&in.h_stage, want, hipHostMallocDefault));
+        KP_HIP_CHECK(ctx, pinned_alloc((void **)&in.h_stage, want));
         in.h_stage_bytes = want;
     }
     uint8_t *p = in.h_stage;
@@ -506,8 +530,8 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     std::vector<int8_t> m(256 * 256);
     fill_blosum(m.data());
     std::vector<float> ln(KP_MAPQ_LN_HALF_SIZE + KP_MAPQ_LN_INT_SIZE, 0.0f);
-    for (int i = 1; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln[(size_t)i] = logf((float)i / 2.0f);
-    for (int i = 1; i < KP_MAPQ_LN_INT_SIZE; ++i) ln[(size_t)KP_MAPQ_LN_HALF_SIZE + i] = logf((float)i);
+    for (int i = 1; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln[(size_t)i] = kp_mapq_ln((double)i / 2.0);
+    for (int i = 1; i < KP_MAPQ_LN_INT_SIZE; ++i) ln[(size_t)KP_MAPQ_LN_HALF_SIZE + i] = kp_mapq_ln((double)i);
     if (upload(ctx, ctx->d_blosum, m.data(), m.size()) != KP_OK || upload(ctx, ctx->d_ln, ln.data(), ln.size()) != KP_OK ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
         std::string msg = ctx->error;
@@ -581,13 +605,16 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
 int kp_host_alloc(size_t bytes, void **out) {
     if (!out) return kp_fail(nullptr, KP_EINVAL, "out is null");
     *out = nullptr;
-    const hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+    const hipError_t e = pinned_alloc(out, std::max<size_t>(bytes, 1));
     if (e != hipSuccess) return kp_fail(nullptr, KP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     return KP_OK;
 }
 
-void kp_host_free(void *p) {
-    if (p) (void)hipHostFree(p);
+void kp_host_free(void *p) { pinned_free(p); }
+
+int64_t kp_host_pinned_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    return (int64_t)g_pin_bytes;
 }
 
 int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, int32_t n_genes) {

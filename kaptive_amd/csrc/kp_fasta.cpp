@@ -107,7 +107,6 @@ struct Packer {
 // gzip / zlib stream(s) -> bytes (concatenated gzip members are read through, as gzip.open does)
 int inflate_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
     out.clear();
-    out.reserve((size_t)n * 4 + 1024);
     int64_t at = 0;
     while (at < n) {
         z_stream z;
@@ -122,10 +121,14 @@ int inflate_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
             z.next_out = out.data() + have;
             z.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
             const size_t room = z.avail_out;
+            if (z.avail_in == 0) {  // a member with more than 1 GiB of compressed bytes: hand zlib the next slice
+                const int64_t left = n - (int64_t)(z.next_in - data);
+                z.avail_in = (uInt)std::min<int64_t>(left, 1 << 30);
+            }
             rc = inflate(&z, Z_NO_FLUSH);
             out.resize(have + (room - z.avail_out));
             if (rc != Z_OK && rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && z.avail_in > 0)) { inflateEnd(&z); return KP_EINVAL; }
-            if (rc == Z_BUF_ERROR && z.avail_in == 0) { inflateEnd(&z); return KP_EINVAL; }  // truncated input
+            if (rc == Z_BUF_ERROR && z.avail_in == 0 && z.next_in >= data + n) { inflateEnd(&z); return KP_EINVAL; }  // truncated
         }
         at = (int64_t)(z.next_in - data);
         inflateEnd(&z);

@@ -36,6 +36,13 @@ class Engine:
         self.group = 0
         self.device = device
         self.ctx = _native.Context(device)
+        for d in dbs:  # KP_MAX_GENE_LEN (include/kp_spec.h): the fill kernel's packed 16-bit scores cover genes this long
+            too_long = np.flatnonzero(np.asarray(d.genes.lengths) > _native.MAX_GENE_LEN)
+            if len(too_long):
+                g = int(too_long[0])
+                raise ValueError(f"database {d.metadata.keyword!r}: gene {d.genes.ids[g]!r} is {int(d.genes.lengths[g])} bases long; "
+                                 f"the aligner handles genes up to {_native.MAX_GENE_LEN} bases (KP_MAX_GENE_LEN) -- "
+                                 f"{len(too_long)} gene(s) exceed it")  # fmt: skip
         packed = [pack_sequences_flat(d.genes) for d in dbs]
         counts = [len(d.genes) for d in dbs]
         self.gene_ranges = [(sum(counts[:i]), sum(counts[: i + 1])) for i in range(len(dbs))]
@@ -123,14 +130,51 @@ class Engine:
         return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes)
 
     def type_batches(self, typer, batches: Sequence, ids: Sequence[Sequence[str]], aligned: bool = False) -> list:
-        """Several resident batches through the same context, software-pipelined: all alignment passes are enqueued up
-        front and every host-side step of batch i (reading scores back, choosing best loci, copying records,
-        array finishing) runs while the device works on batches i+1..: the stream never waits for the host."""
-        return self.collect_batches(typer, batches, ids, self.reduce_batches(typer, batches, aligned))
+        """Any number of resident batches through the same context, software-pipelined as a sliding window.
+
+        A context keeps the results of its ``_native.WORK_SLOTS`` most recent alignment passes (the work sets rotate
+        at ``kp_batch_align``), so at most that many batches are between "alignment enqueued" and "records
+        collected" at any time: batch i's scores are read and its reduction enqueued, then batch i-1's records are
+        collected (its reduction ran while i was being scored), and alignment passes are enqueued ahead only as far
+        as the free work sets allow.  The stream never waits for the host and no pass is displaced before it was
+        read.  ``aligned=True`` (the caller already enqueued every pass) is only possible for up to WORK_SLOTS batches."""
+        from kaptive_amd.serotyping import batch as B
+
+        n, depth = len(batches), _native.WORK_SLOTS
+        if aligned and n > depth:
+            raise ValueError(f"{n} batches were aligned up front but a context keeps only {depth} alignment results "
+                             "(WORK_SLOTS); pass aligned=False and let type_batches schedule the passes")  # fmt: skip
+        out: list = []
+        enqueued = n if aligned else 0
+        pending = None  # (index, scores, best) of the batch whose reduction is enqueued but not yet collected
+
+        def collect(item) -> None:
+            i, scores, best = item
+            sums, kept, pieces = batches[i].typing(self.group)
+            out.append(B.BatchTyping(typer, ids[i], sums, kept, pieces, scores, best))
+
+        for i in range(n):
+            first_live = pending[0] if pending is not None else i
+            while enqueued < n and enqueued < first_live + depth:
+                batches[enqueued].align_async()
+                enqueued += 1
+            scores, counts = batches[i].score(typer.min_gene_coverage, self.group)
+            best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
+            batches[i].reduce_async(best, self.typing_params(typer), self.group)
+            if pending is not None:
+                collect(pending)
+            pending = (i, scores, best)
+        if pending is not None:
+            collect(pending)
+        return out
 
     def reduce_batches(self, typer, batches: Sequence, aligned: bool = False) -> list:
-        """First half of ``type_batches``: scores back, best loci chosen (numpy), reductions enqueued.  Returns what
-        ``collect_batches`` needs; callers driving several databases put the other database's host work in between."""
+        """Scores back, best loci chosen (numpy), reductions enqueued, for up to WORK_SLOTS batches at once.  Returns what
+        ``collect_batches`` needs; callers driving several databases put the other database's host work in between
+        (bench.py does, one batch at a time).  Longer lists go through ``type_batches``, which slides a window."""
+        if len(batches) > _native.WORK_SLOTS:
+            raise ValueError(f"{len(batches)} batches at once, but a context keeps only {_native.WORK_SLOTS} alignment "
+                             "results (WORK_SLOTS): use type_batches")  # fmt: skip
         if not aligned:
             for b in batches:
                 b.align_async()

@@ -159,6 +159,8 @@ def make_assembly(
     second_locus: int | None = None,
     n_run: int = 0,
     also: tuple = (),
+    tandem_gene: int = 0,
+    indel_rate: float = 2e-5,
 ) -> GenomeAssembly:
     """One synthetic assembly holding a mutated copy of one database locus.
     ``locus`` < 0 plants no locus at all."""
@@ -189,7 +191,13 @@ def make_assembly(
             if at + 3 < len(copy):
                 stop = np.frombuffer(b"TAA", np.uint8)
                 copy[at : at + 3] = stop if db.gene_intervals.strands[gi] > 0 else revcomp(stop)
-        copy = mutate(rng, copy, 0.0, indel_rate=2e-5)
+        copy = mutate(rng, copy, 0.0, indel_rate=indel_rate)
+        if tandem_gene:  # `tandem_gene` extra copies of one gene, head to tail, each mutated on its own (multi-copy stress)
+            gi = int(rng.integers(g0, g1))
+            s, e = int(db.gene_intervals.starts[gi]), min(int(db.gene_intervals.ends[gi]), len(copy))
+            unit = copy[s:e]
+            reps = [mutate(rng, unit, 0.01) for _ in range(tandem_gene)]
+            copy = np.concatenate([copy[:e], *reps, copy[e:]])
         if rng.random() < p_is:  # IS-like 1.2 kb insertion inside the locus
             at = int(rng.integers(len(copy) // 4, 3 * len(copy) // 4))
             copy = np.concatenate([copy[:at], random_dna(rng, 1200, 0.5), copy[at:]])

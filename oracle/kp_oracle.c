@@ -514,7 +514,7 @@ static const float *ln_half_table(void) {
     static float *t = NULL;
     if (!t) {
         t = malloc(sizeof(float) * KP_MAPQ_LN_HALF_SIZE);
-        for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; i++) t[i] = i ? logf((float)i / 2.0f) : 0.0f;
+        for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; i++) t[i] = i ? kp_mapq_ln((double)i / 2.0) : 0.0f;
     }
     return t;
 }
@@ -522,7 +522,7 @@ static const float *ln_int_table(void) {
     static float *t = NULL;
     if (!t) {
         t = malloc(sizeof(float) * KP_MAPQ_LN_INT_SIZE);
-        for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; i++) t[i] = i ? logf((float)i) : 0.0f;
+        for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; i++) t[i] = i ? kp_mapq_ln((double)i) : 0.0f;
     }
     return t;
 }

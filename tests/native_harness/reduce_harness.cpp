@@ -27,8 +27,8 @@ int kph_finalise_hits(kp_hit *hits, int n) {
         hits[m++] = sorted[i];
     }
     std::vector<float> ln_half(KP_MAPQ_LN_HALF_SIZE), ln_int(KP_MAPQ_LN_INT_SIZE);
-    for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln_half[i] = i ? logf((float)i / 2.0f) : 0.0f;
-    for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; ++i) ln_int[i] = i ? logf((float)i) : 0.0f;
+    for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln_half[i] = i ? kp_mapq_ln((double)i / 2.0) : 0.0f;
+    for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; ++i) ln_int[i] = i ? kp_mapq_ln((double)i) : 0.0f;
     std::vector<int32_t> scratch(3 * (size_t)(m > 0 ? m : 1));
     for (int i = 0; i < m;) {
         int j = i;

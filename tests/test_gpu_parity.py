@@ -413,6 +413,35 @@ def test_one_alignment_pass_for_two_databases(small_db):
     both.close()
 
 
+def test_type_batches_slides_a_window_over_more_batches_than_work_slots(small_db):
+    """Engine.type_batches with 2 * WORK_SLOTS + 1 batches: no pass is displaced before its records are read, and every
+    batch's rows equal those of the same batch typed alone; more than WORK_SLOTS batches aligned up front are refused."""
+    from kaptive_amd.engine import Engine
+
+    n = 2 * _native.WORK_SLOTS + 1
+    groups = [[make_assembly(small_db, seed=1200 + 10 * b + i, length=60_000, median_contigs=4, min_contig=200,
+                             sub_rate=0.01 * i) for i in range(3)] for b in range(n)]  # fmt: skip
+    typer = Serotyper(small_db)
+    eng = Engine(small_db)
+    batches = [eng.ctx.batch([g.packed() for g in grp]) for grp in groups]
+    ids = [[g.id for g in grp] for grp in groups]
+    got = eng.type_batches(typer, batches, ids)
+    assert len(got) == n
+    for b, grp in enumerate(groups):
+        one = eng.ctx.batch([g.packed() for g in grp])
+        want = eng.type_batch(typer, one, ids[b])
+        assert want.rows() == got[b].rows(), f"batch {b}"
+        assert want.sums.tobytes() == got[b].sums.tobytes(), f"batch {b}"
+        one.close()
+    with pytest.raises(ValueError, match="WORK_SLOTS"):
+        eng.type_batches(typer, batches, ids, aligned=True)
+    with pytest.raises(ValueError, match="WORK_SLOTS"):
+        eng.reduce_batches(typer, batches)
+    for b in batches:
+        b.close()
+    eng.close()
+
+
 def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
     monkeypatch.setenv("KAPTIVE_AMD_KEPT_CAP", "4")
     monkeypatch.setenv("KAPTIVE_AMD_PIECE_CAP", "1")

@@ -1,0 +1,148 @@
+"""kp-align next to an independent model of the published minimap2 pipeline (oracle/mm2_model.c).  CPU only.
+
+The reference's aligner is a closed wheel, so kp-align cannot be compared with it.  What can be
+checked here, on every machine: (1) the model itself behaves like the published algorithm on known answers; (2) on the
+config-2/3/4 generators both aligners, fed through the SAME reduction (`Serotyper.reduce`, pinned to the reference by
+tests/golden/typing_*.npz), call the same locus, type and confidence for every assembly, and agree on the coordinates
+and scores of the hits both of them report.  The 560-assembly run of the same comparison through the REFERENCE's own
+Serotyper is tools/concordance.py -> profiles/concordance_r3.md (build container only).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from kaptive_amd.core.pairwise import PairwiseAlignments
+from kaptive_amd.pack import pack_sequences_flat
+from kaptive_amd.serotyping.core import Serotyper
+from kaptive_amd.serotyping.io import KaptiveRow
+from kaptive_amd.synth import make_assembly, make_db, mutate, random_dna
+from oracle import mm2
+from oracle import oracle as O
+from tests.golden_util import hits_to_alignments
+
+
+# ---- the model on known answers ----------------------------------------------------------------------------------------
+def test_ksw_known_answers():
+    assert mm2.ksw(b"ACGTACGTAC", b"ACGTACGTAC")[::5] == (20, "10M")
+    # one substitution: 17 matches * 2 - 4
+    assert mm2.ksw(b"ACGTACGTACGGTTAACC", b"ACGTACGAACGGTTAACC")[::5] == (30, "18M")
+    # a 3-base deletion is charged 4 + 2 * 3 and is left-aligned
+    assert mm2.ksw(b"ACGTACGTACGGTTAACC", b"ACGTACGTACTTTGGTTAACC")[::5] == (26, "10M3D8M")
+    rng = np.random.default_rng(1)
+    a = random_dna(rng, 300, 0.5).tobytes()
+    b = a[:150] + random_dna(rng, 60, 0.5).tobytes() + a[150:]
+    score, *_, cigar = mm2.ksw(a, b)
+    import re
+
+    ops = re.findall(r"(\d+)([MID])", cigar)  # one 60-base deletion (left-aligned: it may slide over chance-equal bases)
+    assert score == 600 - (24 + 60) and [o for _, o in ops] == ["M", "D", "M"] and int(ops[1][0]) == 60  # second piece: 24 + n
+    assert int(ops[0][0]) + int(ops[2][0]) == 300 and int(ops[0][0]) <= 150
+    # extension stops at the best cell; a z-drop ends the search
+    _, mx, mt, mq, dropped, cigar = mm2.ksw(b"ACGTACGTACGGTTAACC" + b"T" * 30, b"ACGTACGTACGGTTAACC" + b"GA" * 15, zdrop=400, ext_only=True)
+    assert (mx, mt, mq, dropped, cigar) == (36, 17, 17, 0, "18M")
+    junk_q, junk_t = random_dna(rng, 600, 0.5).tobytes(), random_dna(rng, 600, 0.5).tobytes()
+    _, mx, mt, mq, dropped, _ = mm2.ksw(a[:100] + junk_q, a[:100] + junk_t, zdrop=100, ext_only=True)
+    assert dropped == 1 and mx >= 200 and 99 <= mt <= 110 and 99 <= mq <= 110
+
+
+def test_sketch_density_strand_symmetry_and_window_guarantee():
+    rng = np.random.default_rng(2)
+    seq = random_dna(rng, 20_000, 0.5).tobytes()
+    x, y = mm2.sketch(seq)
+    assert abs(len(x) / len(seq) - 2 / 11) < 0.01  # (w = 10: 2 / (w + 1))
+    pos = (y & 0xFFFFFFFF) >> 1
+    assert np.all(np.diff(pos.astype(np.int64)) <= 10) and np.all(np.diff(pos.astype(np.int64)) >= 0)
+    # the reverse complement has the same minimizers (hashes of canonical k-mers), mirrored
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    xr, yr = mm2.sketch(seq.translate(comp)[::-1])
+    assert sorted((x >> 8).tolist()) == sorted((xr >> 8).tolist())
+    posr = (yr & 0xFFFFFFFF) >> 1
+    assert sorted((len(seq) - 1 - posr.astype(np.int64) + 14).tolist()) == sorted(pos.astype(np.int64).tolist())
+    # an N resets the window
+    xn, _ = mm2.sketch(seq[:500] + b"N" + seq[501:1000])
+    assert 0 < len(xn) <= len(mm2.sketch(seq[:1000])[0]) + 2
+
+
+def test_planted_gene_maps_full_length_on_both_strands():
+    db = make_db("kpsc_k", seed=7, n_loci=3)
+    rng = np.random.default_rng(5)
+    g = 4
+    o, n = int(db.genes.offsets[g]), int(db.genes.lengths[g])
+    gene = db.genes.seqs[o : o + n]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    fwd = np.concatenate([random_dna(rng, 3000, 0.5), gene, random_dna(rng, 3000, 0.5)])
+    rev = np.concatenate([random_dna(rng, 2000, 0.5), np.frombuffer(gene.tobytes().translate(comp)[::-1], np.uint8),
+                          random_dna(rng, 500, 0.5)])  # fmt: skip
+    seqs = np.concatenate([fwd, rev])
+    idx = mm2.Mm2Index(seqs, [0, len(fwd)], [len(fwd), len(rev)])
+    assert idx.mid_occ == 10  # -f 2e-4 on a small index falls to min_mid_occ
+    hits = idx.map(db.genes)
+    mine = hits[hits["gene"] == g]
+    assert len(mine) == 2
+    for h, (ctg, strand, t0) in zip(sorted(mine, key=lambda r: r["contig"]), ((0, 1, 3000), (1, -1, 2000))):
+        assert (h["contig"], h["strand"], h["q_start"], h["q_end"], h["t_start"], h["t_end"]) == (ctg, strand, 0, n, t0, t0 + n)
+        assert h["score"] == 2 * n and h["matches"] == n and h["block_len"] == n
+        assert h["mapq"] == 0  # two equally good placements of the query: mm_set_mapq gives both 0
+
+
+# ---- concordance of the calls ------------------------------------------------------------------------------------------------
+def _oracle_proteins(q, t):
+    return PairwiseAlignments.from_table(O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths))
+
+
+CONFIGS = {
+    # SURVEY.md section 8d generators at reduced background length (the iid background only adds chance seeds)
+    "config2": dict(db=("kpsc_k", 100), also=None, kw=dict(length=300_000, median_contigs=8)),
+    "config3": dict(db=("kpsc_k", 100), also=("kpsc_o", 101), kw=dict(length=300_000, median_contigs=8)),
+    "config4": dict(db=("ab_k", 102), also=None, kw=dict(length=300_000, median_contigs=110, min_contig=200, force_split=True)),
+}
+
+
+@pytest.fixture(scope="module")
+def dbs():
+    return {}
+
+
+def _db(cache, kind, seed):
+    if (kind, seed) not in cache:
+        db = make_db(kind, seed=seed)
+        cache[(kind, seed)] = (db, O.OracleDB(*pack_sequences_flat(db.genes)),
+                               Serotyper(db, aligner=lambda g: None, protein_aligner=_oracle_proteins))  # fmt: skip
+    return cache[(kind, seed)]
+
+
+def _span(h):
+    return (int(h["gene"]), int(h["contig"]), int(h["strand"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]))
+
+
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_locus_type_and_confidence_agree_with_the_minimap2_model(dbs, config):
+    cfg = CONFIGS[config]
+    main = _db(dbs, *cfg["db"])
+    typed = [main] + ([_db(dbs, *cfg["also"])] if cfg["also"] else [])
+    shared = scores_equal = only_k = only_m = 0
+    for i in range(4):
+        genome = make_assembly(main[0], seed=7000 + 37 * i, also=tuple(t[0] for t in typed[1:]), **cfg["kw"])
+        packed = genome.packed()
+        index = mm2.Mm2Index.from_contigs(genome.contigs)
+        for db, odb, typer in typed:
+            hk, hm = odb.align(packed), index.map(db.genes)
+            rk = typer.reduce(genome, hits_to_alignments(db, genome, hk))
+            rm = typer.reduce(genome, hits_to_alignments(db, genome, hm))
+            for field in ("best_locus_name", "phenotype", "typeable"):
+                assert getattr(rk, field) == getattr(rm, field), (config, genome.id, db.metadata.keyword, field)
+            fk = bytes(KaptiveRow.from_result(rk)).split(b"\t")
+            fm = bytes(KaptiveRow.from_result(rm)).split(b"\t")
+            assert fk[:7] == fm[:7], (config, genome.id)  # assembly, locus, type, confidence ... up to the problems column
+            sk, sm = {_span(h): h for h in hk}, {_span(h): h for h in hm}
+            both = set(sk) & set(sm)
+            shared += len(both)
+            only_k += len(sk) - len(both)
+            only_m += len(sm) - len(both)
+            scores_equal += sum(int(sk[s]["score"]) == int(sm[s]["score"]) for s in both)
+    # the two seeding schemes differ in which weak cross-locus homologs they find, not in where a hit ends or what it scores
+    assert shared > 300 and scores_equal >= 0.995 * shared, (shared, scores_equal)
+    assert only_m <= 0.05 * (shared + only_m), "hits of the minimap2 model that kp-align does not report with the same span"
+    assert only_k <= 0.35 * (shared + only_k)
