@@ -199,6 +199,48 @@ def ingest_rate(seed0: int, length: float) -> dict:
                     "outside every timed leg above"}
 
 
+def usable_cores() -> tuple[int, str]:
+    """Cores this process may actually keep busy: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a container that sees 256 CPUs but is given 16 CPUs' worth of time runs 256 busy processes at 1/16 speed each)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = f"{n} in the affinity mask"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, why = q, f"{why}, cgroup quota {float(quota) / period:.1f} CPUs ({path})"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if n > 1:  # ... and to what the box really gives: n spinning processes get sum(CPU seconds) / wall cores between them
+        ctx = get_context("fork")
+        with ctx.Pool(n, initializer=_cpu_init, initargs=(ctx.Barrier(n),)) as pool:
+            parts = pool.map(_spin, [0.4] * n, chunksize=1)
+        got = sum(p[0] for p in parts) / max(max(p[2] for p in parts) - min(p[1] for p in parts), 1e-9)
+        if got < 0.8 * n:
+            why = f"{why}; {n} spinning processes were given {got:.1f} cores' worth of CPU time"
+            n = max(1, int(round(got)))
+    return n, why
+
+
+def _spin(seconds: float):
+    barrier = _CPU.get("barrier")
+    if barrier is not None:
+        barrier.wait(timeout=120)
+    t0, c0 = time.time(), time.process_time()
+    x = 0
+    while time.time() - t0 < seconds:
+        for i in range(20000):
+            x += i * i
+    return time.process_time() - c0, t0, time.time()
+
+
 def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
     """The CPU oracle (C aligner + C protein DP + numpy reduction) typing the first assemblies of the workload against
     every database: all host cores at once (one process per core, one thread each, one shared seed index, clock started
@@ -207,7 +249,7 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
 
     native = O.build_native()  # -O3 -march=native for this box; None when no compiler is here (then the portable build)
     flags = "-O3 -march=native" if native else "-O2 (prebuilt; no compiler on this box)"
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, cores_why = usable_cores()
     n_dbs = 2 if _DBS["also"] is not None else 1
     _cpu_prepare(native)
     ctx = get_context("fork")
@@ -232,6 +274,7 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
         "sample": f"{cores} single-threaded processes x {per_worker} assemblies of the same workload each ({what}), started "
                   f"together on a barrier after input generation: CPU oracle (oracle/kp_oracle.c aligner + protein DP built "
                   f"{flags}, one seed index shared by all processes, numpy reduction); {n_all} assemblies in {wall:.1f} s",
+        "cores_note": cores_why,
         "parallel_efficiency": round(rate_all / (cores * rate_one), 3),
         "cpu_seconds_per_assembly_all_cores": round(cpu_s / n_all, 3),
         "aligner_share_all_cores": round(align_s / max(sum(p[2] - p[1] for p in parts), 1e-9), 3),
@@ -274,6 +317,9 @@ def main() -> None:
     ap.add_argument("--assemblies-total", type=int, default=0,
                     help="assemblies of the WHOLE job, sharded evenly over the ranks (overrides --assemblies): BASELINE.json "
                          "config 5 is `--gpus 8 --assemblies-total 100000`, i.e. 12 500 per rank")
+    ap.add_argument("--as-rank", type=int, default=-1,
+                    help="single process only: type the assemblies rank R of a multi-rank job would hold (same seeds), so "
+                         "that a rank's rows can be checked against a one-process run")
     ap.add_argument("--batch", type=int, default=1000, help="assemblies per device batch")
     ap.add_argument("--db", choices=sorted(WORKLOADS), default="kpsc")
     ap.add_argument("--length", type=float, default=0.0, help="mean assembly length (0 = the workload's own)")
@@ -316,7 +362,9 @@ def main() -> None:
     import torch  # noqa: F401
     _load_dbs(args.db)
     length = args.length or _WL["length"]
-    seed0 = rank_seed0(rank, args.assemblies)
+    if args.as_rank >= 0 and world > 1:
+        raise SystemExit("--as-rank is for single-process runs")
+    seed0 = rank_seed0(args.as_rank if args.as_rank >= 0 else rank, args.assemblies)
     t_gen = time.perf_counter()
     ids, packed = build_workload(args.assemblies, seed0, length, workers)
     t_gen = time.perf_counter() - t_gen

@@ -161,8 +161,8 @@ class OracleDB:
         self._h = C.c_void_p(lib().kpo_db_create(_p(self.codes), _p(self.off), C.c_int(self.n_genes)))
 
     def __del__(self) -> None:
-        if getattr(self, "_h", None):
-            lib().kpo_db_free(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:  # (module globals are gone at interpreter shutdown)
+            _LIB.kpo_db_free(self._h)
             self._h = None
 
     @property

@@ -56,6 +56,37 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert two["config"]["typeable_in_last_step"] > 0
 
 
+def test_eight_ranks_rehearse_config5_on_one_gpu():
+    """BASELINE.json config 5 in miniature on whatever one box has: 8 ranks (8 processes, 8 HIP contexts, 8 driving
+    threads) share device 0, `--assemblies-total` shards 256 assemblies over them with the product's partitioning rule,
+    no collective on the data path.  Every rank's rows equal those of a single process typing the same seeds, no rank
+    re-runs a pass for buffer growth after the warm-up, and the line says what each rank took of the host."""
+    common = ["--batch", "16", "--length", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--workers", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "8", "--assemblies-total", "256",
+           "--dist-backend", "gloo", "--share-gpu", *common]  # fmt: skip
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    eight = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = eight["config"]
+    assert eight["n_gpus"] == 8 and cfg["assemblies_per_gpu"] == 32 and cfg["assemblies_total"] == 256
+    assert "256 assemblies sharded over 8 ranks" in cfg["workload"]
+    digests = cfg["tsv_rows_sha1_per_rank"]
+    assert len(digests) == 8 and len(set(digests)) == 8
+    per_rank = cfg["host_per_rank"]
+    assert [h["rank"] for h in per_rank] == list(range(8))
+    for h in per_rank:
+        assert h["buffer_growth_reruns_in_timed_steps"] == [0], h
+        assert h["process_cpu_s"] > 0 and h["driving_thread_cpu_s"] > 0 and h["max_rss_MB"] > 0 and h["pinned_host_MB"] >= 0
+    for rank in (0, 3, 7):  # the same seeds in a process of their own
+        one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--assemblies", "32", "--as-rank", str(rank), *common],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT)  # fmt: skip
+        assert one.returncode == 0, one.stderr[-3000:]
+        single = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+        assert single["config"]["tsv_rows_sha1"] == digests[rank], f"rank {rank}"
+
+
 def test_schedule_does_not_change_the_rows():
     """One or two alignment passes ahead, resident batches or shards streamed from pinned host memory (with the TSV bytes
     formatted beside the main thread): the same rows, no buffer-growth rerun inside the timed steps, every leg reported."""
