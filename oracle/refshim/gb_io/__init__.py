@@ -3,40 +3,40 @@
 ``sequence`` (bytes) and ``features``; a feature has ``kind``, ``qualifiers`` (``key`` / ``value``) and ``location``
 (``start``, ``end`` 0-based half-open, ``strand``).
 
-TEST INFRASTRUCTURE.  The flat-file text is split by this repository's own reader (kaptive_amd/db/genbank.py), so what
-the reference's compile step pins through this shim is everything AFTER record parsing: id and cluster rules, gene
-positions, vocabularies, translations, phenotype masks.  The reader itself is pinned by the hand-written fixture whose
-contents the test also states literally (tests/test_genbank_fixture.py).
+TEST INFRASTRUCTURE, and deliberately INDEPENDENT of the product: the flat file is parsed HERE, from the INSDC feature
+table layout (LOCUS line; feature keys in column 6, locations and ``/qualifier=value`` lines from column 22, quoted
+values continued over lines with ``""`` for a quote; ORIGIN blocks), by a line-oriented state machine that shares no
+code with ``kaptive_amd/db/genbank.py``.  So when ``oracle/make_golden.py genbank`` runs the reference's
+``Database.from_genbank`` through this module, the expected arrays in tests/golden/db_genbank_expected.npz pin the
+product's reader as well as everything after record parsing: two independent readers of the same file must agree.
+Location model as gb-io documents it: ``Range(start, end)`` 0-based half-open; ``Complement(x)`` has strand "-" and
+the bounds of x; ``Join`` / ``Order`` take the bounds of their parts (the crate's ``find_bounds``: smallest start,
+largest end) and the strand of their parts; ``<`` / ``>`` (fuzzy ends) do not move a bound; ``n`` alone is ``[n-1, n)``.
 """
 
 from __future__ import annotations
 
-import re
-import tempfile
-from dataclasses import dataclass
-from pathlib import Path
-
-_NUM = re.compile(r"\d+")
+from dataclasses import dataclass, field
 
 
 @dataclass
 class Qualifier:
     key: str
-    value: str
+    value: str | None
 
 
 @dataclass
 class Location:
     start: int
     end: int
-    strand: int
+    strand: str  # "+" / "-" (the reference accepts -1 or "-" for the reverse strand: db/core.py:403)
 
 
 @dataclass
 class Feature:
     kind: str
     location: Location
-    qualifiers: list
+    qualifiers: list = field(default_factory=list)
 
 
 @dataclass
@@ -46,19 +46,116 @@ class Record:
     features: list
 
 
-def iter(handle):  # noqa: A001
-    from kaptive_amd.db.genbank import read_genbank
+def _bounds(expr: str) -> Location:
+    """Bounds and strand of a location expression, by recursive descent over complement( join( order( a..b a^b a"""
+    expr = expr.strip()
+    for op in ("complement", "join", "order"):
+        if expr.startswith(op + "(") and expr.endswith(")"):
+            inner = expr[len(op) + 1 : -1]
+            parts, depth, cur = [], 0, ""
+            for ch in inner:
+                if ch == "," and depth == 0:
+                    parts.append(cur)
+                    cur = ""
+                    continue
+                depth += ch == "("
+                depth -= ch == ")"
+                cur += ch
+            parts.append(cur)
+            locs = [_bounds(p) for p in parts if p.strip()]
+            strand = locs[0].strand if locs else "+"
+            if op == "complement":
+                strand = "-" if strand == "+" else "+"
+            return Location(min(x.start for x in locs), max(x.end for x in locs), strand)
+    if ":" in expr:  # remote reference "accession:location": bounds of the local part
+        expr = expr.split(":", 1)[1]
+    sep = ".." if ".." in expr else ("^" if "^" in expr else None)
+    if sep:
+        a, b = expr.split(sep, 1)
+    else:
+        a = b = expr
+    lo = int(a.strip().lstrip("<>"))
+    hi = int(b.strip().lstrip("<>"))
+    return Location(lo - 1, hi, "+")
 
-    with tempfile.NamedTemporaryFile(suffix=".gbk", delete=False) as tmp:
-        tmp.write(handle.read())
-    try:
-        records = read_genbank(tmp.name)
-    finally:
-        Path(tmp.name).unlink()
-    for rec in records:
-        feats = []
-        for f in rec["features"]:
-            nums = [int(x) for x in _NUM.findall(f["location"])]
-            loc = Location(min(nums) - 1, max(nums), -1 if "complement" in f["location"] else 1) if len(nums) >= 2 else Location(0, 0, 1)
-            feats.append(Feature(f["kind"], loc, [Qualifier(q["key"], q["value"]) for q in f["quals"]]))
-        yield Record(rec["name"], rec["seq"], feats)
+
+def _finish_qualifier(text: str) -> Qualifier:
+    body = text[1:]
+    if "=" not in body:
+        return Qualifier(body.strip(), None)
+    key, value = body.split("=", 1)
+    value = value.strip()
+    if value.startswith('"'):
+        value = value[1:-1] if value.endswith('"') and len(value) >= 2 else value[1:]
+        value = value.replace('""', '"')
+    return Qualifier(key.strip(), value)
+
+
+def iter(handle):  # noqa: A001
+    text = handle.read()
+    if isinstance(text, bytes):
+        text = text.decode("utf-8")
+    name, features, seq, section = None, [], [], None
+    loc_text, qual_text, in_quote = None, None, False
+
+    def close_qualifier():
+        nonlocal qual_text, in_quote
+        if qual_text is not None and features:
+            features[-1].qualifiers.append(_finish_qualifier(qual_text))
+        qual_text, in_quote = None, False
+
+    def close_location():
+        nonlocal loc_text
+        if loc_text is not None and features:
+            features[-1].location = _bounds(loc_text)
+        loc_text = None
+
+    for raw in text.splitlines():
+        if raw.startswith("//"):
+            close_location()
+            close_qualifier()
+            if name is not None:
+                yield Record(name, "".join(seq).encode("ascii"), features)
+            name, features, seq, section = None, [], [], None
+            continue
+        if raw.startswith("LOCUS"):
+            name = raw.split()[1] if len(raw.split()) > 1 else ""
+            section = "header"
+            continue
+        if raw.startswith("FEATURES"):
+            section = "features"
+            continue
+        if raw.startswith("ORIGIN"):
+            close_location()
+            close_qualifier()
+            section = "origin"
+            continue
+        if section == "origin":
+            seq.append("".join(ch for ch in raw if ch.isalpha()))
+            continue
+        if section != "features":
+            continue
+        if raw[:5] == "     " and len(raw) > 5 and raw[5] != " ":  # a new feature key in column 6
+            close_location()
+            close_qualifier()
+            kind = raw[5:21].strip()
+            features.append(Feature(kind, Location(0, 0, "+")))
+            loc_text = raw[21:].strip()
+            continue
+        body = raw[21:] if len(raw) > 21 else raw.strip()
+        if in_quote:  # continuation of a quoted value
+            joiner = "" if qual_text.split("=", 1)[0].strip("/") == "translation" else " "
+            qual_text += joiner + body.strip()
+            if body.rstrip().endswith('"') and not body.rstrip().endswith('""'):
+                in_quote = False
+            continue
+        stripped = body.strip()
+        if stripped.startswith("/"):
+            close_location()
+            close_qualifier()
+            qual_text = stripped
+            value = stripped.split("=", 1)[1] if "=" in stripped else ""
+            in_quote = value.startswith('"') and not (len(value) >= 2 and value.endswith('"') and not value.endswith('""'))
+            continue
+        if loc_text is not None:  # a location continued on the next line
+            loc_text += stripped
