@@ -34,7 +34,7 @@
 #define KP_K 15
 #define KP_KMER_MASK 0x3FFFFFFFu
 #define KP_SEED_RULE_VALUE 1u
-#define KP_MAX_GENE_LEN 16000 /* q positions fit 16 bits; biased scores (<= 2 * length + 14) fit 15 bits (kp_sw.hip) */
+#define KP_MAX_GENE_LEN 15800 /* q positions fit 16 bits; biased scores (<= 2 * length + 14) stay below 0x7C00 (kp_sw.hip) */
 #define KP_MAX_GENES 131071   /* (gene*2+strand) is stored in 18 bits */
 #define KP_MAX_ASM_LEN ((1u << 30) - 65536u)
 

@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
-MAX_GENE_LEN = 16000  # KP_MAX_GENE_LEN of include/kp_spec.h (tests/test_native_abi.py compares the two)
+MAX_GENE_LEN = 15800  # KP_MAX_GENE_LEN of include/kp_spec.h (tests/test_native_abi.py compares the two)
 WORK_SLOTS = 3  # KP_WORK_SLOTS of include/kaptive_amd.h: alignment results a context keeps resident
 
 HIT_DTYPE = np.dtype(

@@ -1471,7 +1471,7 @@ int kp_protein_align(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const 
 int kp_protein_align_seeded(kp_ctx *ctx, const uint8_t *q, const int32_t *q_off, const int32_t *q_len, const uint8_t *t,
                             const int32_t *t_off, const int32_t *t_len, int32_t n, const int32_t *diagonal_offsets,
                             int32_t k, int32_t *out8) {
-    if (ctx && n > 0 && (!diagonal_offsets || k < 0 || k > 16000)) return kp_fail(ctx, KP_EINVAL, "bad seed arguments");
+    if (ctx && n > 0 && (!diagonal_offsets || k < 0 || k > KP_MAX_GENE_LEN)) return kp_fail(ctx, KP_EINVAL, "bad seed arguments");
     return protein_align(ctx, q, q_off, q_len, t, t_off, t_len, n, diagonal_offsets, k, out8);
 }
 

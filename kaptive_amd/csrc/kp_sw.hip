@@ -16,7 +16,7 @@
 // This one keeps TWO tasks in every register -- task X in the low 16 bits, task Y in the high 16 -- so that
 //   * additions and subtractions of scores are one cheap v_add_u32 for two cells (all values are kept biased into
 //     [0, 32767], so no carry or borrow ever crosses bit 16),
-//   * maxima are one v_pk_max_u16 for two cells,
+//   * maxima are one v_pk_max_u16 -- or, three ways, one v_pk_maximum3_f16 (see pk_max3) -- for two cells,
 //   * a comparison a >= b is (a | 0x80008000) - b: two cheap instructions leave the answer for both cells in bits 15
 //     and 31 (the guard bit survives exactly when no borrow reaches it) -- no v_cmp, no lane mask, no carry push,
 //   * the four direction bits of a cell are gathered from those words byte-wise (v_perm_b32, one v_bfi),
@@ -65,7 +65,8 @@ constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
 static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1 && OE == 6 && EX == 2,
               "the profile fields and the biases below encode these scores");
-static_assert(2 * KP_MAX_GENE_LEN + 14 < 32768, "biased scores must leave bit 15 of a half-word free for the guard");
+static_assert(2 * KP_MAX_GENE_LEN + 14 < 0x7C00, "biased scores must stay below the half-precision infinity pattern (pk_max3) "
+                                                 "and leave bit 15 of a half-word free for the guard");
 
 constexpr unsigned K1 = 0x00010001u;                        // a value in both halves: x * K1
 constexpr unsigned GUARD = 0x80008000u;
@@ -142,6 +143,20 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// Three-way maximum of both halves in one instruction: v_pk_maximum3_f16 (new in gfx950).  Positive half-precision bit
+// patterns below 0x7C00 order like unsigned integers and the instruction returns the winning operand's bits unchanged,
+// denormal patterns included (tools/microbench/pk_max3.hip: all 6.0e9 checked triples exact, same issue cost as
+// v_pk_max_u16) -- and every biased score of this kernel is in [0, 2 * KP_MAX_GENE_LEN + 14] < 0x7C00.
+__device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+#ifdef KP_SW_NO_MAX3  // (A/B builds: KAPTIVE_AMD_EXTRA_FLAGS=-DKP_SW_NO_MAX3)
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(r), "v"(c));
+#else
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+#endif
+    return r;
+}
 __device__ __forceinline__ unsigned pk_shr(unsigned v, unsigned by) {  // each half of v shifted right by the same half of `by`
     unsigned r;
     asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(by), "v"(v));
@@ -185,7 +200,7 @@ __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, u
     const unsigned nz = add_k<0u - (CB - OE + 1u) * K1>(c.hg);   // H of the diagonal predecessor >= 1
     const unsigned d = add_v(c.hmoe, s);                         // diagonal candidate - 2, biased by 12
     const unsigned en = add_k<0u - (unsigned)EX * K1>(e), fn = add_k<0u - (unsigned)EX * K1>(f);
-    const unsigned m = pk_max(pk_max(d, en), fn);
+    const unsigned m = pk_max3(d, en, fn);
     const unsigned dw = ge_word(d, m), ew = ge_word(en, m);      // == m, as neither exceeds it
     const unsigned h = pk_max(m, ten);                           // H + 10
     c.hmoe = add_k<0u - 4u * K1>(h);
@@ -230,9 +245,9 @@ __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned s
     dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), sub_v(s.C.hg, s.C.emex), fD, foD, ten);
 
     // best cell of the lane so far: a strict rise keeps the first row; the cells of that step tell the column later
-    const unsigned top = pk_max(pk_max(s.A.hmoe, s.B.hmoe), pk_max(s.C.hmoe, s.D.hmoe));
-    const unsigned keep = pk_sign_mask(ge_word(s.best, top), fifteen);  // halves that did not rise
-    s.best = pk_max(s.best, top);
+    const unsigned risen = pk_max3(pk_max3(s.A.hmoe, s.B.hmoe, s.C.hmoe), s.D.hmoe, s.best);
+    const unsigned keep = pk_sign_mask(ge_word(s.best, risen), fifteen);  // halves that did not rise (best == risen there)
+    s.best = risen;
     s.brow = bfi_v(keep, s.brow, step_k);
     s.sA = bfi_v(keep, s.sA, s.A.hmoe); s.sB = bfi_v(keep, s.sB, s.B.hmoe);
     s.sC = bfi_v(keep, s.sC, s.C.hmoe); s.sD = bfi_v(keep, s.sD, s.D.hmoe);

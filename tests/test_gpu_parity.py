@@ -666,12 +666,12 @@ def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, oracle, sm
 
 def test_longest_genes_reach_the_packed_score_range(oracle):
     """Genes at KP_MAX_GENE_LEN: the fill kernel's biased 16-bit scores (2 * length + 12) come within a few hundred of the
-    guard bit.  Exact copies, copies with substitutions, with an insertion and a deletion (wide bands), with an N run,
+    half-precision infinity pattern 0x7C00 its three-way maxima (v_pk_maximum3_f16 on integer bit patterns) must stay below.  Exact copies, copies with substitutions, with an insertion and a deletion (wide bands), with an N run,
     on both strands, and a gene one base too long (rejected at load)."""
     from kaptive_amd.synth import revcomp
 
     rng = np.random.default_rng(4242)
-    max_len = 16000
+    max_len = _native.MAX_GENE_LEN
     g1, g2, g3 = (random_dna(rng, n, 0.5) for n in (max_len, max_len - 1, 15000))
     genes = Sequences.from_records([SeqRecord("g1", g1.tobytes()), SeqRecord("g2", g2.tobytes()), SeqRecord("g3", g3.tobytes())])
     codes, off = pack_sequences_flat(genes)
@@ -695,7 +695,7 @@ def test_longest_genes_reach_the_packed_score_range(oracle):
     batch = ctx.batch([pa])
     hits, _ = batch.align()
     want = odb.align(pa)
-    _same_records(hits, want, "hits of 16 kb genes")
+    _same_records(hits, want, "hits of the longest genes")
     assert hits["score"].max() == 2 * max_len and len(hits) >= 5
     batch.close()
     too_long = Sequences.from_records([SeqRecord("g", random_dna(rng, max_len + 1, 0.5).tobytes())])
