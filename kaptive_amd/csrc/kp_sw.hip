@@ -211,8 +211,10 @@ __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, u
     // the bytes that hold the four answers of both tasks, side by side: [D_Y L_Y D_X L_X] and [EO_Y FO_Y EO_X FO_X], each
     // answer in bit 7 of its byte; the second set goes to bit 6, and a step's two bits per byte move down as steps follow
     const unsigned p1 = (unsigned)__builtin_amdgcn_perm(dw, lw, 0x07030501u), p2 = (unsigned)__builtin_amdgcn_perm(eo, fo, 0x07030501u);
-    const unsigned n = and_k<0xC0C0C0C0u>(bfi(0x80808080u, p1, shr_k<1>(p2)));
-    acc = FIRST ? n : or_v(shr_k<2>(acc), n);
+    // bit 7 of every byte from p1, bit 6 from p2 (the bits below are leftovers); the accumulator takes exactly those two
+    // bits of each byte and moves what it holds two down, so after four steps every bit of it has come through the mask
+    const unsigned n = bfi(0x80808080u, p1, shr_k<1>(p2));
+    acc = FIRST ? n : bfi(0xC0C0C0C0u, n, shr_k<2>(acc));
 }
 
 struct State {
@@ -222,17 +224,19 @@ struct State {
 };
 
 template <int P, bool FIRST>
-__device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned step_k, int l, unsigned prof_in, unsigned t_in,
+__device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned step_k, unsigned prof_mine, unsigned t_next,
                                         unsigned first_all, unsigned last_all, unsigned edge, unsigned ten, unsigned fifteen) {
     constexpr bool ROW = P <= 16;
-    const unsigned q_shift = from_lower<ROW>(s.qb);
-    s.qb = (l == 0) ? prof_in : q_shift;  // profiles of row m enter at lane 0
+    s.qb = prof_mine;  // profile of this lane's row m - l, read from LDS by the lane itself (the LDS pipe is idle otherwise;
+                       // streaming the rows up the lanes cost a DPP move and a select per step on the busy vector pipe)
 
     // A: the left neighbour is lane l-1's D of the previous step; left of the band's first diagonal H = 0, E = -inf, so
     // the band's first lane takes E = -(open + ext), "opened" (one select on the result instead of one per operand)
     const unsigned l_hmoe = from_lower<ROW>(s.D.hmoe), l_emex = from_lower<ROW>(s.D.emex);
     const unsigned eA = bfi_v(first_all, edge, pk_max(l_hmoe, l_emex));
-    const unsigned eoA = or_v(ge_word(l_hmoe, l_emex), first_all);  // (only bits 15 and 31 are looked at)
+    // (the band's first lane would have to say "opened" here; nobody ever asks: E of that cell is -(open + ext), it loses
+    // to the restart and no path with a positive score stands in state E on the band's first diagonal)
+    const unsigned eoA = ge_word(l_hmoe, l_emex);  // (only bits 15 and 31 are looked at)
     dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), sub_v(s.B.hg, s.B.fmex), ten);
     dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max(s.A.hmoe, s.A.emex), sub_v(s.A.hg, s.A.emex),
                    pk_max(s.C.hmoe, s.C.fmex), sub_v(s.C.hg, s.C.fmex), ten);
@@ -241,7 +245,7 @@ __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned s
     // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal the same boundary applies
     const unsigned u_hmoe = from_upper<ROW>(s.A.hmoe), u_fmex = from_upper<ROW>(s.A.fmex);
     const unsigned fD = bfi_v(last_all, edge, pk_max(u_hmoe, u_fmex));
-    const unsigned foD = or_v(ge_word(u_hmoe, u_fmex), last_all);
+    const unsigned foD = ge_word(u_hmoe, u_fmex);  // (same remark for F on the band's last diagonal)
     dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), sub_v(s.C.hg, s.C.emex), fD, foD, ten);
 
     // best cell of the lane so far: a strict rise keeps the first row; the cells of that step tell the column later
@@ -252,12 +256,11 @@ __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned s
     s.sA = bfi_v(keep, s.sA, s.A.hmoe); s.sB = bfi_v(keep, s.sB, s.B.hmoe);
     s.sC = bfi_v(keep, s.sC, s.C.hmoe); s.sD = bfi_v(keep, s.sD, s.D.hmoe);
 
-    const unsigned t_shift = from_upper<ROW>(s.t1);  // lane l+1's x = m + 3l + 4 = this lane's next t3
     s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
-    s.t3 = (l == P - 1) ? t_in : t_shift;  // target codes x = m + 1 + 3P enter at lane P-1
+    s.t3 = t_next;  // the code of x = m + 3l + 4, this lane's cell D at the next step (also read by the lane itself)
 }
 
-constexpr int PROF_WORDS = 16 * CH;                      // LDS of one block: profile pairs of 64/P groups x CH rows (P >= 4)
+constexpr int PROF_WORDS = 16 * (CH + 4);                // LDS of one block: profile pairs of 64/P groups x (P + CH) rows (P >= 4)
 constexpr int TCODE_HALVES = 16 * (CH + 3 * 4 + 4 + 4);  // ... their target shift amounts, a byte per task (largest for P = 4)
 constexpr int TWORD_WORDS = 2 * 128;                     // ... and the packed words those are cut from
 
@@ -275,8 +278,11 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     // on an 8-byte boundary (one ds_read_b64 feeds four steps)
     constexpr int PAD = (4 - (3 * P + 1) % 4) % 4;
     constexpr int TROW = (TW + PAD + 3) & ~3;
-    static_assert(G * CH <= PROF_WORDS && G * TROW <= TCODE_HALVES, "LDS carve-up");
-    uint32_t(*s_prof)[CH] = reinterpret_cast<uint32_t(*)[CH]>(s_prof_raw);
+    // profiles: entry i of a group's row is query row m0 - P + i of the chunk being computed: the P rows before the chunk
+    // stay, because lane l works on row m - l
+    constexpr int PROW = CH + P;
+    static_assert(G * PROW <= PROF_WORDS && G * TROW <= TCODE_HALVES, "LDS carve-up");
+    uint32_t(*s_prof)[PROW] = reinterpret_cast<uint32_t(*)[PROW]>(s_prof_raw);
     uint16_t(*s_t)[TROW] = reinterpret_cast<uint16_t(*)[TROW]>(s_t_raw);  // byte 0: task X, byte 1: task Y
 
     const int lane = threadIdx.x;
@@ -385,8 +391,13 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         };
         request(0);
         for (int m0 = 0; m0 < steps8; m0 += CH) {
-            // ---- stage this chunk: profiles of query rows [m0, m0+CH), target codes of window x in [m0, m0+CH+3P] ----
+            // ---- stage this chunk: profiles of query rows [m0-P, m0+CH), target codes of window x in [m0, m0+CH+3P] ----
             __syncthreads();
+            {   // the last P rows of the previous chunk move to the front (a block is one wave: every lane has read its
+                // entry before any lane's stores below are issued); before the first chunk they are rows outside the gene
+                const uint32_t keep = m0 == 0 ? PROF_OUT : s_prof[g][CH + l];
+                s_prof[g][l] = keep;
+            }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int w = l + i * P, r = m0 + 8 * w;
@@ -400,7 +411,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                             pair |= (live ? row_profile(nibble(qreg[h][i], j)) : PROF_OUT) << (16 * h);
                             saw_n[h] |= live && nibble(qreg[h][i], j) >= 4u;
                         }
-                        s_prof[g][8 * w + j] = pair;
+                        s_prof[g][P + 8 * w + j] = pair;
                     }
                 }
             }
@@ -465,15 +476,18 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int mm = m + 4 * half;
-                    const uint4 pr = *reinterpret_cast<const uint4 *>(&s_prof[g][mm - m0]);
-                    const uint2 tc = *reinterpret_cast<const uint2 *>(&s_t[g][mm - m0 + 3 * P + 1 + PAD]);
+                    // this lane's rows mm - l .. mm - l + 3 and the codes of x = mm + 3l + 4 .. + 3, straight from LDS
+                    const uint32_t *pp = &s_prof[g][mm - m0 + P - l];
+                    const uint16_t *tp = &s_t[g][mm - m0 + 3 * l + 4 + PAD];
+                    const unsigned p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+                    const unsigned c0 = tp[0], c1 = tp[1], c2 = tp[2], c3 = tp[3];
                     // byte pairs -> (X | Y << 16): selector bytes 0x0c are zeros
-                    const unsigned ta = __builtin_amdgcn_perm(0u, tc.x, 0x0c010c00u), tb = __builtin_amdgcn_perm(0u, tc.x, 0x0c030c02u);
-                    const unsigned tcw = __builtin_amdgcn_perm(0u, tc.y, 0x0c010c00u), td = __builtin_amdgcn_perm(0u, tc.y, 0x0c030c02u);
-                    dp_step<P, true>(st, acc, (unsigned)mm * K1, l, pr.x, ta, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, l, pr.y, tb, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, l, pr.z, tcw, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, l, pr.w, td, first_all, last_all, edge, ten, fifteen);
+                    const unsigned ta = __builtin_amdgcn_perm(0u, c0, 0x0c010c00u), tb = __builtin_amdgcn_perm(0u, c1, 0x0c010c00u);
+                    const unsigned tcw = __builtin_amdgcn_perm(0u, c2, 0x0c010c00u), td = __builtin_amdgcn_perm(0u, c3, 0x0c010c00u);
+                    dp_step<P, true>(st, acc, (unsigned)mm * K1, p0, ta, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, p1, tb, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, p2, tcw, first_all, last_all, edge, ten, fifteen);
+                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, p3, td, first_all, last_all, edge, ten, fifteen);
                     if (half == 0) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) held[c] = acc[c];
