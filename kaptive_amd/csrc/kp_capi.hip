@@ -119,6 +119,7 @@ struct KpOptions {
     uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
     int no_lds_filter = 0;       // tests compare the two filter tiers
+    int library_sort = 0;        // anchors through kp_anchor_compact + rocPRIM's segmented radix sort instead of kp_bsort.hip
 };
 
 // Page-locked host memory the library holds (kp_host_alloc and the batches' table staging), for kp_host_pinned_bytes.
@@ -321,6 +322,7 @@ void options_from_env(KpOptions &o) {
     o.prot_cap = env_u32("KAPTIVE_AMD_PROT_CAP", o.prot_cap);
     o.scan_mode = (int)env_u32("KAPTIVE_AMD_SCAN_ABLATE", 0);
     o.no_lds_filter = (int)env_u32("KAPTIVE_AMD_NO_LDS_FILTER", 0);
+    o.library_sort = (int)env_u32("KAPTIVE_AMD_LIBRARY_SORT", 0);
 }
 
 // BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
@@ -598,6 +600,7 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
     else if (n == "prot_cap") { o.prot_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.prot_cap = 0; }
     else if (n == "scan_mode") o.scan_mode = (int)value;
     else if (n == "no_lds_filter") o.no_lds_filter = value != 0;
+    else if (n == "library_sort") o.library_sort = value != 0;
     else return kp_fail(ctx, KP_EINVAL, "unknown option: " + n);
     return KP_OK;
 }
@@ -834,13 +837,19 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
     kp_launch_scan(b->view, ctx->index, w->d_cand.p, w->d_cand_count.p, w->cand_cap, w->d_anchors_a.p, w->d_sub_counts.p,
                    sub_cap, w->key_bits, ctx->opt.scan_mode, ctx->opt.no_lds_filter != 0, stream, ev[1]);
-    kp_launch_anchor_compact(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_counts.p,
-                             w->d_counts.p + n_asm + KP_N_CLASSES, stream);
-    int rc = kp_sort_anchors(ctx, w->d_anchors_b.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, b->n_asm,
-                             &w->sort_temp, &w->sort_temp_bytes, w->d_seg.p, w->d_seg.p + n_asm,
-                             (int)(w->key_bits.qb + w->key_bits.db) + ctx->gs_bits,
-                             stream);
-    if (rc) return rc;
+    if (!ctx->opt.library_sort && kp_bsort_fits(2u * (uint32_t)ctx->n_genes)) {
+        // buckets of the gene/strand field, each sorted on its own (kp_bsort.hip); sorted keys end up where the chaining reads them
+        kp_launch_anchor_bsort(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_anchors_a.p,
+                               w->d_counts.p, w->d_counts.p + n_asm + KP_N_CLASSES, 2u * (uint32_t)ctx->n_genes, w->key_bits, stream);
+    } else {  // databases with more genes than the bucket counters hold in LDS (or `library_sort`): compaction + library sort
+        kp_launch_anchor_compact(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_counts.p,
+                                 w->d_counts.p + n_asm + KP_N_CLASSES, stream);
+        int rc = kp_sort_anchors(ctx, w->d_anchors_b.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, b->n_asm,
+                                 &w->sort_temp, &w->sort_temp_bytes, w->d_seg.p, w->d_seg.p + n_asm,
+                                 (int)(w->key_bits.qb + w->key_bits.db) + ctx->gs_bits,
+                                 stream);
+        if (rc) return rc;
+    }
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, stream);

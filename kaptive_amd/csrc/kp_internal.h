@@ -196,6 +196,12 @@ void kp_launch_protein(const uint8_t *q, const int32_t *q_off, const int32_t *q_
                        int32_t *out8, int32_t *scratch, size_t scratch_ints_per_block, int n_blocks, hipStream_t stream,
                        hipStream_t aux, hipEvent_t fork, hipEvent_t join,  // aux != null: wide-band kernel runs beside the other
                        const int32_t *seed_off = nullptr, int seed_k = 0);  // seeded mode: one diagonal offset per pair, band k
+// kp_bsort.hip: sub-slices -> sorted run per assembly by buckets of the key's gene/strand field (one block per assembly);
+// count[a] / need[a] as kp_launch_anchor_compact leaves them.  n_bins = 2 * genes; kp_bsort_fits says whether it can run.
+bool kp_bsort_fits(uint32_t n_bins);
+void kp_launch_anchor_bsort(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
+                            uint64_t *grouped, uint64_t *out, uint32_t *count, uint32_t *need, uint32_t n_bins,
+                            KpKeyBits kb, hipStream_t stream);
 // kp_sort.hip: segmented sort of the anchor regions (wraps rocPRIM)
 int kp_sort_anchors(kp_ctx *ctx, uint64_t *keys_in, uint64_t *keys_out, const uint32_t *d_count, uint32_t cap,
                     int32_t n_asm, void **temp, size_t *temp_bytes, uint32_t *d_seg_begin, uint32_t *d_seg_end,

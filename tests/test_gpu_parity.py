@@ -183,6 +183,64 @@ def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
     l2.close()
 
 
+def test_bucket_sort_and_library_sort_give_the_same_anchors(oracle):
+    """kp_bsort.hip against rocPRIM's segmented radix sort (`library_sort`) and the oracle, on an assembly built to hit
+    every bucket size class of the bucket sort: single anchors, a few (sorting network in one lane), tens (wave ranking),
+    hundreds (LDS-staged ranking), and thousands in one gene/strand bucket (a long gene present several times: the
+    block-wide pass)."""
+    from kaptive_amd.synth import mutate, revcomp
+
+    rng = np.random.default_rng(99)
+    long_gene = random_dna(rng, 6000, 0.5)
+    genes = [long_gene] + [random_dna(rng, int(n), 0.5) for n in rng.integers(300, 1500, size=50)]
+    db_genes = Sequences.from_records([SeqRecord(f"g{i}", g.tobytes()) for i, g in enumerate(genes)])
+    codes, off = pack_sequences_flat(db_genes)
+    c = _native.Context(0)
+    c.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    parts = [random_dna(rng, 500, 0.5)]
+    for _ in range(5):  # five copies of the long gene: ~7500 anchors in one bucket
+        parts += [mutate(rng, long_gene, 0.002), random_dna(rng, 300, 0.5)]
+    parts += [revcomp(long_gene)[:2500], random_dna(rng, 200, 0.5)]
+    for i, g in enumerate(genes[1:41]):
+        if i % 3 == 0:
+            parts += [mutate(rng, g, 0.01 * (i % 7)), random_dna(rng, 150, 0.5)]  # full copies: hundreds of anchors
+        elif i % 3 == 1:
+            parts += [g[: 40 + 5 * i], random_dna(rng, 100, 0.5)]  # short pieces: a few anchors
+        else:
+            parts += [mutate(rng, g, 0.12), random_dna(rng, 90, 0.5)]  # diverged: tens of anchors
+    for g in genes[41:]:  # 19 bases of a gene that occurs nowhere else: one or two anchors
+        parts += [g[100:119], random_dna(rng, 60, 0.5)]
+    asm = GenomeAssembly("buckets", Sequences.from_records([SeqRecord("c1", np.concatenate(parts).tobytes()),
+                                                            SeqRecord("c2", random_dna(rng, 50_000, 0.5).tobytes())]))
+    plain = make_assembly(make_db("kpsc_k", seed=7, n_loci=3), seed=5, length=40_000, median_contigs=3, locus=-1)
+    packed = [asm.packed(), plain.packed(), asm.packed()]
+    mine = c.batch(packed)
+    hits, offs = mine.align()
+    c.set_option("library_sort", 1)
+    try:
+        lib = c.batch(packed)
+        hits_lib, offs_lib = lib.align()
+    finally:
+        c.set_option("library_sort", 0)
+    sizes = []
+    for i, pa in enumerate(packed):
+        want = odb.anchors(pa)
+        got = mine.anchors(i)
+        assert np.array_equal(got, want), f"bucket sort, assembly {i}: {len(got)} vs {len(want)}"
+        assert np.array_equal(lib.anchors(i), want), f"library sort, assembly {i}"
+        if len(want):
+            sizes.append(np.bincount((want >> np.uint64(46)).astype(np.int64)))
+    assert np.array_equal(offs, offs_lib)
+    _same_records(hits, hits_lib, "bucket sort vs library sort")
+    s = sizes[0]
+    assert (s == 1).any() and ((s >= 2) & (s <= 8)).any() and ((s > 8) & (s <= 64)).any() and ((s > 64) & (s <= 512)).any() \
+        and (s > 4096).any(), np.unique(s)  # fmt: skip
+    for b in (mine, lib):
+        b.close()
+    c.close()
+
+
 def test_sw_raw_results_match_oracle(ctx, small_setup, small_db):
     """Every band task's DP result (also the ones below the score cut-off) equals the oracle's traceback."""
     odb = small_setup
