@@ -65,7 +65,10 @@ template <bool LDSF> struct ScanShape {
     static constexpr int FILTER_BLOCKS = LDSF ? KP_LDS_FILTER_BLOCKS : 1;
 };
 
-constexpr int PROBES = 4;
+#ifndef KP_SCAN_PROBES
+#define KP_SCAN_PROBES 4
+#endif
+constexpr int PROBES = KP_SCAN_PROBES;  // filter reads a lane has in flight
 
 template <int MODE, bool LDSF>
 __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx,
@@ -172,6 +175,151 @@ __global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(Kp
     }
     if (MODE == 0 && staged) flush();
     if (MODE != 0 && checksum == 0x9E3779B1u) n_cand[0] = checksum;  // practically never; keeps the work alive
+}
+
+// ---- pass 1, dense form (the L2 tier of the filter: every database but the smallest) ---------------------------------------
+// Same reads, same rule, same filters, same candidates as kp_scan_kernel<0, false>; what changes is who probes what.  There
+// a lane walks the selected positions of its OWN 64 bases, and a wave runs at the pace of its fullest lane: a quarter of
+// the positions is selected on average (8 per half of 32), the fullest of 64 lanes holds about 14, so half of the probe
+// slots were idle lanes.  Here the wave first COMPACTS its selected positions into a list in LDS (a cheap loop: find the
+// bit, store 16 bits), keeps its 257 packed words in LDS as well, and then walks the list 64 entries at a time with every
+// lane busy: entry -> position within the wave's 4096 bases -> two words from LDS -> k-mer -> filter block (one L2 read,
+// PROBES rounds in flight).  About 30 vector instructions per selected position instead of 60.
+// MODE as above (0 product, 1 no filter reads, 2 stream only).
+constexpr int DENSE_WAVES = 4;
+constexpr int DENSE_LIST = 2048;   // selected positions of a wave's iteration the list holds (mean 1024; see `groups`)
+constexpr int DENSE_STAGE = 512;   // candidates staged per wave before a flush
+
+template <int MODE>
+__global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatchView b, KpSeedIndex idx,
+                                                                         uint64_t *__restrict__ cand,
+                                                                         unsigned long long *__restrict__ n_cand,
+                                                                         uint64_t cand_cap) {
+    __shared__ uint64_t s_stage[DENSE_WAVES][DENSE_STAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_words[DENSE_WAVES][260];
+    __shared__ uint16_t s_list[DENSE_WAVES][DENSE_LIST];
+    const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
+    const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
+    uint32_t checksum = 0;
+    const int64_t n_units = b.total_words >> 2;
+    const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *stage = s_stage[wave];
+    uint32_t *words = s_words[wave];
+    uint16_t *list = s_list[wave];
+    uint32_t staged = 0;  // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    auto flush = [&]() {  // second filter on what is staged, survivors out with one atomic (as in kp_scan_kernel)
+        uint32_t kept = 0;
+        for (uint32_t i0 = 0; i0 < staged; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint64_t c = 0;
+            bool ok = false;
+            if (i < staged) {
+                c = stage[i];
+                const uint32_t kmer = (uint32_t)c & KP_KMER_MASK;
+                const uint2 got = g_filter2[kp_filter2_block(kmer)], need = kp_filter2_mask2(kmer);
+                ok = (got.x & need.x) == need.x && (got.y & need.y) == need.y;
+            }
+            const unsigned long long pass = __ballot(ok);
+            if (ok) stage[kept + (uint32_t)__builtin_popcountll(pass & below)] = c;
+            kept += (uint32_t)__builtin_popcountll(pass);
+        }
+        unsigned long long base = 0;
+        if (lane == 0 && kept) base = atomicAdd(n_cand, (unsigned long long)kept);
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < kept; i += 64)
+            if (base + i < cand_cap) cand[base + i] = stage[i];
+        staged = 0;
+    };
+
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_iter_units; u += stride) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (u < n_units) v = vec[u];
+        uint32_t next = __shfl_down(v.x, 1);
+        if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
+        if (MODE == 2) { checksum += v.x ^ v.y ^ v.z ^ v.w ^ next; continue; }
+        const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
+        // selected positions of the lane's 64 bases: two masks of 32 (bit 2i: position i of the even word, bit 2i + 1:
+        // position i of the odd word of the pair)
+        uint32_t m2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t sel[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t lo = w[2 * h + k], hi = w[2 * h + k + 1];
+                const uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, lo, 2) ^ __builtin_amdgcn_alignbit(hi, lo, 6);
+                sel[k] = x & ~(x >> 1) & 0x55555555u;
+            }
+            m2[h] = sel[0] | (sel[1] << 1);
+        }
+        *reinterpret_cast<uint4 *>(&words[4 * lane]) = v;
+        if (lane == 63) words[256] = next;
+        const uint32_t mine = (uint32_t)__builtin_popcount(m2[0]) + (uint32_t)__builtin_popcount(m2[1]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        // the list holds DENSE_LIST entries: an iteration with more selected positions (a low-complexity stretch: the rule
+        // can select every position) goes through in two groups of 32 lanes, each at most 32 x 64 = 2048 positions
+        const int groups = total > (uint32_t)DENSE_LIST ? 2 : 1;
+        const uint32_t before_half = __shfl(incl, 31);  // selected positions of lanes 0..31
+        const uint64_t wave_base = (uint64_t)((u - lane) << 2) << 4;  // batch-wide position of the wave's first base
+        for (int g = 0; g < groups; ++g) {
+            const bool active = groups == 1 || (lane >> 5) == g;
+            const uint32_t n_list = groups == 1 ? total : (g == 0 ? before_half : total - before_half);
+            uint32_t off = incl - mine - ((groups == 2 && g == 1) ? before_half : 0u);
+            wave_lds_sync();  // (the previous walk is done with the list; the words are visible)
+            if (active) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t m = m2[h];
+                    while (m) {
+                        const int bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        list[off++] = (uint16_t)(64 * lane + 32 * h + 16 * (bit & 1) + (bit >> 1));
+                    }
+                }
+            }
+            wave_lds_sync();
+            for (uint32_t e0 = 0; e0 < n_list; e0 += 64 * PROBES) {
+                uint32_t kmers[PROBES], pos[PROBES];
+                bool have[PROBES];
+                uint2 got[PROBES];
+#pragma unroll
+                for (int j = 0; j < PROBES; ++j) {
+                    const uint32_t e = e0 + 64 * j + lane;
+                    have[j] = e < n_list;
+                    const uint32_t p = have[j] ? list[e] : 0u;
+                    const uint32_t lo = words[p >> 4], hi = words[(p >> 4) + 1];
+                    kmers[j] = __builtin_amdgcn_alignbit(hi, lo, 2 * (p & 15u)) & KP_KMER_MASK;
+                    pos[j] = p;
+                    if (MODE == 1) { checksum += have[j] ? kmers[j] * 2654435769u : 0u; continue; }
+                    got[j] = have[j] ? g_filter[kp_filter_block(kmers[j])] : make_uint2(0u, 0u);
+                }
+                if (MODE != 0) continue;
+#pragma unroll
+                for (int j = 0; j < PROBES; ++j) {
+                    const uint2 need = kp_filter_mask2(kmers[j]);
+                    const bool hit = have[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
+                    const unsigned long long ballot = __ballot(hit);
+                    if (!ballot) continue;
+                    if (hit) stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] = kp_cand_pack(wave_base + pos[j], kmers[j]);
+                    staged += (uint32_t)__builtin_popcountll(ballot);
+                }
+                if (staged > DENSE_STAGE - 64 * PROBES) flush();
+            }
+        }
+    }
+    if (MODE == 0 && staged) flush();
+    if (MODE != 0 && checksum == 0x9E3779B1u) n_cand[0] = checksum;
 }
 
 // ---- pass 2: candidates -> anchors -------------------------------------------------------------------------------------
@@ -326,9 +474,15 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
         int64_t blocks = (n_units + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
         const dim3 grid((unsigned)blocks), block(256);
+#ifdef KP_SCAN_LANE_OWNED  // (A/B builds: the round-2 kernel, every lane walking its own selected positions)
         if (mode == 1) hipLaunchKernelGGL((kp_scan_kernel<1, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
         else if (mode == 2) hipLaunchKernelGGL((kp_scan_kernel<2, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
         else hipLaunchKernelGGL((kp_scan_kernel<0, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+#else
+        if (mode == 1) hipLaunchKernelGGL((kp_scan_dense_kernel<1>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+        else if (mode == 2) hipLaunchKernelGGL((kp_scan_dense_kernel<2>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+        else hipLaunchKernelGGL((kp_scan_dense_kernel<0>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+#endif
     }
     if (after_scan) (void)hipEventRecord(after_scan, stream);
     hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap,
