@@ -291,14 +291,14 @@ def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
 
 
 L2_GATHER_ROOF_G = 269.0  # G independent 8-byte reads per second out of a 2 MB table (profiles/l2_gather_r2.txt)
-FILL_CYCLES_PER_WAVE_STEP = 3320 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r2.txt)
+FILL_CYCLES_PER_WAVE_STEP = 2948 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r3.txt)
 FILL_CLOCK_HZ = 2.26e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/r2_pmc.txt)
 
 
 def offline_pmc(args) -> dict | None:
     """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
-    collection of this same command (profiles/scan_pmc_r2.json) and are reported only for the workload it ran."""
-    path = ROOT / "profiles" / "scan_pmc_r2.json"
+    collection of this same command (profiles/scan_pmc_r3.json) and are reported only for the workload it ran."""
+    path = ROOT / "profiles" / "scan_pmc_r3.json"
     try:
         pmc = json.loads(path.read_text())
     except OSError:
@@ -698,7 +698,7 @@ def main() -> None:
             },
             "e2e": e2e,
             "roofline": {
-                "bound": "hbm", "kernel": "kp_scan_kernel (" + ("pass over K and O genes" if shared else "K database pass") + ")", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": "kp_scan_dense_kernel (" + ("pass over K and O genes" if shared else "K database pass") + ")", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "device_copy_GBps_measured": round(copy_gbps, 1),  # torch copy of 1 GiB, read + write bytes
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,

@@ -31,6 +31,9 @@ for what in "$@"; do
       (cd /tmp && rocprofv3 -L > $OUT/${TAG}_counters.txt 2>&1); wc -l $OUT/${TAG}_counters.txt;;
     pmc_clk)
       (cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/${TAG}_pmc_clk -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_pmc_clk.log 2>&1); tail -2 $OUT/${TAG}_pmc_clk.log | cut -c1-200;;
+    pmc_prot)  # the latency-bound kernels after the fill: instruction counts and wave cycles
+      (cd /tmp && timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY \
+        --output-format csv -d $OUT/${TAG}_pmc_prot -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_pmc_prot.log 2>&1); tail -2 $OUT/${TAG}_pmc_prot.log | cut -c1-200;;
     pmc_mem)
       (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_pmc_fetch.log 2>&1)
       (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python $GRAFT_REPO_ROOT/bench.py $SMALL > $OUT/${TAG}_pmc_write.log 2>&1)

@@ -38,7 +38,7 @@ def cost(op: str) -> float:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("kernel", nargs="?", default="kp_sw_kernel")
-    ap.add_argument("--marker", default="v_pk_max_u16", help="comma-separated opcodes that identify the hot blocks")
+    ap.add_argument("--marker", default="v_pk_max_u16,v_pk_maximum3_f16", help="comma-separated opcodes that identify the hot blocks")
     ap.add_argument("--top", type=int, default=1)
     ap.add_argument("--source", default="kp_sw.hip")
     ap.add_argument("--flags", default="", help="extra compile flags")

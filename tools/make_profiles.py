@@ -68,7 +68,7 @@ def pmc(tag: str) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--round", default="r2")
+    ap.add_argument("--round", default="r3")
     args = ap.parse_args()
     rd, tag = args.round, args.tag
     done = []
@@ -96,31 +96,33 @@ def main() -> int:
                  "# FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled for wide streaming reads (MI355X guide, HBM section).",
                  "# GRBM_GUI_ACTIVE sums the 8 XCDs: shader clock = GRBM_GUI_ACTIVE / 8 / dispatches / launch duration."]
         for k in sorted(counters):
-            if not any(x in k for x in ("kp_sw", "kp_scan", "kp_expand", "rocprim", "kp_chain")):
+            if not any(x in k for x in ("kp_sw", "kp_scan", "kp_expand", "rocprim", "kp_chain", "kp_anchor", "kp_protein", "kp_reduce", "kp_hit")):
                 continue
             lines.append(k)
             for c, (v, n) in sorted(counters[k].items()):
                 lines.append(f"    {c:<24} {v:>16.6g}  over {n} dispatches  = {v / max(n, 1):.6g} per launch")
         (PROF / f"{rd}_pmc.txt").write_text("\n".join(lines) + "\n")
-        scan = next((v for k, v in counters.items() if k.startswith("kp_scan_kernel")), None)
+        scan_name = next((k for k in counters if k.startswith("kp_scan_dense_kernel<0")), None) or \
+            next((k for k in counters if k.startswith("kp_scan_kernel")), None)
+        scan = counters.get(scan_name)
         if scan and "FETCH_SIZE" in scan and "WRITE_SIZE" in scan:
             fetch = scan["FETCH_SIZE"][0] / scan["FETCH_SIZE"][1] * 1024 * 2
             write = scan["WRITE_SIZE"][0] / scan["WRITE_SIZE"][1] * 1024
             js = {"workload": {"db": "kpsc", "batch": 1000, "length": 5.0e6},
                   "traffic_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "source": f"profiles/{rd}_pmc.txt: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 "
-                            "(gfx950 note of the MI355X guide), averages over the dispatches of kp_scan_kernel<0, false>"}
+                            f"(gfx950 note of the MI355X guide), averages over the dispatches of {scan_name}"}
             if "TCC_REQ_sum" in scan:
                 js["tcc_req_per_launch"] = scan["TCC_REQ_sum"][0] / scan["TCC_REQ_sum"][1]
                 js["tcc_hit_per_launch"] = scan["TCC_HIT_sum"][0] / scan["TCC_HIT_sum"][1]
             (PROF / f"scan_pmc_{rd}.json").write_text(json.dumps(js, indent=1) + "\n")
         done.append("pmc")
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_cost.py"), "kp_sw_kernel", "--top", "1"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "isa_cost.py"), "kp_sw_kernel", "--marker", "v_pk_max_u16,v_pk_maximum3_f16", "--top", "1"], capture_output=True, text=True)
     if r.returncode == 0:
         (PROF / f"fill_isa_cost_{rd}.txt").write_text(
             "# python tools/isa_cost.py kp_sw_kernel --top 1: the 8-step body of the 16-diagonal class (two tasks per register:\n"
             "# 8 steps x 64 lanes x 4 cells x 2 tasks = 4096 cells per wave), priced with the issue costs measured by\n"
-            "# tools/microbench/valu_rate*.hip (profiles/valu_rate*_r2.txt)\n" + r.stdout)
+            "# tools/microbench/valu_rate*.hip (profiles/valu_rate*_r2.txt; v_pk_maximum3_f16: profiles/pk_max3_r3.txt)\n" + r.stdout)
         done.append("isa_cost")
     print("wrote:", ", ".join(done))
     return 0
