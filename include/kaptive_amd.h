@@ -36,6 +36,7 @@ extern "C" {
 #define KP_ENOMEM (-3)    /* host or device allocation failed */
 #define KP_ESTATE (-4)    /* call out of order (no database loaded, no batch aligned, ...) */
 #define KP_EOVERFLOW (-5) /* an internal device buffer overflowed and the automatic retry also failed */
+#define KP_ENOTSUP (-6)   /* the host lacks what the call needs (kp_fasta_ingest: no libbz2 / liblzma to load) */
 
 typedef struct kp_ctx kp_ctx;     /* one GPU + stream + resident database */
 typedef struct kp_batch kp_batch; /* a set of packed assemblies resident in HBM, plus its results */
@@ -97,6 +98,8 @@ KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
  * packed form (src/kaptive/core/genome.py:194-214: open by suffix, read everything, parse). */
 #define KP_FASTA_GZIP 1
 #define KP_FASTA_KEEP_TEXT 2
+#define KP_FASTA_BZ2 4 /* bzip2 stream(s): libbz2 of the host, looked up at first use; KP_ENOTSUP when the host has none */
+#define KP_FASTA_XZ 8  /* .xz stream(s): liblzma of the host, likewise (the reference opens .gz / .bz2 / .xz by suffix) */
 KP_API int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out);
 /* Many files in one call, on `threads` host threads of the library's own (0 = one per core, at most n_files): file i is
  * data[i][0 .. n[i]) with flags[i]; out[i] and rc[i] are what kp_fasta_ingest would have returned for it.  A reader that

@@ -105,13 +105,29 @@ def pack_contigs(seqs: np.ndarray, offsets: np.ndarray, lengths: np.ndarray):
         h.kp_fasta_free(out)
 
 
-def fasta_ingest(data: bytes, gzipped: bool = False):
+FASTA_FLAGS = {None: 0, "": 0, False: 0, True: 1, "gz": 1, "bz2": 4, "xz": 8}  # KP_FASTA_GZIP / _BZ2 / _XZ
+ENOTSUP = -6
+
+
+def _host_inflate(data: bytes, compression) -> bytes:
+    """bz2 / xz through Python's own modules: only for hosts whose libbz2 / liblzma the library could not load."""
+    import bz2
+    import lzma
+
+    return (bz2.decompress if compression == "bz2" else lzma.decompress)(data)
+
+
+def fasta_ingest(data: bytes, gzipped: "bool | str | None" = False):
     """A FASTA file's bytes -> (PackedAssembly, contig names, sequence text uint8, contig lengths int32) in one native
-    pass (kp_fasta_ingest: inflate if gzipped, split records, strip whitespace, pack; no GPU needed)."""
+    pass (kp_fasta_ingest: inflate -- `gzipped` is True / "gz", "bz2" or "xz" --, split records, strip whitespace, pack;
+    no GPU needed)."""
     h = lib()
     h.kp_fasta_free.restype = None
     out = C.POINTER(PackedFasta)()
-    rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32((1 if gzipped else 0) | 2), C.byref(out))
+    rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(FASTA_FLAGS[gzipped] | 2), C.byref(out))
+    if rc == ENOTSUP:
+        data = _host_inflate(data, gzipped)
+        rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(2), C.byref(out))
     if rc != 0:
         raise ValueError(f"kp_fasta_ingest failed ({rc}): not a readable FASTA / gzip stream, or longer than KP_MAX_ASM_LEN")
     record = _FastaRecord(out)  # frees the native record when the arrays below are gone
@@ -119,6 +135,20 @@ def fasta_ingest(data: bytes, gzipped: bool = False):
     p = out.contents
     seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)
     return pa, names, seqs, pa.ctg_len.copy()
+
+
+def compression_is_native() -> bool:
+    """Whether the library found libbz2 and liblzma on this host (both tried with an empty stream)."""
+    h = lib()
+    out = C.POINTER(PackedFasta)()
+    h.kp_fasta_free.restype = None
+    ok = True
+    for f in (4, 8):
+        rc = h.kp_fasta_ingest(b"", C.c_int64(0), C.c_int32(f), C.byref(out))
+        if rc == 0:
+            h.kp_fasta_free(out)
+        ok = ok and rc != ENOTSUP
+    return ok
 
 
 def fasta_ingest_many(datas: "list[bytes]", gzipped: "list[bool] | bool" = False, threads: int = 0) -> list:
@@ -129,10 +159,13 @@ def fasta_ingest_many(datas: "list[bytes]", gzipped: "list[bool] | bool" = False
     n = len(datas)
     if n == 0:
         return []
-    flags = [gzipped] * n if isinstance(gzipped, bool) else list(gzipped)
+    flags = [gzipped] * n if isinstance(gzipped, (bool, str)) or gzipped is None else list(gzipped)
+    if any(FASTA_FLAGS[g] & 12 for g in flags) and not compression_is_native():
+        datas = [_host_inflate(d, g) if FASTA_FLAGS[g] & 12 else d for d, g in zip(datas, flags)]
+        flags = [None if FASTA_FLAGS[g] & 12 else g for g in flags]
     ptrs = (C.c_char_p * n)(*datas)
     lens = (C.c_int64 * n)(*[len(d) for d in datas])
-    fl = (C.c_int32 * n)(*[(1 if g else 0) | 2 for g in flags])
+    fl = (C.c_int32 * n)(*[FASTA_FLAGS[g] | 2 for g in flags])
     outs = (C.POINTER(PackedFasta) * n)()
     rcs = (C.c_int32 * n)()
     rc = h.kp_fasta_ingest_many(ptrs, lens, fl, C.c_int32(n), C.c_int32(threads), outs, rcs)

@@ -128,13 +128,8 @@ class GenomeAssembly:
         # reference opens by suffix, reads everything and hands the bytes to rammappy's parser (genome.py:194-214, 35-46).
         from kaptive_amd import _native
 
-        comp = m.group("compression")
-        if comp in ("bz2", "xz"):
-            with _OPENERS[comp](filepath, mode="rb") as handle:
-                data = handle.read()
-        else:
-            data = filepath.read_bytes()
-        return cls._from_ingest(filepath.name.removesuffix(m.group()), _native.fasta_ingest(data, gzipped=comp == "gz"))
+        comp = m.group("compression")  # None, "gz", "bz2" or "xz": all inflated natively (zlib; libbz2 / liblzma of the host)
+        return cls._from_ingest(filepath.name.removesuffix(m.group()), _native.fasta_ingest(filepath.read_bytes(), gzipped=comp))
 
     @classmethod
     def _from_ingest(cls, id_: str, ingested) -> "GenomeAssembly":
@@ -160,13 +155,8 @@ class GenomeAssembly:
             m = _FASTA_NAME.search(filepath.name)
             if not m:
                 raise NotImplementedError(f"Unsupported format: {filepath}")
-            comp = m.group("compression")
-            if comp in ("bz2", "xz"):
-                with _OPENERS[comp](filepath, mode="rb") as handle:
-                    datas.append(handle.read())
-            else:
-                datas.append(filepath.read_bytes())
-            gz.append(comp == "gz")
+            datas.append(filepath.read_bytes())
+            gz.append(m.group("compression"))
             ids.append(filepath.name.removesuffix(m.group()))
         return [cls._from_ingest(i, r) for i, r in zip(ids, _native.fasta_ingest_many(datas, gz, threads))]
 

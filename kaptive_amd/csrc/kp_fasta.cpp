@@ -5,6 +5,7 @@
 // row (f1).  Record name = first word of the header line; sequence = every following line up to the next '>' with
 // whitespace removed; A C G T/U (either case) -> 0..3, anything else is an N run.  No GPU involved; ctypes releases the
 // GIL, so callers pack many files from a thread pool.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -137,6 +138,112 @@ int inflate_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
     return KP_OK;
 }
 
+// ---- bzip2 and xz: the image ships the shared libraries (libbz2.so.1.0, liblzma.so.5) without their headers, so the two
+// stream structures are declared here from the libraries' stable, documented ABI and the entry points are looked up at
+// first use.  A host without the libraries gets KP_ENOTSUP and the Python side falls back to its own bz2 / lzma modules.
+struct BzStream {  // bz_stream of bzlib.h (1.0.x)
+    char *next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+    char *next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+    void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+};
+struct LzmaStream {  // lzma_stream of lzma/base.h (5.x)
+    const uint8_t *next_in; size_t avail_in; uint64_t total_in;
+    uint8_t *next_out; size_t avail_out; uint64_t total_out;
+    const void *allocator; void *internal;
+    void *reserved_ptr1, *reserved_ptr2, *reserved_ptr3, *reserved_ptr4;
+    uint64_t reserved_int1, reserved_int2; size_t reserved_int3, reserved_int4;
+    int reserved_enum1, reserved_enum2;
+};
+struct Codecs {
+    int (*bz_init)(BzStream *, int, int) = nullptr;
+    int (*bz_run)(BzStream *) = nullptr;
+    int (*bz_end)(BzStream *) = nullptr;
+    int (*xz_decoder)(LzmaStream *, uint64_t, uint32_t) = nullptr;
+    int (*xz_code)(LzmaStream *, int) = nullptr;
+    void (*xz_end)(LzmaStream *) = nullptr;
+    Codecs() {
+        for (const char *name : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                bz_init = reinterpret_cast<decltype(bz_init)>(dlsym(h, "BZ2_bzDecompressInit"));
+                bz_run = reinterpret_cast<decltype(bz_run)>(dlsym(h, "BZ2_bzDecompress"));
+                bz_end = reinterpret_cast<decltype(bz_end)>(dlsym(h, "BZ2_bzDecompressEnd"));
+                if (bz_init && bz_run && bz_end) break;
+                bz_init = nullptr;
+            }
+        }
+        for (const char *name : {"liblzma.so.5", "liblzma.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                xz_decoder = reinterpret_cast<decltype(xz_decoder)>(dlsym(h, "lzma_stream_decoder"));
+                xz_code = reinterpret_cast<decltype(xz_code)>(dlsym(h, "lzma_code"));
+                xz_end = reinterpret_cast<decltype(xz_end)>(dlsym(h, "lzma_end"));
+                if (xz_decoder && xz_code && xz_end) break;
+                xz_decoder = nullptr;
+            }
+        }
+    }
+};
+const Codecs &codecs() {
+    static const Codecs c;
+    return c;
+}
+
+// bzip2 stream(s) -> bytes (concatenated streams are read through, as bz2.open does)
+int bunzip_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
+    const Codecs &c = codecs();
+    if (!c.bz_init) return KP_ENOTSUP;
+    out.clear();
+    int64_t at = 0;
+    while (at < n) {
+        BzStream z;
+        std::memset(&z, 0, sizeof z);
+        if (c.bz_init(&z, 0, 0) != 0) return KP_ENOMEM;
+        z.next_in = reinterpret_cast<char *>(const_cast<uint8_t *>(data + at));
+        int rc = 0;
+        while (rc != 4 /* BZ_STREAM_END */) {
+            if (z.avail_in == 0) z.avail_in = (unsigned)std::min<int64_t>(n - (reinterpret_cast<uint8_t *>(z.next_in) - data), 1 << 30);
+            const size_t have = out.size();
+            out.resize(have + std::max<size_t>(1 << 20, have / 2));
+            z.next_out = reinterpret_cast<char *>(out.data() + have);
+            z.avail_out = (unsigned)std::min<size_t>(out.size() - have, 1u << 30);
+            const size_t room = z.avail_out;
+            const unsigned in_before = z.avail_in;
+            rc = c.bz_run(&z);
+            out.resize(have + (room - z.avail_out));
+            if (rc != 0 /* BZ_OK */ && rc != 4) { c.bz_end(&z); return KP_EINVAL; }
+            if (rc == 0 && z.avail_in == 0 && in_before == 0 && room == z.avail_out) { c.bz_end(&z); return KP_EINVAL; }  // truncated
+        }
+        at = (int64_t)(reinterpret_cast<uint8_t *>(z.next_in) - data);
+        c.bz_end(&z);
+    }
+    return KP_OK;
+}
+
+// .xz stream(s) -> bytes (LZMA_CONCATENATED, as lzma.open does)
+int unxz_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
+    const Codecs &c = codecs();
+    if (!c.xz_decoder) return KP_ENOTSUP;
+    out.clear();
+    if (n == 0) return KP_OK;
+    LzmaStream z;
+    std::memset(&z, 0, sizeof z);
+    if (c.xz_decoder(&z, UINT64_MAX, 0x08u /* LZMA_CONCATENATED */) != 0) return KP_ENOMEM;
+    z.next_in = data;
+    z.avail_in = (size_t)n;
+    int rc = 0;
+    while (rc != 1 /* LZMA_STREAM_END */) {
+        const size_t have = out.size();
+        out.resize(have + std::max<size_t>(1 << 20, have / 2));
+        z.next_out = out.data() + have;
+        z.avail_out = out.size() - have;
+        const size_t room = z.avail_out;
+        rc = c.xz_code(&z, z.avail_in == 0 ? 3 /* LZMA_FINISH */ : 0 /* LZMA_RUN */);
+        out.resize(have + (room - z.avail_out));
+        if (rc != 0 && rc != 1) { c.xz_end(&z); return KP_EINVAL; }  // (LZMA_BUF_ERROR = 10 on truncated input)
+    }
+    c.xz_end(&z);
+    return KP_OK;
+}
+
 int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **out);
 
 }  // namespace
@@ -152,9 +259,10 @@ int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out) {
 int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out) {
     if (!out || (n > 0 && !data) || n < 0) return KP_EINVAL;
     *out = nullptr;
-    if (flags & KP_FASTA_GZIP) {
+    if (flags & (KP_FASTA_GZIP | KP_FASTA_BZ2 | KP_FASTA_XZ)) {
         std::vector<uint8_t> text;
-        const int rc = inflate_all(data, n, text);
+        const int rc = (flags & KP_FASTA_GZIP) ? inflate_all(data, n, text)
+                       : (flags & KP_FASTA_BZ2) ? bunzip_all(data, n, text) : unxz_all(data, n, text);
         if (rc) return rc;
         return pack_text(text.data(), (int64_t)text.size(), (flags & KP_FASTA_KEEP_TEXT) != 0, out);
     }

@@ -206,6 +206,16 @@ def test_from_file_goes_through_the_native_ingest(tmp_path):
         GenomeAssembly.from_file(cut)
     with pytest.raises(NotImplementedError):
         GenomeAssembly.from_file(tmp_path / "x.txt")
+    # bz2 and xz are inflated inside the library too (libbz2 / liblzma of the host, looked up at first use): several
+    # streams in one file are read through, a truncated stream raises
+    assert _native.compression_is_native(), "libbz2.so.1 / liblzma.so.5 are part of the image"
+    for ext, squeeze in ((".bz2", bz2.compress), (".xz", lzma.compress)):
+        pa, names, seqs, _ = _native.fasta_ingest(squeeze(fa[:10000]) + squeeze(fa[10000:]), gzipped=ext[1:])
+        assert np.array_equal(seqs, genome.contigs.seqs) and tuple(names) == genome.contigs.ids
+        with pytest.raises(ValueError):
+            _native.fasta_ingest(squeeze(fa)[:3000], gzipped=ext[1:])
+        with pytest.raises(ValueError):
+            _native.fasta_ingest(b"not a compressed stream at all", gzipped=ext[1:])
 
 
 def test_ingest_views_outlive_the_call_and_buffers_are_recycled():
