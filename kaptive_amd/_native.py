@@ -29,7 +29,7 @@ EXPORTS = (
     "kp_host_free", "kp_host_pinned_bytes", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
-    "kp_batch_tasks", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
+    "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
@@ -314,7 +314,7 @@ def lib() -> C.CDLL:
                 h = C.CDLL(str(LIB_PATH))
                 h.kp_last_error.restype = C.c_char_p
                 h.kp_ctx_stream.restype = C.c_void_p
-                for f in ("kp_db_n_postings", "kp_batch_anchors", "kp_batch_tasks"):
+                for f in ("kp_db_n_postings", "kp_batch_anchors", "kp_batch_tasks", "kp_batch_task_results"):
                     getattr(h, f).restype = C.c_int64
                 h.kp_ctx_destroy.restype = None
                 h.kp_batch_destroy.restype = None
@@ -586,6 +586,16 @@ class Batch:
         self.ctx._check(n, "kp_batch_tasks")
         out = np.zeros(n, TASK_DTYPE)
         lib().kp_batch_tasks(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
+        return out
+
+
+    def task_results(self, asm_index: int) -> np.ndarray:
+        """[n_tasks, 7] int32 -- score, q_start, q_end, t_start, t_end, matches, block_len -- row for row with ``tasks``;
+        tasks below the score cut-off carry their score and zeros (kp_batch_task_results)."""
+        n = lib().kp_batch_task_results(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))
+        self.ctx._check(n, "kp_batch_task_results")
+        out = np.zeros((n, 7), np.int32)
+        lib().kp_batch_task_results(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
         return out
 
 

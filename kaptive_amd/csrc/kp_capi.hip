@@ -1111,6 +1111,32 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64
     return n;
 }
 
+int64_t kp_batch_task_results(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
+    if (!ctx || !b || b->ctx != ctx || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    const int64_t n_tasks = kp_batch_tasks(ctx, b, a, nullptr, 0);  // (also fetches the task lists)
+    if (n_tasks < 0) return n_tasks;
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    int64_t n = 0;
+    std::vector<KpSwResult> res;
+    for (int c = 0; c < KP_N_CLASSES; ++c) {
+        const size_t nt = w->h_tasks[c].size();
+        res.resize(nt);
+        if (nt && hipMemcpy(res.data(), w->d_results.p + (size_t)c * w->task_cap, nt * sizeof(KpSwResult), hipMemcpyDeviceToHost) != hipSuccess)
+            return kp_fail(ctx, KP_EHIP, "D2H task results failed");
+        for (size_t i = 0; i < nt; ++i) {
+            if (w->h_tasks[c][i].asm_id != a) continue;
+            if (out7 && n < cap) {
+                const KpSwResult &r = res[i];
+                int32_t *o = out7 + 7 * n;
+                o[0] = r.score; o[1] = r.q_start; o[2] = r.q_end; o[3] = r.t_start; o[4] = r.t_end; o[5] = r.matches; o[6] = r.block_len;
+            }
+            ++n;
+        }
+    }
+    return n;
+}
+
 // ---- batched typing ---------------------------------------------------------------------------------------------------
 int kp_db_load_typing(kp_ctx *ctx, const kp_typing_tables *t) {
     if (!ctx) return kp_fail(nullptr, KP_EINVAL, "null context");

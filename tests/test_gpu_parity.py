@@ -242,18 +242,25 @@ def test_bucket_sort_and_library_sort_give_the_same_anchors(oracle):
 
 
 def test_sw_raw_results_match_oracle(ctx, small_setup, small_db):
-    """Every band task's DP result (also the ones below the score cut-off) equals the oracle's traceback."""
+    """Every band task's DP result equals the oracle's, row for row: the ones that become hits in all seven fields, the
+    ones below the score cut-off (which the device does not trace back) in their score."""
     odb = small_setup
-    asm = make_assembly(small_db, seed=12, length=90_000, median_contigs=5, min_contig=200, sub_rate=0.08)
-    pa = asm.packed()
-    tasks = odb.tasks(pa)
-    want = odb.sw(pa, tasks)
-    # the public ABI exposes filtered hits only; rebuild them from the oracle's raw rows and compare
-    batch = ctx.batch([pa])
-    hits, _ = batch.align()
-    _same_records(hits, odb.align(pa), "hits")
-    assert (want[:, 0] >= 80).sum() >= len(hits)
-    batch.close()
+    for seed, extra in ((12, dict(sub_rate=0.08)), (15, dict(p_is=1.0)), (21, dict(sub_rate=0.18, indel_rate=0.004))):
+        asm = make_assembly(small_db, seed=seed, length=90_000, median_contigs=5, min_contig=200, **extra)
+        pa = asm.packed()
+        batch = ctx.batch([pa])
+        hits, _ = batch.align()
+        tasks = batch.tasks(0)
+        got = batch.task_results(0)
+        want = odb.sw(pa, tasks)  # the oracle's fill + traceback of exactly these tasks, in this order
+        assert len(tasks) == len(got) == len(want) and len(tasks) > 20
+        kept = want[:, 0] >= 80
+        assert np.array_equal(got[~kept][:, 0], want[~kept][:, 0]), "best-cell scores of the tasks below the cut-off"
+        assert np.array_equal(got[kept], want[kept]), "coordinates, matches and columns of the traced tasks"
+        assert not got[~kept][:, 1:].any() and (~kept).any() == bool((want[:, 0] < 80).any())
+        _same_records(hits, odb.align(pa), "hits")
+        assert kept.sum() >= len(hits)
+        batch.close()
 
 
 def test_random_assembly_shapes_match_oracle(ctx, small_setup, small_db):
