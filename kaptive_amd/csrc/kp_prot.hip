@@ -321,6 +321,21 @@ __device__ __forceinline__ void stage_blosum(const int8_t *__restrict__ blosum, 
     __syncthreads();
 }
 
+// ---- exact prefix: no DP needed ------------------------------------------------------------------------------------------------
+// When the query (the protein translated from the assembly, stop excluded) consists of the 20 standard residues only and
+// equals the first len1 residues of the target (the database protein, stop included), the reference's result is known
+// without filling a matrix: score = sum of the residues' self-scores, matches = len1, no mismatch, no gap, both spans
+// [0, len1).  Why: every aligned pair scores at most the query residue's self-score, which only the identical residue
+// reaches (true of BLOSUM62 for the 20 standard residues; not for B / Z / X), and every gap costs; so an alignment ending
+// at (i, i) other than the diagonal from (0, 0) scores strictly less than that diagonal, which also never drops to <= 0
+// (self-scores are >= 4): the diagonal wins every cell of the traceback, the path starts at (0, 0), and the global
+// maximum sum(self) is reached at (len1, len1) -- another placement of the whole query further right would end in the
+// same row at a larger column, i.e. later in the reference's row-major scan.  The band always holds the main diagonal
+// (k >= 20).  Most genes of a typed isolate in real data are identical to their reference; in the synthetic benchmark
+// (0-3 % substitutions per locus) practically none is, there the check costs a pass over the residues.
+// `idx` = index in ARNDCQEGHILKMFPSTWYVBJZX*: the standard residues are 0..19.
+__device__ __forceinline__ bool standard_residue(unsigned idx) { return idx < 20u; }
+
 // pairs whose band fits 64 diagonals (and the empty ones): four pairs per wave
 __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                         const int32_t *__restrict__ q_len,
@@ -352,11 +367,33 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
             for (int x = l; x < len2; x += QP) s_seq2[g][x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
         }
         __syncthreads();
-        int steps = mine ? len1 + QP - 1 : 0;
+        bool exact = false;
+        if (!seed_off) {  // (unseeded mode only: a seeded band need not hold the main diagonal)
+            bool same = mine && len1 <= len2;
+            int self = 0;
+            if (same)
+                for (int x = l; x < len1; x += QP) {
+                    const unsigned c1 = s_seq1[g][x], i1 = c1 & 255u;
+                    same = same && standard_residue(i1) && (c1 >> 8) == ((unsigned)s_seq2[g][x] >> 8);
+                    self += (int)s_mat[(i1 * 33u) & 1023u];
+                }
+#pragma unroll
+            for (int o = 1; o < QP; o <<= 1) {
+                same = (__shfl_xor((int)same, o) != 0) && same;
+                self += __shfl_xor(self, o);
+            }
+            exact = same;
+            if (exact && l == 0) {
+                int32_t *o = out8 + 8 * (size_t)p;
+                o[0] = self; o[1] = len1; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = len1; o[6] = 0; o[7] = len1;
+            }
+        }
+        const bool dp = mine && !exact;
+        int steps = dp ? len1 + QP - 1 : 0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
-        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, mine ? len1 : 0, mine ? len2 : 0, k, shift, l, steps);
-        store_result(r, l, out8 + 8 * (size_t)(p < n ? p : 0), QP, mine || empty);
+        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, dp ? len1 : 0, dp ? len2 : 0, k, shift, l, steps);
+        store_result(r, l, out8 + 8 * (size_t)(p < n ? p : 0), QP, dp || empty);
     }
 }
 
@@ -395,6 +432,28 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
             const int shift = seed_off ? seed_off[p] : 0;
             if (fits_registers(len1, len2, 2 * k + 1)) continue;
             if (!staged) { stage_blosum(blosum, s_mat, s_idx, lane); staged = true; }  // many blocks find nothing to do
+            if (!seed_off && len1 <= len2) {  // exact prefix (a gene cut short by a stop or a contig end, otherwise unchanged)
+                const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+                bool same = true;
+                int self = 0;
+                for (int x = lane; x < len1; x += 64) {
+                    const unsigned i1 = s_idx[s1[x]];
+                    same = same && standard_residue(i1) && s1[x] == s2[x];
+                    self += (int)s_mat[(i1 * 33u) & 1023u];
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    same = (__shfl_xor((int)same, o) != 0) && same;
+                    self += __shfl_xor(self, o);
+                }
+                if (same) {
+                    if (lane == 0) {
+                        int32_t *o = out8 + 8 * (size_t)p;
+                        o[0] = self; o[1] = len1; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = len1; o[6] = 0; o[7] = len1;
+                    }
+                    continue;
+                }
+            }
             const RowBuf rb{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1};
             const Result r = protein_pair_strips(rb, s_chunk, s_out, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2,
                                                  k, shift, lane);

@@ -94,6 +94,40 @@ def test_protein_dp_long_and_wide_vs_oracle(ctx, oracle):
     assert (want[:, 0] > 0).sum() >= 8
 
 
+def test_protein_exact_prefix_shortcut_vs_oracle(ctx, oracle):
+    """Pairs the kernels answer without DP (query = standard residues only and a prefix of the target) and their near
+    misses, in both kernels' territory: identical full-length proteins, truncated ones (wide bands), very long ones,
+    repeats where the whole query also fits further right (tie broken by the row-major scan), one substitution, an X or
+    a B in an otherwise identical query, lower case, a query longer than its target."""
+    rng = np.random.default_rng(23)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+    qs, ts = [], []
+    for n in (1, 2, 19, 20, 21, 64, 330, 767, 768, 769, 1500, 4000):
+        t = aa[rng.integers(0, 20, size=n)].tobytes()
+        qs.append(t); ts.append(t + b"*")                      # identical
+        for cut in {1, n // 3, n - 1} - {0}:
+            qs.append(t[:cut]); ts.append(t + b"*")            # exact prefix (premature stop / contig edge)
+        if n > 4:
+            m = bytearray(t); m[n // 2] = ord("W") if m[n // 2] != ord("W") else ord("A")
+            qs.append(bytes(m)); ts.append(t + b"*")           # one substitution
+            x = bytearray(t); x[n // 4] = ord("X")
+            qs.append(bytes(x)); ts.append(bytes(x) + b"*")    # identical but with an X: the DP decides
+            b = bytearray(t); b[n // 4] = ord("B")
+            qs.append(bytes(b)); ts.append(bytes(b) + b"*")
+            qs.append(t.lower()); ts.append(t + b"*")
+            qs.append(t + b"AC"); ts.append(t)                 # query longer than target
+    for unit, reps in ((b"A", 40), (b"MK", 30), (b"GSG", 200)):
+        qs.append(unit * (reps // 2)); ts.append(unit * reps + b"*")  # the query also matches further right
+    q, t = Sequences.from_bytes(qs), Sequences.from_bytes(ts)
+    want = oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    got = ctx.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert len(bad) == 0, (bad[:5], want[bad[:3]], got[bad[:3]], [qs[i][:30] for i in bad[:3]], q.lengths[bad[:3]], t.lengths[bad[:3]])
+    # the shortcut's closed form on the pairs it applies to (first of every length group): all matches, no gaps
+    full = [i for i in range(len(qs)) if ts[i] == qs[i] + b"*" and qs[i].isupper() and not set(qs[i]) & set(b"XB")]
+    assert len(full) >= 12 and all(got[i][1] == len(qs[i]) and got[i][2] == got[i][3] == 0 and got[i][5] == len(qs[i]) for i in full)
+
+
 # ---- aligner stages --------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def small_db():
