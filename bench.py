@@ -323,6 +323,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=1000, help="assemblies per device batch")
     ap.add_argument("--db", choices=sorted(WORKLOADS), default="kpsc")
     ap.add_argument("--length", type=float, default=0.0, help="mean assembly length (0 = the workload's own)")
+    ap.add_argument("--sub-rate", type=float, default=-1.0,
+                    help="substitution rate of the planted loci (default: the generator's own, uniform 0-3 %% per assembly; 0 = "
+                         "loci identical to the database, the common case in real collections)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="steps per end-to-end leg (back to back: the pipeline fills and drains once per leg)")
@@ -361,6 +364,8 @@ def main() -> None:
     # already needs: in the other order the process ends up with two HIP runtimes and sees no device
     import torch  # noqa: F401
     _load_dbs(args.db)
+    if args.sub_rate >= 0:
+        _WL["asm_kw"] = dict(_WL["asm_kw"], sub_rate=args.sub_rate)
     length = args.length or _WL["length"]
     if args.as_rank >= 0 and world > 1:
         raise SystemExit("--as-rank is for single-process runs")
@@ -675,7 +680,9 @@ def main() -> None:
             "config": {
                 "workload": (f"{args.assemblies_total} assemblies sharded over {world} ranks (BASELINE.json config 5 shape): "
                              if args.assemblies_total else "")
-                            + f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU {what}; one step "
+                            + f"{args.assemblies} synthetic {length / 1e6:g} Mbp {args.db} assemblies per GPU "
+                            + (f"(planted loci at {100 * args.sub_rate:g} % substitutions) " if args.sub_rate >= 0 else "")
+                            + f"{what}; one step "
                             f"= all of them, as {n_batches} batches of {args.batch} through context-owned work buffers; packed "
                             "assemblies resident in HBM before the timed region; "
                             + ("one alignment pass over the genes of both databases, one reduction per database" if shared
