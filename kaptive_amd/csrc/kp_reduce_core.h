@@ -73,7 +73,11 @@ KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t seeds_a, uint32_t ia, cons
 }
 
 // Primary / secondary and mapping quality of one gene's hits, in emission order (kp_spec.h).  `parent`, `sub`, `n_sub`:
-// scratch of n ints each.
+// scratch of n ints each.  Cost: a hit is compared with the PRIMARY hits before it and stops at the first one it overlaps
+// by more than half.  Primaries of one gene overlap each other by at most half of the shorter one on the query, and a
+// hit spans at least KP_MIN_SEED_SPAN query bases, so a gene of length L has at most ~2 L / 40 of them (in practice a
+// handful: the gene and its fragments); the n copies of a multi-copy gene (IS elements, hundreds of hits) all cover the
+// same query span, so every one after the first stops at j = 0: n steps, not n^2.
 KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *sub, int32_t *n_sub, const float *ln_half,
                           const float *ln_int) {
     for (int i = 0; i < n; ++i) { sub[i] = 0; n_sub[i] = 0; }
