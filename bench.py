@@ -487,6 +487,7 @@ def main() -> None:
 
         for j in range(min(args.ahead, n_batches)):
             enqueue(j)
+            mark(f"align {j} enqueued")
         for i in range(n_batches):
             if i + args.ahead < n_batches:
                 enqueue(i + args.ahead)
@@ -528,6 +529,7 @@ def main() -> None:
     t0 = time.perf_counter()
     cpu0 = time.thread_time()  # CPU seconds of this (the driving) thread: what a rank needs of a host core
     proc0 = time.process_time()  # ... and of the whole process (driving thread + the HIP runtime's helper threads)
+    allocs0 = _native.device_allocations()  # a device buffer that grows inside the timed steps stalls every pass in flight
     step_ms = []
     for _ in range(args.steps):
         t_step = time.perf_counter()
@@ -542,7 +544,8 @@ def main() -> None:
                  "process_cpu_s": round(time.process_time() - proc0, 3), "elapsed_s": round(elapsed, 3),
                  "max_rss_MB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, 1),
                  "pinned_host_MB": round(_native.pinned_bytes() / 2**20, 1),
-                 "buffer_growth_reruns_in_timed_steps": [sum(x["retries"] for x in slist) for slist in stats]}
+                 "buffer_growth_reruns_in_timed_steps": [sum(x["retries"] for x in slist) for slist in stats],
+                 "device_reallocations_in_timed_steps": _native.device_allocations() - allocs0}
     # (untimed) the alignment kernels of one batch with nothing else on the device: what a launch takes on its own; in
     # the timed steps the passes of consecutive batches overlap and stretch each other's kernels
     alone = []

@@ -65,6 +65,10 @@ KP_API void kp_host_free(void *p);
 /* Page-locked bytes this process currently holds through the library: kp_host_alloc blocks plus the table staging of
  * the contexts' input buffers.  (What a rank pins matters when eight of them share one host.) */
 KP_API int64_t kp_host_pinned_bytes(void);
+/* Device buffers the library has had to RE-allocate (free + allocate a larger one) since the process started.  Each of
+ * those waits for the whole device, i.e. for every pass in flight: a stream of batches should settle at a constant
+ * (work buffers are sized from what the context has learnt, with head-room) and a caller can check that it does. */
+KP_API int64_t kp_device_allocations(void);
 
 /* ---- database ---------------------------------------------------------------------------------------------------
  * Replaces what Serotyper.__init__ prepares for the aligner -- the list of (name, gene bytes) handed to

@@ -26,7 +26,7 @@ TASK_DTYPE = np.dtype(
 
 EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
-    "kp_host_free", "kp_host_pinned_bytes", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
+    "kp_host_free", "kp_host_pinned_bytes", "kp_device_allocations", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
@@ -633,6 +633,14 @@ def randstrobe_top_hits(q_records: np.ndarray, n_queries: int, t_records: np.nda
 def pinned_bytes() -> int:
     """Page-locked host bytes this process holds through the library (kp_host_pinned_bytes)."""
     f = lib().kp_host_pinned_bytes
+    f.restype = C.c_int64
+    return int(f())
+
+
+def device_allocations() -> int:
+    """How many device buffers the library has re-allocated so far (kp_device_allocations): each one stalls every pass
+    in flight, so a settled stream of batches must not add to it."""
+    f = lib().kp_device_allocations
     f.restype = C.c_int64
     return int(f())
 

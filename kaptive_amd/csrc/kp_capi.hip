@@ -1,6 +1,8 @@
 // kp_capi.hip -- the C ABI of libkaptive_amd.so (include/kaptive_amd.h): context, resident database, batches,
 // orchestration of the alignment kernels on the context's stream, and host-side finalisation of the hit table.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,12 +38,17 @@ constexpr size_t ORDER_HEAD = KP_N_CLASSES * 128;  // task-order histogram + cur
 std::mutex g_err_mutex;
 std::string g_global_error = "";
 
+std::atomic<long long> g_dev_allocs{0};  // re-allocations of device buffers since the process started
+
 template <class T>
 struct DevBuf {  // growable device allocation
     T *p = nullptr;
     size_t n = 0;
     hipError_t reserve(size_t want) {
         if (want <= n) return hipSuccess;
+        // hipFree / hipMalloc wait for the whole device: a buffer that grows while passes are in flight stalls the pipeline for
+        // as long as those passes take (kp_device_allocations counts them, so that a caller can show a stream of batches does none)
+        if (p) g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T));
@@ -239,6 +246,8 @@ struct kp_ctx {
     uint32_t anchor_cap = 0, hit_cap = 0;
     uint32_t tasks_per_asm = 0;  // task_cap of a pass = n_asm * tasks_per_asm
     double cand_frac = 0.0;      // cand_cap of a pass = total selected positions * cand_frac
+    int64_t words_hw = 0;        // most packed words any batch of this context held: candidate lists are sized for that, so a
+                                 // work set that meets a slightly larger batch than before does not re-allocate (and stall)
     uint64_t trace_units_per_asm = 0;  // trace buffer of a pass = n_asm * this many 16-byte units
     // resident database
     bool has_db = false;
@@ -615,6 +624,8 @@ int kp_host_alloc(size_t bytes, void **out) {
 
 void kp_host_free(void *p) { pinned_free(p); }
 
+int64_t kp_device_allocations(void) { return (int64_t)g_dev_allocs.load(std::memory_order_relaxed); }
+
 int64_t kp_host_pinned_bytes(void) {
     std::lock_guard<std::mutex> lk(g_pin_mutex);
     return (int64_t)g_pin_bytes;
@@ -804,6 +815,12 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     if (!w->astream) KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->astream, hipStreamNonBlocking));
     hipStream_t stream = w->astream;
     hipEvent_t *ev = w->ev;
+    static const bool dbg = std::getenv("KAPTIVE_AMD_DEBUG_ALIGN") != nullptr;
+    const auto t_e = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) std::fprintf(stderr, "[enqueue_align] %s: %.3f ms\n", what,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_e).count());
+    };
     if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
     if (((uint64_t)b->view.total_words << 4) >> KP_CAND_POS_BITS)
@@ -821,6 +838,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
     KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
+    lap("buffers reserved");
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->in->ready, 0));  // the batch's H2D copies
     if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->after->in->ready, 0));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), stream));
@@ -828,6 +846,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
+    lap("memsets");
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
@@ -850,6 +869,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
                                  stream);
         if (rc) return rc;
     }
+    lap("scan, expand, sort launched");
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, stream);
@@ -862,6 +882,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p,
                  stream, ev[4]);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
+    lap("all launched");
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -875,7 +896,8 @@ static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
     if (ctx->hit_cap == 0) ctx->hit_cap = ctx->opt.hit_cap;
     w->anchor_cap = ctx->anchor_cap;
     w->task_cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max(b->n_asm, 1) * ctx->tasks_per_asm, 1u << 28);
-    w->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)((double)b->view.total_words * 4.0 * ctx->cand_frac));
+    ctx->words_hw = std::max(ctx->words_hw, b->view.total_words + b->view.total_words / 64);  // (batches of one stream differ by a per cent or so)
+    w->cand_cap = std::max<uint64_t>(1 << 16, (uint64_t)((double)ctx->words_hw * 4.0 * ctx->cand_frac));
     w->hit_cap = ctx->hit_cap;
     if (ctx->trace_units_per_asm == 0) ctx->trace_units_per_asm = (uint64_t)ctx->opt.trace_kb_per_asm * 64;
     w->trace_cap = std::max<uint64_t>(4096, (uint64_t)std::max(b->n_asm, 1) * ctx->trace_units_per_asm);
@@ -886,6 +908,12 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
     if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "no database loaded");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KpWork *w = work_of(ctx, b);
+    static const bool dbg = std::getenv("KAPTIVE_AMD_DEBUG_ALIGN") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) std::fprintf(stderr, "[kp_batch_align] %s: %.3f ms\n", what,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
+    };
     if (!w) {  // next work set, round-robin; whoever held it loses its results
         w = &ctx->work[ctx->next_slot++ % KP_WORK_SLOTS];
         if (w->owner) {
@@ -898,6 +926,7 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         w->owner = b;
         b->w = w; b->last_w = w;
     }
+    lap("work set taken");
     size_work(ctx, b, w);
     w->aligned = false; w->finalised = false;
     for (auto &v : w->h_tasks) v.clear();
@@ -905,6 +934,7 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         if (r) { r->split = false; r->scored = false; r->reduced = false; r->sums_valid = false; }
     w->stats[4] = 0;
     int rc = enqueue_align(ctx, b, w);
+    lap("enqueued");
     if (rc) return rc;
     w->aligned = true;
     return KP_OK;

@@ -537,7 +537,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 // (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of the grid and
 // run underneath the 16-diagonal class that fills the chip.
 constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
-constexpr uint32_t NARROW_BLOCKS_PER_CU = 32;  // blocks of the 16-diagonal class (they take quads off a counter)
+#ifndef KP_SW_NARROW_BLOCKS_PER_CU
+#define KP_SW_NARROW_BLOCKS_PER_CU 32
+#endif
+constexpr uint32_t NARROW_BLOCKS_PER_CU = KP_SW_NARROW_BLOCKS_PER_CU;  // blocks of the 16-diagonal class (they take quads off a counter)
 
 #ifndef KP_SW_WAVES
 #define KP_SW_WAVES 4  // waves per SIMD the register budget is set for (two tasks per register: 128 VGPRs)

@@ -77,7 +77,7 @@ def test_eight_ranks_rehearse_config5_on_one_gpu():
     per_rank = cfg["host_per_rank"]
     assert [h["rank"] for h in per_rank] == list(range(8))
     for h in per_rank:
-        assert h["buffer_growth_reruns_in_timed_steps"] == [0], h
+        assert h["buffer_growth_reruns_in_timed_steps"] == [0] and h["device_reallocations_in_timed_steps"] == 0, h
         assert h["process_cpu_s"] > 0 and h["driving_thread_cpu_s"] > 0 and h["max_rss_MB"] > 0 and h["pinned_host_MB"] >= 0
     for rank in (0, 3, 7):  # the same seeds in a process of their own
         one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--assemblies", "32", "--as-rank", str(rank), *common],
@@ -101,6 +101,7 @@ def test_schedule_does_not_change_the_rows():
     assert a["config"]["tsv_rows_sha1"] == b["config"]["tsv_rows_sha1"]
     for line in (a, b):
         assert line["config"]["buffer_growth_reruns_in_timed_steps"] == [0]
+        assert line["config"]["host_per_rank"][0]["device_reallocations_in_timed_steps"] == 0
         assert line["e2e"]["from_host_shards"] > 0 and line["e2e"]["with_tsv"] > 0 and line["e2e"]["tsv_bytes_per_step"] > 0
         assert line["roofline"]["alone"]["ms_per_launch"] > 0 and 0 < line["dp"]["fill_issue_model"]["frac"] < 1.5
 
