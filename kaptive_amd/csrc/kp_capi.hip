@@ -48,7 +48,13 @@ struct DevBuf {  // growable device allocation
         if (want <= n) return hipSuccess;
         // hipFree / hipMalloc wait for the whole device: a buffer that grows while passes are in flight stalls the pipeline for
         // as long as those passes take (kp_device_allocations counts them, so that a caller can show a stream of batches does none)
-        if (p) g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
+        if (p) {
+            g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
+            if (std::getenv("KAPTIVE_AMD_DEBUG_ALLOC"))
+                std::fprintf(stderr, "[DevBuf] re-allocation: %zu -> %zu items of %zu bytes\n", n, want, sizeof(T));
+            want += want / 8;  // a buffer that had to grow once gets head-room: sizes that creep by a per cent from batch to
+                               // batch (the fullest assembly of a batch decides several of them) must not re-allocate each time
+        }
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T));

@@ -33,9 +33,15 @@ constexpr int GO = KP_PROT_GAP_OPEN + KP_PROT_GAP_EXT;
 constexpr int GE = KP_PROT_GAP_EXT;
 constexpr int REG_MAX_LEN = 768;  // residues per sequence the register kernel stages (four pairs per block: 12 KB of LDS)
 
-struct Pay {  // path statistics: a = matches << 16 | mismatches, g = gaps, s = start_i << 16 | start_j
-    unsigned a, g, s;
+// Path statistics a DP state carries: a = matches << 16 | mismatches, g = gaps that consumed a query row << 16 | gaps that
+// consumed a target column.  The start of the path is not carried (round 2 did: a third register through every select):
+// a path that ends in (bi, bj) has consumed matches + mismatches + row gaps rows and matches + mismatches + column gaps
+// columns, so start_i = bi - (m + mm + g_row) and start_j = bj - (m + mm + g_col) -- exactly what the reference's traceback
+// would reach (it stops at the first cell whose M is 0, which is where the counts were reset here).
+struct Pay {
+    unsigned a, g;
 };
+constexpr unsigned GAP_ROW = 0x10000u, GAP_COL = 1u;
 
 // one-lane wave shifts; the edge lane reads 0 (bound_ctrl) and is overridden by the caller where that matters
 __device__ __forceinline__ int from_lower(int v) {  // lane b <- lane b-1
@@ -65,10 +71,10 @@ __device__ __forceinline__ int row_upper(int v) {  // lane b <- lane b+1
     return __builtin_amdgcn_mov_dpp(v, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
 }
 __device__ __forceinline__ Pay row_lower(Pay p) {
-    return Pay{(unsigned)row_lower((int)p.a), (unsigned)row_lower((int)p.g), (unsigned)row_lower((int)p.s)};
+    return Pay{(unsigned)row_lower((int)p.a), (unsigned)row_lower((int)p.g)};
 }
 __device__ __forceinline__ Pay row_upper(Pay p) {
-    return Pay{(unsigned)row_upper((int)p.a), (unsigned)row_upper((int)p.g), (unsigned)row_upper((int)p.s)};
+    return Pay{(unsigned)row_upper((int)p.a), (unsigned)row_upper((int)p.g)};
 }
 
 struct PCell {
@@ -77,7 +83,7 @@ struct PCell {
 };
 
 __device__ __forceinline__ Pay pick(bool c, const Pay &x, const Pay &y) {
-    return Pay{c ? x.a : y.a, c ? x.g : y.g, c ? x.s : y.s};
+    return Pay{c ? x.a : y.a, c ? x.g : y.g};
 }
 
 // one cell (i, j); `left` = (i, j-1): its M, I and their payloads; `up` = (i-1, j): its M, D and their payloads; the
@@ -87,19 +93,19 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
                                           const int8_t *s_mat, int lm, int li, Pay lpm, Pay lpi, int um, int ud, Pay upm,
                                           Pay upd) {
     // D: gap arriving from above (a path would start at a neighbour whose M is 0)
-    upm = pick(um == 0, Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)j}, upm);
+    upm = pick(um == 0, Pay{0, 0}, upm);
     const int d_open = um - GO, d_ext = ud - GE;
     int ndv = max(d_open, d_ext);
     Pay npd = pick(d_open >= d_ext, upm, upd);
-    npd.g += 1;
+    npd.g += GAP_ROW;
     // I: gap arriving from the left
-    lpm = pick(lm == 0, Pay{0, 0, ((unsigned)i << 16) | (unsigned)(j - 1)}, lpm);
+    lpm = pick(lm == 0, Pay{0, 0}, lpm);
     const int i_open = lm - GO, i_ext = li - GE;
     int niv = max(i_open, i_ext);
     Pay npi = pick(i_open >= i_ext, lpm, lpi);
-    npi.g += 1;
+    npi.g += GAP_COL;
     // M: diagonal first, then D, then I, each only if strictly better
-    Pay npm = pick(c.m == 0, Pay{0, 0, ((unsigned)(i - 1) << 16) | (unsigned)(j - 1)}, c.pm);
+    Pay npm = pick(c.m == 0, Pay{0, 0}, c.pm);
     const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
     const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[(x1 * 32 + x2) & 1023u];  // 32: byte outside the alphabet
     int bv = c.m + sc;
@@ -121,9 +127,9 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
                                                          const int8_t *s_mat, int len1, int len2, int k, int shift,
                                                          int l, int max_steps) {
     const int nb = 2 * k + 1;
-    PCell A{0, NEGP, NEGP, Pay{0, 0, 0}, Pay{0, 0, 0}, Pay{0, 0, 0}};
+    PCell A{0, NEGP, NEGP, Pay{0, 0}, Pay{0, 0}, Pay{0, 0}};
     PCell B = A, C = A, D = A;
-    Result r{0, 0, 0, Pay{0, 0, 0}};
+    Result r{0, 0, 0, Pay{0, 0}};
     for (int m = 0; m < max_steps; ++m) {  // max_steps is wave-uniform (the longest pair of the quad)
         const int i = m - l + 1, j0 = i - shift + 4 * l - k;  // column of cell A
         const bool row_ok = i >= 1 && i <= len1;
@@ -163,7 +169,8 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
 // small LDS array that the whole wave flushes one column per lane; the next strip's lanes fetch one column each into
 // registers a chunk ahead and publish it to LDS when its turn comes, so the per-step accesses are LDS only, global
 // latency is paid once per 64 steps, and the kernel needs 10 KB of LDS (it shares the CUs with kp_protein_kernel).
-constexpr int RB_FIELDS = KP_PROT_ROWBUF_FIELDS;  // M, D, payload of M (3), payload of D (3)
+constexpr int RB_FIELDS = 6;  // M, D, payload of M (2), payload of D (2)
+static_assert(RB_FIELDS <= KP_PROT_ROWBUF_FIELDS, "the callers size the scratch with KP_PROT_ROWBUF_FIELDS ints per column");
 constexpr int RB_CHUNK = 64;   // columns published per refill (one per lane)
 constexpr int S2_CAP = 2048;   // residues of the second sequence staged per strip window
 
@@ -189,7 +196,7 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
                                                       const uint8_t *s_idx, const int8_t *s_mat,
                                                       const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
                                                       int len1, int len2, int k, int shift, int lane) {
-    Result r{0, 0, 0, Pay{0, 0, 0}};
+    Result r{0, 0, 0, Pay{0, 0}};
     int pj_lo = 1, pj_hi = 0;  // columns the previous strip left in the row buffer (none yet)
     for (int i0 = 1; i0 <= len1; i0 += 64) {
         const int i = i0 + lane;
@@ -206,12 +213,12 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
         unsigned c1 = 0;
         if (i <= len1) { const uint8_t c = s1[i - 1]; c1 = ((unsigned)c << 8) | s_idx[c]; }
         int m = 0, dv = NEGP, iv = NEGP;  // this lane's previous cell (i, j-1); D of it is what the lane below reads
-        Pay pm{0, 0, 0}, pd{0, 0, 0}, pi{0, 0, 0};
+        Pay pm{0, 0}, pd{0, 0}, pi{0, 0};
         int dm = 0;  // M of (i-1, j-1) and its payload: the upper neighbour of the previous step
-        Pay dpm{0, 0, 0};
+        Pay dpm{0, 0};
         if (lane == 0 && j_lo - 1 >= pj_lo && j_lo - 1 <= pj_hi) {  // only row i0 can have an in-band cell left of the window
             dm = rb.at(0, j_lo - 1);
-            dpm = Pay{(unsigned)rb.at(2, j_lo - 1), (unsigned)rb.at(3, j_lo - 1), (unsigned)rb.at(4, j_lo - 1)};
+            dpm = Pay{(unsigned)rb.at(2, j_lo - 1), (unsigned)rb.at(3, j_lo - 1)};
         }
         int ahead[RB_FIELDS];  // this lane's column of the chunk that is published next
         row_buf_column(rb, j_lo + lane, pj_lo, pj_hi, ahead);
@@ -228,13 +235,13 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
             const int x = t - lane, j = j_lo + x;
             // upper neighbour (i-1, j): lane l-1's cell of the previous step; row i0 reads the previous strip's last row
             int um = from_lower(m), ud = from_lower(dv);
-            Pay upm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g), (unsigned)from_lower((int)pm.s)};
-            Pay upd{(unsigned)from_lower((int)pd.a), (unsigned)from_lower((int)pd.g), (unsigned)from_lower((int)pd.s)};
+            Pay upm{(unsigned)from_lower((int)pm.a), (unsigned)from_lower((int)pm.g)};
+            Pay upd{(unsigned)from_lower((int)pd.a), (unsigned)from_lower((int)pd.g)};
             if (lane == 0) {
                 const int c = t & (RB_CHUNK - 1);
                 um = s_chunk[0][c]; ud = s_chunk[1][c];
-                upm = Pay{(unsigned)s_chunk[2][c], (unsigned)s_chunk[3][c], (unsigned)s_chunk[4][c]};
-                upd = Pay{(unsigned)s_chunk[5][c], (unsigned)s_chunk[6][c], (unsigned)s_chunk[7][c]};
+                upm = Pay{(unsigned)s_chunk[2][c], (unsigned)s_chunk[3][c]};
+                upd = Pay{(unsigned)s_chunk[4][c], (unsigned)s_chunk[5][c]};
             }
             const int raw_um = um;
             const Pay raw_upm = upm;
@@ -258,8 +265,8 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
                 const int slot = xo & (RB_CHUNK - 1);
                 if (lane == 63) {
                     s_out[0][slot] = m; s_out[1][slot] = dv;
-                    s_out[2][slot] = (int)pm.a; s_out[3][slot] = (int)pm.g; s_out[4][slot] = (int)pm.s;
-                    s_out[5][slot] = (int)pd.a; s_out[6][slot] = (int)pd.g; s_out[7][slot] = (int)pd.s;
+                    s_out[2][slot] = (int)pm.a; s_out[3][slot] = (int)pm.g;
+                    s_out[4][slot] = (int)pd.a; s_out[5][slot] = (int)pd.g;
                 }
                 if (slot == RB_CHUNK - 1 || xo == width - 1) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -290,15 +297,16 @@ __device__ __forceinline__ void store_result(Result r, int lane_in_group, int32_
     for (int off = 1; off < 64; off <<= 1) {
         if (off >= width) break;
         const int b2 = __shfl_xor(best, off), i2 = __shfl_xor(bi, off), j2 = __shfl_xor(bj, off);
-        const unsigned a2 = __shfl_xor(bp.a, off), g2 = __shfl_xor(bp.g, off), s2v = __shfl_xor(bp.s, off);
+        const unsigned a2 = __shfl_xor(bp.a, off), g2 = __shfl_xor(bp.g, off);
         // lanes that never saw a positive cell carry best = 0 and must lose against any positive score
         const bool take = b2 > best || (b2 == best && b2 > 0 && (i2 < bi || (i2 == bi && j2 < bj)));
-        if (take) { best = b2; bi = i2; bj = j2; bp = Pay{a2, g2, s2v}; }
+        if (take) { best = b2; bi = i2; bj = j2; bp = Pay{a2, g2}; }
     }
     if (lane_in_group == 0 && active) {
         if (best > 0) {
-            o[0] = best; o[1] = (int)(bp.a >> 16); o[2] = (int)(bp.a & 0xFFFFu); o[3] = (int)bp.g;
-            o[4] = (int)(bp.s >> 16); o[5] = bi; o[6] = (int)(bp.s & 0xFFFFu); o[7] = bj;
+            const int m = (int)(bp.a >> 16), mm = (int)(bp.a & 0xFFFFu), g_row = (int)(bp.g >> 16), g_col = (int)(bp.g & 0xFFFFu);
+            o[0] = best; o[1] = m; o[2] = mm; o[3] = g_row + g_col;
+            o[4] = bi - (m + mm + g_row); o[5] = bi; o[6] = bj - (m + mm + g_col); o[7] = bj;
         } else {
             for (int x = 0; x < 8; ++x) o[x] = 0;
         }
