@@ -275,7 +275,7 @@ struct kp_ctx {
     // typing tables (kp_db_load_typing / kp_db_load_typing_group): one set per database whose genes are in the index
     std::vector<std::unique_ptr<KpTypingGroup>> groups;
     // per typing group: learnt sizes of the reduction buffers
-    struct RunCaps { int kept_cap = 0, piece_cap = 0, prot_cap = 0; };
+    struct RunCaps { int kept_cap = 0, piece_cap = 0, prot_cap = 0; size_t pack_items = 0; /* most words kp_batch_typing packed */ };
     std::vector<RunCaps> run_caps;
     struct GroupStreams { hipStream_t stream = nullptr, aux = nullptr; };
     std::vector<GroupStreams> group_streams;  // reduction streams, per typing group
@@ -1443,7 +1443,13 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
     // then one linear copy each
     const size_t kw = (size_t)std::min(kept_stride, R.kept_cap) * sizeof(KpKept) / 4;
     const size_t pw = (size_t)std::min(piece_stride, R.piece_cap) * sizeof(KpPiece) / 4;
-    KP_HIP_CHECK(ctx, R.d_pack.reserve(n_asm * ((size_t)kept_stride * sizeof(KpKept) + (size_t)piece_stride * sizeof(KpPiece)) / 4));
+    {   // sized from the most any batch of this typing group has needed (plus a quarter), whichever work set it ran on: the
+        // fullest assembly of a batch decides the strides, and three work sets learning that one by one re-allocate for steps
+        size_t &hw = run_caps(ctx, b->group).pack_items;
+        const size_t need = n_asm * ((size_t)kept_stride * sizeof(KpKept) + (size_t)piece_stride * sizeof(KpPiece)) / 4;
+        if (need > hw) hw = need + need / 4;
+        KP_HIP_CHECK(ctx, R.d_pack.reserve(hw));
+    }
     uint32_t *pk = R.d_pack.p, *pp = pk + n_asm * (size_t)kept_stride * sizeof(KpKept) / 4;
     kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(R.d_kept.p), (size_t)R.kept_cap * sizeof(KpKept) / 4, pk,
                         (size_t)kept_stride * sizeof(KpKept) / 4, kw, (int)n_asm, R.stream);
