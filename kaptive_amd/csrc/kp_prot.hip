@@ -123,36 +123,49 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
     c.pm = npm; c.pd = npd; c.pi = npi;
 }
 
+// NC adjacent diagonals per lane: 4 covers any band of up to 64 diagonals; 3 covers 48, which is enough for the default band
+// (k = 20: 41 diagonals) of every pair whose proteins differ by at most 22 residues in length -- nearly all of them -- and
+// costs a quarter less per step.
+template <int NC>
 __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
                                                          const int8_t *s_mat, int len1, int len2, int k, int shift,
                                                          int l, int max_steps) {
     const int nb = 2 * k + 1;
-    PCell A{0, NEGP, NEGP, Pay{0, 0}, Pay{0, 0}, Pay{0, 0}};
-    PCell B = A, C = A, D = A;
+    PCell cell[NC];
+    bool band_ok[NC];  // the lane's diagonals that exist in this pair's band
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cell[c] = PCell{0, NEGP, NEGP, Pay{0, 0}, Pay{0, 0}, Pay{0, 0}};
+        band_ok[c] = NC * l + c < nb;
+    }
     Result r{0, 0, 0, Pay{0, 0}};
     for (int m = 0; m < max_steps; ++m) {  // max_steps is wave-uniform (the longest pair of the quad)
-        const int i = m - l + 1, j0 = i - shift + 4 * l - k;  // column of cell A
+        const int i = m - l + 1, j0 = i - shift + NC * l - k;  // column of the lane's first cell
         const bool row_ok = i >= 1 && i <= len1;
         const unsigned c1 = row_ok ? s_seq1[i - 1] : 0u;
-        unsigned c2[4];
+        unsigned c2[NC];
+        bool in[NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) c2[c] = (j0 + c >= 1 && j0 + c <= len2) ? s_seq2[j0 + c - 1] : 0u;
-        // A: left neighbour = lane l-1's D of the previous step
-        int lm = row_lower(D.m), li = row_lower(D.iv);
-        Pay lpm = row_lower(D.pm), lpi = row_lower(D.pi);
+        for (int c = 0; c < NC; ++c) {
+            const bool col_ok = (unsigned)(j0 + c - 1) < (unsigned)len2;  // 1 <= j <= len2
+            c2[c] = col_ok ? s_seq2[j0 + c - 1] : 0u;
+            in[c] = row_ok && col_ok && band_ok[c];
+        }
+        // first cell: left neighbour = lane l-1's last cell of the previous step
+        int lm = row_lower(cell[NC - 1].m), li = row_lower(cell[NC - 1].iv);
+        Pay lpm = row_lower(cell[NC - 1].pm), lpi = row_lower(cell[NC - 1].pi);
         if (l == 0) { lm = 0; li = NEGP; }
-        prot_cell(A, r, row_ok && j0 >= 1 && j0 <= len2 && 4 * l < nb, i, j0, c1, c2[0], s_mat, lm, li, lpm, lpi, B.m, B.dv,
-                  B.pm, B.pd);
-        prot_cell(B, r, row_ok && j0 + 1 >= 1 && j0 + 1 <= len2 && 4 * l + 1 < nb, i, j0 + 1, c1, c2[1], s_mat, A.m, A.iv, A.pm,
-                  A.pi, C.m, C.dv, C.pm, C.pd);
-        prot_cell(C, r, row_ok && j0 + 2 >= 1 && j0 + 2 <= len2 && 4 * l + 2 < nb, i, j0 + 2, c1, c2[2], s_mat, B.m, B.iv, B.pm,
-                  B.pi, D.m, D.dv, D.pm, D.pd);
-        // D: upper neighbour = lane l+1's A of this step
-        int um = row_upper(A.m), ud = row_upper(A.dv);
-        Pay upm = row_upper(A.pm), upd = row_upper(A.pd);
+        prot_cell(cell[0], r, in[0], i, j0, c1, c2[0], s_mat, lm, li, lpm, lpi, cell[1].m, cell[1].dv, cell[1].pm, cell[1].pd);
+#pragma unroll
+        for (int c = 1; c < NC - 1; ++c)  // inner cells: left = the cell just computed, up = the next cell's previous value
+            prot_cell(cell[c], r, in[c], i, j0 + c, c1, c2[c], s_mat, cell[c - 1].m, cell[c - 1].iv, cell[c - 1].pm, cell[c - 1].pi,
+                      cell[c + 1].m, cell[c + 1].dv, cell[c + 1].pm, cell[c + 1].pd);
+        // last cell: upper neighbour = lane l+1's first cell of this step
+        int um = row_upper(cell[0].m), ud = row_upper(cell[0].dv);
+        Pay upm = row_upper(cell[0].pm), upd = row_upper(cell[0].pd);
         if (l == QP - 1) { um = 0; ud = NEGP; }
-        prot_cell(D, r, row_ok && j0 + 3 >= 1 && j0 + 3 <= len2 && 4 * l + 3 < nb, i, j0 + 3, c1, c2[3], s_mat, C.m, C.iv, C.pm,
-                  C.pi, um, ud, upm, upd);
+        prot_cell(cell[NC - 1], r, in[NC - 1], i, j0 + NC - 1, c1, c2[NC - 1], s_mat, cell[NC - 2].m, cell[NC - 2].iv,
+                  cell[NC - 2].pm, cell[NC - 2].pi, um, ud, upm, upd);
     }
     return r;
 }
@@ -400,7 +413,10 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
         int steps = dp ? len1 + QP - 1 : 0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
-        const Result r = protein_quad_registers(s_seq1[g], s_seq2[g], s_mat, dp ? len1 : 0, dp ? len2 : 0, k, shift, l, steps);
+        // (wave-uniform choice: every pair of the quad that needs the DP fits 48 diagonals)
+        const bool narrow = __all(!dp || 2 * k + 1 <= 3 * QP);
+        const Result r = narrow ? protein_quad_registers<3>(s_seq1[g], s_seq2[g], s_mat, dp ? len1 : 0, dp ? len2 : 0, k, shift, l, steps)
+                                : protein_quad_registers<4>(s_seq1[g], s_seq2[g], s_mat, dp ? len1 : 0, dp ? len2 : 0, k, shift, l, steps);
         store_result(r, l, out8 + 8 * (size_t)(p < n ? p : 0), QP, dp || empty);
     }
 }
