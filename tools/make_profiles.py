@@ -61,7 +61,7 @@ def pmc(tag: str) -> dict:
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+                disp[k][r["Counter_Name"]].add((d, r["Dispatch_Id"]))  # (a counter may be collected in more than one pass)
     return {k: {c: (v, len(disp[k][c])) for c, v in cs.items()} for k, cs in agg.items()}
 
 
