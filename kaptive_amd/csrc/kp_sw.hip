@@ -179,6 +179,18 @@ __device__ __forceinline__ unsigned bfi_v(unsigned mask, unsigned a, unsigned b)
 }
 // a >= b for both halves: the answer in bits 15 and 31, the bits below are of no use to anyone
 __device__ __forceinline__ unsigned ge_word(unsigned a, unsigned b) { return sub_v(or_k<GUARD>(a), b); }
+// a < b for both halves, one instruction: the sign of the 16-bit difference (values are below 2^15, it cannot wrap)
+__device__ __forceinline__ unsigned lt_word(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <unsigned LIT>
+__device__ __forceinline__ unsigned lit_minus(unsigned a) {  // LIT - a
+    unsigned r;
+    asm("v_sub_u32_e32 %0, %2, %1" : "=v"(r) : "v"(a), "n"(LIT));
+    return r;
+}
 
 struct Cell {
     // H - (open + ext) + 12 (= H + 6), the same with the guard bits set, E - ext + 12, F - ext + 12 -- task X low, task Y high
@@ -188,7 +200,8 @@ struct Cell {
 // Direction nibble of a cell, most significant bit first: [D][L][E opened][F opened].  D: the diagonal won (it wins
 // ties, then E).  L: with D, "the diagonal predecessor holds H > 0" (0 = the path starts in this cell); without D,
 // 1 = E, 0 = F.  e / f: the gap states arriving from the left / from above, eo / fo: comparison words "the gap was
-// opened there" (open wins ties) -- computed by the caller, which also knows the band's edge lanes.
+// opened there" (open wins ties) -- computed by the caller, which also knows the band's edge lanes.  In the trace D and L
+// are stored INVERTED (the comparisons that make them are one instruction cheaper that way; the traceback flips them).
 // The three candidates are compared two below their value (d - 2, e - 2, f - 2: the last two are the cell's own
 // pre-charged gap states, and d - 2 is the predecessor's H - (open + ext) plus the biased score), so H itself is never
 // formed.  Four steps share 16 bits per task: a byte of [D, E opened] pairs above a byte of [L, F opened] pairs, the first
@@ -197,20 +210,22 @@ template <bool FIRST>
 __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, unsigned tsh, unsigned e, unsigned eo, unsigned f,
                                         unsigned fo, unsigned ten) {
     const unsigned s = and_k<7u * K1>(pk_shr(prof, tsh));        // score + 4
-    const unsigned nz = add_k<0u - (CB - OE + 1u) * K1>(c.hg);   // H of the diagonal predecessor >= 1
+    // The D and L answers are produced INVERTED (one v_pk_sub_i16 each instead of an OR and a subtraction; the traceback reads
+    // them that way): nzn = "H of the diagonal predecessor is 0", dwn = "the diagonal lost", ewn = "E lost too".
+    const unsigned nzn = lit_minus<(CB - OE) * K1 | GUARD>(c.hmoe);
     const unsigned d = add_v(c.hmoe, s);                         // diagonal candidate - 2, biased by 12
     const unsigned en = add_k<0u - (unsigned)EX * K1>(e), fn = add_k<0u - (unsigned)EX * K1>(f);
     const unsigned m = pk_max3(d, en, fn);
-    const unsigned dw = ge_word(d, m), ew = ge_word(en, m);      // == m, as neither exceeds it
+    const unsigned dwn = lt_word(d, m), ewn = lt_word(en, m);    // (neither exceeds m)
     const unsigned h = pk_max(m, ten);                           // H + 10
     c.hmoe = add_k<0u - 4u * K1>(h);
     c.hg = or_k<GUARD>(c.hmoe);
     c.emex = en;
     c.fmex = fn;
-    const unsigned lw = bfi_v(dw, nz, ew);
+    const unsigned lwn = bfi_v(dwn, ewn, nzn);
     // the bytes that hold the four answers of both tasks, side by side: [D_Y L_Y D_X L_X] and [EO_Y FO_Y EO_X FO_X], each
     // answer in bit 7 of its byte; the second set goes to bit 6, and a step's two bits per byte move down as steps follow
-    const unsigned p1 = (unsigned)__builtin_amdgcn_perm(dw, lw, 0x07030501u), p2 = (unsigned)__builtin_amdgcn_perm(eo, fo, 0x07030501u);
+    const unsigned p1 = (unsigned)__builtin_amdgcn_perm(dwn, lwn, 0x07030501u), p2 = (unsigned)__builtin_amdgcn_perm(eo, fo, 0x07030501u);
     // bit 7 of every byte from p1, bit 6 from p2 (the bits below are leftovers); the accumulator takes exactly those two
     // bits of each byte and moves what it holds two down, so after four steps every bit of it has come through the mask
     const unsigned n = bfi(0x80808080u, p1, shr_k<1>(p2));
@@ -665,14 +680,14 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
                 cur = (pc & 2) ? hi2 : cur;
             }
             const uint32_t word = piece_word(cur, k);
-            if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xAAAAAAAAu) == 0xAAAAAAAAu) {  // eight plain diagonal steps
+            if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xAAAAAAAAu) == 0u) {  // eight plain diagonal steps (D and L are stored inverted)
                 cols += 8; diag += 8; r -= 8;
                 continue;
             }
             // a cell's word: steps 0-3 in the low half, 4-7 in the high half; per half a byte of [L, F opened] pairs below
             // a byte of [D, E opened] pairs, step j's pair at bits 2j+1, 2j
             const uint32_t half = word >> (16 * ((step >> 2) & 1)), sh = 2 * (step & 3);
-            const uint32_t de = (half >> (8 + sh)) & 3u, lf = (half >> sh) & 3u;
+            const uint32_t de = ((half >> (8 + sh)) & 3u) ^ 2u, lf = ((half >> sh) & 3u) ^ 2u;  // (D, L: stored inverted)
             const uint32_t nib = ((de & 2u) << 2) | ((lf & 2u) << 1) | ((de & 1u) << 1) | (lf & 1u);  // [D][L][EO][FO]
             // -> source 0 = diagonal, 1 = diagonal and the path starts here, 2 = E, 3 = F
             const uint32_t src = (nib & 8u) ? ((nib & 4u) ? 0u : 1u) : ((nib & 4u) ? 2u : 3u);
