@@ -2,7 +2,6 @@
 // orchestration of the alignment kernels on the context's stream, and host-side finalisation of the hit table.
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -821,12 +820,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     if (!w->astream) KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->astream, hipStreamNonBlocking));
     hipStream_t stream = w->astream;
     hipEvent_t *ev = w->ev;
-    static const bool dbg = std::getenv("KAPTIVE_AMD_DEBUG_ALIGN") != nullptr;
-    const auto t_e = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (dbg) std::fprintf(stderr, "[enqueue_align] %s: %.3f ms\n", what,
-                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_e).count());
-    };
     if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
         return kp_fail(ctx, KP_EOVERFLOW, "anchor buffer would exceed 2^32 entries; use smaller batches");
     if (((uint64_t)b->view.total_words << 4) >> KP_CAND_POS_BITS)
@@ -844,7 +837,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
     KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
-    lap("buffers reserved");
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->in->ready, 0));  // the batch's H2D copies
     if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->after->in->ready, 0));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), stream));
@@ -852,7 +844,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
-    lap("memsets");
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
@@ -875,7 +866,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
                                  stream);
         if (rc) return rc;
     }
-    lap("scan, expand, sort launched");
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, stream);
@@ -888,7 +878,6 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p,
                  stream, ev[4]);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
-    lap("all launched");
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }
@@ -914,12 +903,6 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
     if (!ctx->has_db) return kp_fail(ctx, KP_ESTATE, "no database loaded");
     KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KpWork *w = work_of(ctx, b);
-    static const bool dbg = std::getenv("KAPTIVE_AMD_DEBUG_ALIGN") != nullptr;
-    const auto t_a = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (dbg) std::fprintf(stderr, "[kp_batch_align] %s: %.3f ms\n", what,
-                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
-    };
     if (!w) {  // next work set, round-robin; whoever held it loses its results
         w = &ctx->work[ctx->next_slot++ % KP_WORK_SLOTS];
         if (w->owner) {
@@ -932,7 +915,6 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         w->owner = b;
         b->w = w; b->last_w = w;
     }
-    lap("work set taken");
     size_work(ctx, b, w);
     w->aligned = false; w->finalised = false;
     for (auto &v : w->h_tasks) v.clear();
@@ -940,7 +922,6 @@ int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
         if (r) { r->split = false; r->scored = false; r->reduced = false; r->sums_valid = false; }
     w->stats[4] = 0;
     int rc = enqueue_align(ctx, b, w);
-    lap("enqueued");
     if (rc) return rc;
     w->aligned = true;
     return KP_OK;

@@ -21,7 +21,10 @@ constexpr int CHAIN_SLICES = 16;  // waves per assembly
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
 // produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
-constexpr int STAGE0 = 256, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
+#ifndef KP_CHAIN_STAGE0
+#define KP_CHAIN_STAGE0 256
+#endif
+constexpr int STAGE0 = KP_CHAIN_STAGE0, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
 
 struct TaskStage {
     KpTask t0[STAGE0], rest[KP_N_CLASSES - 1][STAGE_REST];
