@@ -208,17 +208,19 @@ struct Cell {
 // step's pair lowest in each.
 template <bool FIRST>
 __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, unsigned tsh, unsigned e, unsigned eo, unsigned f,
-                                        unsigned fo, unsigned ten) {
+                                        unsigned fo) {
     const unsigned s = and_k<7u * K1>(pk_shr(prof, tsh));        // score + 4
     // The D and L answers are produced INVERTED (one v_pk_sub_i16 each instead of an OR and a subtraction; the traceback reads
     // them that way): nzn = "H of the diagonal predecessor is 0", dwn = "the diagonal lost", ewn = "E lost too".
     const unsigned nzn = lit_minus<(CB - OE) * K1 | GUARD>(c.hmoe);
     const unsigned d = add_v(c.hmoe, s);                         // diagonal candidate - 2, biased by 12
     const unsigned en = add_k<0u - (unsigned)EX * K1>(e), fn = add_k<0u - (unsigned)EX * K1>(f);
+    // H + 10: the caller floors the arriving E at 0 (e >= 12, so en >= 10 = "H is 0" on this scale) and that makes the
+    // restart at 0 part of the three-way maximum.  A floored gap state changes no H anywhere (H >= 0 beats it as it beats
+    // the true, negative one), and the direction bits of a path with a positive score only ever come from positive states.
     const unsigned m = pk_max3(d, en, fn);
     const unsigned dwn = lt_word(d, m), ewn = lt_word(en, m);    // (neither exceeds m)
-    const unsigned h = pk_max(m, ten);                           // H + 10
-    c.hmoe = add_k<0u - 4u * K1>(h);
+    c.hmoe = add_k<0u - 4u * K1>(m);
     c.hg = or_k<GUARD>(c.hmoe);
     c.emex = en;
     c.fmex = fn;
@@ -235,42 +237,54 @@ __device__ __forceinline__ void dp_cell(Cell &c, unsigned &acc, unsigned prof, u
 struct State {
     Cell A, B, C, D;
     unsigned qb, t0, t1, t2, t3;
-    unsigned best, brow, sA, sB, sC, sD;  // running maximum of the lane's cells (H + 6), step of its last rise, the cells then
+    // running maximum of the lane's cells (H + 6), the PAIR of steps in which it last rose (its first step) and the eight
+    // cells of that pair
+    unsigned best, brow;
+    unsigned s0[4], s1[4];
 };
 
+// Best cell of the lane so far, once per two steps (the comparison, the mask and the row select are shared by eight cells
+// instead of four; the selects of the cells themselves cost the same): a strict rise keeps the first pair, and the saved
+// cells tell the step of the pair and the column later.
+__device__ __forceinline__ void track_pair(State &s, const unsigned (&h0)[4], const unsigned (&h1)[4], unsigned step_k, unsigned fifteen) {
+    const unsigned risen = pk_max3(pk_max3(h0[0], h0[1], h0[2]), pk_max3(h0[3], h1[0], h1[1]), pk_max3(h1[2], h1[3], s.best));
+    const unsigned rose = pk_sign_mask(lt_word(s.best, risen), fifteen);  // halves that rose (best <= risen everywhere)
+    s.best = risen;
+    s.brow = bfi_v(rose, step_k, s.brow);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s.s0[k] = bfi_v(rose, h0[k], s.s0[k]);
+        s.s1[k] = bfi_v(rose, h1[k], s.s1[k]);
+    }
+}
+
 template <int P, bool FIRST>
-__device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned step_k, unsigned prof_mine, unsigned t_next,
-                                        unsigned first_all, unsigned last_all, unsigned edge, unsigned ten, unsigned fifteen) {
+__device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned (&hs)[4], unsigned prof_mine, unsigned t_next,
+                                        unsigned first_all, unsigned last_all, unsigned twelve) {
     constexpr bool ROW = P <= 16;
     s.qb = prof_mine;  // profile of this lane's row m - l, read from LDS by the lane itself (the LDS pipe is idle otherwise;
                        // streaming the rows up the lanes cost a DPP move and a select per step on the busy vector pipe)
 
-    // A: the left neighbour is lane l-1's D of the previous step; left of the band's first diagonal H = 0, E = -inf, so
-    // the band's first lane takes E = -(open + ext), "opened" (one select on the result instead of one per operand)
-    const unsigned l_hmoe = from_lower<ROW>(s.D.hmoe), l_emex = from_lower<ROW>(s.D.emex);
-    const unsigned eA = bfi_v(first_all, edge, pk_max(l_hmoe, l_emex));
-    // (the band's first lane would have to say "opened" here; nobody ever asks: E of that cell is -(open + ext), it loses
-    // to the restart and no path with a positive score stands in state E on the band's first diagonal)
-    const unsigned eoA = ge_word(l_hmoe, l_emex);  // (only bits 15 and 31 are looked at)
-    dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), sub_v(s.B.hg, s.B.fmex), ten);
-    dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max(s.A.hmoe, s.A.emex), sub_v(s.A.hg, s.A.emex),
-                   pk_max(s.C.hmoe, s.C.fmex), sub_v(s.C.hg, s.C.fmex), ten);
-    dp_cell<FIRST>(s.C, acc[2], s.qb, s.t2, pk_max(s.B.hmoe, s.B.emex), sub_v(s.B.hg, s.B.emex),
-                   pk_max(s.D.hmoe, s.D.fmex), sub_v(s.D.hg, s.D.fmex), ten);
-    // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal the same boundary applies
-    const unsigned u_hmoe = from_upper<ROW>(s.A.hmoe), u_fmex = from_upper<ROW>(s.A.fmex);
-    const unsigned fD = bfi_v(last_all, edge, pk_max(u_hmoe, u_fmex));
-    const unsigned foD = ge_word(u_hmoe, u_fmex);  // (same remark for F on the band's last diagonal)
-    dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max(s.C.hmoe, s.C.emex), sub_v(s.C.hg, s.C.emex), fD, foD, ten);
+    // The gap state a cell hands to its right neighbour is max(H - open - ext, E - ext, 0): the floor at 0 (twelve on the
+    // biased scale) is what lets dp_cell leave out the restart (see there); it rides in the three-way maximum for free.
+    // A: the left neighbour is lane l-1's D of the previous step -- that lane forms what it hands over (it has the guard
+    // word of its D already) and the two results cross; left of the band's first diagonal H = 0, so the band's first lane
+    // takes E = 0 (any E <= 0 does), "opened" or not (nobody ever asks: that E loses to the restart and no path with a
+    // positive score stands in state E on the band's first diagonal)
+    const unsigned eA = bfi_v(first_all, twelve, from_lower<ROW>(pk_max3(s.D.hmoe, s.D.emex, twelve)));
+    const unsigned eoA = from_lower<ROW>(sub_v(s.D.hg, s.D.emex));  // (only bits 15 and 31 are looked at)
+    dp_cell<FIRST>(s.A, acc[0], s.qb, s.t0, eA, eoA, pk_max(s.B.hmoe, s.B.fmex), sub_v(s.B.hg, s.B.fmex));
+    dp_cell<FIRST>(s.B, acc[1], s.qb, s.t1, pk_max3(s.A.hmoe, s.A.emex, twelve), sub_v(s.A.hg, s.A.emex),
+                   pk_max(s.C.hmoe, s.C.fmex), sub_v(s.C.hg, s.C.fmex));
+    dp_cell<FIRST>(s.C, acc[2], s.qb, s.t2, pk_max3(s.B.hmoe, s.B.emex, twelve), sub_v(s.B.hg, s.B.emex),
+                   pk_max(s.D.hmoe, s.D.fmex), sub_v(s.D.hg, s.D.fmex));
+    // D: the upper neighbour is lane l+1's A of this step; above the band's last diagonal H = 0 as well (F = 0 there
+    // stands for any F <= 0, as above)
+    const unsigned fD = bfi_v(last_all, twelve, from_upper<ROW>(pk_max(s.A.hmoe, s.A.fmex)));
+    const unsigned foD = from_upper<ROW>(sub_v(s.A.hg, s.A.fmex));
+    dp_cell<FIRST>(s.D, acc[3], s.qb, s.t3, pk_max3(s.C.hmoe, s.C.emex, twelve), sub_v(s.C.hg, s.C.emex), fD, foD);
 
-    // best cell of the lane so far: a strict rise keeps the first row; the cells of that step tell the column later
-    const unsigned risen = pk_max3(pk_max3(s.A.hmoe, s.B.hmoe, s.C.hmoe), s.D.hmoe, s.best);
-    const unsigned keep = pk_sign_mask(ge_word(s.best, risen), fifteen);  // halves that did not rise (best == risen there)
-    s.best = risen;
-    s.brow = bfi_v(keep, s.brow, step_k);
-    s.sA = bfi_v(keep, s.sA, s.A.hmoe); s.sB = bfi_v(keep, s.sB, s.B.hmoe);
-    s.sC = bfi_v(keep, s.sC, s.C.hmoe); s.sD = bfi_v(keep, s.sD, s.D.hmoe);
-
+    hs[0] = s.A.hmoe; hs[1] = s.B.hmoe; hs[2] = s.C.hmoe; hs[3] = s.D.hmoe;
     s.t0 = s.t1; s.t1 = s.t2; s.t2 = s.t3;
     s.t3 = t_next;  // the code of x = m + 3l + 4, this lane's cell D at the next step (also read by the lane itself)
 }
@@ -306,8 +320,8 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     // statements becomes a branch)
     unsigned first_all = l == 0 ? ~0u : 0u, last_all = l == P - 1 ? ~0u : 0u;
     // (VGPR copies of constants that VOP3 / VOP3P instructions cannot take as literals)
-    unsigned ten = (CB - 2u) * K1, fifteen = 15u * K1, edge = GAP_EDGE;
-    asm volatile("" : "+v"(ten), "+v"(fifteen), "+v"(edge), "+v"(first_all), "+v"(last_all));
+    unsigned twelve = CB * K1, fifteen = 15u * K1;  // twelve: a gap state of 0 on the biased scale
+    asm volatile("" : "+v"(twelve), "+v"(fifteen), "+v"(first_all), "+v"(last_all));
 
     // The narrow class hands its quads out by a counter (longest tasks first) to a fixed number of single-wave blocks that
     // keep taking until it is exhausted: 32 per CU, twice what is resident, so the dispatcher always has a block to put
@@ -377,7 +391,9 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
         st.A.hmoe = GAP_EDGE; st.A.hg = GAP_EDGE | GUARD; st.A.emex = GAP_NONE; st.A.fmex = GAP_NONE;
         st.B = st.A; st.C = st.A; st.D = st.A;
         st.qb = PROF_OUT; st.t0 = st.t1 = st.t2 = st.t3 = T_OUT * K1;
-        st.best = GAP_EDGE; st.brow = 0; st.sA = st.sB = st.sC = st.sD = GAP_EDGE;  // H = 0
+        st.best = GAP_EDGE; st.brow = 0;  // H = 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st.s0[k] = st.s1[k] = GAP_EDGE;
         unsigned acc[4] = {0, 0, 0, 0}, held[4] = {0, 0, 0, 0};
         bool saw_n[2] = {false, false};  // an N in the gene or in the target window: the traceback then compares bases itself
 
@@ -499,10 +515,13 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                     // byte pairs -> (X | Y << 16): selector bytes 0x0c are zeros
                     const unsigned ta = __builtin_amdgcn_perm(0u, c0, 0x0c010c00u), tb = __builtin_amdgcn_perm(0u, c1, 0x0c010c00u);
                     const unsigned tcw = __builtin_amdgcn_perm(0u, c2, 0x0c010c00u), td = __builtin_amdgcn_perm(0u, c3, 0x0c010c00u);
-                    dp_step<P, true>(st, acc, (unsigned)mm * K1, p0, ta, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 1) * K1, p1, tb, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 2) * K1, p2, tcw, first_all, last_all, edge, ten, fifteen);
-                    dp_step<P, false>(st, acc, (unsigned)(mm + 3) * K1, p3, td, first_all, last_all, edge, ten, fifteen);
+                    unsigned h0[4], h1[4];
+                    dp_step<P, true>(st, acc, h0, p0, ta, first_all, last_all, twelve);
+                    dp_step<P, false>(st, acc, h1, p1, tb, first_all, last_all, twelve);
+                    track_pair(st, h0, h1, (unsigned)mm * K1, fifteen);
+                    dp_step<P, false>(st, acc, h0, p2, tcw, first_all, last_all, twelve);
+                    dp_step<P, false>(st, acc, h1, p3, td, first_all, last_all, twelve);
+                    track_pair(st, h0, h1, (unsigned)(mm + 2) * K1, fifteen);
                     if (half == 0) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) held[c] = acc[c];
@@ -523,9 +542,19 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned v = (st.best >> (16 * h)) & 0xFFFFu;  // H + 6
-            const int mstar = (int)((st.brow >> (16 * h)) & 0xFFFFu);
-            const unsigned a = (st.sA >> (16 * h)) & 0xFFFFu, bq = (st.sB >> (16 * h)) & 0xFFFFu, cq = (st.sC >> (16 * h)) & 0xFFFFu;
-            int eb = 4 * l + (a == v ? 0 : bq == v ? 1 : cq == v ? 2 : 3);
+            // the first step of the saved pair that holds the maximum, then the first of its cells
+            int mstar = (int)((st.brow >> (16 * h)) & 0xFFFFu), cell = 3;
+            bool in0 = false;
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (((st.s0[k] >> (16 * h)) & 0xFFFFu) == v) { cell = k; in0 = true; }
+            if (!in0) {
+                ++mstar;
+#pragma unroll
+                for (int k = 2; k >= 0; --k)
+                    if (((st.s1[k] >> (16 * h)) & 0xFFFFu) == v) cell = k;
+            }
+            int eb = 4 * l + cell;
             unsigned key = v > ZB ? ((v - ZB) << 15) | (unsigned)(32767 - (q0[h] + mstar - l)) : 0u;
             if (key == 0u) eb = 4 * l;
             bool sn = saw_n[h];
