@@ -264,6 +264,8 @@ struct kp_ctx {
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
+    DevBuf<uint4> d_gene_prof;   // row profiles of the genes for the fill kernel (KpGenes::prof)
+    DevBuf<uint8_t> d_gene_has_n;
     KpSeedIndex index{};
     KpGenes genes{};
     // protein stage
@@ -570,7 +572,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (KpInput *in : ctx->free_inputs) { in->release(); delete in; }
     ctx->free_inputs.clear();
     for (auto &w : ctx->work) w.release();
-    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release();
+    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release(); ctx->d_gene_prof.release(); ctx->d_gene_has_n.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_ln.release();
     for (auto &g : ctx->groups)
@@ -661,6 +663,8 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         n_words += (size_t)(ctx->gene_len[(size_t)g] + 7) / 8;
     }
     std::vector<uint32_t> nib(std::max<size_t>(n_words, 1), 0x44444444u);
+    std::vector<uint16_t> prof(8 * nib.size(), 0);  // eight rows per word of `nib`
+    std::vector<uint8_t> has_n(std::max<size_t>((size_t)n_genes, 1), 0);
     std::vector<uint8_t> rc;
     std::vector<HostPosting> post;
     for (int g = 0; g < n_genes; ++g) {
@@ -677,6 +681,8 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
             for (int i = 0; i < len; ++i) {
                 const uint32_t code = c[i] > 3 ? 4u : c[i];
                 dst[i >> 3] = (dst[i >> 3] & ~(15u << (4 * (i & 7)))) | (code << (4 * (i & 7)));
+                prof[8 * (size_t)(dst - nib.data()) + (size_t)i] = (uint16_t)kp_row_profile(code);
+                if (code > 3u) has_n[(size_t)g] = 1;
             }
             for (int p = 0; p + KP_K <= len; ++p) {  // seed rule + N check, as in kp_spec.h
                 if (c[p] > 3 || c[p + 1] > 3 || c[p + 3] > 3 || ((c[p] ^ c[p + 1] ^ c[p + 3]) & 3u) != KP_SEED_RULE_VALUE)
@@ -738,11 +744,13 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_gene_prof, reinterpret_cast<const uint4 *>(prof.data()), nib.size()))) return rcode;
+    if ((rcode = upload(ctx, ctx->d_gene_has_n, has_n.data(), has_n.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_filter2.p, lds_blocks ? ctx->d_lds_filter.p : nullptr, lds_blocks, ctx->d_slots.p,
                              ctx->d_postings.p, mask, shift};
-    ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes};
+    ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes, ctx->d_gene_prof.p, ctx->d_gene_has_n.p};
     ctx->n_genes = n_genes;
     ctx->gs_bits = 1;
     while (ctx->gs_bits < 18 && (2ull * (uint64_t)n_genes) >> ctx->gs_bits) ++ctx->gs_bits;

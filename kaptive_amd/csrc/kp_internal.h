@@ -73,7 +73,17 @@ struct KpGenes {
     const int32_t *word_off;  // [2 * n_genes] first word of gene g (forward) / n_genes + g (reverse complement)
     const int32_t *len;       // [n_genes]
     int32_t n_genes;
+    // the same sequences as the fill kernel wants them: the score profile of every row (kp_row_profile, 16 bits), eight
+    // rows per uint4 -- entry i belongs to word i of `nib`; rows past a gene's end hold 0 (a row outside the gene)
+    const uint4 *prof;
+    const uint8_t *has_n;     // [n_genes] the gene holds an N
 };
+
+// Score profile of a query row for the fill kernel (kp_sw.hip): five 3-bit fields, field t = score against target code t
+// (0..3 ACGT, 4 = N) + 4 under kp_spec.h's scores (match 2, mismatch -4, N -1); 0 = a row outside the gene (-4 everywhere).
+__host__ __device__ inline uint32_t kp_row_profile(uint32_t qcode) {
+    return qcode < 4u ? ((6u << (3u * qcode)) | (3u << 12)) : (3u | (3u << 3) | (3u << 6) | (3u << 9) | (3u << 12));
+}
 
 // Anchors are sorted (and chained) on a compact form of the spec's key -- same fields in the same order, but only as
 // many bits per field as this database / batch can set -- so that the radix sort has fewer digits to go through:

@@ -76,8 +76,9 @@ constexpr unsigned GAP_NONE = (CB - OE - EX) * K1;          // "no gap": -(open 
 constexpr unsigned GAP_EDGE = (CB - OE) * K1;               // the gap state a band-edge cell sees: opened from H = 0
 constexpr unsigned T_OUT = 12u;                             // shift amount of the N field: columns outside the contig
 // profile of a query row, per task 15 bits: field t (3 bits at 3t) = score against target code t (0..3 ACGT, 4 = N) + 4
-constexpr unsigned PROF_N = 3u | (3u << 3) | (3u << 6) | (3u << 9) | (3u << 12);
+// (kp_row_profile, kp_internal.h: the database holds every gene as a stream of them)
 constexpr unsigned PROF_OUT = 0u;  // -4 everywhere
+__device__ __forceinline__ unsigned nibble(unsigned word, int i) { return (word >> (4 * i)) & 15u; }
 
 // One-lane shifts.  The lane without a source reads 0 (bound_ctrl); every group-edge lane overrides what it receives
 // anyway.  Groups of up to 16 lanes never straddle a DPP row, so the row shifts do; the 32-lane class needs wave shifts.
@@ -92,10 +93,6 @@ __device__ __forceinline__ unsigned from_upper(unsigned v) {  // lane i <- lane 
                           : __builtin_amdgcn_mov_dpp((int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 
-__device__ __forceinline__ unsigned nibble(unsigned word, int i) { return (word >> (4 * i)) & 15u; }
-__device__ __forceinline__ unsigned row_profile(unsigned qcode) {
-    return qcode < 4u ? ((6u << (3u * qcode)) | (3u << 12)) : PROF_N;
-}
 
 // The instructions of the cell, spelled out so that constants stay literals of 2-cycle VOP2 encodings (an SGPR operand
 // makes them 4-cycle) and packed operations are not taken apart.  Plain asm (not volatile): the compiler schedules them.
@@ -292,6 +289,7 @@ __device__ __forceinline__ void dp_step(State &s, unsigned (&acc)[4], unsigned (
 constexpr int PROF_WORDS = 16 * (CH + 4);                // LDS of one block: profile pairs of 64/P groups x (P + CH) rows (P >= 4)
 constexpr int TCODE_HALVES = 16 * (CH + 3 * 4 + 4 + 4);  // ... their target shift amounts, a byte per task (largest for P = 4)
 constexpr int TWORD_WORDS = 2 * 128;                     // ... and the packed words those are cut from
+constexpr int SPREAD_WORDS = 256;                        // four 2-bit codes -> four shift amounts (3 * code), a byte each
 
 // all tasks of one band class, seen from block `block` of `n_blocks` that work on the class
 template <int P>
@@ -300,13 +298,13 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
                                          KpSwEnd *__restrict__ ends, uint4 *__restrict__ trace,
                                          unsigned long long *__restrict__ trace_top, uint64_t trace_cap, uint32_t block,
                                          uint32_t n_blocks, unsigned int *__restrict__ next_quad, uint32_t *s_prof_raw,
-                                         uint16_t *s_t_raw, uint32_t *s_tw_raw) {
+                                         uint16_t *s_t_raw, uint32_t *s_tw_raw, const uint32_t *s_spread) {
     constexpr int G = 64 / P;
     constexpr int TW = CH + 3 * P + 4;  // staged target codes per chunk: window x in [m0, m0 + CH + 3P]
     // the codes a step pulls in start at x = step + 3P + 1: the row is shifted by PAD so that every fourth step's lies
     // on an 8-byte boundary (one ds_read_b64 feeds four steps)
     constexpr int PAD = (4 - (3 * P + 1) % 4) % 4;
-    constexpr int TROW = (TW + PAD + 3) & ~3;
+    constexpr int TROW = (TW + PAD + 3) & ~3;  // byte pair y of the row = position lo + m0 - PAD + y
     // profiles: entry i of a group's row is query row m0 - P + i of the chunk being computed: the P rows before the chunk
     // stay, because lane l works on row m - l
     constexpr int PROW = CH + P;
@@ -395,24 +393,26 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 #pragma unroll
         for (int k = 0; k < 4; ++k) st.s0[k] = st.s1[k] = GAP_EDGE;
         unsigned acc[4] = {0, 0, 0, 0}, held[4] = {0, 0, 0, 0};
-        bool saw_n[2] = {false, false};  // an N in the gene or in the target window: the traceback then compares bases itself
+        // an N in the gene or in the target window: the traceback then compares bases itself
+        bool saw_n[2] = {have[0] && genes.has_n[tk[0].gs >> 1] != 0, have[1] && genes.has_n[tk[1].gs >> 1] != 0};
 
         const int steps8 = (max_steps + 7) & ~7;
         // Staging of a chunk (profiles of its query rows, codes of its target window) works from packed words that were
         // requested one chunk earlier: NQ gene words (8 rows each) and NT assembly words (16 bases each) per lane and task.
-        constexpr int NQ = (CH / 8 + P - 1) / P, NTW = (TW + 15) / 16 + 1, NT = (NTW + P - 1) / P;
+        constexpr int NQ = (CH / 8 + P - 1) / P, NTW = (TROW + 15) / 16 + 1, NT = (NTW + P - 1) / P;
         static_assert(2 * G * NTW <= TWORD_WORDS, "LDS carve-up");
         uint32_t(*s_tw)[G][NTW] = reinterpret_cast<uint32_t(*)[G][NTW]>(s_tw_raw);
-        uint32_t qreg[2][NQ], treg[2][NT];
+        uint4 qreg[2][NQ];  // eight row profiles each (KpGenes::prof: nothing to compute, rows past the gene's end are 0 there)
+        uint32_t treg[2][NT];
         auto request = [&](int m0) {  // global loads only; nothing waits for them here
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     const int w = l + i * P, r = q0[h] + m0 + 8 * w;
-                    qreg[h][i] = (have[h] && w < CH / 8 && r < qlen[h]) ? genes.nib[q_off[h] + (uint32_t)(r >> 3)] : 0u;
+                    qreg[h][i] = (have[h] && w < CH / 8 && r < qlen[h]) ? genes.prof[q_off[h] + (uint32_t)(r >> 3)] : make_uint4(0u, 0u, 0u, 0u);
                 }
-                const int w0 = (lo[h] + m0) >> 4;
+                const int w0 = (lo[h] + m0 - PAD) >> 4;
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const int wi = w0 + l + i * P;
@@ -431,19 +431,14 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const int w = l + i * P, r = m0 + 8 * w;
-                if (w < CH / 8) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        unsigned pair = 0;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const bool live = have[h] && q0[h] + r + j < qlen[h];
-                            pair |= (live ? row_profile(nibble(qreg[h][i], j)) : PROF_OUT) << (16 * h);
-                            saw_n[h] |= live && nibble(qreg[h][i], j) >= 4u;
-                        }
-                        s_prof[g][P + 8 * w + j] = pair;
-                    }
+                const int w = l + i * P;
+                if (w < CH / 8) {  // rows 8w .. 8w + 7 of the chunk, task X in the low halves and task Y in the high ones
+                    const uint4 x = qreg[0][i], y = qreg[1][i];
+                    uint4 *dst = reinterpret_cast<uint4 *>(&s_prof[g][P + 8 * w]);
+                    dst[0] = make_uint4(__builtin_amdgcn_perm(y.x, x.x, 0x05040100u), __builtin_amdgcn_perm(y.x, x.x, 0x07060302u),
+                                        __builtin_amdgcn_perm(y.y, x.y, 0x05040100u), __builtin_amdgcn_perm(y.y, x.y, 0x07060302u));
+                    dst[1] = make_uint4(__builtin_amdgcn_perm(y.z, x.z, 0x05040100u), __builtin_amdgcn_perm(y.z, x.z, 0x07060302u),
+                                        __builtin_amdgcn_perm(y.w, x.w, 0x05040100u), __builtin_amdgcn_perm(y.w, x.w, 0x07060302u));
                 }
             }
 #pragma unroll
@@ -454,25 +449,25 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             __syncthreads();
             {
                 // shift amounts (3 * code) of the window, four positions at a time: byte pair y of the padded row =
-                // position p0 + y - PAD.  Whole groups inside the contig of an assembly without N runs -- nearly all -- are
-                // cut out of the packed words with one funnel shift and spread to bytes; the rest go base by base.
+                // position pw + y with pw = lo + m0 - PAD (the PAD entries before the window are never read; they get real
+                // codes like the rest).  Whole groups inside the contig of an assembly without N runs -- nearly all -- are
+                // cut out of the packed words with one funnel shift and spread to bytes by a table; the rest go base by base.
                 for (int y = 4 * l; y < TROW; y += 4 * P) {
                     uint32_t four[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int p0 = lo[h] + m0, w0 = p0 >> 4;
-                        const int t0 = p0 + y - PAD;
-                        if (have[h] && n_runs[h] == 0 && y >= PAD && t0 >= cstart[h] && t0 + 3 < cend[h]) {
+                        const int pw = lo[h] + m0 - PAD, w0 = pw >> 4;
+                        const int t0 = pw + y;
+                        if (have[h] && n_runs[h] == 0 && t0 >= cstart[h] && t0 + 3 < cend[h]) {
                             const int wi = (t0 >> 4) - w0;
                             const uint32_t lo_w = s_tw[h][g][wi], hi_w = wi + 1 < NTW ? s_tw[h][g][wi + 1] : 0u;
-                            const uint32_t v = __builtin_amdgcn_alignbit(hi_w, lo_w, 2 * (t0 & 15)) & 255u;
-                            four[h] = ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18)) * 3u;
+                            four[h] = s_spread[__builtin_amdgcn_alignbit(hi_w, lo_w, 2 * (t0 & 15)) & 255u];
                         } else {
                             four[h] = 0;
                             for (int i = 0; i < 4; ++i) {
                                 const int t = t0 + i;
                                 unsigned code = 5u;
-                                if (have[h] && t >= p0 && t >= cstart[h] && t < cend[h]) {  // (bytes before the window are never read)
+                                if (have[h] && t >= cstart[h] && t < cend[h]) {
                                     code = (s_tw[h][g][(t >> 4) - w0] >> (2 * (t & 15))) & 3u;
                                     if (n_runs[h] > 0) {  // rare: assemblies with scaffold gaps
                                         int a = 0, z = n_runs[h];
@@ -597,6 +592,10 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     __shared__ __attribute__((aligned(16))) uint32_t s_prof[PROF_WORDS];
     __shared__ __attribute__((aligned(16))) uint16_t s_t[TCODE_HALVES];
     __shared__ uint32_t s_tw[TWORD_WORDS];
+    __shared__ uint32_t s_spread[SPREAD_WORDS];
+    for (uint32_t v = threadIdx.x; v < SPREAD_WORDS; v += 64)
+        s_spread[v] = 3u * ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18));
+    // (every use comes after the first chunk's barriers)
     // class c (0..3 = 16/32/64/128 diagonals): tasks, order and results at c * task_cap, count at task_count[c]
     const uint32_t blk = blockIdx.x;
     const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : 0;
@@ -604,10 +603,10 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     uint32_t n = task_count[c];
     if (n > task_cap) n = task_cap;
     unsigned int *next_quad = reinterpret_cast<unsigned int *>(trace_top + 1);  // zeroed with trace_top before the launch
-    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
-    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
-    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw);
-    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, next_quad, s_prof, s_t, s_tw);
+    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
+    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
+    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
+    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, next_quad, s_prof, s_t, s_tw, s_spread);
 }
 
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
