@@ -217,6 +217,43 @@ def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
     l2.close()
 
 
+def test_genes_with_ambiguous_bases_match_oracle(oracle, small_db):
+    """N inside the GENES (code 4 on the query side): the fill kernel reads the genes as ready-made row profiles
+    (KpGenes::prof) and takes "this gene holds an N" from the database's per-gene flag, and the traceback then counts
+    matches base by base.  Single N, runs of N, an N in the first and in the last row, against clean and N-run assemblies."""
+    codes, off = pack_sequences_flat(small_db.genes)
+    codes = codes.copy()
+    rng = np.random.default_rng(5)
+    touched = 0
+    for g in range(len(off) - 1):
+        o, n = int(off[g]), int(off[g + 1] - off[g])
+        if g % 3 == 2 or n < 200:
+            continue  # a third of the genes stay clean: their tasks share waves with the others
+        codes[o + rng.integers(0, n, size=3)] = 4
+        codes[o + 100 : o + 100 + int(rng.integers(1, 9))] = 4
+        if g % 2:
+            codes[o] = 4
+            codes[o + n - 1] = 4
+        touched += 1
+    assert touched > 20
+    c = _native.Context(0)
+    c.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    asms = _assemblies(small_db)[:5]
+    packed = [a.packed() for a in asms]
+    batch = c.batch(packed)
+    hits, hoff = batch.align()
+    for i, pa in enumerate(packed):
+        tasks, got = batch.tasks(i), batch.task_results(i)
+        want = odb.sw(pa, tasks)  # the oracle's fill + traceback of exactly these tasks
+        kept = want[:, 0] >= 80
+        assert np.array_equal(got[~kept][:, 0], want[~kept][:, 0]) and np.array_equal(got[kept], want[kept]), asms[i].id
+        _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert len(hits) > 100
+    batch.close()
+    c.close()
+
+
 def test_bucket_sort_and_library_sort_give_the_same_anchors(oracle):
     """kp_bsort.hip against rocPRIM's segmented radix sort (`library_sort`) and the oracle, on an assembly built to hit
     every bucket size class of the bucket sort: single anchors, a few (sorting network in one lane), tens (wave ranking),
