@@ -291,7 +291,7 @@ def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
 
 
 L2_GATHER_ROOF_G = 269.0  # G independent 8-byte reads per second out of a 2 MB table (profiles/l2_gather_r2.txt)
-FILL_CYCLES_PER_WAVE_STEP = 2903 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r3.txt)
+FILL_CYCLES_PER_WAVE_STEP = 2674 / 8  # tools/isa_cost.py on kp_sw_kernel's 8-step body (profiles/fill_isa_cost_r3.txt)
 FILL_CLOCK_HZ = 2.26e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/r2_pmc.txt)
 
 

@@ -21,7 +21,7 @@
 //     and 31 (the guard bit survives exactly when no borrow reaches it) -- no v_cmp, no lane mask, no carry push,
 //   * the four direction bits of a cell are gathered from those words byte-wise (v_perm_b32, one v_bfi),
 //   * every cross-lane move (DPP) and every band-edge select serves two cells.
-// 52 issue cycles per cell of a lane (3320 per 8 steps of 8 cells, tools/isa_cost.py) instead of 82.
+// 41.8 issue cycles per cell of a lane (2674 per 8 steps of 8 cells, tools/isa_cost.py; round 2: 52) instead of 82.
 //
 // Mapping (wavefront-parallel anti-diagonals, no MFMA -- this is dependent integer DP, not a contraction):
 //   * a task's band has W = 4P diagonals; P lanes own a PAIR of tasks of that width (neighbours in the length-ordered task
@@ -30,10 +30,11 @@
 //     that skew A's left neighbour is lane l-1's D of the previous step, D's upper neighbour is lane l+1's A of the
 //     same step, and every other neighbour is one of the lane's own registers -- two one-lane shifts per step, both
 //     done with DPP (v_mov_b32_dpp row_shr:1 / row_shl:1, wave_* for the 32-lane class), all state stays in registers.
-//   * sequences are streamed systolically: the query enters at lane 0 as a per-row score profile (five 3-bit fields per
-//     task, score + 4, indexed by the target code: a substitution score is one v_pk_lshrrev_b16 and one v_and for two
-//     cells) and moves up one lane per step, the target code (as the shift amount 3 * code) enters at lane P-1 and moves
-//     down; both are staged per chunk in LDS.
+//   * sequences: the query is a per-row score profile (five 3-bit fields per task, score + 4, indexed by the target code:
+//     a substitution score is one v_pk_lshrrev_b16 and one v_and for two cells), the target a shift amount 3 * code per
+//     column; both are staged per chunk in LDS -- the profiles ready-made from the database's stream of them
+//     (KpGenes::prof), the shift amounts cut from the packed words four at a time and spread by a 256-entry table -- and
+//     every lane reads its own row and column there (the LDS pipe is idle otherwise).
 //   * no boundary masks: rows outside the gene carry a profile of -4 in every field and columns outside the contig score
 //     like N (-1).  Substitution scores <= 0 are all it takes: cells before the contig or above the gene then hold H = 0
 //     and gap states <= -(open + ext), which is what kp_spec.h prescribes for their neighbours inside (H = 0, E = F = -inf
@@ -47,9 +48,11 @@
 //     and f - 2 are the cell's own E - ext and F - ext), so H itself is never formed.  The smallest value the recurrence can
 //     produce is -(open + 2 ext) = -8, and "no gap yet" is represented by exactly that (it loses every maximum it takes
 //     part in, like -inf), so everything is >= 0; the largest is 2 * length + 12 < 32768 (KP_MAX_GENE_LEN).
-//   * best cell: per lane and task the running maximum of its four cells, the step at which it last rose and the four H
-//     of that step (packed max, guard compare, v_pk_ashrrev_i16 to a half-word mask, v_bfi selects): first maximum in
-//     row order, then the first of the lane's cells that holds it.
+//   * the restart at 0 costs nothing: the gap state a cell hands to its right neighbour is floored at 0 inside the
+//     three-way maximum that forms it, so one of a cell's three candidates is always >= 0 (dp_cell).
+//   * best cell: per lane and task the running maximum of its cells, the PAIR of steps in which it last rose and the eight
+//     H of that pair (packed three-way maxima, one sign compare, v_pk_ashrrev_i16 to a half-word mask, v_bfi selects):
+//     first maximum in row order, then the first of the lane's cells that holds it.
 //   * direction bits, four steps per 16 bits, eight steps per 32-bit word and cell: the two tasks' halves are
 //     separated with v_perm_b32 every eight steps and each task's 16 bytes go to its own trace block.
 #include "kp_internal.h"
