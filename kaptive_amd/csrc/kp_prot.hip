@@ -126,7 +126,18 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
 // NC adjacent diagonals per lane: 4 covers any band of up to 64 diagonals; 3 covers 48, which is enough for the default band
 // (k = 20: 41 diagonals) of every pair whose proteins differ by at most 22 residues in length -- nearly all of them -- and
 // costs a quarter less per step.
-template <int NC>
+// W lanes per pair: 16 (four pairs per wave, neighbours by DPP row shifts) or 64 (one pair per wave, wave shifts: bands of
+// up to 64 * NC diagonals -- the truncated genes of kp_protein_wide_kernel, whose strips cost several times as much per cell).
+template <int W>
+__device__ __forceinline__ int pair_lower(int v) { return W == 16 ? row_lower(v) : from_lower(v); }
+template <int W>
+__device__ __forceinline__ int pair_upper(int v) { return W == 16 ? row_upper(v) : from_upper(v); }
+template <int W>
+__device__ __forceinline__ Pay pair_lower(Pay p) { return Pay{(unsigned)pair_lower<W>((int)p.a), (unsigned)pair_lower<W>((int)p.g)}; }
+template <int W>
+__device__ __forceinline__ Pay pair_upper(Pay p) { return Pay{(unsigned)pair_upper<W>((int)p.a), (unsigned)pair_upper<W>((int)p.g)}; }
+
+template <int NC, int W = QP>
 __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1, const uint16_t *s_seq2,
                                                          const int8_t *s_mat, int len1, int len2, int k, int shift,
                                                          int l, int max_steps) {
@@ -152,8 +163,8 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
             in[c] = row_ok && col_ok && band_ok[c];
         }
         // first cell: left neighbour = lane l-1's last cell of the previous step
-        int lm = row_lower(cell[NC - 1].m), li = row_lower(cell[NC - 1].iv);
-        Pay lpm = row_lower(cell[NC - 1].pm), lpi = row_lower(cell[NC - 1].pi);
+        int lm = pair_lower<W>(cell[NC - 1].m), li = pair_lower<W>(cell[NC - 1].iv);
+        Pay lpm = pair_lower<W>(cell[NC - 1].pm), lpi = pair_lower<W>(cell[NC - 1].pi);
         if (l == 0) { lm = 0; li = NEGP; }
         prot_cell(cell[0], r, in[0], i, j0, c1, c2[0], s_mat, lm, li, lpm, lpi, cell[1].m, cell[1].dv, cell[1].pm, cell[1].pd);
 #pragma unroll
@@ -161,9 +172,9 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
             prot_cell(cell[c], r, in[c], i, j0 + c, c1, c2[c], s_mat, cell[c - 1].m, cell[c - 1].iv, cell[c - 1].pm, cell[c - 1].pi,
                       cell[c + 1].m, cell[c + 1].dv, cell[c + 1].pm, cell[c + 1].pd);
         // last cell: upper neighbour = lane l+1's first cell of this step
-        int um = row_upper(cell[0].m), ud = row_upper(cell[0].dv);
-        Pay upm = row_upper(cell[0].pm), upd = row_upper(cell[0].pd);
-        if (l == QP - 1) { um = 0; ud = NEGP; }
+        int um = pair_upper<W>(cell[0].m), ud = pair_upper<W>(cell[0].dv);
+        Pay upm = pair_upper<W>(cell[0].pm), upd = pair_upper<W>(cell[0].pd);
+        if (l == W - 1) { um = 0; ud = NEGP; }
         prot_cell(cell[NC - 1], r, in[NC - 1], i, j0 + NC - 1, c1, c2[NC - 1], s_mat, cell[NC - 2].m, cell[NC - 2].iv,
                   cell[NC - 2].pm, cell[NC - 2].pi, um, ud, upm, upd);
     }
@@ -425,6 +436,7 @@ __global__ __launch_bounds__(64) void kp_protein_kernel(const uint8_t *__restric
 // steps for a single wave, so the launch lasts as long as its slowest block: the blocks take the pairs off a shared
 // counter instead of striding over them, and skip what kp_protein_kernel handles.
 constexpr int QUEUE_GRAB = 1;
+constexpr int WAVE_NC_MAX = 8;  // diagonals per lane of the wave-register path: bands of up to 512 diagonals
 
 __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__restrict__ q, const int32_t *__restrict__ q_off,
                                                              const int32_t *__restrict__ q_len,
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
                                                              const int32_t *__restrict__ seed_off, int seed_k) {
     __shared__ int s_chunk[RB_FIELDS][RB_CHUNK], s_out[RB_FIELDS][RB_CHUNK];
     __shared__ uint16_t s_seq2[S2_CAP];
+    __shared__ uint16_t s_seq1[REG_MAX_LEN];  // (wave-register path)
     __shared__ int8_t s_mat[32 * 32];
     __shared__ uint8_t s_idx[256];
     const int lane = threadIdx.x;
@@ -477,6 +490,19 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
                     }
                     continue;
                 }
+            }
+            if (2 * k + 1 <= 64 * WAVE_NC_MAX && len1 <= REG_MAX_LEN && len2 <= S2_CAP) {
+                // the whole band in the registers of one wave: len1 + 63 steps instead of (len1 / 64) strips x (window + 63)
+                const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+                __syncthreads();  // (a block is one wave: orders the LDS stores below after the previous pair's reads)
+                for (int x = lane; x < len1; x += 64) s_seq1[x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
+                for (int x = lane; x < len2; x += 64) s_seq2[x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
+                __syncthreads();
+                const int steps = len1 + 63;
+                const Result r = 2 * k + 1 <= 64 * 4 ? protein_quad_registers<4, 64>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane, steps)
+                                                     : protein_quad_registers<WAVE_NC_MAX, 64>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane, steps);
+                store_result(r, lane, out8 + 8 * (size_t)p);
+                continue;
             }
             const RowBuf rb{scratch + (size_t)blockIdx.x * scratch_ints_per_block, len2 + 1};
             const Result r = protein_pair_strips(rb, s_chunk, s_out, s_seq2, s_idx, s_mat, q + q_off[p], t + t_off[p], len1, len2,
