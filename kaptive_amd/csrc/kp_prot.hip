@@ -89,6 +89,7 @@ __device__ __forceinline__ Pay pick(bool c, const Pay &x, const Pay &y) {
 // one cell (i, j); `left` = (i, j-1): its M, I and their payloads; `up` = (i-1, j): its M, D and their payloads; the
 // diagonal neighbour (i-1, j-1) comes in as c.m / c.pm.  Same statements as the reference's kernel (see top), written
 // as selects: every lane executes the same instructions whatever its cell decides.
+template <bool ROW_MAJOR = true>  // false: the lane does not visit its cells in row-major order and ties are settled by (i, j)
 __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, int j, unsigned c1, unsigned c2,
                                           const int8_t *s_mat, int lm, int li, Pay lpm, Pay lpi, int um, int ud, Pay upm,
                                           Pay upd) {
@@ -118,7 +119,10 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
     npm = pick(take_i, npi, npm);
     // cells outside the matrix or the band take boundary values, exactly as the reference's band array holds them
     const int nm = in ? max(bv, 0) : 0;
-    if (nm > r.best) { r.best = nm; r.bi = i; r.bj = j; r.bp = npm; }  // a lane's cells come in row-major order
+    // the first maximum in row-major order: a lane's cells come in that order (strict rise), or the tie is looked at
+    if (nm > r.best || (!ROW_MAJOR && nm == r.best && nm > 0 && (i < r.bi || (i == r.bi && j < r.bj)))) {
+        r.best = nm; r.bi = i; r.bj = j; r.bp = npm;
+    }
     c.m = nm; c.dv = in ? ndv : NEGP; c.iv = in ? niv : NEGP;
     c.pm = npm; c.pd = npd; c.pi = npi;
 }
@@ -177,6 +181,57 @@ __device__ __forceinline__ Result protein_quad_registers(const uint16_t *s_seq1,
         if (l == W - 1) { um = 0; ud = NEGP; }
         prot_cell(cell[NC - 1], r, in[NC - 1], i, j0 + NC - 1, c1, c2[NC - 1], s_mat, cell[NC - 2].m, cell[NC - 2].iv,
                   cell[NC - 2].pm, cell[NC - 2].pi, um, ud, upm, upd);
+    }
+    return r;
+}
+
+// ---- whole matrix in one wave, NR adjacent ROWS per lane --------------------------------------------------------------------
+// For the pairs whose band is wider than the diagonal form above holds -- a fragment of at most 64 * NR residues against
+// a much longer protein: the band then covers most of the matrix anyway.  Lane l owns rows NR * l + 1 .. NR * l + NR and
+// walks the columns one step behind lane l - 1 (column j = t - l + 1 at step t): the upper neighbour of its first row is
+// lane l - 1's last row of the previous step (one DPP shift), every other neighbour is one of its own registers.  One
+// strip of 64 * NR rows, len2 + 63 steps -- the row strips take (len1 / 64) x (window + 63) steps of a costlier kind.
+template <int NR>
+__device__ __forceinline__ Result protein_wave_rows(const uint16_t *s_seq1, const uint16_t *s_seq2, const int8_t *s_mat,
+                                                    int len1, int len2, int k, int shift, int lane) {
+    PCell cell[NR];  // (i, j - 1) of the lane's rows
+    unsigned c1[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        cell[q] = PCell{0, NEGP, NEGP, Pay{0, 0}, Pay{0, 0}, Pay{0, 0}};
+        const int i = NR * lane + q + 1;
+        c1[q] = i <= len1 ? s_seq1[i - 1] : 0u;
+    }
+    int dm = 0;  // M of (first row - 1, j - 1) and its payload: what came from lane l - 1 a step earlier
+    Pay dpm{0, 0};
+    Result r{0, 0, 0, Pay{0, 0}};
+    const int n_steps = len2 + 63;
+    for (int t = 0; t < n_steps; ++t) {
+        const int j = t - lane + 1;
+        const bool col_ok = j >= 1 && j <= len2;
+        const unsigned c2 = col_ok ? s_seq2[j - 1] : 0u;
+        // upper neighbour of the lane's first row: lane l - 1's last row at this column (it was there in the previous step)
+        int um = from_lower(cell[NR - 1].m), ud = from_lower(cell[NR - 1].dv);
+        Pay upm{(unsigned)from_lower((int)cell[NR - 1].pm.a), (unsigned)from_lower((int)cell[NR - 1].pm.g)};
+        Pay upd{(unsigned)from_lower((int)cell[NR - 1].pd.a), (unsigned)from_lower((int)cell[NR - 1].pd.g)};
+        if (lane == 0) { um = 0; ud = NEGP; upm = Pay{0, 0}; upd = Pay{0, 0}; }
+        int next_dm = um;
+        Pay next_dpm = upm;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int i = NR * lane + q + 1;
+            int db = i - shift - j;
+            if (db < 0) db = -db;
+            const bool in = col_ok && i <= len1 && db <= k;
+            const PCell left = cell[q];  // (i, j - 1): the left neighbour, and the diagonal one of the row below
+            PCell c;
+            c.m = dm; c.pm = dpm;  // diagonal neighbour (i - 1, j - 1)
+            prot_cell<false>(c, r, in, i, j, c1[q], c2, s_mat, left.m, left.iv, left.pm, left.pi, um, ud, upm, upd);
+            cell[q] = c;
+            dm = left.m; dpm = left.pm;                          // for the row below
+            um = c.m; ud = c.dv; upm = c.pm; upd = c.pd;         // (i, j) is the upper neighbour of the row below
+        }
+        dm = next_dm; dpm = next_dpm;  // (first row - 1, j) is the diagonal neighbour at the next column
     }
     return r;
 }
@@ -501,6 +556,18 @@ __global__ __launch_bounds__(64) void kp_protein_wide_kernel(const uint8_t *__re
                 const int steps = len1 + 63;
                 const Result r = 2 * k + 1 <= 64 * 4 ? protein_quad_registers<4, 64>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane, steps)
                                                      : protein_quad_registers<WAVE_NC_MAX, 64>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane, steps);
+                store_result(r, lane, out8 + 8 * (size_t)p);
+                continue;
+            }
+            if (len1 <= 64 * 6 && len2 <= S2_CAP) {  // a fragment against a long protein: the whole matrix, rows per lane
+                const uint8_t *s1 = q + q_off[p], *s2 = t + t_off[p];
+                __syncthreads();
+                for (int x = lane; x < len1; x += 64) s_seq1[x] = (uint16_t)(((unsigned)s1[x] << 8) | s_idx[s1[x]]);
+                for (int x = lane; x < len2; x += 64) s_seq2[x] = (uint16_t)(((unsigned)s2[x] << 8) | s_idx[s2[x]]);
+                __syncthreads();
+                const Result r = len1 <= 64 * 2 ? protein_wave_rows<2>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane)
+                                 : len1 <= 64 * 4 ? protein_wave_rows<4>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane)
+                                                  : protein_wave_rows<6>(s_seq1, s_seq2, s_mat, len1, len2, k, shift, lane);
                 store_result(r, lane, out8 + 8 * (size_t)p);
                 continue;
             }

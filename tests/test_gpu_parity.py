@@ -94,6 +94,46 @@ def test_protein_dp_long_and_wide_vs_oracle(ctx, oracle):
     assert (want[:, 0] > 0).sum() >= 8
 
 
+def test_protein_fragments_in_one_wave_vs_oracle(ctx, oracle):
+    """The two whole-wave forms of kp_protein_wide_kernel: bands of 65..512 diagonals in a wave's registers (four or eight
+    diagonals per lane) and, beyond that, the whole matrix with two, four or six rows per lane -- fragments of every
+    length class from anywhere in a 400..1900-residue protein, diverged, with indels, and low-complexity targets whose
+    repeats tie the best score in several cells (the rows-per-lane form does not visit its cells in row-major order)."""
+    rng = np.random.default_rng(41)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+    qs, ts = [], []
+    for len_t in (400, 601, 900, 1300, 1900):
+        t = aa[rng.integers(0, 20, size=len_t)]
+        for len_q in (1, 7, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 383, 384, 385):
+            if len_q >= len_t - 22:
+                continue
+            start = int(rng.integers(0, len_t - len_q))
+            q = t[start : start + len_q].copy()
+            hit = rng.random(len_q) < rng.uniform(0.0, 0.3)
+            q[hit] = aa[rng.integers(0, 20, size=int(hit.sum()))]
+            for s_ in np.flatnonzero(rng.random(len(q)) < 0.01)[::-1]:
+                q = np.delete(q, slice(s_, s_ + 2)) if rng.random() < 0.5 else np.insert(q, s_, aa[rng.integers(0, 20, size=3)])
+            qs.append(q.tobytes()); ts.append(t.tobytes() + b"*")
+    for len_t, len_q in ((300, 260), (300, 200), (300, 100), (450, 400), (450, 330), (450, 250), (600, 560), (600, 500),
+                         (600, 400), (767, 700), (767, 600), (768, 520), (500, 380), (640, 385)):  # bands of 65..512 diagonals
+        t = aa[rng.integers(0, 20, size=len_t)]
+        start = int(rng.integers(0, len_t - len_q))
+        q = t[start : start + len_q].copy()
+        hit = rng.random(len_q) < 0.15
+        q[hit] = aa[rng.integers(0, 20, size=int(hit.sum()))]
+        qs.append(q.tobytes()); ts.append(t.tobytes() + b"*")
+    for unit, n_q, n_t in ((b"GS", 90, 700), (b"A", 150, 500), (b"MKL", 60, 300), (b"PT", 190, 420), (b"Q", 300, 1000)):
+        qs.append(unit * n_q); ts.append(b"W" + unit * n_t + b"*")   # every placement of the query scores the same
+        qs.append(unit * n_q + b"W"); ts.append(unit * n_t + b"*")
+    q, t = Sequences.from_bytes(qs), Sequences.from_bytes(ts)
+    d = np.abs(q.lengths.astype(np.int64) - t.lengths.astype(np.int64))
+    assert (d > 255).sum() > 30 and ((d > 31) & (d <= 255)).sum() > 10  # both forms are exercised
+    want = oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    got = ctx.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert len(bad) == 0, (bad[:5], want[bad[:3]], got[bad[:3]], [qs[i][:20] for i in bad[:3]], q.lengths[bad[:3]], t.lengths[bad[:3]])
+
+
 def test_protein_exact_prefix_shortcut_vs_oracle(ctx, oracle):
     """Pairs the kernels answer without DP (query = standard residues only and a prefix of the target) and their near
     misses, in both kernels' territory: identical full-length proteins, truncated ones (wide bands), very long ones,
