@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
     int32_t *s_ctg = reinterpret_cast<int32_t *>(s_raw), *s_s = s_ctg + KEPT_LDS, *s_e = s_s + KEPT_LDS,
             *s_perm = s_e + KEPT_LDS;
     __shared__ uint8_t s_codon[128];
-    __shared__ int s_fail, s_base;
+    __shared__ int s_fail, s_base, s_total;
     const int a = blockIdx.x, lane = threadIdx.x;
     const int n = (int)n_hits[a];
     const kp_hit *h = hits + (size_t)a * hit_cap;
@@ -231,31 +231,34 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         if (n == 1 && lane == 0) { flag[0] = 1; s_ctg[0] = h[0].contig; s_s[0] = h[0].t_start; s_e[0] = h[0].t_end; }
         nk = n;
     } else {
+        // 64 candidates at a time, a lane each: first against everything kept so far (the list is read by all lanes at
+        // once), then the survivors one after the other in visit order -- each one kept is tested by the lanes behind it.
+        // (A candidate at a time, tested by all lanes against the kept list, spent a hundred instructions and a barrier
+        // per hit on what is a few compares: 0.3 of this kernel's 1.2 ms.)
         for (int p0 = 0; p0 < n && !fail; p0 += 64) {
             const int mine = p0 + lane < n ? (int)ord[p0 + lane] : -1;
             int mc = 0, ms = 0, me = 0;
             if (mine >= 0) { mc = h[mine].contig; ms = h[mine].t_start; me = h[mine].t_end; }
-            const int lim = n - p0 < 64 ? n - p0 : 64;
-            for (int l = 0; l < lim; ++l) {
-                const int id = __shfl(mine, l), c = __shfl(mc, l), s = __shfl(ms, l), e = __shfl(me, l);
-                const int len = e - s;
-                bool clash = false;
-                if (len > 0)
-                    for (int j = lane; j < nk; j += 64) {
-                        if (s_ctg[j] != c) continue;
-                        const int ov = min(e, s_e[j]) - max(s, s_s[j]);
-                        const int klen = s_e[j] - s_s[j];
-                        if (ov > 0 && (int64_t)ov * 10 > (int64_t)min(len, klen)) clash = true;
-                    }
-                const bool keep = len > 0 && !__any(clash);
-                if (keep && nk >= cap) { fail = true; break; }
-                if (lane == 0) {
-                    flag[id] = keep ? 1 : 0;
-                    if (keep) { s_ctg[nk] = c; s_s[nk] = s; s_e[nk] = e; }
-                }
-                if (keep) ++nk;
-                __syncthreads();  // kept list update visible to all lanes before the next candidate
+            const int len = me - ms;
+            auto clashes = [&](int c, int s, int e) {  // the reference's rule (interval.py:698-751): overlap > 10 % of the shorter
+                const int ov = min(me, e) - max(ms, s);
+                return c == mc && ov > 0 && (int64_t)ov * 10 > (int64_t)min(len, e - s);
+            };
+            bool alive = mine >= 0 && len > 0;
+            for (int j = 0; j < nk; ++j) alive = alive && !clashes(s_ctg[j], s_s[j], s_e[j]);
+            bool keep = false;
+            unsigned long long pending = __ballot(alive);
+            while (pending) {
+                const int l = __builtin_ctzll(pending);  // the next survivor in visit order: kept
+                if (nk >= cap) { fail = true; break; }
+                const int c = __shfl(mc, l), s0 = __shfl(ms, l), e0 = __shfl(me, l);
+                if (lane == l) { keep = true; s_ctg[nk] = c; s_s[nk] = s0; s_e[nk] = e0; }
+                ++nk;
+                if (lane > l && alive && clashes(c, s0, e0)) alive = false;
+                pending = __ballot(alive && lane > l);
             }
+            if (mine >= 0) flag[mine] = keep ? 1 : 0;
+            __syncthreads();  // the kept list is complete for the next 64
         }
     }
     if (fail) {
@@ -263,28 +266,46 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         return;
     }
     __syncthreads();
-    // kept list in emission order, clusters, pieces, inside flags, missing genes, protein slots: short sequential tail
-    if (lane == 0) {
+    // The kept records live in LDS while one lane clusters them (insertion sort, single linkage, pieces, inside flags,
+    // missing genes: a few thousand dependent reads of their fields, otherwise at the latency of the L2s); the cull's
+    // scratch is free by now.  More kept hits than fit there: in place, in global memory.
+    const bool in_lds = (size_t)nk * sizeof(KpKept) <= 3 * (size_t)KEPT_LDS * sizeof(int32_t);
+    KpKept *lk = in_lds ? reinterpret_cast<KpKept *>(s_raw) : out;
+    __threadfence_block();  // (lane 0's flags are read by every lane below)
+    __syncthreads();        // (every lane is done with the cull's lists)
+    // kept list in emission order: 64 hits per round, the kept ones of a round land behind those of the rounds before
+    {
+        const unsigned long long below = (1ull << lane) - 1ull;
         int m = 0;
-        for (int i = 0; i < n; ++i) {
-            if (!flag[i]) continue;
-            KpKept o;
-            o.gene = h[i].gene; o.contig = h[i].contig; o.q_start = h[i].q_start; o.q_end = h[i].q_end;
-            o.t_start = h[i].t_start; o.t_end = h[i].t_end; o.score = h[i].score; o.strand = h[i].strand;
-            o.prot_off = 0; o.prot_len = 0; o.cluster = 0; o.pident = 0.f; o.coverage = 0.f; o.state = 0; o.flags = 0;
-            o.pad_ = 0;
-            for (int x = 0; x < 8; ++x) o.dp[x] = 0;
-            out[m++] = o;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool f = i < n && flag[i] != 0;
+            const unsigned long long mask = __ballot(f);
+            if (f) {
+                KpKept o;
+                o.gene = h[i].gene; o.contig = h[i].contig; o.q_start = h[i].q_start; o.q_end = h[i].q_end;
+                o.t_start = h[i].t_start; o.t_end = h[i].t_end; o.score = h[i].score; o.strand = h[i].strand;
+                o.prot_off = 0; o.prot_len = 0; o.cluster = 0; o.pident = 0.f; o.coverage = 0.f; o.state = 0; o.flags = 0;
+                o.pad_ = 0;
+                for (int x = 0; x < 8; ++x) o.dp[x] = 0;
+                lk[m + __builtin_popcountll(mask & below)] = o;
+            }
+            m += __builtin_popcountll(mask);
         }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // clusters, pieces, inside flags, missing genes, protein slots: short sequential tail
+    if (lane == 0) {
         sum->n_kept = nk;
-        kp_cluster_and_pieces(out, nk, db, best_locus, prm.max_locus_length, s_perm, pc, piece_cap, sum);
+        kp_cluster_and_pieces(lk, nk, db, best_locus, prm.max_locus_length, s_perm, pc, piece_cap, sum);
         int used = 0;
         for (int i = 0; i < nk; ++i) {
-            const int frame = (3 - out[i].q_start % 3) % 3, len = out[i].t_end - out[i].t_start;
+            const int frame = (3 - lk[i].q_start % 3) % 3, len = lk[i].t_end - lk[i].t_start;
             const int max_codons = len > frame ? (len - frame) / 3 : 0;
             if (used + max_codons > prot_cap) { sum->overflow |= 8; s_fail = 1; break; }
-            out[i].prot_off = used;
-            out[i].prot_len = max_codons;  // upper bound; the translation below shortens it at the first stop
+            lk[i].prot_off = used;
+            lk[i].prot_len = max_codons;  // upper bound; the translation below shortens it at the first stop
             used += max_codons;
         }
         if (s_fail) sum->n_kept = 0;
@@ -293,36 +314,70 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         pair_base[a] = s_base;
     }
     __syncthreads();
+    if (in_lds) {  // the records go to their place in global memory (also when the protein buffer overflowed: flags and clusters are valid)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lk);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out);
+        static_assert(sizeof(KpKept) % 4 == 0, "copied as words");
+        for (int x = lane; x < nk * (int)(sizeof(KpKept) / 4); x += 64) dst[x] = src[x];
+        __threadfence_block();
+        __syncthreads();
+    }
     if (s_fail) return;
     const size_t base = (size_t)s_base;
-    // translation: all lanes work on one kept hit at a time, one codon per lane per round
+    // Translation: the codons of all kept hits as one list, one codon per lane and round, four rounds' loads in flight
+    // (a hit at a time, round after round until its first stop, was a chain of dependent trips to memory).  Every codon of a hit's slot is written; the first stop codon of each hit is found with an LDS
+    // minimum and becomes the protein's length -- what lies behind it in the slot is never read.
     const uint32_t *asm_words = b.words + b.asm_word_off[a];
     const int c0 = b.asm_first_ctg[a];
     const int r0 = b.asm_first_nrun[a], n_runs = b.asm_first_nrun[a + 1] - r0;
     const int32_t *runs = b.n_runs + 2 * (size_t)r0;
     uint8_t *pa = prot + (size_t)a * prot_cap;
-    for (int i = 0; i < nk; ++i) {
-        const KpKept o = out[i];
-        const int frame = (3 - o.q_start % 3) % 3, max_codons = o.prot_len;
-        const int32_t cs = b.ctg_start[c0 + o.contig];
-        const int32_t a0 = cs + o.t_start, a1 = cs + o.t_end;
-        int first_stop = max_codons;
-        for (int base = 0; base < max_codons && first_stop == max_codons; base += 64) {
-            const int c = base + lane;
-            uint8_t aa = 0;
-            if (c < max_codons) aa = kp_codon_aa(asm_words, runs, n_runs, a0, a1, o.strand, frame, c, s_codon);
-            const unsigned long long stops = __ballot(c < max_codons && aa == '*');
-            if (stops) first_stop = base + __builtin_ctzll(stops);
-            if (c < first_stop && c < max_codons) pa[o.prot_off + c] = aa;
+    int32_t *s_off = s_ctg, *s_stop = s_s;  // (the cull's and the clustering's scratch is free again)
+    for (int i = lane; i < nk; i += 64) { s_off[i] = out[i].prot_off; s_stop[i] = out[i].prot_len; }
+    if (lane == 0) s_total = nk ? out[nk - 1].prot_off + out[nk - 1].prot_len : 0;
+    __syncthreads();
+    const int total = s_total;
+    constexpr int TR = 4;
+    for (int x0 = 0; x0 < total; x0 += 64 * TR) {
+        int hit[TR], cod[TR];
+        uint8_t aa[TR];
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {
+            const int x = x0 + 64 * u + lane;
+            hit[u] = -1; cod[u] = 0; aa[u] = 0;
+            if (x < total) {
+                int lo = 0, hi = nk - 1;  // the last hit whose slot starts at or before x (empty slots share their start with the next)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
+                }
+                hit[u] = lo; cod[u] = x - s_off[lo];
+            }
         }
-        if (lane == 0) {
-            out[i].prot_len = first_stop;
-            const size_t slot = base + i;
-            pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + o.prot_off);  // offset into the batch protein buffer
-            pair_q_len[slot] = first_stop;
-            pair_t_off[slot] = db.prot_off[o.gene];
-            pair_t_len[slot] = db.prot_len[o.gene];
-        }
+#pragma unroll
+        for (int u = 0; u < TR; ++u)
+            if (hit[u] >= 0) {
+                const KpKept &o = out[hit[u]];
+                const int frame = (3 - o.q_start % 3) % 3;
+                const int32_t cs = b.ctg_start[c0 + o.contig];
+                aa[u] = kp_codon_aa(asm_words, runs, n_runs, cs + o.t_start, cs + o.t_end, o.strand, frame, cod[u], s_codon);
+            }
+#pragma unroll
+        for (int u = 0; u < TR; ++u)
+            if (hit[u] >= 0) {
+                pa[s_off[hit[u]] + cod[u]] = aa[u];
+                if (aa[u] == '*') atomicMin(&s_stop[hit[u]], cod[u]);
+            }
+    }
+    __syncthreads();
+    for (int i = lane; i < nk; i += 64) {
+        const int first_stop = s_stop[i];
+        out[i].prot_len = first_stop;
+        const size_t slot = base + i;
+        pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + s_off[i]);  // offset into the batch protein buffer
+        pair_q_len[slot] = first_stop;
+        pair_t_off[slot] = db.prot_off[out[i].gene];
+        pair_t_len[slot] = db.prot_len[out[i].gene];
     }
 }
 
