@@ -332,8 +332,17 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
     const int r0 = b.asm_first_nrun[a], n_runs = b.asm_first_nrun[a + 1] - r0;
     const int32_t *runs = b.n_runs + 2 * (size_t)r0;
     uint8_t *pa = prot + (size_t)a * prot_cap;
-    int32_t *s_off = s_ctg, *s_stop = s_s;  // (the cull's and the clustering's scratch is free again)
-    for (int i = lane; i < nk; i += 64) { s_off[i] = out[i].prot_off; s_stop[i] = out[i].prot_len; }
+    // per kept hit, in LDS (the cull's and the clustering's scratch is free again): slot offset * 4 + reading frame, first
+    // stop so far, first base, last base + 1 (negative: minus strand) -- a codon then costs LDS reads and its own words only
+    int32_t *s_off4 = s_ctg, *s_stop = s_s, *s_a0 = s_e, *s_a1 = s_perm;
+    for (int i = lane; i < nk; i += 64) {
+        const KpKept &o = out[i];
+        const int32_t cs = b.ctg_start[c0 + o.contig];
+        s_off4[i] = (o.prot_off << 2) | ((3 - o.q_start % 3) % 3);
+        s_stop[i] = o.prot_len;
+        s_a0[i] = cs + o.t_start;
+        s_a1[i] = o.strand >= 0 ? cs + o.t_end : -(cs + o.t_end);
+    }
     if (lane == 0) s_total = nk ? out[nk - 1].prot_off + out[nk - 1].prot_len : 0;
     __syncthreads();
     const int total = s_total;
@@ -349,23 +358,22 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
                 int lo = 0, hi = nk - 1;  // the last hit whose slot starts at or before x (empty slots share their start with the next)
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
-                    if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
+                    if ((s_off4[mid] >> 2) <= x) lo = mid; else hi = mid - 1;
                 }
-                hit[u] = lo; cod[u] = x - s_off[lo];
+                hit[u] = lo; cod[u] = x - (s_off4[lo] >> 2);
             }
         }
 #pragma unroll
         for (int u = 0; u < TR; ++u)
             if (hit[u] >= 0) {
-                const KpKept &o = out[hit[u]];
-                const int frame = (3 - o.q_start % 3) % 3;
-                const int32_t cs = b.ctg_start[c0 + o.contig];
-                aa[u] = kp_codon_aa(asm_words, runs, n_runs, cs + o.t_start, cs + o.t_end, o.strand, frame, cod[u], s_codon);
+                const int32_t a1 = s_a1[hit[u]];
+                aa[u] = kp_codon_aa(asm_words, runs, n_runs, s_a0[hit[u]], a1 < 0 ? -a1 : a1, a1 < 0 ? -1 : 1, s_off4[hit[u]] & 3,
+                                    cod[u], s_codon);
             }
 #pragma unroll
         for (int u = 0; u < TR; ++u)
             if (hit[u] >= 0) {
-                pa[s_off[hit[u]] + cod[u]] = aa[u];
+                pa[(s_off4[hit[u]] >> 2) + cod[u]] = aa[u];
                 if (aa[u] == '*') atomicMin(&s_stop[hit[u]], cod[u]);
             }
     }
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         const int first_stop = s_stop[i];
         out[i].prot_len = first_stop;
         const size_t slot = base + i;
-        pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + s_off[i]);  // offset into the batch protein buffer
+        pair_q_off[slot] = (int32_t)((size_t)a * prot_cap + (s_off4[i] >> 2));  // offset into the batch protein buffer
         pair_q_len[slot] = first_stop;
         pair_t_off[slot] = db.prot_off[out[i].gene];
         pair_t_len[slot] = db.prot_len[out[i].gene];
