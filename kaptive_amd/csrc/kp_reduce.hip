@@ -91,25 +91,30 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += SORT_THREADS) {  // rank sort: all lanes read the same key j -> LDS broadcast
-        const uint64_t mine[3] = {k[3 * (size_t)i], k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
-        uint32_t rank = 0;
+        // The leading key (gene, score, contig) decides almost every comparison, so the loop over the other hits only counts
+        // the smaller and the equal leading keys -- no branch, two compares and two adds per hit (with the tie test inside
+        // it the loop was 30 instructions per hit, most of them the scalar bookkeeping of a divergent branch, and the
+        // kernel's longest phase) -- and the rare hit that shares its leading key with another one settles its ties in a
+        // second loop by the full order.
+        const uint64_t m0 = k[3 * (size_t)i];
+        uint32_t rank = 0, equal = 0;
         const uint32_t n_lds = n < SORT_LDS ? n : SORT_LDS;
         uint32_t j = 0;
-        for (; j + 8 <= n_lds; j += 8) {  // eight broadcast reads in flight, then eight compares
+        for (; j + 8 <= n_lds; j += 8) {  // eight broadcast reads in flight, then the compares
             uint64_t o[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) o[u] = s_k0[j + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (o[u] < mine[0]) ++rank;
-                else if (o[u] == mine[0])
-                    rank += kp_keys_less(k + 3 * (size_t)(j + u), src[j + u].n_seeds, j + u, mine, src[i].n_seeds, i) ? 1u : 0u;
-            }
+            for (int u = 0; u < 8; ++u) { rank += o[u] < m0 ? 1u : 0u; equal += o[u] == m0 ? 1u : 0u; }
         }
-        for (; j < n; ++j) {
-            const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
-            if (other < mine[0]) ++rank;
-            else if (other == mine[0]) rank += kp_keys_less(k + 3 * (size_t)j, src[j].n_seeds, j, mine, src[i].n_seeds, i) ? 1u : 0u;
+        for (; j < n_lds; ++j) { rank += s_k0[j] < m0 ? 1u : 0u; equal += s_k0[j] == m0 ? 1u : 0u; }
+        for (; j < n; ++j) { const uint64_t other = k[3 * (size_t)j]; rank += other < m0 ? 1u : 0u; equal += other == m0 ? 1u : 0u; }
+        if (equal > 1) {  // (one is the hit itself)
+            const uint64_t mine[3] = {m0, k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
+            for (j = 0; j < n; ++j) {
+                const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
+                if (other == m0) rank += kp_keys_less(k + 3 * (size_t)j, src[j].n_seeds, j, mine, src[i].n_seeds, i) ? 1u : 0u;
+            }
         }
         dst[rank] = src[i];
     }
