@@ -18,11 +18,14 @@
 namespace {
 
 constexpr int CHAIN_SLICES = 16;  // waves per assembly
+constexpr int CHAIN_WAVES = 4;    // ... of which a block holds this many: they share one task stage, so that its 9.5 KB of LDS
+                                  // do not keep the CUs at half of the waves they could hold (the kernel is a chain of memory trips)
+static_assert(CHAIN_SLICES % CHAIN_WAVES == 0, "whole blocks");
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
 // produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
 #ifndef KP_CHAIN_STAGE0
-#define KP_CHAIN_STAGE0 256
+#define KP_CHAIN_STAGE0 512
 #endif
 constexpr int STAGE0 = KP_CHAIN_STAGE0, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
 
@@ -49,7 +52,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
-    const uint32_t s = st.n[cls]++;
+    const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
     if (s < TaskStage::room(cls)) {
         st.list(cls)[s] = t;
         return;
@@ -64,17 +67,17 @@ struct Cluster {  // wave-uniform
     int ctg, cnt;
 };
 
-__global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb,
                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
                                                       uint32_t task_cap) {
     __shared__ TaskStage st;
-    const int a = blockIdx.y, lane = threadIdx.x;
+    const int a = blockIdx.y, lane = threadIdx.x & 63;
     uint32_t n = count[a];
     if (n > cap) n = cap;
     const uint32_t per = (((n + CHAIN_SLICES - 1) / CHAIN_SLICES) + 63u) & ~63u;  // whole rounds of 64 anchors
-    const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
-    if (lo >= n) return;
+    const uint32_t lo = (blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * per, hi = min(n, lo + per);
+    const bool idle = lo >= n;  // (a slice past the list's end: the wave only takes part in the block's barriers)
     const uint64_t *k = keys + (size_t)a * cap;
     const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
     const int32_t *starts = b.ctg_start + c0;
@@ -87,9 +90,9 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
         }
         return l - 1;
     };
-    if (lane < KP_N_CLASSES) st.n[lane] = 0;
+    if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
     __syncthreads();
-
+    if (!idle) {
     uint64_t prev_key = 0;  // the anchor before the round's first one
     int prev_ctg = -1;
     bool have_prev = lo > 0;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
     auto merge = [&](int from, int to, uint32_t d, uint32_t q) {
         const uint32_t d_last = __shfl(d, to - 1);
         if (d_last - cur.d0 <= KP_MAX_SPREAD) {  // the whole piece joins the cluster
-            const bool mine = threadIdx.x >= (unsigned)from && threadIdx.x < (unsigned)to;
+            const bool mine = lane >= from && lane < to;
             uint32_t mn = mine ? q : 0xFFFFFFFFu, mx = mine ? q : 0u;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
@@ -176,17 +179,18 @@ __global__ __launch_bounds__(64) void kp_chain_kernel(KpBatchView b, const uint6
         }
     }
     flush();
+    }
     __syncthreads();
-    if (lane < KP_N_CLASSES) {
-        const uint32_t room = TaskStage::room(lane);
-        const uint32_t m = st.n[lane] < room ? st.n[lane] : room;
-        st.n[lane] = m;
-        st.base[lane] = m ? atomicAdd(&task_count[lane], m) : 0u;
+    if (threadIdx.x < KP_N_CLASSES) {
+        const uint32_t room = TaskStage::room(threadIdx.x);
+        const uint32_t m = st.n[threadIdx.x] < room ? st.n[threadIdx.x] : room;
+        st.n[threadIdx.x] = m;
+        st.base[threadIdx.x] = m ? atomicAdd(&task_count[threadIdx.x], m) : 0u;
     }
     __syncthreads();
     for (int cls = 0; cls < KP_N_CLASSES; ++cls) {
         const KpTask *src = st.list(cls);
-        for (uint32_t i = lane; i < st.n[cls]; i += 64) {
+        for (uint32_t i = threadIdx.x; i < st.n[cls]; i += 64 * CHAIN_WAVES) {
             const uint32_t slot = st.base[cls] + i;
             if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = src[i];
         }
@@ -282,6 +286,6 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, hipStream_t stream) {
     if (b.n_asm == 0) return;
-    hipLaunchKernelGGL(kp_chain_kernel, dim3(CHAIN_SLICES, b.n_asm), dim3(64), 0, stream, b, sorted_anchors, anchor_count,
+    hipLaunchKernelGGL(kp_chain_kernel, dim3(CHAIN_SLICES / CHAIN_WAVES, b.n_asm), dim3(64 * CHAIN_WAVES), 0, stream, b, sorted_anchors, anchor_count,
                        cap, key_bits, tasks, task_count, task_cap);
 }
