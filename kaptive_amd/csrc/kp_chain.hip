@@ -17,8 +17,14 @@
 
 namespace {
 
-constexpr int CHAIN_SLICES = 16;  // waves per assembly
-constexpr int CHAIN_WAVES = 4;    // ... of which a block holds this many: they share one task stage, so that its 9.5 KB of LDS
+#ifndef KP_CHAIN_SLICES
+#define KP_CHAIN_SLICES 16
+#endif
+#ifndef KP_CHAIN_WAVES
+#define KP_CHAIN_WAVES 4
+#endif
+constexpr int CHAIN_SLICES = KP_CHAIN_SLICES;  // waves per assembly
+constexpr int CHAIN_WAVES = KP_CHAIN_WAVES;  // ... of which a block holds this many: they share one task stage, so that its 9.5 KB of LDS
                                   // do not keep the CUs at half of the waves they could hold (the kernel is a chain of memory trips)
 static_assert(CHAIN_SLICES % CHAIN_WAVES == 0, "whole blocks");
 
