@@ -632,6 +632,30 @@ def test_reduction_buffer_overflow_retry(small_db, monkeypatch):
     typer.engine.close()
 
 
+def test_hundreds_of_kept_hits_cluster_outside_lds(small_db):
+    """More kept hits than the reduction kernel's LDS copy holds (292 records): every gene of the database planted twice,
+    far apart, so that nothing overlaps and ~360 hits survive the cull -- the kept-hit buffer grows past its default 256
+    and the clustering runs on the records in global memory.  Against the host statement of the reduction."""
+    rng = np.random.default_rng(61)
+    parts, recs = [], []
+    for copy in range(2):
+        for i in range(len(small_db.genes)):
+            parts.append(random_dna(rng, 150, 0.5).tobytes() + small_db.genes[i].seq)
+            if len(parts) == 12:
+                recs.append(SeqRecord(f"c{len(recs)}", b"".join(parts) + random_dna(rng, 150, 0.5).tobytes()))
+                parts = []
+    if parts:
+        recs.append(SeqRecord(f"c{len(recs)}", b"".join(parts) + random_dna(rng, 150, 0.5).tobytes()))
+    genome = GenomeAssembly("every_gene_twice", Sequences.from_records(recs))
+    typer = Serotyper(small_db)
+    got = typer.type_many([genome, _assemblies(small_db)[0]])
+    want = typer.call_with_host_reduction(genome)
+    _results_equal(got[0], want, genome.id)
+    n_hits = len(np.asarray(next(iter(want.to_dict()["gene_hits"].values()))))
+    assert n_hits > 292, n_hits  # (the records did not fit the kernel's LDS copy)
+    typer.engine.close()
+
+
 def test_cli_types_fasta_files_like_the_reference(tmp_path):
     """`python -m kaptive_amd assembly db.npz *.fasta -o out.tsv -j out.jsonl`: rows equal the reference's golden rows."""
     from kaptive_amd import KAPTIVE_COMPAT_VERSION
