@@ -276,6 +276,11 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
     // scratch is free by now.  More kept hits than fit there: in place, in global memory.
     const bool in_lds = (size_t)nk * sizeof(KpKept) <= 3 * (size_t)KEPT_LDS * sizeof(int32_t);
     KpKept *lk = in_lds ? reinterpret_cast<KpKept *>(s_raw) : out;
+    // ... and beside them (behind the permutation scratch, in the same LDS block) what the database says about their genes
+    // and the pieces' extents: both are read again and again by that one lane
+    static_assert(KEPT_LDS >= 640 + (3 * KEPT_LDS * 4 / sizeof(KpKept)) * sizeof(KpGeneInfo) / 4 + 4, "LDS carve-up of the clustering");
+    int32_t *piece_tmp = in_lds && piece_cap <= 40 ? s_perm + 512 : nullptr;
+    KpGeneInfo *info = in_lds ? reinterpret_cast<KpGeneInfo *>(s_perm + 640) : nullptr;
     __threadfence_block();  // (lane 0's flags are read by every lane below)
     __syncthreads();        // (every lane is done with the cull's lists)
     // kept list in emission order: 64 hits per round, the kept ones of a round land behind those of the rounds before
@@ -293,7 +298,9 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
                 o.prot_off = 0; o.prot_len = 0; o.cluster = 0; o.pident = 0.f; o.coverage = 0.f; o.state = 0; o.flags = 0;
                 o.pad_ = 0;
                 for (int x = 0; x < 8; ++x) o.dp[x] = 0;
-                lk[m + __builtin_popcountll(mask & below)] = o;
+                const int at = m + __builtin_popcountll(mask & below);
+                lk[at] = o;
+                if (info) info[at] = KpGeneInfo{db.gene_locus[o.gene], db.gene_pos[o.gene], db.gene_strand[o.gene], db.gene_extra[o.gene]};
             }
             m += __builtin_popcountll(mask);
         }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
     // clusters, pieces, inside flags, missing genes, protein slots: short sequential tail
     if (lane == 0) {
         sum->n_kept = nk;
-        kp_cluster_and_pieces(lk, nk, db, best_locus, prm.max_locus_length, s_perm, pc, piece_cap, sum);
+        kp_cluster_and_pieces(lk, nk, db, best_locus, prm.max_locus_length, s_perm, pc, piece_cap, sum, info, piece_tmp);
         int used = 0;
         for (int i = 0; i < nk; ++i) {
             const int frame = (3 - lk[i].q_start % 3) % 3, len = lk[i].t_end - lk[i].t_start;

@@ -183,9 +183,19 @@ KP_HD int kp_cull_sequential(const kp_hit *hits, int n, const uint32_t *order, u
 }
 
 // ---- clustering, pieces, inside, missing (core.py:219-301) ---------------------------------------------------------------
-// kept[] is in emission order.  scratch: perm[nk].
+// What the database says about a kept hit's gene, next to the hit (optional): on the device one lane runs this function
+// and every look-up by gene index would be a trip to global memory on its own.
+typedef struct KpGeneInfo {
+    uint16_t locus, pos;
+    int8_t strand;
+    uint8_t extra;
+} KpGeneInfo;
+
+// kept[] is in emission order.  scratch: perm[nk]; info (optional): nk entries; piece_tmp (optional): 3 * piece_cap ints,
+// the pieces' contig / start / end where the caller can read them back fast.
 KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int best_locus, int64_t tolerance,
-                                 int32_t *perm, KpPiece *pieces, int piece_cap, KpAsmSummary *sum) {
+                                 int32_t *perm, KpPiece *pieces, int piece_cap, KpAsmSummary *sum,
+                                 const KpGeneInfo *info = nullptr, int32_t *piece_tmp = nullptr) {
     // stable order by (contig, t_start, t_end): insertion sort of indices (nk is small)
     for (int i = 0; i < nk; ++i) {
         int j = i;
@@ -214,8 +224,8 @@ KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int
     for (int i = 0; i < nk; ++i) {
         KpKept &k = kept[i];
         uint8_t f = 0;
-        if (db.gene_extra[k.gene]) f |= KP_F_EXTRA;
-        else if ((int)db.gene_locus[k.gene] == best_locus) f |= KP_F_EXPECTED;
+        if (info ? info[i].extra : db.gene_extra[k.gene]) f |= KP_F_EXTRA;
+        else if ((int)(info ? info[i].locus : db.gene_locus[k.gene]) == best_locus) f |= KP_F_EXPECTED;
         if ((f & KP_F_EXPECTED) && (i == 0 || kept[i - 1].gene != k.gene)) f |= KP_F_PRIMARY;
         k.flags = f;
     }
@@ -232,8 +242,8 @@ KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int
             if (!(k.flags & KP_F_PRIMARY)) continue;
             if (nprim == 0 || k.t_start < smin) smin = k.t_start;
             if (nprim == 0 || k.t_end > emax) emax = k.t_end;
-            pos_sum += db.gene_pos[k.gene];
-            vote += (int)k.strand * (int)db.gene_strand[k.gene];
+            pos_sum += info ? info[i].pos : db.gene_pos[k.gene];
+            vote += (int)k.strand * (int)(info ? info[i].strand : db.gene_strand[k.gene]);
             ++nprim;
         }
         if (nprim == 0) continue;
@@ -241,15 +251,19 @@ KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int
         pieces[np].contig = ctg; pieces[np].start = smin; pieces[np].end = emax;
         pieces[np].strand = vote < 0 ? -1 : 1;
         pieces[np].mean_pos = (double)pos_sum / (double)nprim;
+        if (piece_tmp) { piece_tmp[3 * np] = ctg; piece_tmp[3 * np + 1] = smin; piece_tmp[3 * np + 2] = emax; }
         ++np;
     }
     for (int i = 0; i < nk; ++i) {  // closed-interval overlap with any piece on the same contig
         KpKept &k = kept[i];
-        for (int p = 0; p < np; ++p)
-            if (k.contig == pieces[p].contig && k.t_start <= pieces[p].end && k.t_end >= pieces[p].start) {
+        for (int p = 0; p < np; ++p) {
+            const int pc = piece_tmp ? piece_tmp[3 * p] : pieces[p].contig, ps = piece_tmp ? piece_tmp[3 * p + 1] : pieces[p].start,
+                      pe = piece_tmp ? piece_tmp[3 * p + 2] : pieces[p].end;
+            if (k.contig == pc && k.t_start <= pe && k.t_end >= ps) {
                 k.flags |= KP_F_INSIDE;
                 break;
             }
+        }
     }
     // expected genes of the best locus that were not found inside
     const int g0 = db.locus_gene_off[best_locus], gl = db.locus_gene_len[best_locus];
