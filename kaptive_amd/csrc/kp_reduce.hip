@@ -211,7 +211,26 @@ __global__ __launch_bounds__(64) void kp_reduce_kernel(KpBatchView b, const kp_h
         if (i < SORT_LDS) s_raw[i] = k[i];
     }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
+    if (n <= SORT_LDS) {
+        // Keys are unique (the hit's index is their last field): a bitonic network over the LDS copy, (log n)^2 / 2 rounds of
+        // n / 128 compare-exchanges per lane, and the sorted keys give the order.  (Counting, for every hit, the keys below
+        // its own -- n / 64 x n compares per lane -- was a third of this kernel.)
+        int np2 = 64;
+        while (np2 < n) np2 <<= 1;
+        for (int i = n + lane; i < np2; i += 64) s_raw[i] = ~0ull;
+        __syncthreads();
+        for (int kk = 2; kk <= np2; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (np2 >> 1); t += 64) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;  // pair t of this round
+                    const uint64_t x = s_raw[lo], y = s_raw[hi];
+                    if ((x > y) == ((lo & kk) == 0)) { s_raw[lo] = y; s_raw[hi] = x; }
+                }
+                __syncthreads();
+            }
+        for (int r = lane; r < n; r += 64) ord[r] = (uint32_t)(s_raw[r] & 0x7FFFFull);  // kp_cull_key: the index is the low 19 bits
+    } else
+    for (int i = lane; i < n; i += 64) {  // more hits than the LDS copy holds: ranks by counting, against global memory
         const uint64_t mine = k[i];
         uint32_t rank = 0;
         const int n_lds = n < SORT_LDS ? n : SORT_LDS;
