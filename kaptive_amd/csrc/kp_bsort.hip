@@ -27,6 +27,7 @@ constexpr int BS_THREADS = 512, BS_WAVES = BS_THREADS / 64;
 constexpr int BS_STAGE = 512;     // keys one wave ranks in registers (8 per lane)
 constexpr int BS_RANK_MAX = 24;   // buckets up to this size are ranked against lane broadcasts, larger ones go through a bitonic network
 constexpr int BS_TILE = 1024;     // keys per LDS tile of the block-wide pass
+constexpr int BS_BIG_LIST = 1024; // buckets of BS_RANK_MAX + 1 .. BS_STAGE keys remembered for the shared pass (more: sorted where they are met)
 constexpr int BS_HUGE_LIST = 64;  // buckets larger than BS_STAGE remembered for the block-wide pass (more: ranked in place, slowly)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -82,6 +83,22 @@ __device__ __forceinline__ void bitonic_bucket(const uint64_t *__restrict__ grp,
         if (64u * r + lane < bm) dst[bs + 64u * r + lane] = k[r];
 }
 
+// the same network for one key per lane that is already in a register (64 keys, padded with the largest value)
+__device__ __forceinline__ uint64_t bitonic64(uint64_t k, int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j >= 1; j >>= 1) {
+            const uint64_t other = __shfl_xor(k, j);
+            const bool asc = kk >= 64 ? true : ((lane & kk) == 0);
+            const bool keep_min = ((lane & j) == 0) == asc;
+            const bool other_less = other < k;
+            k = (other_less == keep_min) ? other : k;
+        }
+    }
+    return k;
+}
+
 // `out` may be the buffer `sliced` points into: a block reads only its own assembly's region of `sliced`, all of it before
 // the first store to that region of `out` (phase 2 starts behind a barrier).
 __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint64_t *sliced,
@@ -95,6 +112,8 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
     __shared__ uint64_t s_tile[BS_TILE];  // the block-wide pass streams a huge bucket through it
     __shared__ uint32_t s_huge[BS_HUGE_LIST][2];
     __shared__ uint32_t s_n_huge;
+    __shared__ uint32_t s_big[BS_BIG_LIST][2];
+    __shared__ uint32_t s_n_big, s_big_next;
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t cap = (size_t)sub_cap * KP_ANCHOR_SUBS;
     const uint32_t *sc = sub_count + (size_t)a * KP_ANCHOR_SUBS;
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
             s_off[KP_ANCHOR_SUBS] = incl;
             count[a] = incl;
             need[a] = mx;
-            s_n_huge = 0;
+            s_n_huge = 0; s_n_big = 0; s_big_next = 0;
         }
     }
     for (uint32_t i = tid; i < n_bins; i += BS_THREADS) s_bin[i] = 0;
@@ -238,8 +257,26 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
                 if ((uint32_t)lane < bm[u]) dst[bs[u] + rank] = key[u];
             }
         }
-        unsigned long long big = __ballot(m > BS_RANK_MAX);
-        while (big) {  // the whole wave on one bucket
+        // Buckets that take a wave's network (BS_RANK_MAX + 1 .. BS_STAGE keys) are only listed here and shared out below: they
+        // are the genes of the typed locus and their relatives, neighbours in the gene order, so they all fall into one or
+        // two of these 64-bin pieces -- one wave sorted them one after the other while the block's other seven waited
+        // (1.80 against 1.64 ms; A/B: -DKP_BS_NO_LIST).
+        const bool listed_size = m > BS_RANK_MAX && m <= BS_STAGE;
+        const unsigned long long to_list = __ballot(listed_size);
+        uint32_t list_base = 0;
+        if (to_list) {
+            if (lane == 0) list_base = atomicAdd(&s_n_big, (uint32_t)__builtin_popcountll(to_list));
+            list_base = (uint32_t)__shfl((int)list_base, 0);
+        }
+        const uint32_t list_at = list_base + (uint32_t)__builtin_popcountll(to_list & ((1ull << lane) - 1ull));
+#ifdef KP_BS_NO_LIST
+        const bool listed = false;
+#else
+        const bool listed = listed_size && list_at < BS_BIG_LIST;
+#endif
+        if (listed) { s_big[list_at][0] = start; s_big[list_at][1] = m; }
+        unsigned long long big = __ballot(m > BS_RANK_MAX && !listed);
+        while (big) {  // the whole wave on one bucket (the list was full, or the bucket is larger than BS_STAGE)
             const int owner = __builtin_ctzll(big);
             big &= big - 1;
             const uint32_t bs = (uint32_t)__shfl((int)start, owner), bm = (uint32_t)__shfl((int)m, owner);
@@ -263,6 +300,39 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
         }
     }
     __syncthreads();
+    // ---- 2b. the listed buckets: every wave takes the next one until none is left ----------------------------------------------
+    {
+        const uint32_t n_big = min(s_n_big, (uint32_t)BS_BIG_LIST);
+#ifndef KP_BS_NB
+#define KP_BS_NB 1
+#endif
+        constexpr int NB = KP_BS_NB;  // buckets taken at a time (more, with their loads in flight together: 1.72 / 1.74 ms for 4 / 8 against 1.64)
+        for (;;) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&s_big_next, (uint32_t)NB);
+            at = (uint32_t)__shfl((int)at, 0);
+            if (at >= n_big) break;
+            uint32_t bs[NB], bm[NB];
+            uint64_t key[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const bool have = at + u < n_big;
+                bs[u] = have ? s_big[at + u][0] : 0u;
+                bm[u] = have ? s_big[at + u][1] : 0u;
+                key[u] = (bm[u] <= 64 && (uint32_t)lane < bm[u]) ? grp[bs[u] + lane] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (bm[u] == 0) continue;  // (uniform)
+                if (bm[u] <= 64) {
+                    const uint64_t k = bitonic64(key[u], lane);
+                    if ((uint32_t)lane < bm[u]) dst[bs[u] + lane] = k;
+                } else if (bm[u] <= 128) bitonic_bucket<2>(grp, dst, bs[u], bm[u], lane);
+                else if (bm[u] <= 256) bitonic_bucket<4>(grp, dst, bs[u], bm[u], lane);
+                else bitonic_bucket<BS_STAGE / 64>(grp, dst, bs[u], bm[u], lane);
+            }
+        }
+    }
     // ---- 3. the few buckets beyond BS_STAGE keys: ranked by the whole block, tile by tile through LDS ---------------------
     const uint32_t n_huge = min(s_n_huge, (uint32_t)BS_HUGE_LIST);
     uint64_t *tile = s_tile;
