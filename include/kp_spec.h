@@ -1,4 +1,4 @@
-/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v2") and of the packed data layout.
+/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v3") and of the packed data layout.
  *
  * The reference delegates gene-vs-contig alignment to the third-party rammappy 0.1.3 wheel
  * (src/kaptive/serotyping/core.py:147-155), whose source is not in the reference tree; parity at that stage is
@@ -25,15 +25,58 @@
 #define KP_CONTIG_ALIGN 32u
 #define KP_ASM_ALIGN 64u
 
-/* ---- seeding ----------------------------------------------------------------------------------------------------
- * A k-mer starts at position p of a sequence iff the context-free rule
- *        (c[p] ^ c[p+1] ^ c[p+3]) == KP_SEED_RULE_VALUE              (c = 2-bit codes)
- * holds, p+K <= sequence end, and no N lies in [p, p+K).  Contigs are scanned on their forward strand only; the
- * database side indexes every gene twice (forward sequence and its reverse complement) under the same rule, so a
- * shared k-mer gives the anchor its strand.  Expected density 1/4. */
+/* ---- seeding (kp-align v3): minimap2's (w = 10, k = 15) minimizers on BOTH sides ----------------------------------------
+ * The reference indexes the assembly and queries it with the genes (src/kaptive/core/genome.py:177-191,
+ * src/kaptive/serotyping/core.py:147-155: Aligner(index, preset=None)); with no preset minimap2 samples both with
+ * mm_sketch(w = 10, k = 15).  This section restates that sampling; it is the one place where v2 (a context-free rule at
+ * density 1/4) measurably left the published algorithm (profiles/concordance_r3.md).
+ *
+ * Value of the 15-mer that STARTS at base p of a sequence (codes c[p..p+14], all in 0..3):
+ *     fwd = sum c[p+j] << 2(14-j)   (first base in the high bits)      rev = sum (3 - c[p+j]) << 2j   (its reverse complement)
+ *     z = fwd < rev ? 0 : 1  (k is odd: fwd != rev)                    x(p) = kp_hash30(z ? rev : fwd)
+ * A 15-mer with an ambiguous base has no value (x = +inf).  kp_hash30 is minimap2's hash64 under the 30-bit mask; it is a
+ * bijection of 30-bit values, so equal x means equal canonical 15-mers.
+ *
+ * Which positions are SEEDS is defined by the state machine of mm_sketch, restated here (KP_W = 10, steps over the bases
+ * i = 0..len-1 of one contig or gene; the 15-mer ending at base i starts at i - 14):
+ *     l(i)   = number of consecutive unambiguous bases ending at i (0 at an ambiguous base)
+ *     info(i) = x(i - 14) if l(i) >= KP_K else +inf;   buf = info of the last KP_W steps;   min = (+inf) initially
+ *     step i:  (1) if l(i) == KP_W + KP_K - 1 and min != +inf: every buffered entry other than this step's and other than
+ *                  `min` itself whose value equals min's is a seed                      [ties of the first full window]
+ *              (2) if info(i) <= min:  `min` is a seed if l(i) >= KP_W + KP_K and min != +inf;  min = info(i)
+ *                  else if `min` is the entry that leaves the buffer at this step:
+ *                       `min` is a seed if l(i) >= KP_W + KP_K - 1;  min = the LAST smallest buffered entry;
+ *                       if l(i) >= KP_W + KP_K - 1 and min != +inf: every other buffered entry equal to it is a seed
+ *     after the last base: `min` is a seed if it is not +inf.
+ * Away from sequence ends and ambiguous bases this is: p is a seed iff x(p) is a smallest value (ties included) of at
+ * least one of the KP_W windows of KP_W consecutive 15-mers that contain it -- the form the scan kernel evaluates for
+ * every position whose 15-mer starts at least KP_W bases after the start of its clean stretch and ends at least KP_W bases
+ * before the end of it; the remaining positions (contig ends, the flanks of N runs) are decided by running the state
+ * machine itself (kp_scan.hip: kp_edge_kernel).  Expected density 2 / (KP_W + 1).
+ *
+ * A gene seed (start qs on the gene's forward strand, strand bit zq) and a contig seed (start ts, strand bit zt) with the
+ * same x make one ANCHOR: same strand if zq == zt, query position qs; otherwise the gene's reverse complement, query
+ * position gene_len - KP_K - qs.  (v3.0 applies no occurrence cut: minimap2's -f 2e-4 / min_mid_occ = 10 would drop a gene
+ * seed that occurs more than 10 times among the assembly's minimizers.) */
 #define KP_K 15
+#define KP_W 10
 #define KP_KMER_MASK 0x3FFFFFFFu
-#define KP_SEED_RULE_VALUE 1u
+#ifndef KP_SPEC_FN
+#ifdef __HIPCC__ /* the HIP sources use the same statement on the device */
+#define KP_SPEC_FN __host__ __device__ inline
+#else
+#define KP_SPEC_FN static inline
+#endif
+#endif
+KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, (1 << 30) - 1), all in 32 bits */
+    key = (~key + (key << 21)) & KP_KMER_MASK;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & KP_KMER_MASK;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & KP_KMER_MASK;
+    key = key ^ key >> 28;
+    return key; /* the last step, key + (key << 31), adds nothing below bit 30 */
+}
 #define KP_MAX_GENE_LEN 15800 /* q positions fit 16 bits; biased scores (<= 2 * length + 14) stay below 0x7C00 (kp_sw.hip) */
 #define KP_MAX_GENES 131071   /* (gene*2+strand) is stored in 18 bits */
 #define KP_MAX_ASM_LEN ((1u << 30) - 65536u)

@@ -37,7 +37,7 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    headers = [CSRC / "kp_internal.h", CSRC / "kp_reduce_core.h", INCLUDE / "kaptive_amd.h", INCLUDE / "kp_spec.h", INCLUDE / "kp_mapq.h"]
+    headers = [CSRC / "kp_internal.h", CSRC / "kp_sketch.h", CSRC / "kp_reduce_core.h", INCLUDE / "kaptive_amd.h", INCLUDE / "kp_spec.h", INCLUDE / "kp_mapq.h"]
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     hipcc = _hipcc()

@@ -12,6 +12,7 @@
 #include <unordered_map>
 
 #include "kp_internal.h"
+#include "kp_sketch.h"
 #include "kp_reduce_core.h"
 
 // kp_reduce.hip
@@ -294,6 +295,7 @@ struct kp_batch {
     const uint32_t *d_words = nullptr;  // in->d_words.p, or the caller's device pointer (kp_batch_create_device)
     KpBatchView view{};
     int64_t max_asm_bases = 0;  // longest assembly of the batch (padded)
+    int32_t n_ctg_total = 0;    // contigs of all its assemblies (one thread each in the edge kernel)
     KpWork *w = nullptr;        // the work set holding this batch's alignment results, while it still does
     KpWork *last_w = nullptr;   // the work set of its most recent pass (for completion waits; may have a new owner)
     kp_batch *after = nullptr;  // its words are another batch's device copy: passes wait for that batch's upload
@@ -377,7 +379,7 @@ void fill_blosum(int8_t *m) {
         for (int y = 0; y < 25; ++y) m[(uint8_t)alphabet[x] * 256 + (uint8_t)alphabet[y]] = b[x][y];
 }
 
-struct HostPosting { uint32_t key, gs, pos; };
+struct HostPosting { uint32_t key, gene, pos, z; };  // a gene seed: x, gene, first base on the forward strand, strand bit
 
 template <class T>
 int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n, hipStream_t stream = nullptr) {
@@ -461,6 +463,7 @@ int batch_tables(kp_ctx *ctx, kp_batch *b, int32_t n_asm, const int64_t *asm_wor
     b->view.asm_first_nrun = in.d_asm_first_nrun.p;
     b->view.n_asm = n_asm;
     b->view.total_words = asm_word_off[n_asm];
+    b->n_ctg_total = (int32_t)n_ctg;
     KP_HIP_CHECK(ctx, hipEventRecord(in.ready, ctx->copy));
     return KP_OK;
 }
@@ -684,22 +687,17 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
                 prof[8 * (size_t)(dst - nib.data()) + (size_t)i] = (uint16_t)kp_row_profile(code);
                 if (code > 3u) has_n[(size_t)g] = 1;
             }
-            for (int p = 0; p + KP_K <= len; ++p) {  // seed rule + N check, as in kp_spec.h
-                if (c[p] > 3 || c[p + 1] > 3 || c[p + 3] > 3 || ((c[p] ^ c[p + 1] ^ c[p + 3]) & 3u) != KP_SEED_RULE_VALUE)
-                    continue;
-                uint32_t v = 0;
-                bool ok = true;
-                for (int i = 0; i < KP_K; ++i) {
-                    if (c[p + i] > 3) { ok = false; break; }
-                    v |= (uint32_t)c[p + i] << (2 * i);
-                }
-                if (ok) post.push_back(HostPosting{v, (uint32_t)(2 * g + s), (uint32_t)p});
-            }
         }
+        // the gene's seeds: minimap2 sketches a query on its forward strand (kp_spec.h; kp_sketch.h is the state machine)
+        KpSketchState st;
+        kp_sketch_reset(st);
+        auto emit = [&](int64_t start, uint32_t z, uint32_t x) { post.push_back(HostPosting{x, (uint32_t)g, (uint32_t)start, z}); };
+        for (int i = 0; i < len; ++i) kp_sketch_step(st, i, fwd[i], emit);
+        if (len > 0) kp_sketch_final(st, len - 1, emit);
     }
     std::sort(post.begin(), post.end(), [](const HostPosting &a, const HostPosting &b) {
         if (a.key != b.key) return a.key < b.key;
-        if (a.gs != b.gs) return a.gs < b.gs;
+        if (a.gene != b.gene) return a.gene < b.gene;
         return a.pos < b.pos;
     });
     size_t n_unique = 0;
@@ -716,7 +714,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         lds_blocks = (uint32_t)std::min<size_t>(KP_LDS_FILTER_BLOCKS, std::max<size_t>(256, (n_unique * 16 + 63) / 64));
     std::vector<uint64_t> lds_filter(std::max<uint32_t>(lds_blocks, 1), 0ull);
     std::vector<uint64_t> flat;
-    flat.reserve(post.size() + n_unique + 1);
+    flat.reserve(2 * post.size() + n_unique + 1);
     for (size_t i = 0; i < post.size();) {
         size_t j = i;
         while (j < post.size() && post[j].key == post[i].key) ++j;
@@ -730,8 +728,12 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         }
         if (lds_blocks) lds_filter[kp_lds_filter_block(post[i].key, lds_blocks)] |= kp_filter_mask(post[i].key);
         flat.push_back((uint64_t)(j - i));
-        for (size_t x = i; x < j; ++x)
-            flat.push_back(((uint64_t)post[x].gs << 46) | ((uint64_t)(KP_DIAG_BIAS - post[x].pos) << 16) | post[x].pos);
+        for (uint32_t zt = 0; zt < 2; ++zt)  // the anchors a contig seed with strand bit zt makes with these gene seeds
+            for (size_t x = i; x < j; ++x) {
+                const uint32_t rev = post[x].z != zt ? 1u : 0u;
+                const uint32_t qpos = rev ? (uint32_t)(ctx->gene_len[post[x].gene] - KP_K) - post[x].pos : post[x].pos;
+                flat.push_back(((uint64_t)(2u * post[x].gene + rev) << 46) | ((uint64_t)(KP_DIAG_BIAS - qpos) << 16) | qpos);
+            }
         i = j;
     }
     if (flat.size() > 0xFFFFFFFFull) return kp_fail(ctx, KP_EINVAL, "seed index too large");
@@ -841,7 +843,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
-    KP_HIP_CHECK(ctx, w->d_cand_count.reserve(1));
+    KP_HIP_CHECK(ctx, w->d_cand_count.reserve(2));  // [0] the streaming kernel's candidates (front), [1] the edge kernel's (back)
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
     KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
@@ -849,7 +851,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->after->in->ready, 0));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, sizeof(unsigned long long), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, 2 * sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
     uint32_t *d_task_count = w->d_counts.p + n_asm;
@@ -860,7 +862,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     w->key_bits.db = std::min<uint32_t>(30, bits_for((uint64_t)b->max_asm_bases + KP_DIAG_BIAS));
     KP_HIP_CHECK(ctx, hipEventRecord(ev[0], stream));
     kp_launch_scan(b->view, ctx->index, w->d_cand.p, w->d_cand_count.p, w->cand_cap, w->d_anchors_a.p, w->d_sub_counts.p,
-                   sub_cap, w->key_bits, ctx->opt.scan_mode, ctx->opt.no_lds_filter != 0, stream, ev[1]);
+                   sub_cap, w->key_bits, ctx->opt.scan_mode, b->n_ctg_total, stream, ev[1]);
     if (!ctx->opt.library_sort && kp_bsort_fits(2u * (uint32_t)ctx->n_genes)) {
         // buckets of the gene/strand field, each sorted on its own (kp_bsort.hip); sorted keys end up where the chaining reads them
         kp_launch_anchor_bsort(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_anchors_a.p,
@@ -895,7 +897,7 @@ static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
     if (ctx->anchor_cap == 0) ctx->anchor_cap = ctx->opt.anchor_cap;
     ctx->anchor_cap = std::max<uint32_t>((ctx->anchor_cap + KP_ANCHOR_SUBS - 1) / KP_ANCHOR_SUBS, 16u) * KP_ANCHOR_SUBS;
     if (ctx->tasks_per_asm == 0) ctx->tasks_per_asm = ctx->opt.tasks_per_asm;
-    if (ctx->cand_frac <= 0.0) ctx->cand_frac = 0.012;  // a quarter of the positions are selected; ~1 % of those pass both filters
+    if (ctx->cand_frac <= 0.0) ctx->cand_frac = 0.004;  // 2 / 11 of the positions are seeds; ~1 % of those pass both filters
     if (ctx->hit_cap == 0) ctx->hit_cap = ctx->opt.hit_cap;
     w->anchor_cap = ctx->anchor_cap;
     w->task_cap = (uint32_t)std::min<uint64_t>((uint64_t)std::max(b->n_asm, 1) * ctx->tasks_per_asm, 1u << 28);
@@ -983,10 +985,11 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         w->h_counts.resize(2 * n_asm + KP_N_CLASSES);
         KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->post));
-        unsigned long long n_cand = 0, trace_need = 0;
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&n_cand, w->d_cand_count.p, sizeof n_cand, hipMemcpyDeviceToHost, ctx->post));
+        unsigned long long n_cand2[2] = {0, 0}, trace_need = 0;
+        KP_HIP_CHECK(ctx, hipMemcpyAsync(n_cand2, w->d_cand_count.p, sizeof n_cand2, hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipMemcpyAsync(&trace_need, w->d_trace_top.p, sizeof trace_need, hipMemcpyDeviceToHost, ctx->post));
         KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+        const unsigned long long n_cand = n_cand2[0] + n_cand2[1];
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);

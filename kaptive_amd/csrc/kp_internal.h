@@ -10,9 +10,11 @@
 #include "../../include/kaptive_amd.h"
 
 // ---- device-side views -------------------------------------------------------------------------------------------
-// Seed index: open-addressing table keyed by the 30-bit k-mer; slot = {key, first posting}; postings[first] holds the
-// count in its low word, followed by `count` posting words.  A posting word is the anchor key of the seed for target
-// position 0:  (gs << 46) | ((KP_DIAG_BIAS - qpos) << 16) | qpos ; adding (tpos << 16) yields the anchor key.
+// Seed index over the genes' minimizers (kp_spec.h, v3): open-addressing table keyed by x = kp_hash30(canonical 15-mer);
+// slot = {x, first posting}; postings[first] holds the count n, followed by 2 n posting words: n for a contig seed whose
+// strand bit is 0, then the same n gene seeds as a contig seed with strand bit 1 meets them (the other strand of the gene).
+// A posting word is the anchor key of the seed for target position 0:
+// (gs << 46) | ((KP_DIAG_BIAS - qpos) << 16) | qpos ; adding (tpos << 16) yields the anchor key.
 // Presence filter: a blocked Bloom filter of 2^KP_FILTER_LOG2 bits in 64-bit blocks.  A k-mer owns block
 // (kmer * 2654435769u) >> (32 - (KP_FILTER_LOG2 - 6)) and KP_FILTER_K bits of it (kp_filter_mask), so a probe is one
 // 8-byte gather; 2 MB stays resident in every XCD's L2.  With the ~1.2 M distinct k-mers of the KpSC K database 0.8 %
@@ -46,9 +48,13 @@ __host__ __device__ inline uint2 kp_filter2_mask2(uint32_t kmer) {
     m.y = (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
     return m;
 }
-// A candidate is one word: batch-wide base position (33 bits: a batch holds less than 2^33 bases) and the k-mer (30 bits).
+// A candidate is one word: batch-wide base position of the seed's first base (33 bits: a batch holds less than 2^33 bases),
+// the seed's strand bit z and its value x (30 bits).
 #define KP_CAND_POS_BITS 33
-__host__ __device__ inline uint64_t kp_cand_pack(uint64_t pos, uint32_t kmer) { return (pos << 30) | kmer; }
+__host__ __device__ inline uint64_t kp_cand_pack(uint64_t pos, uint32_t z, uint32_t x) { return (pos << 31) | ((uint64_t)z << 30) | x; }
+// Which seeds the streaming kernel decides and which the edge kernel (kp_spec.h): inside a clean stretch [S, E) of a contig
+// (no ambiguous base) a 15-mer that starts at t is the streaming kernel's iff t >= S + KP_W and t + KP_K + KP_W <= E.
+__host__ __device__ inline bool kp_seed_is_interior(int64_t t, int64_t S, int64_t E) { return t >= S + KP_W && t + KP_K + KP_W <= E; }
 
 // Small databases also get an LDS-sized copy of the filter: lds_filter_blocks 64-bit blocks (0 = none), block of a
 // k-mer = high word of hash * lds_filter_blocks, same KP_FILTER_K bits within the block.
@@ -168,7 +174,8 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------------------
 // kp_scan.hip: pass 1 streams the packed contigs and records candidate positions (selected k-mers that pass the presence
-//   filters) in `cand` (cand_cap words, kp_cand_pack; n_cand keeps counting past cand_cap = overflow); pass 2 turns
+//   filters) at the front of `cand` (cand_cap words, kp_cand_pack; n_cand[0] counts them), the edge kernel the seeds next
+//   to contig ends and N runs at its back (n_cand[1]); n_cand[0] + n_cand[1] > cand_cap = overflow; pass 2 turns
 //   candidates into anchor keys.  Each
 //   assembly's anchor region of sub_cap * KP_ANCHOR_SUBS keys is cut into KP_ANCHOR_SUBS sub-slices with their own
 //   counters (sub_count[a * KP_ANCHOR_SUBS + s] keeps counting past sub_cap = overflow); kp_launch_anchor_compact then
@@ -176,7 +183,7 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg);
 #define KP_ANCHOR_SUBS 64
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
                     uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
-                    int ablate_mode, bool no_lds_filter, hipStream_t stream, hipEvent_t after_scan);
+                    int ablate_mode, int32_t n_ctg_total, hipStream_t stream, hipEvent_t after_scan);
 void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                               uint64_t *out, uint32_t *count, uint32_t *need, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).

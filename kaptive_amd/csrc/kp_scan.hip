@@ -4,14 +4,16 @@
 // rule and key layout are those of include/kp_spec.h.  This is the only kernel that touches every base of every
 // assembly, so it is the one priced against the HBM-read roofline: algorithmic bytes = total_words * 4 per launch.
 //
-// Mapping: one lane owns 64 consecutive bases (one 16-byte load, lanes of a wave are contiguous -> 1 KiB per wave
-// instruction).  The 65th..80th base needed by k-mers that start near the end of the lane's span come from the next
-// lane's first word (DPP/shuffle), so every word is fetched from HBM exactly once.  The context-free seed rule
-// (c[p]^c[p+1]^c[p+3]==1) is evaluated for 16 positions at a time with word-wide bit operations; only the selected
-// quarter of positions goes on to the blocked-Bloom presence filter (2 MB, stays in each XCD's L2; kp_internal.h).  What passes
-// the filter is only recorded (kp_scan_kernel); a second, perfectly balanced kernel (kp_expand_kernel) probes the
-// k-mer table (tens of MB, Infinity Cache), validates and expands the postings into anchors.
+// Seeds are minimap2's (10, 15) minimizers (kp_spec.h, v3).  Mapping: one lane owns 64 consecutive bases (one 16-byte
+// load, lanes of a wave are contiguous), computes the value of the 64 15-mers that start there (canonical 15-mer ->
+// kp_hash30, all 32-bit) and decides which of them are window minima; the nine values it needs from either neighbour
+// cross lanes by DPP.  Only the selected positions (2 / 11 of all) go on to the blocked-Bloom presence filter (2 MB, stays
+// in each XCD's L2; kp_internal.h).  What passes the filters is only recorded (kp_scan_dense_kernel); contig ends and
+// the flanks of N runs, where minimap2's state machine does not reduce to the window rule, are handled by
+// kp_edge_kernel; a balanced kernel (kp_expand_kernel) probes the seed table, validates and expands the postings into
+// anchors.
 #include "kp_internal.h"
+#include "kp_sketch.h"
 
 namespace {
 
@@ -40,155 +42,51 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
     return lo;
 }
 
-// ---- pass 1: stream + select + presence filter -> candidate positions --------------------------------------------------
-// Every base is read once.  A selected k-mer that passes the filter becomes a candidate: its batch-wide base position
-// is staged in the wave's own LDS slice (ballot + popcount, no atomics) and flushed to the global candidate list with
-// one atomic per flush, so the streaming kernel has no data-dependent slow path: what a candidate costs later
-// (table probe, contig / N validation, posting expansion) is done by kp_expand_kernel with one thread per candidate.
-// MODE 0 = product; 1 = no filter reads (stream + select + hash only); 2 = stream only.  Modes 1 and 2 exist for the
-// ablation in tools/scan_ablate.py and write a checksum so that the work is not optimised away.
-//
-// A lane's 64 positions are handled as two halves of 32 (two packed words each): the selected positions of a half are
-// one 32-bit mask (word 0's at the even bits, word 1's at the odd bits), and the lane walks exactly its own set bits,
-// PROBES at a time, so that a round's filter reads are all in flight before the first is looked at.  (The round-1 kernel
-// ran 8 probe slots per word and round whatever the word had selected: three quarters of its instructions were idle.)
-//
-// Two filter tiers.  A database with few k-mers (O loci: tens of thousands) gets a filter small enough for LDS
-// (idx.lds_filter, <= KP_LDS_FILTER_BLOCKS 64-bit blocks): LDSF = true copies it into the block's LDS once and probes it
-// there, so the kernel no longer pays one L2 request per selected k-mer (the L2 tier runs at the L2's request rate);
-// blocks are 16 waves wide (one per CU: the filter takes most of its LDS) with a small candidate stage per wave.
-// Otherwise the 2 MB filter is probed in L2 (LDSF = false, 4-wave blocks, several per CU).
-template <bool LDSF> struct ScanShape {
-    static constexpr int WAVES = LDSF ? 16 : 4;
-    // a round of PROBES positions per lane adds at most 64 * PROBES entries (flush after the round)
-    static constexpr int STAGE = LDSF ? 320 : 1024;
-    static constexpr int FILTER_BLOCKS = LDSF ? KP_LDS_FILTER_BLOCKS : 1;
-};
-
+// ---- pass 1: stream + minimizers + presence filter -> candidate positions ------------------------------------------------
+// Every lane computes y(p) = (x(p) << 1) | nz(p) for the 64 positions of its unit (x: kp_spec.h; nz = 1 when the forward
+// 15-mer is the canonical one); the stream is taken as one clean sequence (N runs and the padding between contigs are code
+// 0): positions whose answer that falsifies are not this kernel's (kp_seed_is_interior) and are rejected by the expansion.
+// p is a seed iff x(p) is a smallest value of one of the ten windows of ten consecutive 15-mers that contain it, i.e. iff
+//      max over s in [p - 9, p] of ( min over [s, s + 9] of x )  ==  x(p)
+// (every window that contains p has a minimum <= x(p)).  Minima and maxima are taken on y -- the strand bit rides along
+// in bit 0 and cannot reorder different x -- and the comparison ignores bit 0, so ties (equal canonical 15-mers within a
+// window) select all their positions, as mm_sketch does.  A wave's lanes 0 and 63 only supply their neighbours' flanks:
+// successive wave iterations overlap by two units (62 of 64 lanes emit).
+// The selected positions are then COMPACTED into a 16-bit list in LDS and walked 64 entries at a time with every lane
+// busy (round 3's dense form): entry -> two words from LDS -> canonical 15-mer -> x -> filter block (one L2 read, PROBES
+// rounds in flight); what passes is staged per wave, checked against the second filter at flush time and written as one
+// word each.  MODE 0 = product; 1 = no filter reads; 2 = stream only (tools/scan_ablate.py).
 #ifndef KP_SCAN_PROBES
 #define KP_SCAN_PROBES 4
 #endif
 constexpr int PROBES = KP_SCAN_PROBES;  // filter reads a lane has in flight
-
-template <int MODE, bool LDSF>
-__global__ __launch_bounds__(64 * ScanShape<LDSF>::WAVES) void kp_scan_kernel(KpBatchView b, KpSeedIndex idx,
-                                                                              uint64_t *__restrict__ cand,
-                                                                              unsigned long long *__restrict__ n_cand,
-                                                                              uint64_t cand_cap) {
-    constexpr int WAVES = ScanShape<LDSF>::WAVES, STAGE_PER_WAVE = ScanShape<LDSF>::STAGE;
-    __shared__ uint64_t s_stage[WAVES][STAGE_PER_WAVE];
-    __shared__ uint2 s_filter[ScanShape<LDSF>::FILTER_BLOCKS];
-    const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
-    if (LDSF) {
-        const uint2 *src = reinterpret_cast<const uint2 *>(idx.lds_filter);
-        for (uint32_t i = threadIdx.x; i < idx.lds_filter_blocks; i += blockDim.x) s_filter[i] = src[i];
-        __syncthreads();
-    }
-    uint32_t checksum = 0;
-    const int64_t n_units = b.total_words >> 2;  // 16-byte units; every assembly is a whole number of them
-    const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;  // whole waves iterate together (shuffle below)
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t *stage = s_stage[wave];
-    uint32_t staged = 0;  // wave-uniform
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
-
-    // The staged candidates go through the second filter (one read each, all lanes busy), the survivors are packed to the
-    // front of the stage and leave with one atomic for the whole flush.
-    auto flush = [&]() {
-        uint32_t kept = 0;  // wave-uniform
-        for (uint32_t i0 = 0; i0 < staged; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            uint64_t c = 0;
-            bool ok = false;
-            if (i < staged) {
-                c = stage[i];
-                const uint32_t kmer = (uint32_t)c & KP_KMER_MASK;
-                const uint2 got = g_filter2[kp_filter2_block(kmer)], need = kp_filter2_mask2(kmer);
-                ok = (got.x & need.x) == need.x && (got.y & need.y) == need.y;
-            }
-            const unsigned long long pass = __ballot(ok);
-            if (ok) stage[kept + (uint32_t)__builtin_popcountll(pass & below)] = c;  // kept <= i0: never ahead of the reads
-            kept += (uint32_t)__builtin_popcountll(pass);
-        }
-        unsigned long long base = 0;
-        if (lane == 0 && kept) base = atomicAdd(n_cand, (unsigned long long)kept);
-        base = __shfl(base, 0);
-        for (uint32_t i = lane; i < kept; i += 64)
-            if (base + i < cand_cap) cand[base + i] = stage[i];
-        staged = 0;
-    };
-
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_iter_units; u += stride) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (u < n_units) v = vec[u];
-        uint32_t next = __shfl_down(v.x, 1);
-        if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
-        const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
-        if (MODE == 2) { checksum += v.x ^ v.y ^ v.z ^ v.w ^ next; continue; }
-        uint32_t sel[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = w[k], hi = w[k + 1];
-            // 2-bit lanes: x = c[p] ^ c[p+1] ^ c[p+3] for the 16 positions of this word
-            const uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, lo, 2) ^ __builtin_amdgcn_alignbit(hi, lo, 6);
-            sel[k] = x & ~(x >> 1) & 0x55555555u;  // value 01: low bit set, high bit clear
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const uint32_t w0 = w[2 * half], w1 = w[2 * half + 1], w2 = w[2 * half + 2];
-            uint32_t m = sel[2 * half] | (sel[2 * half + 1] << 1);  // bit 2i: word 0 position i; bit 2i + 1: word 1 position i
-            const uint64_t half_base = (uint64_t)((u << 2) + 2 * half) << 4;  // batch-wide position of the half's first base
-            while (__any(m != 0)) {  // wave-uniform: a lane that ran out of selected positions idles along
-                uint32_t kmers[PROBES], pos[PROBES], pass[PROBES];
-                uint2 got[PROBES];
-#pragma unroll
-                for (int j = 0; j < PROBES; ++j) {
-                    const bool have = m != 0;
-                    const int bit = have ? __builtin_ctz(m) : 0;
-                    m &= m - 1;  // no-op once m is 0
-                    const bool odd = bit & 1;
-                    const uint32_t lo = odd ? w1 : w0, hi = odd ? w2 : w1;
-                    const uint32_t kmer = kmers[j] = __builtin_amdgcn_alignbit(hi, lo, bit & 30) & KP_KMER_MASK;
-                    pos[j] = (uint32_t)(bit >> 1) + (odd ? 16u : 0u);
-                    pass[j] = have ? 1u : 0u;
-                    if (MODE == 1) { checksum += have ? kmer * 2654435769u : 0u; continue; }
-                    const uint32_t blk = LDSF ? kp_lds_filter_block(kmer, idx.lds_filter_blocks) : kp_filter_block(kmer);
-                    got[j] = LDSF ? s_filter[blk] : (have ? g_filter[blk] : make_uint2(0u, 0u));
-                }
-                if (MODE != 0) continue;
-#pragma unroll
-                for (int j = 0; j < PROBES; ++j) {
-                    const uint2 need = kp_filter_mask2(kmers[j]);
-                    const bool hit = pass[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
-                    const unsigned long long ballot = __ballot(hit);
-                    if (!ballot) continue;  // ~99 % of selected positions stop at the filter (KpSC K database)
-                    if (hit)  // position and k-mer in one word: the expansion pass does not touch the bases again
-                        stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] = kp_cand_pack(half_base + pos[j], kmers[j]);
-                    staged += (uint32_t)__builtin_popcountll(ballot);
-                }
-                if (staged > STAGE_PER_WAVE - 64 * PROBES) flush();
-            }
-        }
-    }
-    if (MODE == 0 && staged) flush();
-    if (MODE != 0 && checksum == 0x9E3779B1u) n_cand[0] = checksum;  // practically never; keeps the work alive
-}
-
-// ---- pass 1, dense form (the L2 tier of the filter: every database but the smallest) ---------------------------------------
-// Same reads, same rule, same filters, same candidates as kp_scan_kernel<0, false>; what changes is who probes what.  There
-// a lane walks the selected positions of its OWN 64 bases, and a wave runs at the pace of its fullest lane: a quarter of
-// the positions is selected on average (8 per half of 32), the fullest of 64 lanes holds about 14, so half of the probe
-// slots were idle lanes.  Here the wave first COMPACTS its selected positions into a list in LDS (a cheap loop: find the
-// bit, store 16 bits), keeps its 257 packed words in LDS as well, and then walks the list 64 entries at a time with every
-// lane busy: entry -> position within the wave's 4096 bases -> two words from LDS -> k-mer -> filter block (one L2 read,
-// PROBES rounds in flight).  About 30 vector instructions per selected position instead of 60.
-// MODE as above (0 product, 1 no filter reads, 2 stream only).
 constexpr int DENSE_WAVES = 4;
-constexpr int DENSE_LIST = 2048;   // selected positions of a wave's iteration the list holds (mean 1024; see `groups`)
+constexpr int DENSE_LIST = 2048;   // selected positions of a wave's iteration the list holds (mean ~ 720; see `groups`)
 constexpr int DENSE_STAGE = 512;   // candidates staged per wave before a flush
+constexpr int SCAN_OWN = 62;       // lanes of a wave iteration that emit (lanes 1..62)
+
+__device__ __forceinline__ uint32_t lane_from_below(uint32_t v) {  // lane L receives lane L - 1's value (lane 0: 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ uint32_t lane_from_above(uint32_t v) {  // lane L receives lane L + 1's value (lane 63: 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
+}
+// the sixteen 2-bit groups of a word in reverse order
+__device__ __forceinline__ uint32_t reverse_groups(uint32_t w) {
+    const uint32_t r = __builtin_bitreverse32(w);
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+
+// y of the 15-mer whose bases sit in the low 30 bits of `e` (first base in bits 0-1)
+__device__ __forceinline__ uint32_t seed_value_from_low(uint32_t e) {
+    const uint32_t rev = e ^ KP_KMER_MASK;  // complement; the stream's layout is the reverse complement's
+    const uint32_t r = __builtin_bitreverse32(e) >> 2;
+    const uint32_t fwd = ((r >> 1) & 0x15555555u) | ((r & 0x15555555u) << 1);
+    const uint32_t nz = fwd < rev ? 1u : 0u;
+    return (kp_hash30(nz ? fwd : rev) << 1) | nz;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatchView b, KpSeedIndex idx,
@@ -202,8 +100,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
     const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
     uint32_t checksum = 0;
     const int64_t n_units = b.total_words >> 2;
-    const int64_t n_iter_units = (n_units + 63) & ~(int64_t)63;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_iters = (n_units + SCAN_OWN - 1) / SCAN_OWN;
     const uint4 *vec = reinterpret_cast<const uint4 *>(b.words);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t *stage = s_stage[wave];
@@ -212,7 +109,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
     uint32_t staged = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    auto flush = [&]() {  // second filter on what is staged, survivors out with one atomic (as in kp_scan_kernel)
+    auto flush = [&]() {  // second filter on what is staged, survivors out with one atomic
         uint32_t kept = 0;
         for (uint32_t i0 = 0; i0 < staged; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -220,8 +117,8 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
             bool ok = false;
             if (i < staged) {
                 c = stage[i];
-                const uint32_t kmer = (uint32_t)c & KP_KMER_MASK;
-                const uint2 got = g_filter2[kp_filter2_block(kmer)], need = kp_filter2_mask2(kmer);
+                const uint32_t x = (uint32_t)c & KP_KMER_MASK;
+                const uint2 got = g_filter2[kp_filter2_block(x)], need = kp_filter2_mask2(x);
                 ok = (got.x & need.x) == need.x && (got.y & need.y) == need.y;
             }
             const unsigned long long pass = __ballot(ok);
@@ -236,30 +133,62 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
         staged = 0;
     };
 
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_iter_units; u += stride) {
+    const int64_t wave_stride = (int64_t)gridDim.x * DENSE_WAVES;
+    for (int64_t it = (int64_t)blockIdx.x * DENSE_WAVES + wave; it < n_iters; it += wave_stride) {
+        const int64_t u = it * SCAN_OWN - 1 + lane;  // lane 0 repeats the previous iteration's last unit, lane 63 the next's first
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (u < n_units) v = vec[u];
-        uint32_t next = __shfl_down(v.x, 1);
-        if (lane == 63) next = (u + 1 < n_units) ? b.words[(u + 1) << 2] : 0u;
+        if (u >= 0 && u < n_units) v = vec[u];
+        const uint32_t next = lane_from_above(v.x);
         if (MODE == 2) { checksum += v.x ^ v.y ^ v.z ^ v.w ^ next; continue; }
         const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
-        // selected positions of the lane's 64 bases: two masks of 32 (bit 2i: position i of the even word, bit 2i + 1:
-        // position i of the odd word of the pair)
-        uint32_t m2[2];
+        uint32_t rw[5];  // the same words with their bases in reverse order: the forward 15-mer's layout
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t sel[2];
+        for (int k = 0; k < 5; ++k) rw[k] = reverse_groups(w[k]);
+        // y of the lane's 64 positions, with nine of either neighbour's on both sides: Y[9 + p], p in [-9, 72]
+        uint32_t Y[82];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t lo = w[2 * h + k], hi = w[2 * h + k + 1];
-                const uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, lo, 2) ^ __builtin_amdgcn_alignbit(hi, lo, 6);
-                sel[k] = x & ~(x >> 1) & 0x55555555u;
-            }
-            m2[h] = sel[0] | (sel[1] << 1);
+        for (int p = 0; p < 64; ++p) {
+            const int a = p >> 4, o = p & 15;
+            const uint32_t rev = (__builtin_amdgcn_alignbit(w[a + 1], w[a], 2 * o) & KP_KMER_MASK) ^ KP_KMER_MASK;
+            uint32_t fwd;
+            if (o == 0) fwd = rw[a] >> 2;
+            else if (o == 1) fwd = rw[a] & KP_KMER_MASK;
+            else fwd = __builtin_amdgcn_alignbit(rw[a], rw[a + 1], 34 - 2 * o) & KP_KMER_MASK;
+            const uint32_t nz = (fwd - rev) >> 31;  // both below 2^30: the sign of the difference says which is smaller
+            Y[9 + p] = (kp_hash30(nz ? fwd : rev) << 1) | nz;
         }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            Y[j] = lane_from_below(Y[9 + 55 + j]);
+            Y[9 + 64 + j] = lane_from_above(Y[9 + j]);
+        }
+        // window minima (index s + 9 holds the minimum of Y over positions [s, s + 9]), then the maxima of ten of those
+        uint32_t sel[2] = {0u, 0u};
+        {
+            uint32_t c1[80], c2[76], wm[73];
+#pragma unroll
+            for (int i = 0; i < 80; ++i) c1[i] = min3u(Y[i], Y[i + 1], Y[i + 2]);
+#pragma unroll
+            for (int i = 0; i < 76; ++i) c2[i] = min3u(c1[i], c1[i + 2], c1[i + 4]);
+#pragma unroll
+            for (int i = 0; i < 73; ++i) wm[i] = min(c2[i], c2[i + 3]);
+            uint32_t d1[71], d2[67];
+#pragma unroll
+            for (int i = 0; i < 71; ++i) d1[i] = max3u(wm[i], wm[i + 1], wm[i + 2]);
+#pragma unroll
+            for (int i = 0; i < 67; ++i) d2[i] = max3u(d1[i], d1[i + 2], d1[i + 4]);
+#pragma unroll
+            for (int p = 0; p < 64; ++p) {
+                const uint32_t m = max(d2[p], d2[p + 3]);  // over the windows that start in [p - 9, p]
+                if ((m ^ Y[9 + p]) < 2u) sel[p >> 5] |= 1u << (p & 31);
+            }
+        }
+        const bool owner = lane >= 1 && lane <= SCAN_OWN && u < n_units;
+        if (!owner) sel[0] = sel[1] = 0u;
+        if (MODE == 1) { checksum += sel[0] * 2654435769u + sel[1]; }
         *reinterpret_cast<uint4 *>(&words[4 * lane]) = v;
-        if (lane == 63) words[256] = next;
-        const uint32_t mine = (uint32_t)__builtin_popcount(m2[0]) + (uint32_t)__builtin_popcount(m2[1]);
+        if (lane == 63) words[256] = 0u;  // (lane 63 emits nothing: nobody reads past its unit)
+        const uint32_t mine = (uint32_t)__builtin_popcount(sel[0]) + (uint32_t)__builtin_popcount(sel[1]);
         uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -267,11 +196,11 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
             if (lane >= o) incl += t;
         }
         const uint32_t total = __shfl(incl, 63);
-        // the list holds DENSE_LIST entries: an iteration with more selected positions (a low-complexity stretch: the rule
-        // can select every position) goes through in two groups of 32 lanes, each at most 32 x 64 = 2048 positions
+        // the list holds DENSE_LIST entries: an iteration with more selected positions (a low-complexity stretch: equal
+        // 15-mers are all selected) goes through in two groups of 32 lanes, each at most 32 x 64 = 2048 positions
         const int groups = total > (uint32_t)DENSE_LIST ? 2 : 1;
         const uint32_t before_half = __shfl(incl, 31);  // selected positions of lanes 0..31
-        const uint64_t wave_base = (uint64_t)((u - lane) << 2) << 4;  // batch-wide position of the wave's first base
+        const int64_t wave_base = (u - lane) * 64;      // batch-wide position of lane 0's first base (may be -64)
         for (int g = 0; g < groups; ++g) {
             const bool active = groups == 1 || (lane >> 5) == g;
             const uint32_t n_list = groups == 1 ? total : (g == 0 ? before_half : total - before_half);
@@ -280,17 +209,17 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
             if (active) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    uint32_t m = m2[h];
+                    uint32_t m = sel[h];
                     while (m) {
                         const int bit = __builtin_ctz(m);
                         m &= m - 1;
-                        list[off++] = (uint16_t)(64 * lane + 32 * h + 16 * (bit & 1) + (bit >> 1));
+                        list[off++] = (uint16_t)(64 * lane + 32 * h + bit);
                     }
                 }
             }
             wave_lds_sync();
             for (uint32_t e0 = 0; e0 < n_list; e0 += 64 * PROBES) {
-                uint32_t kmers[PROBES], pos[PROBES];
+                uint32_t ys[PROBES], pos[PROBES];
                 bool have[PROBES];
                 uint2 got[PROBES];
 #pragma unroll
@@ -299,19 +228,22 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
                     have[j] = e < n_list;
                     const uint32_t p = have[j] ? list[e] : 0u;
                     const uint32_t lo = words[p >> 4], hi = words[(p >> 4) + 1];
-                    kmers[j] = __builtin_amdgcn_alignbit(hi, lo, 2 * (p & 15u)) & KP_KMER_MASK;
+                    ys[j] = seed_value_from_low(__builtin_amdgcn_alignbit(hi, lo, 2 * (p & 15u)) & KP_KMER_MASK);
                     pos[j] = p;
-                    if (MODE == 1) { checksum += have[j] ? kmers[j] * 2654435769u : 0u; continue; }
-                    got[j] = have[j] ? g_filter[kp_filter_block(kmers[j])] : make_uint2(0u, 0u);
+                    if (MODE == 1) { checksum += have[j] ? ys[j] * 2654435769u : 0u; continue; }
+                    got[j] = have[j] ? g_filter[kp_filter_block(ys[j] >> 1)] : make_uint2(0u, 0u);
                 }
                 if (MODE != 0) continue;
 #pragma unroll
                 for (int j = 0; j < PROBES; ++j) {
-                    const uint2 need = kp_filter_mask2(kmers[j]);
+                    const uint32_t x = ys[j] >> 1;
+                    const uint2 need = kp_filter_mask2(x);
                     const bool hit = have[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
                     const unsigned long long ballot = __ballot(hit);
                     if (!ballot) continue;
-                    if (hit) stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] = kp_cand_pack(wave_base + pos[j], kmers[j]);
+                    if (hit)
+                        stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] =
+                            kp_cand_pack((uint64_t)(wave_base + pos[j]), (ys[j] & 1u) ^ 1u, x);
                     staged += (uint32_t)__builtin_popcountll(ballot);
                 }
                 if (staged > DENSE_STAGE - 64 * PROBES) flush();
@@ -322,9 +254,87 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
     if (MODE != 0 && checksum == 0x9E3779B1u) n_cand[0] = checksum;
 }
 
+// ---- pass 1b: the seeds next to contig ends and N runs ---------------------------------------------------------------------
+// One thread per contig walks its clean stretches [S, E) (no ambiguous base) and runs kp_spec.h's state machine
+// (kp_sketch.h) where kp_seed_is_interior says the streaming kernel must not decide: over the first bases of a stretch
+// from a fresh state (at a contig start that is mm_sketch's own start; after an N run every older entry has left the
+// window and the tracked minimum has been dropped by the time the stretch's first 15-mer is complete), and over its last
+// bases after a warm-up of 48 steps from a fresh state (window, minimum and run length depend on the last KP_W + KP_K
+// steps only; what the warm-up settles wrongly lies before the positions kept).  Past the stretch's end it keeps stepping
+// through ambiguous bases until the tracked minimum has left the window -- dropped, as mm_sketch drops it -- or the
+// contig ends, where the minimum is a seed.  Seeds that pass both presence filters are appended at the BACK of the
+// candidate list (n_cand[1]); they need no validation.
+__global__ __launch_bounds__(256) void kp_edge_kernel(KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ cand,
+                                                       unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
+                                                       int32_t n_ctg_total) {
+    const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
+    const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
+    const int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_ctg_total) return;
+    const int a = upper_bound_i32(b.asm_first_ctg, b.n_asm + 1, c) - 1;  // the contig's assembly
+    const int64_t asm_base = (int64_t)b.asm_word_off[a] << 4;
+    const uint32_t *aw = b.words + b.asm_word_off[a];
+    const int64_t cs = b.ctg_start[c], ce = cs + b.ctg_len[c];
+    const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
+    int r = 0;  // first N run that ends after the contig's start
+    {
+        int lo = 0, hi = nr;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (b.n_runs[2 * (r0 + mid) + 1] <= cs) lo = mid + 1; else hi = mid;
+        }
+        r = lo;
+    }
+    int64_t S = cs;
+    while (S < ce) {
+        // the stretch [S, E): up to the next N run inside the contig
+        int64_t E = ce, resume = ce;
+        if (r < nr && b.n_runs[2 * (r0 + r)] < ce) {
+            E = max((int64_t)b.n_runs[2 * (r0 + r)], S);
+            resume = min((int64_t)b.n_runs[2 * (r0 + r) + 1], ce);
+            ++r;
+        }
+        if (E - S >= KP_K) {
+            bool keep_left = true, keep_right = true;  // which flank the current run settles
+            auto emit = [&](int64_t t, uint32_t z, uint32_t x) {
+                if (t < S || kp_seed_is_interior(t, S, E)) return;  // a warm-up artefact, or the streaming kernel's
+                if (t < S + KP_W ? !keep_left : !keep_right) return;  // (a position in both flanks goes with the left one)
+                const uint2 g1 = g_filter[kp_filter_block(x)], n1 = kp_filter_mask2(x);
+                if ((g1.x & n1.x) != n1.x || (g1.y & n1.y) != n1.y) return;
+                const uint2 g2 = g_filter2[kp_filter2_block(x)], n2 = kp_filter2_mask2(x);
+                if ((g2.x & n2.x) != n2.x || (g2.y & n2.y) != n2.y) return;
+                const unsigned long long k = atomicAdd(n_cand + 1, 1ull);
+                if (k < cand_cap) cand[cand_cap - 1 - k] = kp_cand_pack((uint64_t)(asm_base + t), z, x);
+            };
+            auto run = [&](int64_t from, int64_t to) {  // steps [from, to) from a fresh state; bases at or past E are ambiguous
+                KpSketchState st;
+                kp_sketch_reset(st);
+                for (int64_t i = from; i < to; ++i) {
+                    const uint32_t code = i < E ? ((aw[i >> 4] >> (2 * (i & 15))) & 3u) : 4u;
+                    kp_sketch_step(st, i, code, emit);
+                }
+                if (to == ce) kp_sketch_final(st, ce - 1, emit);
+            };
+            const int64_t stop = min(E + KP_W, ce);  // by then the tracked minimum has left the window
+            const int64_t warm = E - (KP_K + KP_W) - 48;
+            if (warm <= S) {
+                run(S, stop);
+            } else {
+                keep_right = false;
+                run(S, S + 2 * KP_W + KP_K);  // settles every position before S + KP_W (retired by step S + KP_W - 1 + KP_K - 1 + KP_W)
+                keep_right = true, keep_left = false;
+                run(warm, stop);
+            }
+        }
+        S = resume;
+    }
+}
+
 // ---- pass 2: candidates -> anchors -------------------------------------------------------------------------------------
-// One thread per candidate: re-read its k-mer, probe the table, validate against contig bounds and N runs, reserve room
-// for its postings in its assembly's anchor region.  The postings themselves are then copied by the whole wave as one
+// One thread per candidate: probe the table, find its assembly, contig and clean stretch, keep it if it is the streaming
+// kernel's to decide (kp_seed_is_interior; the edge kernel's candidates, at the back of the list, were decided by the
+// state machine and are taken as they are), reserve room for its postings in its assembly's anchor region.  The postings
+// themselves are then copied by the whole wave as one
 // flat list (prefix sums of the counts, every lane finds the owner of its output item by binary search): a shared gene
 // family has ~160 postings per seed, a per-thread copy loop would run the wave at the pace of its longest list.  Appends of one assembly are spread over
 // KP_ANCHOR_SUBS counters because all hits of an assembly come in one burst (the typed locus) and would otherwise
@@ -333,8 +343,12 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
                                                          const unsigned long long *__restrict__ n_cand, uint64_t cand_cap,
                                                          uint64_t *__restrict__ anchors, uint32_t *__restrict__ sub_count,
                                                          uint32_t sub_cap, KpKeyBits kb) {
-    unsigned long long n = *n_cand;
-    if (n > cand_cap) n = cand_cap;
+    unsigned long long n_front = n_cand[0], n_back = n_cand[1];
+    if (n_front + n_back > cand_cap) {  // overflow: the host grows the list and reruns the pass
+        if (n_front > cand_cap) n_front = cand_cap;
+        n_back = cand_cap - n_front;
+    }
+    const unsigned long long n = n_front + n_back;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     struct WaveStage {  // survivors of the wave's current 64 candidates, in lane order
         uint32_t start[64], room[64];
@@ -348,16 +362,19 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
     // whole waves iterate together: the copy phase below needs every lane of the wave
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
         const uint64_t i = i0 + lane;
-        uint32_t first_posting = 0xFFFFFFFFu, cnt = 0, base = 0, t = 0;
+        uint32_t first_posting = 0xFFFFFFFFu, cnt = 0, base = 0, t = 0, zt = 0;
         size_t slice = 0;
         if (i < n) {
-            const uint64_t pos = cand[i] >> 30;
+            const bool edge = i >= n_front;
+            const uint64_t cw = edge ? cand[cand_cap - 1 - (i - n_front)] : cand[i];
+            const uint64_t pos = cw >> 31;
             const int64_t word = (int64_t)(pos >> 4);
-            const uint32_t kmer = (uint32_t)cand[i] & KP_KMER_MASK;
-            uint32_t slot = (kmer * 2654435769u) >> idx.slot_shift;
+            const uint32_t x = (uint32_t)cw & KP_KMER_MASK;
+            zt = (uint32_t)(cw >> 30) & 1u;
+            uint32_t slot = (x * 2654435769u) >> idx.slot_shift;
             for (;;) {
                 const uint2 e = idx.slots[slot];
-                if (e.x == kmer) { first_posting = e.y; break; }
+                if (e.x == x) { first_posting = e.y; break; }
                 if (e.x == 0xFFFFFFFFu) break;
                 slot = (slot + 1) & idx.slot_mask;
             }
@@ -366,18 +383,25 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
                 const int a = upper_bound_i64(b.asm_word_off, b.n_asm + 1, word) - 1;
                 if (a >= 0 && a < b.n_asm) {
                     t = (uint32_t)(pos - ((uint64_t)b.asm_word_off[a] << 4));
-                    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
-                    const int c = upper_bound_i32(b.ctg_start + c0, nc, (int32_t)t) - 1;
-                    // the k-mer must not run past its contig (or sit in padding) ...
-                    ok = c >= 0 && (int32_t)t + KP_K <= b.ctg_start[c0 + c] + b.ctg_len[c0 + c];
-                    const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
-                    if (ok && nr > 0) {  // ... nor overlap an N run: first run whose end is > t starts before t + K
-                        int lo = 0, hi = nr;
-                        while (lo < hi) {
-                            int mid = (lo + hi) >> 1;
-                            if (b.n_runs[2 * (r0 + mid) + 1] <= (int32_t)t) lo = mid + 1; else hi = mid;
+                    ok = edge;
+                    if (!edge) {
+                        const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+                        const int c = upper_bound_i32(b.ctg_start + c0, nc, (int32_t)t) - 1;
+                        if (c >= 0) {
+                            // the clean stretch [S, E) around t: the contig, cut at the nearest N runs on either side
+                            int64_t S = b.ctg_start[c0 + c], E = S + b.ctg_len[c0 + c];
+                            const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
+                            if (nr > 0) {
+                                int lo = 0, hi = nr;  // first run whose end is > t
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (b.n_runs[2 * (r0 + mid) + 1] <= (int32_t)t) lo = mid + 1; else hi = mid;
+                                }
+                                if (lo < nr) E = min(E, (int64_t)b.n_runs[2 * (r0 + lo)]);  // (a run that holds t makes E <= t)
+                                if (lo > 0) S = max(S, (int64_t)b.n_runs[2 * (r0 + lo - 1) + 1]);
+                            }
+                            ok = kp_seed_is_interior((int64_t)t, S, E);
                         }
-                        if (lo < nr && b.n_runs[2 * (r0 + lo)] < (int32_t)t + KP_K) ok = false;
                     }
                     if (ok) {
                         cnt = (uint32_t)idx.postings[first_posting];
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(256) void kp_expand_kernel(KpBatchView b, KpSeedInd
         const int n_live = __builtin_popcountll(live);
         if (cnt) {
             sw.start[rank] = incl - cnt;
-            sw.src[rank] = idx.postings + first_posting + 1;
+            sw.src[rank] = idx.postings + first_posting + 1 + (zt ? cnt : 0u);  // the list for this contig seed's strand bit
             sw.dst[rank] = anchors + slice * sub_cap + base;
             sw.room[rank] = base < sub_cap ? sub_cap - base : 0u;
             sw.shift[rank] = (uint64_t)t << 16;
@@ -462,28 +486,18 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 
 void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand, unsigned long long *n_cand,
                     uint64_t cand_cap, uint64_t *anchors, uint32_t *sub_count, uint32_t sub_cap, KpKeyBits key_bits,
-                    int mode, bool no_lds, hipStream_t stream, hipEvent_t after_scan) {
+                    int mode, int32_t n_ctg_total, hipStream_t stream, hipEvent_t after_scan) {
     if (b.total_words == 0) return;
     const int64_t n_units = b.total_words >> 2;
-    if (idx.lds_filter_blocks && !no_lds && mode == 0) {
-        // one 16-wave block per CU (the filter fills most of its LDS); a few blocks per CU in the grid even out the tail
-        int64_t blocks = (n_units + 1023) / 1024;
-        if (blocks > 256 * 4) blocks = 256 * 4;
-        hipLaunchKernelGGL((kp_scan_kernel<0, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, b, idx, cand, n_cand, cand_cap);
-    } else {
-        int64_t blocks = (n_units + 255) / 256;
-        if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond that
-        const dim3 grid((unsigned)blocks), block(256);
-#ifdef KP_SCAN_LANE_OWNED  // (A/B builds: the round-2 kernel, every lane walking its own selected positions)
-        if (mode == 1) hipLaunchKernelGGL((kp_scan_kernel<1, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-        else if (mode == 2) hipLaunchKernelGGL((kp_scan_kernel<2, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-        else hipLaunchKernelGGL((kp_scan_kernel<0, false>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-#else
-        if (mode == 1) hipLaunchKernelGGL((kp_scan_dense_kernel<1>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-        else if (mode == 2) hipLaunchKernelGGL((kp_scan_dense_kernel<2>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-        else hipLaunchKernelGGL((kp_scan_dense_kernel<0>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
-#endif
-    }
+    int64_t blocks = ((n_units + SCAN_OWN - 1) / SCAN_OWN + DENSE_WAVES - 1) / DENSE_WAVES;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 256 CUs x 8 blocks, wave-iteration stride beyond that
+    const dim3 grid((unsigned)blocks), block(64 * DENSE_WAVES);
+    if (mode == 1) hipLaunchKernelGGL((kp_scan_dense_kernel<1>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    else if (mode == 2) hipLaunchKernelGGL((kp_scan_dense_kernel<2>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    else hipLaunchKernelGGL((kp_scan_dense_kernel<0>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
+    if (mode == 0 && n_ctg_total > 0)
+        hipLaunchKernelGGL(kp_edge_kernel, dim3((unsigned)((n_ctg_total + 255) / 256)), dim3(256), 0, stream, b, idx, cand, n_cand,
+                           cand_cap, n_ctg_total);
     if (after_scan) (void)hipEventRecord(after_scan, stream);
     hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap,
                        anchors, sub_count, sub_cap, key_bits);

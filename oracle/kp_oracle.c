@@ -269,38 +269,88 @@ KPO_API int64_t kpo_extract(const uint8_t *seqs, const int32_t *off, const int32
 }
 
 /* ================================================================================================================
- * Nucleotide aligner "kp-align v1" (include/kp_spec.h) -- parity UNPINNED against the reference (see header)
+ * Nucleotide aligner "kp-align v3" (include/kp_spec.h) -- parity UNPINNED against the reference (see header)
  * ================================================================================================================ */
 
-typedef struct { uint32_t key; uint32_t gs; uint32_t pos; } kpo_posting;
+/* ---- seeds: minimap2's (10, 15) minimizers, kp_spec.h's state machine written out step by step ----------------------------
+ * One call handles one sequence of codes (0..3, anything else ambiguous).  Every seed is reported once through `emit`
+ * as (start of the 15-mer, strand bit z, x).  The ring `ring_x/ring_p/ring_z` holds the last KP_W steps. */
+#define KPO_INF 0xFFFFFFFFu
+typedef void (*kpo_seed_fn)(void *ud, int32_t start, int z, uint32_t x);
+
+static void kpo_sketch(const uint8_t *c, int64_t len, kpo_seed_fn emit, void *ud) {
+    uint32_t ring_x[KP_W];
+    int32_t ring_p[KP_W];
+    uint8_t ring_z[KP_W];
+    for (int j = 0; j < KP_W; j++) { ring_x[j] = KPO_INF; ring_p[j] = -1; ring_z[j] = 0; }
+    uint32_t fwd = 0, rev = 0, min_x = KPO_INF;
+    int32_t min_p = -1;
+    int min_z = 0, min_slot = 0, slot = 0;
+    int64_t run = 0; /* l(i): unambiguous bases ending here */
+    for (int64_t i = 0; i < len; i++) {
+        uint32_t x = KPO_INF;
+        int z = 0;
+        if (c[i] < 4) {
+            fwd = ((fwd << 2) | c[i]) & KP_KMER_MASK;
+            rev = (rev >> 2) | ((uint32_t)(3 - c[i]) << (2 * (KP_K - 1)));
+            run++;
+            if (run >= KP_K) { z = fwd < rev ? 0 : 1; x = kp_hash30(z ? rev : fwd); }
+        } else run = 0;
+        const int32_t p = (int32_t)(i - (KP_K - 1));
+        ring_x[slot] = x; ring_p[slot] = p; ring_z[slot] = (uint8_t)z;
+        if (run == KP_W + KP_K - 1 && min_x != KPO_INF) /* (1) ties of the first full window, oldest first */
+            for (int d = 1; d < KP_W; d++) {
+                const int j = (slot + d) % KP_W;
+                if (ring_x[j] == min_x && ring_p[j] != min_p) emit(ud, ring_p[j], ring_z[j], ring_x[j]);
+            }
+        if (x <= min_x) { /* (2) a new minimum takes over */
+            if (run >= KP_W + KP_K && min_x != KPO_INF) emit(ud, min_p, min_z, min_x);
+            min_x = x; min_p = p; min_z = z; min_slot = slot;
+        } else if (slot == min_slot) { /* this step overwrote the minimum: it has left the window */
+            if (run >= KP_W + KP_K - 1 && min_x != KPO_INF) emit(ud, min_p, min_z, min_x);
+            min_x = KPO_INF;
+            for (int d = 1; d <= KP_W; d++) { /* oldest to newest: the last smallest wins */
+                const int j = (slot + d) % KP_W;
+                if (ring_x[j] <= min_x) { min_x = ring_x[j]; min_p = ring_p[j]; min_z = ring_z[j]; min_slot = j; }
+            }
+            if (run >= KP_W + KP_K - 1 && min_x != KPO_INF)
+                for (int d = 1; d <= KP_W; d++) {
+                    const int j = (slot + d) % KP_W;
+                    if (ring_x[j] == min_x && j != min_slot) emit(ud, ring_p[j], ring_z[j], ring_x[j]);
+                }
+        }
+        slot = (slot + 1) % KP_W;
+    }
+    if (min_x != KPO_INF) emit(ud, min_p, min_z, min_x);
+}
+
+typedef struct { uint32_t key; uint32_t gene; uint32_t pos; uint32_t z; } kpo_posting; /* key = x of the gene seed */
 
 typedef struct kpo_db {
     int n_genes;
     const uint8_t *codes; /* borrowed: one byte per base, 0..4 */
     const int32_t *off;   /* borrowed: n_genes+1 */
     uint8_t *rc;          /* reverse complements, same offsets */
-    kpo_posting *post;    /* sorted by (key, gs, pos) */
-    int64_t n_post;
+    kpo_posting *post;    /* sorted by (key, gene, pos) */
+    int64_t n_post, cap_post;
+    uint32_t cur_gene;
 } kpo_db;
 
 static int cmp_posting(const void *a, const void *b) {
     const kpo_posting *x = a, *y = b;
     if (x->key != y->key) return x->key < y->key ? -1 : 1;
-    if (x->gs != y->gs) return x->gs < y->gs ? -1 : 1;
+    if (x->gene != y->gene) return x->gene < y->gene ? -1 : 1;
     return x->pos < y->pos ? -1 : (x->pos > y->pos);
 }
 
-static inline int seed_rule(const uint8_t *c) { return ((c[0] ^ c[1] ^ c[3]) & 3u) == KP_SEED_RULE_VALUE; }
-
-/* k-mer value with the first base in the low bits; returns 0 and sets *ok=0 if an N is inside */
-static inline uint32_t kmer_at(const uint8_t *c, int *ok) {
-    uint32_t v = 0;
-    for (int i = 0; i < KP_K; i++) {
-        if (c[i] > 3) { *ok = 0; return 0; }
-        v |= (uint32_t)c[i] << (2 * i);
+static void db_seed(void *ud, int32_t start, int z, uint32_t x) {
+    kpo_db *db = ud;
+    if (db->n_post == db->cap_post) {
+        db->cap_post = db->cap_post ? 2 * db->cap_post : 4096;
+        db->post = realloc(db->post, (size_t)db->cap_post * sizeof(kpo_posting));
     }
-    *ok = 1;
-    return v;
+    kpo_posting *q = &db->post[db->n_post++];
+    q->key = x; q->gene = db->cur_gene; q->pos = (uint32_t)start; q->z = (uint32_t)z;
 }
 
 KPO_API kpo_db *kpo_db_create(const uint8_t *codes, const int32_t *off, int n_genes) {
@@ -314,26 +364,10 @@ KPO_API kpo_db *kpo_db_create(const uint8_t *codes, const int32_t *off, int n_ge
             uint8_t c = codes[off[g] + len - 1 - i];
             db->rc[off[g] + i] = c > 3 ? 4 : (uint8_t)(3 - c);
         }
+        db->cur_gene = (uint32_t)g;
+        kpo_sketch(codes + off[g], len, db_seed, db); /* the gene's forward strand, as minimap2 sketches a query */
     }
-    int64_t cap = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        int64_t n = 0;
-        for (int g = 0; g < n_genes; g++) {
-            int len = off[g + 1] - off[g];
-            for (int s = 0; s < 2; s++) {
-                const uint8_t *c = (s ? db->rc : codes) + off[g];
-                for (int p = 0; p + KP_K <= len; p++) {
-                    if (!seed_rule(c + p)) continue;
-                    int ok; uint32_t v = kmer_at(c + p, &ok);
-                    if (!ok) continue;
-                    if (pass) { db->post[n].key = v; db->post[n].gs = (uint32_t)(2 * g + s); db->post[n].pos = (uint32_t)p; }
-                    n++;
-                }
-            }
-        }
-        if (!pass) { cap = n; db->post = malloc((size_t)(cap > 0 ? cap : 1) * sizeof(kpo_posting)); }
-        db->n_post = n;
-    }
+    if (!db->post) db->post = malloc(sizeof(kpo_posting));
     qsort(db->post, (size_t)db->n_post, sizeof(kpo_posting), cmp_posting);
     return db;
 }
@@ -366,28 +400,53 @@ static int cmp_u64(const void *a, const void *b) {
     return x < y ? -1 : (x > y);
 }
 
+typedef struct {
+    const kpo_db *db;
+    int64_t ctg_start; /* of the contig being sketched, in the assembly's padded space */
+    uint64_t *keys;
+    int64_t n, cap;
+    int64_t n_seeds;
+} kpo_collect;
+
+static void asm_seed(void *ud, int32_t start, int z, uint32_t x) {
+    kpo_collect *k = ud;
+    const kpo_db *db = k->db;
+    k->n_seeds++;
+    const int64_t t = k->ctg_start + start;
+    for (int64_t i = lower_bound_key(db, x); i < db->n_post && db->post[i].key == x; i++) {
+        if (k->n == k->cap) { k->cap *= 2; k->keys = realloc(k->keys, (size_t)k->cap * sizeof(uint64_t)); }
+        const kpo_posting *q = &db->post[i];
+        const int rev = (int)q->z != z; /* opposite strand bits: the contig carries the gene's reverse complement */
+        const int glen = db->off[q->gene + 1] - db->off[q->gene];
+        const uint32_t qpos = rev ? (uint32_t)(glen - KP_K - (int)q->pos) : q->pos;
+        k->keys[k->n++] = KP_ANCHOR_KEY(2u * q->gene + (uint32_t)rev, (uint64_t)(t - qpos + KP_DIAG_BIAS), qpos);
+    }
+}
+
 /* all anchors of one assembly, sorted by key; returns count (caller frees *out) */
 static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **out) {
-    int64_t cap = 1 << 16, n = 0;
-    uint64_t *keys = malloc((size_t)cap * sizeof(uint64_t));
+    kpo_collect k = {db, 0, NULL, 0, 1 << 16, 0};
+    k.keys = malloc((size_t)k.cap * sizeof(uint64_t));
     for (int c = 0; c < a->n_ctg; c++) {
-        int64_t s = a->ctg_start[c], e = s + a->ctg_len[c];
-        for (int64_t p = s; p + KP_K <= e; p++) {
-            const uint8_t *cd = a->codes + p;
-            /* rule on raw 2-bit values: an N inside the k-mer rejects it below regardless of the rule outcome */
-            if (cd[0] > 3 || cd[1] > 3 || cd[3] > 3 || !seed_rule(cd)) continue;
-            int ok; uint32_t v = kmer_at(cd, &ok);
-            if (!ok) continue;
-            for (int64_t i = lower_bound_key(db, v); i < db->n_post && db->post[i].key == v; i++) {
-                if (n == cap) { cap *= 2; keys = realloc(keys, (size_t)cap * sizeof(uint64_t)); }
-                uint32_t qpos = db->post[i].pos;
-                keys[n++] = KP_ANCHOR_KEY(db->post[i].gs, (uint64_t)(p - qpos + KP_DIAG_BIAS), qpos);
-            }
-        }
+        k.ctg_start = a->ctg_start[c];
+        kpo_sketch(a->codes + a->ctg_start[c], a->ctg_len[c], asm_seed, &k);
     }
-    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64);
-    *out = keys;
-    return n;
+    qsort(k.keys, (size_t)k.n, sizeof(uint64_t), cmp_u64);
+    *out = k.keys;
+    return k.n;
+}
+
+/* test hook: the seeds of one sequence of codes, in emission order; returns the count (writes at most cap) */
+typedef struct { int32_t *start; uint8_t *z; uint32_t *x; int64_t n, cap; } kpo_seedbuf;
+static void buf_seed(void *ud, int32_t start, int z, uint32_t x) {
+    kpo_seedbuf *b = ud;
+    if (b->n < b->cap) { b->start[b->n] = start; b->z[b->n] = (uint8_t)z; b->x[b->n] = x; }
+    b->n++;
+}
+KPO_API int64_t kpo_seeds(const uint8_t *codes, int64_t len, int32_t *start, uint8_t *z, uint32_t *x, int64_t cap) {
+    kpo_seedbuf b = {start, z, x, 0, cap};
+    kpo_sketch(codes, len, buf_seed, &b);
+    return b.n;
 }
 
 typedef struct kpo_task {

@@ -63,7 +63,7 @@ def _load(path: Path) -> None:
     _LIB = C.CDLL(str(path))
     _LIB.kpo_db_create.restype = C.c_void_p
     _LIB.kpo_db_n_postings.restype = C.c_int64
-    for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract"):
+    for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract", "kpo_seeds"):
         getattr(_LIB, f).restype = C.c_int64
 
 
@@ -151,6 +151,15 @@ def extract(seqs, off, idx, starts, ends, strands):
 
 
 # ---- aligner (spec: include/kp_spec.h; parity vs the reference's rammappy stage is unpinned) ----------------------
+def seeds(codes: np.ndarray):
+    """Seeds of one sequence of codes (0..3, else ambiguous) in emission order: (start, strand bit, x) arrays."""
+    codes = _c(codes, np.uint8)
+    cap = len(codes) + 8
+    start, z, x = np.zeros(cap, np.int32), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+    n = int(lib().kpo_seeds(_p(codes), C.c_int64(len(codes)), _p(start), _p(z), _p(x), C.c_int64(cap)))
+    return start[:n], z[:n], x[:n]
+
+
 class OracleDB:
     """Seed index over gene codes (one byte per base, 0..4) with int32 offsets of length n_genes+1."""
 
