@@ -15,20 +15,22 @@
 // strand bit is 0, then the same n gene seeds as a contig seed with strand bit 1 meets them (the other strand of the gene).
 // A posting word is the anchor key of the seed for target position 0:
 // (gs << 46) | ((KP_DIAG_BIAS - qpos) << 16) | qpos ; adding (tpos << 16) yields the anchor key.
-// Presence filter: a blocked Bloom filter of 2^KP_FILTER_LOG2 bits in 64-bit blocks.  A k-mer owns block
-// (kmer * 2654435769u) >> (32 - (KP_FILTER_LOG2 - 6)) and KP_FILTER_K bits of it (kp_filter_mask), so a probe is one
-// 8-byte gather; 2 MB stays resident in every XCD's L2.  With the ~1.2 M distinct k-mers of the KpSC K database 0.8 %
-// of foreign k-mers pass (one bit per k-mer in the same space: 6.9 %).
+// Presence filter: a blocked Bloom filter of 2^KP_FILTER_LOG2 bits in 64-bit blocks, keyed by the seed value x -- itself
+// the output of an invertible mixing function (kp_hash30), so its own bits address the filter: block = the LOW
+// KP_FILTER_LOG2 - 6 bits of x (seeds are window minima: their high bits crowd towards zero, the low ones stay uniform),
+// one bit in each 32-bit half of the block from bits 18-22 and 23-27.  A probe is one 8-byte gather and six vector
+// instructions; 2 MB stays resident in every XCD's L2.  With the ~0.68 M distinct seeds of the KpSC K database a block
+// holds 2.6 keys: 1.2 % of foreign seeds pass (measured on the seeds of random sequence).
 #define KP_FILTER_LOG2 24
-#define KP_FILTER_K 4
-__host__ __device__ inline uint32_t kp_filter_block(uint32_t kmer) { return (kmer * 2654435769u) >> (32 - (KP_FILTER_LOG2 - 6)); }
-// the k-mer's KP_FILTER_K bits of its block: two in each 32-bit half, so that a probe is 32-bit arithmetic throughout
-__host__ __device__ inline uint2 kp_filter_mask2(uint32_t kmer) {
-    const uint32_t h = kmer * 0x85EBCA6Bu;
+__host__ __device__ inline uint32_t kp_filter_block(uint32_t x) { return x & ((1u << (KP_FILTER_LOG2 - 6)) - 1u); }
+__host__ __device__ inline uint2 kp_filter_mask2(uint32_t x) {
     uint2 m;
-    m.x = (1u << (h >> 27)) | (1u << ((h >> 22) & 31u));
-    m.y = (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+    m.x = 1u << ((x >> 18) & 31u);
+    m.y = 1u << ((x >> 23) & 31u);
     return m;
+}
+__host__ __device__ inline bool kp_filter_test(uint2 got, uint32_t x) {
+    return ((got.x >> ((x >> 18) & 31u)) & (got.y >> ((x >> 23) & 31u)) & 1u) != 0u;
 }
 __host__ __device__ inline uint64_t kp_filter_mask(uint32_t kmer) {
     const uint2 m = kp_filter_mask2(kmer);

@@ -43,27 +43,36 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *a, int n, int32_t 
 }
 
 // ---- pass 1: stream + minimizers + presence filter -> candidate positions ------------------------------------------------
-// Every lane computes y(p) = (x(p) << 1) | nz(p) for the 64 positions of its unit (x: kp_spec.h; nz = 1 when the forward
-// 15-mer is the canonical one); the stream is taken as one clean sequence (N runs and the padding between contigs are code
-// 0): positions whose answer that falsifies are not this kernel's (kp_seed_is_interior) and are rejected by the expansion.
-// p is a seed iff x(p) is a smallest value of one of the ten windows of ten consecutive 15-mers that contain it, i.e. iff
+// Every lane computes x(p) (kp_spec.h) for the 64 positions of its unit; the stream is taken as one clean sequence (N runs
+// and the padding between contigs are code 0): positions whose answer that falsifies are not this kernel's
+// (kp_seed_is_interior) and are rejected by the expansion.  p is a seed iff x(p) is a smallest value of one of the ten
+// windows of ten consecutive 15-mers that contain it, i.e. iff
 //      max over s in [p - 9, p] of ( min over [s, s + 9] of x )  ==  x(p)
-// (every window that contains p has a minimum <= x(p)).  Minima and maxima are taken on y -- the strand bit rides along
-// in bit 0 and cannot reorder different x -- and the comparison ignores bit 0, so ties (equal canonical 15-mers within a
-// window) select all their positions, as mm_sketch does.  A wave's lanes 0 and 63 only supply their neighbours' flanks:
-// successive wave iterations overlap by two units (62 of 64 lanes emit).
-// The selected positions are then COMPACTED into a 16-bit list in LDS and walked 64 entries at a time with every lane
-// busy (round 3's dense form): entry -> two words from LDS -> canonical 15-mer -> x -> filter block (one L2 read, PROBES
-// rounds in flight); what passes is staged per wave, checked against the second filter at flush time and written as one
-// word each.  MODE 0 = product; 1 = no filter reads; 2 = stream only (tools/scan_ablate.py).
+// (every window that contains p has a minimum <= x(p); ties -- equal canonical 15-mers within a window -- select all
+// their positions, as mm_sketch does).  A wave's lanes 0 and 63 only supply their neighbours' flanks: successive wave
+// iterations overlap by two units (62 of 64 lanes emit).
+//
+// Both strands' 15-mers come straight off the packed words with one v_alignbit each: the stream's own bit order is the
+// reverse strand's (complemented words), the words with their sixteen bases reversed give the forward strand's; the two
+// values are taken top-aligned (a stray neighbouring base in bits 0-1 cannot decide the comparison: k is odd, the 30 bits
+// above differ) and the smaller one, shifted down, is hashed.  The strand bit is not needed to select: it is worked out
+// for the one seed in two hundred that passes the filter.
+//
+// Selected positions go into a per-wave list in LDS as (position, x), eight positions of every lane at a time (a ballot
+// ranks the lanes), and the list is walked 64 entries at a time with every lane busy: entry -> filter block (one L2 read,
+// PROBES rounds in flight) -> bit test; what passes is staged per wave, checked against the second filter at flush time
+// and written as one word each.  MODE 0 = product; 1 = no filter reads; 2 = stream only (tools/scan_ablate.py).
 #ifndef KP_SCAN_PROBES
 #define KP_SCAN_PROBES 4
 #endif
 constexpr int PROBES = KP_SCAN_PROBES;  // filter reads a lane has in flight
 constexpr int DENSE_WAVES = 4;
-constexpr int DENSE_LIST = 2048;   // selected positions of a wave's iteration the list holds (mean ~ 720; see `groups`)
-constexpr int DENSE_STAGE = 512;   // candidates staged per wave before a flush
+constexpr int DENSE_LIST = 1280;   // entries of a wave's list (an iteration selects ~720; eight positions add <= 512)
+constexpr int DENSE_STAGE = 320;   // candidates staged per wave (a round of the walk adds <= 64 * PROBES)
 constexpr int SCAN_OWN = 62;       // lanes of a wave iteration that emit (lanes 1..62)
+#ifndef KP_SCAN_WAVES_PER_SIMD
+#define KP_SCAN_WAVES_PER_SIMD 3
+#endif
 
 __device__ __forceinline__ uint32_t lane_from_below(uint32_t v) {  // lane L receives lane L - 1's value (lane 0: 0)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -79,23 +88,22 @@ __device__ __forceinline__ uint32_t reverse_groups(uint32_t w) {
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
 __device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
 
-// y of the 15-mer whose bases sit in the low 30 bits of `e` (first base in bits 0-1)
-__device__ __forceinline__ uint32_t seed_value_from_low(uint32_t e) {
+// strand bit of the 15-mer whose bases sit in the low 30 bits of `e` (first base in bits 0-1): 0 = the forward 15-mer is
+// the canonical one
+__device__ __forceinline__ uint32_t strand_bit_from_low(uint32_t e) {
     const uint32_t rev = e ^ KP_KMER_MASK;  // complement; the stream's layout is the reverse complement's
     const uint32_t r = __builtin_bitreverse32(e) >> 2;
     const uint32_t fwd = ((r >> 1) & 0x15555555u) | ((r & 0x15555555u) << 1);
-    const uint32_t nz = fwd < rev ? 1u : 0u;
-    return (kp_hash30(nz ? fwd : rev) << 1) | nz;
+    return fwd < rev ? 0u : 1u;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatchView b, KpSeedIndex idx,
-                                                                         uint64_t *__restrict__ cand,
-                                                                         unsigned long long *__restrict__ n_cand,
-                                                                         uint64_t cand_cap) {
+__global__ __launch_bounds__(64 * DENSE_WAVES, KP_SCAN_WAVES_PER_SIMD) void kp_scan_dense_kernel(
+    KpBatchView b, KpSeedIndex idx, uint64_t *__restrict__ cand, unsigned long long *__restrict__ n_cand, uint64_t cand_cap) {
     __shared__ uint64_t s_stage[DENSE_WAVES][DENSE_STAGE];
     __shared__ __attribute__((aligned(16))) uint32_t s_words[DENSE_WAVES][260];
-    __shared__ uint16_t s_list[DENSE_WAVES][DENSE_LIST];
+    __shared__ uint32_t s_lx[DENSE_WAVES][DENSE_LIST];
+    __shared__ uint16_t s_lp[DENSE_WAVES][DENSE_LIST];
     const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
     const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
     uint32_t checksum = 0;
@@ -105,8 +113,11 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t *stage = s_stage[wave];
     uint32_t *words = s_words[wave];
-    uint16_t *list = s_list[wave];
+    uint32_t *lx = s_lx[wave];
+    uint16_t *lp = s_lp[wave];
     uint32_t staged = 0;  // wave-uniform
+    uint32_t listed = 0;  // wave-uniform: entries in the list
+    int64_t wave_base = 0;  // batch-wide position of lane 0's first base in the current iteration (may be -64)
     const unsigned long long below = (1ull << lane) - 1ull;
 
     auto flush = [&]() {  // second filter on what is staged, survivors out with one atomic
@@ -133,6 +144,41 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
         staged = 0;
     };
 
+    auto walk = [&]() {  // the list -> filter probes -> stage
+        wave_lds_sync();  // the list and the words are visible
+        for (uint32_t e0 = 0; e0 < listed; e0 += 64 * PROBES) {
+            uint32_t xs[PROBES], pos[PROBES];
+            bool have[PROBES];
+            uint2 got[PROBES];
+#pragma unroll
+            for (int j = 0; j < PROBES; ++j) {
+                const uint32_t e = e0 + 64 * j + lane;
+                have[j] = e < listed;
+                xs[j] = have[j] ? lx[e] : 0u;
+                pos[j] = have[j] ? lp[e] : 0u;
+                if (MODE == 1) { checksum += xs[j] * 2654435769u; continue; }
+                got[j] = have[j] ? g_filter[kp_filter_block(xs[j])] : make_uint2(0u, 0u);
+            }
+            if (MODE != 0) continue;
+#pragma unroll
+            for (int j = 0; j < PROBES; ++j) {
+                const bool hit = have[j] && kp_filter_test(got[j], xs[j]);
+                const unsigned long long ballot = __ballot(hit);
+                if (!ballot) continue;
+                if (hit) {
+                    const uint32_t p = pos[j];
+                    const uint32_t lo = words[p >> 4], hi = words[(p >> 4) + 1];
+                    const uint32_t z = strand_bit_from_low(__builtin_amdgcn_alignbit(hi, lo, 2 * (p & 15u)) & KP_KMER_MASK);
+                    stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] = kp_cand_pack((uint64_t)(wave_base + p), z, xs[j]);
+                }
+                staged += (uint32_t)__builtin_popcountll(ballot);
+            }
+            if (staged > DENSE_STAGE - 64 * PROBES) flush();
+        }
+        listed = 0;
+        wave_lds_sync();  // the walk is done with the list before the next entries arrive
+    };
+
     const int64_t wave_stride = (int64_t)gridDim.x * DENSE_WAVES;
     for (int64_t it = (int64_t)blockIdx.x * DENSE_WAVES + wave; it < n_iters; it += wave_stride) {
         const int64_t u = it * SCAN_OWN - 1 + lane;  // lane 0 repeats the previous iteration's last unit, lane 63 the next's first
@@ -140,114 +186,53 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void kp_scan_dense_kernel(KpBatch
         if (u >= 0 && u < n_units) v = vec[u];
         const uint32_t next = lane_from_above(v.x);
         if (MODE == 2) { checksum += v.x ^ v.y ^ v.z ^ v.w ^ next; continue; }
+        wave_base = (u - lane) * 64;
+        *reinterpret_cast<uint4 *>(&words[4 * lane]) = v;  // (lane 63 emits nothing: nobody reads past its unit)
         const uint32_t w[5] = {v.x, v.y, v.z, v.w, next};
-        uint32_t rw[5];  // the same words with their bases in reverse order: the forward 15-mer's layout
+        uint32_t cw[5], rw[5];  // complemented words: the reverse strand's layout; bases reversed: the forward strand's
 #pragma unroll
-        for (int k = 0; k < 5; ++k) rw[k] = reverse_groups(w[k]);
-        // y of the lane's 64 positions, with nine of either neighbour's on both sides: Y[9 + p], p in [-9, 72]
-        uint32_t Y[82];
+        for (int k = 0; k < 5; ++k) { cw[k] = ~w[k]; rw[k] = reverse_groups(w[k]); }
+        // x of the lane's 64 positions with nine of either neighbour's on both sides: X[9 + p], p in [-9, 72]
+        uint32_t X[82];
 #pragma unroll
         for (int p = 0; p < 64; ++p) {
             const int a = p >> 4, o = p & 15;
-            const uint32_t rev = (__builtin_amdgcn_alignbit(w[a + 1], w[a], 2 * o) & KP_KMER_MASK) ^ KP_KMER_MASK;
-            uint32_t fwd;
-            if (o == 0) fwd = rw[a] >> 2;
-            else if (o == 1) fwd = rw[a] & KP_KMER_MASK;
-            else fwd = __builtin_amdgcn_alignbit(rw[a], rw[a + 1], 34 - 2 * o) & KP_KMER_MASK;
-            const uint32_t nz = (fwd - rev) >> 31;  // both below 2^30: the sign of the difference says which is smaller
-            Y[9 + p] = (kp_hash30(nz ? fwd : rev) << 1) | nz;
+            const uint32_t fwd = o == 0 ? rw[a] : __builtin_amdgcn_alignbit(rw[a], rw[a + 1], 32 - 2 * o);
+            const uint32_t rev = o == 0 ? cw[a] << 2 : __builtin_amdgcn_alignbit(cw[a + 1], cw[a], 2 * o - 2);
+            X[9 + p] = kp_hash30(min(fwd, rev) >> 2);
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            Y[j] = lane_from_below(Y[9 + 55 + j]);
-            Y[9 + 64 + j] = lane_from_above(Y[9 + j]);
+            X[j] = lane_from_below(X[9 + 55 + j]);
+            X[9 + 64 + j] = lane_from_above(X[9 + j]);
         }
-        // window minima (index s + 9 holds the minimum of Y over positions [s, s + 9]), then the maxima of ten of those
-        uint32_t sel[2] = {0u, 0u};
-        {
-            uint32_t c1[80], c2[76], wm[73];
+        // window minima (index s + 9 holds the minimum over positions [s, s + 9]), then the maxima of ten of those
+        uint32_t c1[80], c2[76], wm[73], d1[71], d2[67];
 #pragma unroll
-            for (int i = 0; i < 80; ++i) c1[i] = min3u(Y[i], Y[i + 1], Y[i + 2]);
+        for (int i = 0; i < 80; ++i) c1[i] = min3u(X[i], X[i + 1], X[i + 2]);
 #pragma unroll
-            for (int i = 0; i < 76; ++i) c2[i] = min3u(c1[i], c1[i + 2], c1[i + 4]);
+        for (int i = 0; i < 76; ++i) c2[i] = min3u(c1[i], c1[i + 2], c1[i + 4]);
 #pragma unroll
-            for (int i = 0; i < 73; ++i) wm[i] = min(c2[i], c2[i + 3]);
-            uint32_t d1[71], d2[67];
+        for (int i = 0; i < 73; ++i) wm[i] = min(c2[i], c2[i + 3]);
 #pragma unroll
-            for (int i = 0; i < 71; ++i) d1[i] = max3u(wm[i], wm[i + 1], wm[i + 2]);
+        for (int i = 0; i < 71; ++i) d1[i] = max3u(wm[i], wm[i + 1], wm[i + 2]);
 #pragma unroll
-            for (int i = 0; i < 67; ++i) d2[i] = max3u(d1[i], d1[i + 2], d1[i + 4]);
-#pragma unroll
-            for (int p = 0; p < 64; ++p) {
-                const uint32_t m = max(d2[p], d2[p + 3]);  // over the windows that start in [p - 9, p]
-                if ((m ^ Y[9 + p]) < 2u) sel[p >> 5] |= 1u << (p & 31);
-            }
-        }
+        for (int i = 0; i < 67; ++i) d2[i] = max3u(d1[i], d1[i + 2], d1[i + 4]);
         const bool owner = lane >= 1 && lane <= SCAN_OWN && u < n_units;
-        if (!owner) sel[0] = sel[1] = 0u;
-        if (MODE == 1) { checksum += sel[0] * 2654435769u + sel[1]; }
-        *reinterpret_cast<uint4 *>(&words[4 * lane]) = v;
-        if (lane == 63) words[256] = 0u;  // (lane 63 emits nothing: nobody reads past its unit)
-        const uint32_t mine = (uint32_t)__builtin_popcount(sel[0]) + (uint32_t)__builtin_popcount(sel[1]);
-        uint32_t incl = mine;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        // the list holds DENSE_LIST entries: an iteration with more selected positions (a low-complexity stretch: equal
-        // 15-mers are all selected) goes through in two groups of 32 lanes, each at most 32 x 64 = 2048 positions
-        const int groups = total > (uint32_t)DENSE_LIST ? 2 : 1;
-        const uint32_t before_half = __shfl(incl, 31);  // selected positions of lanes 0..31
-        const int64_t wave_base = (u - lane) * 64;      // batch-wide position of lane 0's first base (may be -64)
-        for (int g = 0; g < groups; ++g) {
-            const bool active = groups == 1 || (lane >> 5) == g;
-            const uint32_t n_list = groups == 1 ? total : (g == 0 ? before_half : total - before_half);
-            uint32_t off = incl - mine - ((groups == 2 && g == 1) ? before_half : 0u);
-            wave_lds_sync();  // (the previous walk is done with the list; the words are visible)
-            if (active) {
+        for (int p0 = 0; p0 < 64; p0 += 8) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t m = sel[h];
-                    while (m) {
-                        const int bit = __builtin_ctz(m);
-                        m &= m - 1;
-                        list[off++] = (uint16_t)(64 * lane + 32 * h + bit);
-                    }
+            for (int p = p0; p < p0 + 8; ++p) {
+                const bool sel = owner && max(d2[p], d2[p + 3]) == X[9 + p];  // over the windows that start in [p - 9, p]
+                const unsigned long long ballot = __ballot(sel);
+                if (sel) {
+                    const uint32_t at = listed + (uint32_t)__builtin_popcountll(ballot & below);
+                    lx[at] = X[9 + p];
+                    lp[at] = (uint16_t)(64 * lane + p);
                 }
+                listed += (uint32_t)__builtin_popcountll(ballot);
             }
-            wave_lds_sync();
-            for (uint32_t e0 = 0; e0 < n_list; e0 += 64 * PROBES) {
-                uint32_t ys[PROBES], pos[PROBES];
-                bool have[PROBES];
-                uint2 got[PROBES];
-#pragma unroll
-                for (int j = 0; j < PROBES; ++j) {
-                    const uint32_t e = e0 + 64 * j + lane;
-                    have[j] = e < n_list;
-                    const uint32_t p = have[j] ? list[e] : 0u;
-                    const uint32_t lo = words[p >> 4], hi = words[(p >> 4) + 1];
-                    ys[j] = seed_value_from_low(__builtin_amdgcn_alignbit(hi, lo, 2 * (p & 15u)) & KP_KMER_MASK);
-                    pos[j] = p;
-                    if (MODE == 1) { checksum += have[j] ? ys[j] * 2654435769u : 0u; continue; }
-                    got[j] = have[j] ? g_filter[kp_filter_block(ys[j] >> 1)] : make_uint2(0u, 0u);
-                }
-                if (MODE != 0) continue;
-#pragma unroll
-                for (int j = 0; j < PROBES; ++j) {
-                    const uint32_t x = ys[j] >> 1;
-                    const uint2 need = kp_filter_mask2(x);
-                    const bool hit = have[j] && (got[j].x & need.x) == need.x && (got[j].y & need.y) == need.y;
-                    const unsigned long long ballot = __ballot(hit);
-                    if (!ballot) continue;
-                    if (hit)
-                        stage[staged + (uint32_t)__builtin_popcountll(ballot & below)] =
-                            kp_cand_pack((uint64_t)(wave_base + pos[j]), (ys[j] & 1u) ^ 1u, x);
-                    staged += (uint32_t)__builtin_popcountll(ballot);
-                }
-                if (staged > DENSE_STAGE - 64 * PROBES) flush();
-            }
+            if (p0 == 56 || listed > DENSE_LIST - 512) walk();
         }
     }
     if (MODE == 0 && staged) flush();
