@@ -173,9 +173,10 @@ KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 KP_API int kp_batch_profile(kp_ctx *ctx, kp_batch *batch, float *ms7, int64_t *bytes_scanned);
 
 /* Stage outputs for stage-by-stage parity tests (valid after kp_batch_wait): sorted anchor keys of one assembly, and
- * the band tasks of one assembly as 7 x int32 rows (gs, contig, lo, width, n_anchors, qmin, qmax) in device order. */
+ * the band tasks of one assembly as 8 x int32 rows (gs, contig, lo, width, n_anchors, qmin, qmax, chain_score) in device
+ * order. */
 KP_API int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, uint64_t *out, int64_t cap);
-KP_API int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, int32_t *out7, int64_t cap);
+KP_API int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, int32_t *out8, int64_t cap);
 /* ... and what the banded Smith-Waterman made of each of those tasks, row for row in the order of kp_batch_tasks: 7 x
  * int32 (score, q_start, q_end, t_start, t_end, matches, block_len).  Tasks whose best cell stays below the score
  * cut-off (KP_MIN_DP_SCORE) are not traced back: their row holds the score and zeros. */

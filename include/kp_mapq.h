@@ -1,18 +1,18 @@
-/* kp_mapq.h -- mapping quality of a primary hit (kp-align v2), shared by the HIP kernels and the CPU oracle.
+/* kp_mapq.h -- mapping quality of a primary hit (kp-align v3), shared by the HIP kernels and the CPU oracle.
  *
- * Modelled on minimap2's mm_set_mapq (the published source of the aligner the reference's rammappy wheel is described as
- * following: docs/serotyping/method.md:23-28 "minimap2-based"), restated from its formula with the quantities this
- * aligner has: the reported alignment score stands for minimap2's chain score and DP score alike, the seeds of the band
- * task for the chain's anchor count, the best secondary's score for subsc / dp_max2.  It cannot be checked against
- * rammappy here (parity unpinned); what it buys is a mapq that varies with the evidence instead of
- * the round-1 constant 60 / 0.  The reference reads mapq only as the third cull key (src/kaptive/core/alignment.py:669-675).
+ * minimap2's mm_set_mapq (the published source of the aligner the reference's rammappy wheel is described as following:
+ * docs/serotyping/method.md:23-28 "minimap2-based") with the quantities it reads there: the chain's score and anchor
+ * count (kp_spec.h: the cluster's chain), the hit's alignment score for dp_max, and from the secondaries that
+ * mm_set_parent hangs on the hit (kp_spec.h, hit record) the best chain score `subsc`, the best alignment score
+ * `dp_max2` and their count `n_sub`.  It cannot be checked against rammappy here (parity unpinned).
+ * The reference reads mapq only as the third cull key (src/kaptive/core/alignment.py:669-675).
  *
- *   pen_s1 = score > 100 ? 1 : 0.01 * score            pen_cm = seeds > 10 ? 1 : 0.1 * seeds;  pen_cm = min(pen_s1, pen_cm)
- *   identity = matches / block_len                     subsc = max(sub, KP_MIN_CHAIN_SCORE)
- *   sub > 0:  x = sub * subsc / score / score;  q = identity * pen_cm * 40 * (1 - x * x) * ln(score / match)
- *             q = min(q, int(6.02 * identity^2 * (score - sub) / match + 0.499))
- *   else:     x = subsc / score;                q = identity * pen_cm * 40 * (1 - x) * ln(score / match)
- *   q -= int(4.343 * ln(n_sub + 1) + 0.499);  clamp to [0, 60];  q == 0 and score > sub -> 1
+ *   pen_s1 = chain > 100 ? 1 : 0.01 * chain            pen_cm = seeds > 10 ? 1 : 0.1 * seeds;  pen_cm = min(pen_s1, pen_cm)
+ *   identity = matches / block_len                     subsc = max(subsc, KP_MIN_CHAIN_SCORE)
+ *   dp_max2 > 0:  x = dp_max2 * subsc / score / chain;  q = identity * pen_cm * 40 * (1 - x * x) * ln(score / match)
+ *                 q = min(q, int(6.02 * identity^2 * (score - dp_max2) / match + 0.499))
+ *   else:         x = subsc / chain;                    q = identity * pen_cm * 40 * (1 - x) * ln(score / match)
+ *   q -= int(4.343 * ln(n_sub + 1) + 0.499);  clamp to [0, 60];  q == 0 and score > dp_max2 -> 1
  *
  * All arithmetic is float32 in exactly this order (no fused multiply-add: the function switches contraction off for
  * clang; gcc in ISO C mode does not contract).  The two logarithms come from tables the caller fills on the host with
@@ -58,20 +58,22 @@ static inline float kp_mapq_ln(double x) {
 #define KP_MAPQ_LN_HALF_SIZE 131072 /* scores are at most 2 * KP_MAX_GENE_LEN plus the two-piece credit of long gaps */
 #define KP_MAPQ_LN_INT_SIZE 4096
 
-KP_MAPQ_FN int kp_mapq_value(int score, int seeds, int matches, int block_len, int sub, int n_sub, const float *ln_half,
-                             const float *ln_int) {
+KP_MAPQ_FN int kp_mapq_value(int score, int chain, int seeds, int matches, int block_len, int subsc_in, int dp_max2, int n_sub,
+                             const float *ln_half, const float *ln_int) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    const float pen_s1 = score > 100 ? 1.0f : 0.01f * (float)score;
+    const float pen_s1 = chain > 100 ? 1.0f : 0.01f * (float)chain;
     float pen_cm = seeds > 10 ? 1.0f : 0.1f * (float)seeds;
     pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
     const float identity = (float)matches / (float)block_len;
-    const int subsc = sub > KP_MIN_CHAIN_SCORE ? sub : KP_MIN_CHAIN_SCORE;
+    const int subsc = subsc_in > KP_MIN_CHAIN_SCORE ? subsc_in : KP_MIN_CHAIN_SCORE;
     const float lg = ln_half[score < KP_MAPQ_LN_HALF_SIZE ? score : KP_MAPQ_LN_HALF_SIZE - 1];
     int q;
-    if (sub > 0) {
-        const float x = (float)sub * (float)subsc / (float)score / (float)score;
+    if (dp_max2 > 0 && score > 0) {
+        float x = (float)dp_max2 * (float)subsc;
+        x = x / (float)score;
+        x = x / (float)chain;
         float v = identity * pen_cm;
         v = v * 40.0f;
         v = v * (1.0f - x * x);
@@ -79,13 +81,13 @@ KP_MAPQ_FN int kp_mapq_value(int score, int seeds, int matches, int block_len, i
         q = (int)v;
         float alt = 6.02f * identity;
         alt = alt * identity;
-        alt = alt * (float)(score - sub);
+        alt = alt * (float)(score - dp_max2);
         alt = alt / (float)KP_SC_MATCH;
         alt = alt + 0.499f;
         const int q_alt = (int)alt;
         q = q < q_alt ? q : q_alt;
     } else {
-        const float x = (float)subsc / (float)score;
+        const float x = (float)subsc / (float)chain;
         float v = identity * pen_cm;
         v = v * 40.0f;
         v = v * (1.0f - x);
@@ -99,7 +101,7 @@ KP_MAPQ_FN int kp_mapq_value(int score, int seeds, int matches, int block_len, i
     }
     q = q > 0 ? q : 0;
     q = q < 60 ? q : 60;
-    if (q == 0 && score > sub) q = 1;
+    if (q == 0 && score > dp_max2) q = 1;
     return q;
 }
 

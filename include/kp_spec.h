@@ -91,8 +91,21 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
 /* ---- anchors -> DP tasks ----------------------------------------------------------------------------------------
  * Anchors of one assembly are sorted by key and cut into clusters: a new cluster starts when gs changes, the contig
  * changes, the diagonal jumps by more than KP_DIAG_GAP, or the cluster would span more than KP_MAX_SPREAD diagonals.
- * A cluster becomes a task when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases
- * (qmax - qmin + K).  Its band is the anchors' diagonal range widened on both sides and centred: by
+ *
+ * Which clusters become tasks follows minimap2's chaining thresholds -n 3 -m 40 (mm_chain_dp + mg_chain_backtrack):
+ *   a cluster of n <= KP_CHAIN_DP_MAX anchors is chained exactly as minimap2 chains that anchor set (with so few anchors
+ *   its max_skip / max_iter heuristics cannot act): anchors in (target, query) order, f[i] = max(KP_K, max over earlier j
+ *   of f[j] + sc(i, j)) with the FIRST maximum met going backwards from i - 1, where for dq = q_i - q_j, dr = t_i - t_j:
+ *       sc = invalid if dq <= 0, dr == 0 (dr > 0 then holds: target order) or dq > KP_CHAIN_MAX_DIST;
+ *       dd = |dr - dq|, dg = min(dr, dq), sc = min(KP_K, dg), minus kp_chain_pen[dd] if dd != 0 or dg > KP_K
+ *   (kp_chain_pen[dd] = int(0.12 dd + 0.5 mg_log2(dd + 1)), minimap2's gap cost for k = 15, tabulated below; dd <= the
+ *   cluster's spread).  The chain is the one ending at the largest f (the later anchor on ties), walked back along the
+ *   chosen predecessors and cut where the score counted from its end peaks (mg_chain_backtrack's max_i); its score is that
+ *   peak.  The cluster becomes a task iff the score is >= KP_MIN_CHAIN_SCORE (which needs >= KP_MIN_ANCHORS anchors); the
+ *   task's n_anchors is the chain's anchor count and chain_score its score.
+ *   A cluster of more anchors becomes a task iff its anchors cover >= KP_MIN_SEED_SPAN query bases (qmax - qmin + K);
+ *   n_anchors = n, chain_score = min(KP_K * n, qmax - qmin + K) (what a co-linear chain of them scores).
+ * The band is the cluster's diagonal range (all its anchors) widened on both sides and centred: by
  * KP_BAND_MARGIN_NARROW when that fits 16 diagonals (anchors on one or two adjacent diagonals: no indel seen), otherwise by
  * KP_BAND_MARGIN, rounded up to 32, 64 or 128 diagonals. */
 #define KP_DIAG_GAP 32
@@ -102,6 +115,15 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
 #define KP_MAX_SPREAD (KP_MAX_BAND - 2 * KP_BAND_MARGIN - 1)
 #define KP_MIN_ANCHORS 3
 #define KP_MIN_SEED_SPAN 40
+#define KP_CHAIN_DP_MAX 24
+#define KP_CHAIN_MAX_DIST 5000 /* minimap2's max_gap */
+#define KP_CHAIN_PEN_SIZE 128
+#define KP_CHAIN_PEN_TABLE                                                                                            \
+    {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 6, 6,                     \
+     6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 10, 10, 10, 10, 10,                 \
+     10, 10, 10, 11, 11, 11, 11, 11, 11, 11, 11, 12, 12, 12, 12, 12, 12, 12, 13, 13, 13, 13, 13, 13, 13, 13, 14, 14, 14,  \
+     14, 14, 14, 14, 14, 15, 15, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 17, 17, 17,  \
+     18, 18, 18, 18, 18, 18}
 
 /* ---- banded local alignment (Smith-Waterman-Gotoh; scores <= 2 * KP_MAX_GENE_LEN) ----------------------------------------------------------
  * H = max(0, Hdiag + s, E, F);  E (gap in query, moves along the target) = max(Hleft - (O+X), Eleft - X);

@@ -21,7 +21,7 @@ HIT_DTYPE = np.dtype(
 )  # fmt: skip
 TASK_DTYPE = np.dtype(
     [("gs", "<i4"), ("contig", "<i4"), ("lo", "<i4"), ("width", "<i4"), ("n_anchors", "<i4"), ("qmin", "<i4"),
-     ("qmax", "<i4")]
+     ("qmax", "<i4"), ("chain_score", "<i4")]
 )  # fmt: skip
 
 EXPORTS = (

@@ -1114,7 +1114,7 @@ int64_t kp_batch_anchors(kp_ctx *ctx, kp_batch *b, int32_t a, uint64_t *out, int
     return n;
 }
 
-int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64_t cap) {
+int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out8, int64_t cap) {
     if (!ctx || !b || b->ctx != ctx || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     KpWork *w = finalised_work(ctx, b);
     if (!w) return KP_ESTATE;
@@ -1130,9 +1130,9 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7, int64
     for (int c = 0; c < KP_N_CLASSES; ++c)
         for (const KpTask &t : w->h_tasks[c]) {
             if (t.asm_id != a) continue;
-            if (out7 && n < cap) {
-                int32_t *o = out7 + 7 * n;
-                o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = t.qmin; o[6] = t.qmax;
+            if (out8 && n < cap) {
+                int32_t *o = out8 + 8 * n;
+                o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = t.qmin; o[6] = t.qmax; o[7] = t.chain_score;
             }
             ++n;
         }

@@ -42,11 +42,58 @@ struct TaskStage {
     __device__ static uint32_t room(int cls) { return cls == 0 ? STAGE0 : STAGE_REST; }
 };
 
-// called by one lane
+__constant__ uint8_t c_chain_pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
+
+// minimap2's chaining of a small cluster (kp_spec.h), by the whole wave: lane l < n arrives with anchor l's target and
+// query position (any order).  Returns the chain's score, *cnt = its anchor count (wave-uniform).
+__device__ __forceinline__ int chain_small(int n, int32_t t, int32_t q, int lane, int *cnt) {
+    const bool have = lane < n;
+    // (target, query) order: rank by counting, then every lane fetches the anchor of its own rank
+    int rank = 0;
+    for (int m = 0; m < n; ++m) {
+        const int32_t tm = __shfl(t, m), qm = __shfl(q, m);
+        rank += (tm < t || (tm == t && qm < q)) ? 1 : 0;
+    }
+    int from = 0;
+    for (int m = 0; m < n; ++m)
+        if (__shfl(rank, m) == lane) from = m;
+    t = __shfl(t, from); q = __shfl(q, from);
+    int f = KP_K, p = -1;
+    for (int i = 1; i < n; ++i) {
+        const int32_t ti = __shfl(t, i), qi = __shfl(q, i);
+        int best = -1;  // (value << 8) | predecessor: the largest value, the later predecessor on ties
+        if (have && lane < i) {
+            const int dq = qi - q, dr = ti - t;
+            if (dq > 0 && dq <= KP_CHAIN_MAX_DIST && dr != 0) {
+                const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+                int sc = dg < KP_K ? dg : KP_K;
+                if (dd || dg > KP_K) sc -= c_chain_pen[dd < KP_CHAIN_PEN_SIZE ? dd : KP_CHAIN_PEN_SIZE - 1];
+                best = ((sc + f) << 8) | lane;  // sc + f >= KP_K - pen + KP_K > 0
+            }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));  // n <= KP_CHAIN_DP_MAX < 32 lanes
+        if (lane == i && best >= 0 && (best >> 8) > KP_K) { f = best >> 8; p = best & 255; }
+    }
+    int top = have ? (f << 8) | lane : -1;  // the largest f, the later anchor on ties
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) top = max(top, __shfl_xor(top, o));
+    const int f_end = top >> 8;
+    int i = top & 255, max_s = 0, steps = 0, cut = 0;
+    do {  // walk back; the chain is cut where the score counted from its end peaks
+        i = __shfl(p, i);
+        ++steps;
+        const int sc = i < 0 ? f_end : f_end - __shfl(f, i < 0 ? 0 : i);
+        if (sc > max_s) { max_s = sc; cut = steps; }
+    } while (i >= 0);
+    *cnt = cut;
+    return max_s;
+}
+
+// called by one lane; cnt / chain_score: the chain's (kp_spec.h), the band comes from the whole cluster
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
-                                              uint32_t qmax, int cnt, KpTask *tasks, uint32_t *task_count,
+                                              uint32_t qmax, int cnt, int chain_score, KpTask *tasks, uint32_t *task_count,
                                               uint32_t task_cap, TaskStage &st) {
-    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
     int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16, cls = 0;
     if (need > 16) {
         margin = KP_BAND_MARGIN;
@@ -55,7 +102,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
         cls = w == 32 ? 1 : (w == 64 ? 2 : 3);
     }
     KpTask t;
-    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt;
+    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = chain_score;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
     const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
@@ -70,6 +117,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
 struct Cluster {  // wave-uniform
     bool open;
     uint32_t gs, d0, dprev, qmin, qmax;
+    uint32_t first;  // index of its first anchor: a cluster is a contiguous piece of the sorted list
     int ctg, cnt;
 };
 
@@ -104,15 +152,29 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
     bool have_prev = lo > 0;
     if (have_prev) { prev_key = k[lo - 1]; prev_ctg = contig_of(prev_key); }
     Cluster cur;
-    cur.open = false; cur.gs = cur.d0 = cur.dprev = cur.qmin = cur.qmax = 0; cur.ctg = 0; cur.cnt = 0;
-    auto flush = [&]() {
-        if (cur.open && lane == 0)
-            flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, cur.cnt, tasks, task_count, task_cap, st);
+    cur.open = false; cur.gs = cur.d0 = cur.dprev = cur.qmin = cur.qmax = cur.first = 0; cur.ctg = 0; cur.cnt = 0;
+    auto flush = [&]() {  // wave-uniform
+        if (cur.open && cur.cnt >= KP_MIN_ANCHORS) {
+            int chain_cnt = cur.cnt, chain_sc;
+            bool ok;
+            if (cur.cnt <= KP_CHAIN_DP_MAX) {
+                const uint64_t key = lane < cur.cnt ? k[cur.first + lane] : 0ull;
+                const int32_t q = (int32_t)kp_ckey_qpos(key, kb), t = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + q;
+                chain_sc = chain_small(cur.cnt, t, q, lane, &chain_cnt);
+                ok = chain_sc >= KP_MIN_CHAIN_SCORE;
+            } else {
+                const int span = (int)(cur.qmax - cur.qmin) + KP_K;
+                ok = span >= KP_MIN_SEED_SPAN;
+                chain_sc = min(KP_K * cur.cnt, span);
+            }
+            if (ok && lane == 0)
+                flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, chain_cnt, chain_sc, tasks, task_count, task_cap, st);
+        }
         cur.open = false;
     };
 
     // [from, to) of the round joins the open cluster (same run: no hard break inside)
-    auto merge = [&](int from, int to, uint32_t d, uint32_t q) {
+    auto merge = [&](int from, int to, uint32_t d, uint32_t q, uint32_t round_base) {
         const uint32_t d_last = __shfl(d, to - 1);
         if (d_last - cur.d0 <= KP_MAX_SPREAD) {  // the whole piece joins the cluster
             const bool mine = lane >= from && lane < to;
@@ -131,7 +193,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
                 if (du - cur.d0 > KP_MAX_SPREAD) {
                     flush();
                     cur.open = true;
-                    cur.d0 = du; cur.qmin = cur.qmax = qu; cur.cnt = 0;
+                    cur.d0 = du; cur.qmin = cur.qmax = qu; cur.cnt = 0; cur.first = round_base + (uint32_t)u;
                 }
                 cur.dprev = du;
                 cur.cnt++;
@@ -161,7 +223,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         prev_ctg = __shfl(ctg, n_valid - 1);
         have_prev = true;
         const int first = heads ? (int)__builtin_ctzll(heads) : n_valid;  // anchors before it continue the open run
-        if (first > 0 && cur.open) merge(0, first, d, q);  // (no open cluster: tail of a run the previous wave owns)
+        if (first > 0 && cur.open) merge(0, first, d, q, w);  // (no open cluster: tail of a run the previous wave owns)
         if (!heads) continue;
         flush();  // the first break ends whatever was open
         if (overrun) break;  // ... and what follows belongs to the next slice
@@ -179,8 +241,8 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
             cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
             cur.d0 = cur.dprev = __shfl(d, pos);
             cur.qmin = cur.qmax = __shfl(q, pos);
-            cur.cnt = 1;
-            if (pos + 1 < end) merge(pos + 1, end, d, q);
+            cur.cnt = 1; cur.first = w + (uint32_t)pos;
+            if (pos + 1 < end) merge(pos + 1, end, d, q, w);
             if (end < n_valid) flush();  // the run ends inside the round; otherwise it stays open for the next one
         }
     }

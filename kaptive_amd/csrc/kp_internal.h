@@ -131,8 +131,9 @@ struct KpTask {
     int32_t contig;     // contig index within the assembly
     int32_t lo;         // lowest diagonal of the band (tpos - qpos, assembly coordinates)
     int32_t width;      // 16 / 32 / 64 / 128
-    int32_t n_anchors;
+    int32_t n_anchors;  // anchors of the cluster's chain (kp_spec.h)
     int32_t qmin, qmax;
+    int32_t chain_score;
 };
 
 // Raw result of one task (before the score filter), same meaning as the oracle's kpo_sw rows.

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
             const int32_t cs = b.ctg_start[b.asm_first_ctg[t.asm_id] + t.contig];
             raw[(size_t)t.asm_id * hit_cap + slot] =
                 kp_make_hit(t.gs, t.contig, cs, qlen, r.score, r.q_start, r.q_end, r.t_start, r.t_end, r.matches, r.block_len,
-                            t.n_anchors);
+                            t.n_anchors, t.chain_score);
         }
     }
     if (my_cells) atomicAdd(cells, my_cells);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
             const uint64_t mine[3] = {m0, k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
             for (j = 0; j < n; ++j) {
                 const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
-                if (other == m0) rank += kp_keys_less(k + 3 * (size_t)j, src[j].n_seeds, j, mine, src[i].n_seeds, i) ? 1u : 0u;
+                if (other == m0) rank += kp_keys_less(k + 3 * (size_t)j, kp_hit_seeds_key(src[j]), j, mine, kp_hit_seeds_key(src[i]), i) ? 1u : 0u;
             }
         }
         dst[rank] = src[i];
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
     __syncthreads();
     // mapping qualities: every gene's run of the list is walked by the thread that holds its first hit (a run is a few
     // hits long: a gene, its fragments and its paralogues in one assembly); scratch = the sort keys, no longer needed
-    int32_t *scratch = reinterpret_cast<int32_t *>(k);  // 6 ints per hit row available, 3 used
+    int32_t *scratch = reinterpret_cast<int32_t *>(k);  // 6 ints per hit row available, 4 used
     for (uint32_t i = tid; i < total; i += SORT_THREADS) {
         if (i > 0 && dst[i - 1].gene == dst[i].gene) continue;
         uint32_t j = i + 1;
         while (j < total && dst[j].gene == dst[i].gene) ++j;
-        kp_assign_mapq(dst + i, (int)(j - i), scratch + 3 * (size_t)i, scratch + 3 * (size_t)i + (j - i),
-                       scratch + 3 * (size_t)i + 2 * (size_t)(j - i), ln_half, ln_int);
+        kp_assign_mapq(dst + i, (int)(j - i), scratch + 4 * (size_t)i, scratch + 4 * (size_t)i + (j - i),
+                       scratch + 4 * (size_t)i + 2 * (size_t)(j - i), scratch + 4 * (size_t)i + 3 * (size_t)(j - i), ln_half, ln_int);
     }
 }
 

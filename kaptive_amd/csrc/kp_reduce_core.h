@@ -40,9 +40,11 @@ typedef struct KpTypingDb {  // device-resident views of the Database arrays the
 } KpTypingDb;
 
 // ---- hit finalisation -----------------------------------------------------------------------------------------------
-// task result -> hit record (strand flip, contig-local coordinates); mapq is filled after sorting
+// task result -> hit record (strand flip, contig-local coordinates); mapq is filled after sorting -- until then the
+// (mapq, pad_) bytes carry the chain's score (low byte in mapq, clamped to 65535), which only the mapq computation reads
+KP_HD int kp_hit_chain_score(const kp_hit &h) { return (int)h.mapq | ((int)h.pad_ << 8); }
 KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int score, int q_start, int q_end,
-                         int t_start, int t_end, int matches, int block_len, int n_anchors) {
+                         int t_start, int t_end, int matches, int block_len, int n_anchors, int chain_score) {
     kp_hit h;
     const int rev = gs & 1;
     h.gene = gs >> 1; h.contig = contig;
@@ -50,7 +52,8 @@ KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int sc
     h.q_end = rev ? qlen - q_start : q_end;
     h.t_start = t_start - ctg_start; h.t_end = t_end - ctg_start;
     h.score = score; h.matches = matches; h.block_len = block_len;
-    h.strand = rev ? -1 : 1; h.mapq = 0; h.n_seeds = (uint8_t)(n_anchors < 255 ? n_anchors : 255); h.pad_ = 0;
+    const int cs = chain_score < 65535 ? chain_score : 65535;
+    h.strand = rev ? -1 : 1; h.mapq = (uint8_t)(cs & 255); h.n_seeds = (uint8_t)(n_anchors < 255 ? n_anchors : 255); h.pad_ = (uint8_t)(cs >> 8);
     return h;
 }
 
@@ -62,8 +65,9 @@ KP_HD void kp_hit_keys(const kp_hit &h, uint64_t k[3]) {
     k[2] = ((uint64_t)(uint32_t)h.t_end << 32) | ((uint64_t)(0xFFFFu - (uint32_t)h.matches) << 16) | (uint32_t)h.block_len;
 }
 
-// (seeds: the last criterion of the emission order -- more seeds first; the records' own indices break what is left,
-// which are hits equal in every field)
+// (seeds: the last criteria of the emission order -- more seeds first, then the higher chain score; `seeds_*` carry both,
+// kp_hit_seeds_key; the records' own indices break what is left, which are hits equal in every field)
+KP_HD uint32_t kp_hit_seeds_key(const kp_hit &h) { return ((uint32_t)h.n_seeds << 16) | (uint32_t)kp_hit_chain_score(h); }
 KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t seeds_a, uint32_t ia, const uint64_t b[3], uint32_t seeds_b, uint32_t ib) {
     if (a[0] != b[0]) return a[0] < b[0];
     if (a[1] != b[1]) return a[1] < b[1];
@@ -72,35 +76,66 @@ KP_HD bool kp_keys_less(const uint64_t a[3], uint32_t seeds_a, uint32_t ia, cons
     return ia < ib;
 }
 
-// Primary / secondary and mapping quality of one gene's hits, in emission order (kp_spec.h).  `parent`, `sub`, `n_sub`:
-// scratch of n ints each.  Cost: a hit is compared with the PRIMARY hits before it and stops at the first one it overlaps
-// by more than half.  Primaries of one gene overlap each other by at most half of the shorter one on the query, and a
-// hit spans at least KP_MIN_SEED_SPAN query bases, so a gene of length L has at most ~2 L / 40 of them (in practice a
-// handful: the gene and its fragments); the n copies of a multi-copy gene (IS elements, hundreds of hits) all cover the
-// same query span, so every one after the first stops at j = 0: n steps, not n^2.
-KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *sub, int32_t *n_sub, const float *ln_half,
+// Primary / secondary and mapping quality of one gene's hits, in emission order (kp_spec.h): minimap2's mm_set_parent
+// (mask level 1/2 with the uncovered-length correction) and mm_set_mapq on the finished hits.  `parent`, `subsc`, `dp2`,
+// `n_sub`: scratch of n ints each.  Cost: a hit is compared with the PRIMARY hits before it and stops at the first one
+// that masks it.  Primaries of one gene overlap each other little on the query, and a hit spans at least
+// KP_MIN_CHAIN_SCORE query bases, so a gene has a handful of them (the gene and its fragments); the n copies of a
+// multi-copy gene (IS elements, hundreds of hits) all cover the same query span, so every one after the first stops at
+// j = 0: n steps, not n^2.
+KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *subsc, int32_t *dp2, int32_t *n_sub, const float *ln_half,
                           const float *ln_int) {
-    for (int i = 0; i < n; ++i) { sub[i] = 0; n_sub[i] = 0; }
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    for (int i = 0; i < n; ++i) { subsc[i] = 0; dp2[i] = 0; n_sub[i] = 0; }
     for (int i = 0; i < n; ++i) {
         parent[i] = i;
-        const int li = h[i].q_end - h[i].q_start;
+        const int si = h[i].q_start, ei = h[i].q_end;
+        // bases of [si, ei) that no earlier primary hit covers: sweep from si, jumping to the furthest end any interval that
+        // has started reaches, or -- over a hole -- to the next start
+        int uncov = 0;
+        bool any = false;
+        for (int x = si; x < ei;) {
+            int reach = x, next = ei;
+            for (int j = 0; j < i; ++j) {
+                if (parent[j] != j || h[j].q_end <= si || h[j].q_start >= ei) continue;
+                any = true;
+                const int sj = h[j].q_start > si ? h[j].q_start : si, ej = h[j].q_end < ei ? h[j].q_end : ei;
+                if (sj <= x) { if (ej > reach) reach = ej; }
+                else if (sj < next) next = sj;
+            }
+            if (reach > x) x = reach;
+            else { uncov += next - x; x = next; }
+        }
+        if (!any) continue;
         for (int j = 0; j < i; ++j) {
-            if (parent[j] != j) continue;
-            const int lj = h[j].q_end - h[j].q_start;
-            const int ol = (h[i].q_end < h[j].q_end ? h[i].q_end : h[j].q_end) - (h[i].q_start > h[j].q_start ? h[i].q_start : h[j].q_start);
-            const int mn = li < lj ? li : lj;
-            if (ol > 0 && (int64_t)ol * KP_MASK_LEVEL_DEN > (int64_t)mn * KP_MASK_LEVEL_NUM) {
+            if (parent[j] != j || h[j].q_end <= si || h[j].q_start >= ei) continue;
+            const int sj = h[j].q_start, ej = h[j].q_end;
+            const int mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
+            const int ol = (ei < ej ? ei : ej) - (si > sj ? si : sj);
+            const float lhs = (float)ol / (float)mn, rhs = (float)uncov / (float)mx;
+            if (lhs - rhs > 0.5f) {  // KP_MASK_LEVEL
+                bool cnt_sub = h[i].n_seeds >= h[j].n_seeds;
+                const int sci = kp_hit_chain_score(h[i]);
                 parent[i] = j;
-                if (h[i].score > sub[j]) sub[j] = h[i].score;
-                n_sub[j]++;
+                if (sci > subsc[j]) subsc[j] = sci;
+                if (h[j].contig != h[i].contig || h[j].t_start != h[i].t_start || h[j].t_end != h[i].t_end || ol != mn) {
+                    if (h[i].score > dp2[j]) dp2[j] = h[i].score;
+                    if (h[j].score - h[i].score <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = true;
+                }
+                if (cnt_sub) n_sub[j]++;
                 break;
             }
         }
     }
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
+        const int cs = kp_hit_chain_score(h[i]);
+        h[i].pad_ = 0;
         h[i].mapq = parent[i] != i ? (uint8_t)0
-                                    : (uint8_t)kp_mapq_value(h[i].score, h[i].n_seeds, h[i].matches, h[i].block_len, sub[i],
+                                    : (uint8_t)kp_mapq_value(h[i].score, cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
                                                              n_sub[i], ln_half, ln_int);
+    }
 }
 
 KP_HD bool kp_same_span(const kp_hit &x, const kp_hit &y) {

@@ -454,9 +454,47 @@ typedef struct kpo_task {
     int32_t contig;
     int32_t lo;      /* lowest diagonal of the band, true value (tpos - qpos, assembly coordinates) */
     int32_t width;   /* 16, 32, 64 or 128 */
-    int32_t n_anchors;
+    int32_t n_anchors; /* anchors of the chain (kp_spec.h) */
     int32_t qmin, qmax;
+    int32_t chain_score;
 } kpo_task;
+
+/* minimap2's chaining of a small anchor set (kp_spec.h): keys[0..n) are one cluster's anchors, n <= KP_CHAIN_DP_MAX.
+ * Returns the chain's score and, through *cnt, its anchor count. */
+static int chain_small(const uint64_t *keys, int n, int *cnt) {
+    static const uint8_t pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
+    int32_t t[KP_CHAIN_DP_MAX], q[KP_CHAIN_DP_MAX], f[KP_CHAIN_DP_MAX], p[KP_CHAIN_DP_MAX];
+    for (int i = 0; i < n; i++) { /* insertion sort by (target, query) */
+        int32_t qi = (int32_t)KP_KEY_QPOS(keys[i]), ti = (int32_t)KP_KEY_DIAG(keys[i]) - KP_DIAG_BIAS + qi;
+        int j = i;
+        while (j > 0 && (t[j - 1] > ti || (t[j - 1] == ti && q[j - 1] > qi))) { t[j] = t[j - 1]; q[j] = q[j - 1]; j--; }
+        t[j] = ti; q[j] = qi;
+    }
+    int best = 0;
+    for (int i = 0; i < n; i++) {
+        int max_f = KP_K, max_j = -1;
+        for (int j = i - 1; j >= 0; j--) {
+            int dq = q[i] - q[j], dr = t[i] - t[j];
+            if (dq <= 0 || dq > KP_CHAIN_MAX_DIST || dr == 0) continue;
+            int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+            int sc = dg < KP_K ? dg : KP_K;
+            if (dd || dg > KP_K) sc -= pen[dd < KP_CHAIN_PEN_SIZE ? dd : KP_CHAIN_PEN_SIZE - 1];
+            sc += f[j];
+            if (sc > max_f) { max_f = sc; max_j = j; }
+        }
+        f[i] = max_f; p[i] = max_j;
+        if (f[i] >= f[best]) best = i; /* the largest f, the later anchor on ties */
+    }
+    /* walk back; the chain is cut where the score counted from its end peaks */
+    int i = best, max_s = 0, steps = 0, cut_steps = 0;
+    do {
+        i = p[i]; steps++;
+        int sc = i < 0 ? f[best] : f[best] - f[i];
+        if (sc > max_s) { max_s = sc; cut_steps = steps; }
+    } while (i >= 0);
+    *cnt = cut_steps;
+    return max_s;
+}
 
 static int contig_of(const kpo_asm *a, int64_t t) { /* largest c with ctg_start[c] <= t */
     int lo = 0, hi = a->n_ctg - 1;
@@ -482,7 +520,16 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
             if (q2 < qmin) qmin = q2;
             if (q2 > qmax) qmax = q2;
         }
-        if (cnt >= KP_MIN_ANCHORS && (int)(qmax - qmin) + KP_K >= KP_MIN_SEED_SPAN) {
+        int chain_cnt = cnt, chain_sc = 0, ok;
+        if (cnt <= KP_CHAIN_DP_MAX) {
+            chain_sc = chain_small(keys + i, cnt, &chain_cnt);
+            ok = chain_sc >= KP_MIN_CHAIN_SCORE;
+        } else {
+            const int span = (int)(qmax - qmin) + KP_K;
+            ok = span >= KP_MIN_SEED_SPAN;
+            chain_sc = KP_K * cnt < span ? KP_K * cnt : span;
+        }
+        if (ok) {
             int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
             if (need > 16) {
                 margin = KP_BAND_MARGIN;
@@ -491,7 +538,7 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
             }
             if (nt == cap) { cap *= 2; tasks = realloc(tasks, (size_t)cap * sizeof(kpo_task)); }
             kpo_task *t = &tasks[nt++];
-            t->gs = (int32_t)gs; t->contig = ctg; t->width = w; t->n_anchors = cnt;
+            t->gs = (int32_t)gs; t->contig = ctg; t->width = w; t->n_anchors = chain_cnt; t->chain_score = chain_sc;
             t->lo = (int32_t)((int64_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2);
             t->qmin = (int32_t)qmin; t->qmax = (int32_t)qmax;
         }
@@ -586,31 +633,59 @@ static const float *ln_int_table(void) {
     return t;
 }
 
-/* primary / secondary and mapping quality of one gene's hits (emission order), kp_spec.h */
+/* primary / secondary and mapping quality of one gene's hits (emission order), kp_spec.h: minimap2's mm_set_parent
+ * (mask level 1/2 with the uncovered-length correction) and mm_set_mapq on the finished hits.  On entry a hit's chain
+ * score sits in its (mapq, pad_) bytes (low byte in mapq), clamped to 65535. */
+static int hit_chain_score(const kp_hit *h) { return (int)h->mapq | ((int)h->pad_ << 8); }
+
 static void assign_mapq(kp_hit *h, int n) {
-    int *parent = malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *sub = calloc((size_t)(n > 0 ? n : 1), sizeof(int)),
-        *n_sub = calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    int *parent = malloc(sizeof(int) * m), *subsc = calloc(m, sizeof(int)), *dp2 = calloc(m, sizeof(int)), *n_sub = calloc(m, sizeof(int));
     for (int i = 0; i < n; i++) {
         parent[i] = i;
-        const int li = h[i].q_end - h[i].q_start;
+        const int si = h[i].q_start, ei = h[i].q_end;
+        /* bases of [si, ei) that no earlier primary hit covers */
+        int uncov = 0, any = 0;
+        for (int x = si; x < ei;) {
+            int reach = x, next = ei;
+            for (int j = 0; j < i; j++) {
+                if (parent[j] != j || h[j].q_end <= si || h[j].q_start >= ei) continue;
+                any = 1;
+                const int sj = h[j].q_start > si ? h[j].q_start : si, ej = h[j].q_end < ei ? h[j].q_end : ei;
+                if (sj <= x) { if (ej > reach) reach = ej; }
+                else if (sj < next) next = sj;
+            }
+            if (reach > x) x = reach;
+            else { uncov += next - x; x = next; }
+        }
+        if (!any) continue;
         for (int j = 0; j < i; j++) {
-            if (parent[j] != j) continue;
-            const int lj = h[j].q_end - h[j].q_start;
-            const int ol = (h[i].q_end < h[j].q_end ? h[i].q_end : h[j].q_end) - (h[i].q_start > h[j].q_start ? h[i].q_start : h[j].q_start);
-            const int mn = li < lj ? li : lj;
-            if (ol > 0 && (int64_t)ol * KP_MASK_LEVEL_DEN > (int64_t)mn * KP_MASK_LEVEL_NUM) {
+            if (parent[j] != j || h[j].q_end <= si || h[j].q_start >= ei) continue;
+            const int sj = h[j].q_start, ej = h[j].q_end;
+            const int mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
+            const int ol = (ei < ej ? ei : ej) - (si > sj ? si : sj);
+            if ((float)ol / (float)mn - (float)uncov / (float)mx > 0.5f) {
+                int cnt_sub = h[i].n_seeds >= h[j].n_seeds;
+                const int sci = hit_chain_score(&h[i]);
                 parent[i] = j;
-                if (h[i].score > sub[j]) sub[j] = h[i].score;
-                n_sub[j]++;
+                if (sci > subsc[j]) subsc[j] = sci;
+                if (h[j].contig != h[i].contig || h[j].t_start != h[i].t_start || h[j].t_end != h[i].t_end || ol != mn) {
+                    if (h[i].score > dp2[j]) dp2[j] = h[i].score;
+                    if (h[j].score - h[i].score <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = 1;
+                }
+                if (cnt_sub) n_sub[j]++;
                 break;
             }
         }
     }
-    for (int i = 0; i < n; i++)
+    for (int i = 0; i < n; i++) {
+        const int cs = hit_chain_score(&h[i]);
+        h[i].pad_ = 0;
         h[i].mapq = parent[i] != i ? 0
-                                    : (uint8_t)kp_mapq_value(h[i].score, h[i].n_seeds, h[i].matches, h[i].block_len, sub[i], n_sub[i],
-                                                             ln_half_table(), ln_int_table());
-    free(parent); free(sub); free(n_sub);
+                                    : (uint8_t)kp_mapq_value(h[i].score, cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
+                                                             n_sub[i], ln_half_table(), ln_int_table());
+    }
+    free(parent); free(subsc); free(dp2); free(n_sub);
 }
 
 static int cmp_hit(const void *a, const void *b) {
@@ -625,7 +700,8 @@ static int cmp_hit(const void *a, const void *b) {
     if (x->t_end != y->t_end) return x->t_end < y->t_end ? -1 : 1;
     if (x->matches != y->matches) return x->matches > y->matches ? -1 : 1;
     if (x->block_len != y->block_len) return x->block_len < y->block_len ? -1 : 1;
-    return x->n_seeds > y->n_seeds ? -1 : (x->n_seeds < y->n_seeds);
+    if (x->n_seeds != y->n_seeds) return x->n_seeds > y->n_seeds ? -1 : 1;
+    return hit_chain_score(x) > hit_chain_score(y) ? -1 : (hit_chain_score(x) < hit_chain_score(y)); /* (still in mapq, pad_) */
 }
 
 static int same_span(const kp_hit *x, const kp_hit *y) {
@@ -685,7 +761,8 @@ KPO_API int64_t kpo_sw(const kpo_db *db, const uint32_t *words, int64_t padded_l
 /* Full aligner for one assembly: hits in emission order.  Returns the number of hits (writes at most cap). */
 KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
                           const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, kp_hit *out,
-                          int64_t cap, int64_t *stats /* optional [3]: anchors, tasks, dp cells */) {
+                          int64_t cap, int64_t *stats /* optional [3]: anchors, tasks, dp cells */,
+                          int32_t *chain_out /* optional [cap]: the chain score behind every hit */) {
     kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
     uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
     kpo_task *tasks; int64_t nt = make_tasks(&a, keys, n, &tasks);
@@ -708,6 +785,7 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         h->t_start = (int32_t)(r[3] - cs); h->t_end = (int32_t)(r[4] - cs);
         h->score = r[7]; h->matches = r[5]; h->block_len = r[6];
         h->n_seeds = (uint8_t)(t->n_anchors < 255 ? t->n_anchors : 255);
+        { const int cs = t->chain_score < 65535 ? t->chain_score : 65535; h->mapq = (uint8_t)(cs & 255); h->pad_ = (uint8_t)(cs >> 8); }
     }
     qsort(hits, (size_t)nh, sizeof(kp_hit), cmp_hit);
     int64_t m = 0;
@@ -715,6 +793,7 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         if (m > 0 && same_span(&hits[m - 1], &hits[i])) continue;
         hits[m++] = hits[i];
     }
+    if (chain_out) for (int64_t i = 0; i < m && i < cap; i++) chain_out[i] = hit_chain_score(&hits[i]);
     for (int64_t i = 0; i < m;) { /* mapping qualities, gene by gene */
         int64_t j = i;
         while (j < m && hits[j].gene == hits[i].gene) j++;

@@ -286,9 +286,9 @@ def gen_typing() -> None:
     for name, key, kw in cases:
         t0 = time.time()
         genome = make_assembly(dbs[key], name=name, **kw)
-        hits = odbs[key].align(genome.packed())
+        hits, chain = odbs[key].align(genome.packed(), with_chain=True)
         exp = run_reference_typing(ref[key], typers[key], genome, hits)
-        save_case(name, key, genome, hits, exp)
+        save_case(name, key, genome, hits, exp, chain)
         index.append(name)
         print(f"typing {name}: {len(hits)} hits -> {bytes(exp['kaptive_row'])[:90]!r} ({time.time() - t0:.1f}s)")
     rng = np.random.default_rng(99)
@@ -303,22 +303,25 @@ def gen_typing() -> None:
         print(f"typing {name}: {len(hits)} hits -> {bytes(exp['kaptive_row'])[:90]!r} ({time.time() - t0:.1f}s)")
     # variants of the confidence switches on one case
     genome = make_assembly(dbs["k"], name="k_divergent", **dict(cases[6][2]))
-    hits = odbs["k"].align(genome.packed())
+    hits, chain = odbs["k"].align(genome.packed(), with_chain=True)
     for tag, kwargs in (("loose", dict(max_other_genes=5, min_completeness=0.1, allow_below_threshold=True)),
                         ("strict", dict(max_other_genes=0, min_completeness=0.99, partial_edge_tolerance=50))):  # fmt: skip
         typer = RefSerotyper(ref["k"], **kwargs)
         exp = run_reference_typing(ref["k"], typer, genome, hits)
         exp["typer_kwargs_json"] = np.frombuffer(json.dumps(kwargs).encode(), np.uint8)
-        save_case(f"k_divergent_{tag}", "k", genome, hits, exp)
+        save_case(f"k_divergent_{tag}", "k", genome, hits, exp, chain)
         index.append(f"k_divergent_{tag}")
     (OUT / "typing_index.json").write_text(json.dumps(index, indent=1) + "\n")
 
 
-def save_case(name, key, genome, hits, exp) -> None:
+def save_case(name, key, genome, hits, exp, chain=None) -> None:
+    """``chain``: the chain score behind every hit (aligner tables only) -- an input of the hit's mapq that the record does
+    not keep; the hit-finalisation test needs it to recompute the recorded mapq."""
     np.savez_compressed(
         OUT / f"typing_{name}.npz",
         db_key=np.array(key), genome_id=np.array(genome.id), contig_ids=np.array(list(genome.contigs.ids), dtype="U"),
         contig_seqs=genome.contigs.seqs, contig_lengths=genome.contigs.lengths, hits=hits,
+        hit_chain_scores=np.zeros(len(hits), np.int32) if chain is None else np.asarray(chain, np.int32),
         **{f"exp.{k}": v for k, v in exp.items()},
     )  # fmt: skip
 

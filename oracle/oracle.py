@@ -22,7 +22,7 @@ HIT_DTYPE = np.dtype(
 )  # fmt: skip
 TASK_DTYPE = np.dtype(
     [("gs", "<i4"), ("contig", "<i4"), ("lo", "<i4"), ("width", "<i4"), ("n_anchors", "<i4"), ("qmin", "<i4"),
-     ("qmax", "<i4")]
+     ("qmax", "<i4"), ("chain_score", "<i4")]
 )  # fmt: skip
 
 
@@ -207,14 +207,17 @@ class OracleDB:
         lib().kpo_sw(*args, _p(tasks), C.c_int64(len(tasks)), _p(out))
         return out
 
-    def align(self, pa, with_stats: bool = False):
+    def align(self, pa, with_stats: bool = False, with_chain: bool = False):
+        """Hits in emission order; ``with_chain`` adds the chain score behind every hit (an input of its mapq that the
+        hit record does not keep)."""
         keep, args = self._asm_args(pa)
         stats = np.zeros(3, np.int64)
         cap = 1 << 14
         while True:
-            out = np.zeros(cap, HIT_DTYPE)
-            n = lib().kpo_align(*args, _p(out), C.c_int64(cap), _p(stats))
+            out, chain = np.zeros(cap, HIT_DTYPE), np.zeros(cap, np.int32)
+            n = lib().kpo_align(*args, _p(out), C.c_int64(cap), _p(stats), _p(chain))
             if n <= cap:
                 break
             cap = int(n)
-        return (out[:n], stats) if with_stats else out[:n]
+        res = (out[:n],) + ((stats,) if with_stats else ()) + ((chain[:n],) if with_chain else ())
+        return res if len(res) > 1 else res[0]

@@ -18,7 +18,7 @@ int kph_finalise_hits(kp_hit *hits, int n) {
     for (int i = 0; i < n; ++i) {  // rank sort, as the kernel does
         int rank = 0;
         for (int j = 0; j < n; ++j)
-            rank += kp_keys_less(&keys[3 * (size_t)j], raw[j].n_seeds, j, &keys[3 * (size_t)i], raw[i].n_seeds, i);
+            rank += kp_keys_less(&keys[3 * (size_t)j], kp_hit_seeds_key(raw[j]), j, &keys[3 * (size_t)i], kp_hit_seeds_key(raw[i]), i);
         sorted[(size_t)rank] = raw[i];
     }
     int m = 0;
@@ -29,12 +29,12 @@ int kph_finalise_hits(kp_hit *hits, int n) {
     std::vector<float> ln_half(KP_MAPQ_LN_HALF_SIZE), ln_int(KP_MAPQ_LN_INT_SIZE);
     for (int i = 0; i < KP_MAPQ_LN_HALF_SIZE; ++i) ln_half[i] = i ? kp_mapq_ln((double)i / 2.0) : 0.0f;
     for (int i = 0; i < KP_MAPQ_LN_INT_SIZE; ++i) ln_int[i] = i ? kp_mapq_ln((double)i) : 0.0f;
-    std::vector<int32_t> scratch(3 * (size_t)(m > 0 ? m : 1));
+    std::vector<int32_t> scratch(4 * (size_t)(m > 0 ? m : 1));
     for (int i = 0; i < m;) {
         int j = i;
         while (j < m && hits[j].gene == hits[i].gene) ++j;
-        kp_assign_mapq(hits + i, j - i, scratch.data(), scratch.data() + m, scratch.data() + 2 * (size_t)m, ln_half.data(),
-                       ln_int.data());
+        kp_assign_mapq(hits + i, j - i, scratch.data(), scratch.data() + m, scratch.data() + 2 * (size_t)m, scratch.data() + 3 * (size_t)m,
+                       ln_half.data(), ln_int.data());
         i = j;
     }
     return m;

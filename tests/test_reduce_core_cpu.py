@@ -8,7 +8,7 @@ import pytest
 from kaptive_amd.serotyping import batch as B
 from kaptive_amd.serotyping.core import Serotyper
 from tests import harness_util as H
-from tests.golden_util import case_names, load_case, load_db
+from tests.golden_util import GOLDEN, case_names, load_case, load_db
 from tests.test_host_golden import _same, check_result_against_golden
 
 
@@ -23,8 +23,12 @@ def test_core_reduction_matches_reference(name, oracle):
     # (the random_hits tables are not aligner output: their mapq/order are arbitrary, so they skip this step)
     if not name.startswith("random_hits"):
         rng = np.random.default_rng(len(hits))
-        shuffled = np.concatenate([hits, hits[: len(hits) // 7]])[rng.permutation(len(hits) + len(hits) // 7)]
-        shuffled["mapq"] = 0
+        perm = rng.permutation(len(hits) + len(hits) // 7)
+        shuffled = np.concatenate([hits, hits[: len(hits) // 7]])[perm]
+        # (between the aligner and the mapq computation a record carries its chain score in the mapq / pad bytes)
+        chain = np.load(GOLDEN / f"typing_{name}.npz")["hit_chain_scores"]
+        chain = np.minimum(np.concatenate([chain, chain[: len(hits) // 7]])[perm], 65535)
+        shuffled["mapq"], shuffled["pad"] = chain & 255, chain >> 8
         again = H.finalise_hits(shuffled)
         assert again.tobytes() == np.ascontiguousarray(hits).tobytes()
 

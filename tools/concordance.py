@@ -154,6 +154,8 @@ def run_case(case):
             n_hits_k=len(hk), n_hits_m=len(hm), n_spans_both=len(both), n_spans_k_only=len(set(spans_k) - both),
             n_spans_m_only=len(set(spans_m) - both),
             score_equal_on_shared=sum(1 for s in both if int(spans_k[s]["score"]) == int(spans_m[s]["score"])),
+            mapq_equal_on_shared=sum(1 for s in both if int(spans_k[s]["mapq"]) == int(spans_m[s]["mapq"])),
+            seeds_equal_on_shared=sum(1 for s in both if int(spans_k[s]["n_seeds"]) == int(spans_m[s]["n_seeds"])),
             n_final_genes_k=len(gk), n_final_genes_m=len(gm), n_genes_both=len(genes_both), coord_same=coord_same,
             state_same=state_same, max_coord_delta=max_delta,
             genes_k_only=sorted(set(gk) - set(gm)), genes_m_only=sorted(set(gm) - set(gk)),
@@ -168,8 +170,8 @@ def summarise(records: list[dict]) -> str:
     for r in records:
         by_tag[r["tag"] + ("/" + r["db"] if r["tag"] == "config3" else "")].append(r)
     lines = []
-    lines.append("| workload | rows | byte-identical rows | locus/type/confidence/problems identical | locus+type+confidence identical | final genes identical in coordinates | in state | raw hit spans shared / kp-only / mm2-only | scores equal on shared spans |")
-    lines.append("|---|---|---|---|---|---|---|---|---|")
+    lines.append("| workload | rows | byte-identical rows | locus/type/confidence/problems identical | locus+type+confidence identical | final genes identical in coordinates | in state | raw hit spans shared / kp-only / mm2-only | scores equal on shared spans | mapq equal | chain anchors equal |")
+    lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
 
     def line(name, rs):
         n = len(rs)
@@ -181,9 +183,10 @@ def summarise(records: list[dict]) -> str:
         cs, ss = sum(r["coord_same"] for r in rs), sum(r["state_same"] for r in rs)
         sb, sk, sm = sum(r["n_spans_both"] for r in rs), sum(r["n_spans_k_only"] for r in rs), sum(r["n_spans_m_only"] for r in rs)
         se = sum(r["score_equal_on_shared"] for r in rs)
+        me, ne = sum(r["mapq_equal_on_shared"] for r in rs), sum(r["seeds_equal_on_shared"] for r in rs)
         return (f"| {name} | {n} | {ident} ({100 * ident / n:.1f} %) | {f4} ({100 * f4 / n:.1f} %) | {f3} ({100 * f3 / n:.1f} %) | "
                 f"{cs}/{gu} ({100 * cs / max(gu, 1):.2f} %) | {ss}/{gb} ({100 * ss / max(gb, 1):.2f} %) | {sb} / {sk} / {sm} | "
-                f"{se}/{sb} ({100 * se / max(sb, 1):.2f} %) |")
+                f"{se}/{sb} ({100 * se / max(sb, 1):.2f} %) | {100 * me / max(sb, 1):.2f} % | {100 * ne / max(sb, 1):.2f} % |")
 
     for name in sorted(by_tag):
         lines.append(line(name, by_tag[name]))
@@ -196,7 +199,7 @@ def main() -> None:
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--procs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--full-size", type=int, default=6)
-    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r3"))
+    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r4"))
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     cs = cases(a.scale, a.full_size)
