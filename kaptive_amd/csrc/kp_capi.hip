@@ -33,7 +33,7 @@ void kp_launch_states(const KpBatchView &b, const KpTypingDb &db, const KpTyping
 
 namespace {
 
-constexpr size_t ORDER_HEAD = KP_N_CLASSES * 128;  // task-order histogram + cursors (kp_chain.hip)
+constexpr size_t ORDER_HEAD = KP_ORDER_HEAD;  // task-order histogram, cursors and per-class counts (kp_chain.hip)
 
 std::mutex g_err_mutex;
 std::string g_global_error = "";
@@ -879,12 +879,12 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, stream);
-    kp_launch_task_order(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD,
-                         stream);
+    kp_launch_task_order(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, d_task_count, w->task_cap,
+                         w->d_results.p, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD, stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
-    kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, d_task_count, w->task_cap, w->d_task_order.p + ORDER_HEAD,
+    kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, w->d_task_order.p + KP_ORDER_COUNTS, w->task_cap, w->d_task_order.p + ORDER_HEAD,
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p,
                  stream, ev[4]);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
@@ -1129,7 +1129,7 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out8, int64
     int64_t n = 0;
     for (int c = 0; c < KP_N_CLASSES; ++c)
         for (const KpTask &t : w->h_tasks[c]) {
-            if (t.asm_id != a) continue;
+            if (t.asm_id != a || t.n_anchors == 0) continue;  // (n_anchors == 0: a cluster the chaining rejected)
             if (out8 && n < cap) {
                 int32_t *o = out8 + 8 * n;
                 o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = t.qmin; o[6] = t.qmax; o[7] = t.chain_score;
@@ -1153,7 +1153,7 @@ int64_t kp_batch_task_results(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7
         if (nt && hipMemcpy(res.data(), w->d_results.p + (size_t)c * w->task_cap, nt * sizeof(KpSwResult), hipMemcpyDeviceToHost) != hipSuccess)
             return kp_fail(ctx, KP_EHIP, "D2H task results failed");
         for (size_t i = 0; i < nt; ++i) {
-            if (w->h_tasks[c][i].asm_id != a) continue;
+            if (w->h_tasks[c][i].asm_id != a || w->h_tasks[c][i].n_anchors == 0) continue;
             if (out7 && n < cap) {
                 const KpSwResult &r = res[i];
                 int32_t *o = out7 + 7 * n;

@@ -44,56 +44,53 @@ struct TaskStage {
 
 __constant__ uint8_t c_chain_pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
 
-// minimap2's chaining of a small cluster (kp_spec.h), by the whole wave: lane l < n arrives with anchor l's target and
-// query position (any order).  Returns the chain's score, *cnt = its anchor count (wave-uniform).
-__device__ __forceinline__ int chain_small(int n, int32_t t, int32_t q, int lane, int *cnt) {
-    const bool have = lane < n;
-    // (target, query) order: rank by counting, then every lane fetches the anchor of its own rank
-    int rank = 0;
-    for (int m = 0; m < n; ++m) {
-        const int32_t tm = __shfl(t, m), qm = __shfl(q, m);
-        rank += (tm < t || (tm == t && qm < q)) ? 1 : 0;
+// minimap2's chaining of a small cluster (kp_spec.h), by one lane: keys[0..n) are the cluster's anchors (compact keys,
+// sorted by diagonal then query position), n <= KP_CHAIN_DP_MAX.  Returns the chain's score, *cnt = its anchor count.
+__device__ int chain_small(const uint64_t *__restrict__ keys, int n, KpKeyBits kb, int *cnt) {
+    int32_t t[KP_CHAIN_DP_MAX], q[KP_CHAIN_DP_MAX];
+    int16_t f[KP_CHAIN_DP_MAX];
+    int8_t p[KP_CHAIN_DP_MAX];
+    for (int i = 0; i < n; ++i) {  // insertion sort by (target, query)
+        const uint64_t key = keys[i];
+        const int32_t qi = (int32_t)kp_ckey_qpos(key, kb), ti = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + qi;
+        int j = i;
+        while (j > 0 && (t[j - 1] > ti || (t[j - 1] == ti && q[j - 1] > qi))) { t[j] = t[j - 1]; q[j] = q[j - 1]; --j; }
+        t[j] = ti; q[j] = qi;
     }
-    int from = 0;
-    for (int m = 0; m < n; ++m)
-        if (__shfl(rank, m) == lane) from = m;
-    t = __shfl(t, from); q = __shfl(q, from);
-    int f = KP_K, p = -1;
-    for (int i = 1; i < n; ++i) {
-        const int32_t ti = __shfl(t, i), qi = __shfl(q, i);
-        int best = -1;  // (value << 8) | predecessor: the largest value, the later predecessor on ties
-        if (have && lane < i) {
-            const int dq = qi - q, dr = ti - t;
-            if (dq > 0 && dq <= KP_CHAIN_MAX_DIST && dr != 0) {
-                const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
-                int sc = dg < KP_K ? dg : KP_K;
-                if (dd || dg > KP_K) sc -= c_chain_pen[dd < KP_CHAIN_PEN_SIZE ? dd : KP_CHAIN_PEN_SIZE - 1];
-                best = ((sc + f) << 8) | lane;  // sc + f >= KP_K - pen + KP_K > 0
-            }
+    int best = 0;
+    for (int i = 0; i < n; ++i) {
+        int max_f = KP_K, max_j = -1;
+        for (int j = i - 1; j >= 0; --j) {
+            const int dq = q[i] - q[j], dr = t[i] - t[j];
+            if (dq <= 0 || dq > KP_CHAIN_MAX_DIST || dr == 0) continue;
+            const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+            int sc = dg < KP_K ? dg : KP_K;
+            if (dd || dg > KP_K) sc -= c_chain_pen[dd < KP_CHAIN_PEN_SIZE ? dd : KP_CHAIN_PEN_SIZE - 1];
+            sc += f[j];
+            if (sc > max_f) { max_f = sc; max_j = j; }
         }
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));  // n <= KP_CHAIN_DP_MAX < 32 lanes
-        if (lane == i && best >= 0 && (best >> 8) > KP_K) { f = best >> 8; p = best & 255; }
+        f[i] = (int16_t)max_f; p[i] = (int8_t)max_j;
+        if (f[i] >= f[best]) best = i;  // the largest f, the later anchor on ties
     }
-    int top = have ? (f << 8) | lane : -1;  // the largest f, the later anchor on ties
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) top = max(top, __shfl_xor(top, o));
-    const int f_end = top >> 8;
-    int i = top & 255, max_s = 0, steps = 0, cut = 0;
+    int i = best, max_s = 0, steps = 0, cut = 0;
     do {  // walk back; the chain is cut where the score counted from its end peaks
-        i = __shfl(p, i);
+        i = p[i];
         ++steps;
-        const int sc = i < 0 ? f_end : f_end - __shfl(f, i < 0 ? 0 : i);
+        const int sc = i < 0 ? f[best] : f[best] - f[i];
         if (sc > max_s) { max_s = sc; cut = steps; }
     } while (i >= 0);
     *cnt = cut;
     return max_s;
 }
 
-// called by one lane; cnt / chain_score: the chain's (kp_spec.h), the band comes from the whole cluster
+// called by one lane.  A cluster whose anchors cover fewer than KP_MIN_SEED_SPAN query bases cannot chain to
+// KP_MIN_CHAIN_SCORE (a chain scores at most its query extent) and is dropped here; the rest become PROVISIONAL tasks
+// -- n_anchors = the cluster's anchor count, chain_score = the index of its first anchor in the assembly's sorted list --
+// which kp_chain_score_kernel settles (kp_spec.h: chain score and anchor count, or rejection).
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
-                                              uint32_t qmax, int cnt, int chain_score, KpTask *tasks, uint32_t *task_count,
+                                              uint32_t qmax, int cnt, uint32_t first, KpTask *tasks, uint32_t *task_count,
                                               uint32_t task_cap, TaskStage &st) {
+    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
     int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16, cls = 0;
     if (need > 16) {
         margin = KP_BAND_MARGIN;
@@ -102,7 +99,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
         cls = w == 32 ? 1 : (w == 64 ? 2 : 3);
     }
     KpTask t;
-    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = chain_score;
+    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = (int32_t)first;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
     const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
@@ -153,23 +150,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
     if (have_prev) { prev_key = k[lo - 1]; prev_ctg = contig_of(prev_key); }
     Cluster cur;
     cur.open = false; cur.gs = cur.d0 = cur.dprev = cur.qmin = cur.qmax = cur.first = 0; cur.ctg = 0; cur.cnt = 0;
-    auto flush = [&]() {  // wave-uniform
-        if (cur.open && cur.cnt >= KP_MIN_ANCHORS) {
-            int chain_cnt = cur.cnt, chain_sc;
-            bool ok;
-            if (cur.cnt <= KP_CHAIN_DP_MAX) {
-                const uint64_t key = lane < cur.cnt ? k[cur.first + lane] : 0ull;
-                const int32_t q = (int32_t)kp_ckey_qpos(key, kb), t = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + q;
-                chain_sc = chain_small(cur.cnt, t, q, lane, &chain_cnt);
-                ok = chain_sc >= KP_MIN_CHAIN_SCORE;
-            } else {
-                const int span = (int)(cur.qmax - cur.qmin) + KP_K;
-                ok = span >= KP_MIN_SEED_SPAN;
-                chain_sc = min(KP_K * cur.cnt, span);
-            }
-            if (ok && lane == 0)
-                flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, chain_cnt, chain_sc, tasks, task_count, task_cap, st);
-        }
+    auto flush = [&]() {
+        if (cur.open && lane == 0)
+            flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, cur.cnt, cur.first, tasks, task_count, task_cap, st);
         cur.open = false;
     };
 
@@ -274,7 +257,37 @@ __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t 
     seg_end[a] = (uint32_t)a * cap + n;
 }
 
+// ---- chain scores: one lane per provisional task (kp_spec.h: which clusters become tasks) -----------------------------------
+// Small clusters are chained as minimap2 chains them (chain_small); a cluster that does not reach KP_MIN_CHAIN_SCORE is
+// REJECTED: n_anchors = 0, its result row reads score 0 (nothing downstream fills or traces it: the order below leaves it
+// out).  Larger clusters keep their anchor count and get the score of a co-linear chain.
+__global__ __launch_bounds__(256) void kp_chain_score_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
+                                                             KpTask *__restrict__ tasks, const uint32_t *__restrict__ task_count,
+                                                             uint32_t task_cap, KpSwResult *__restrict__ results) {
+    const int cls = blockIdx.y;
+    uint32_t n = task_count[cls];
+    if (n > task_cap) n = task_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        KpTask &t = tasks[(size_t)cls * task_cap + i];
+        const int cnt = t.n_anchors;
+        const uint32_t first = (uint32_t)t.chain_score;
+        int chain_cnt = cnt, chain_sc;
+        if (cnt <= KP_CHAIN_DP_MAX) {
+            chain_sc = chain_small(keys + (size_t)t.asm_id * cap + first, cnt, kb, &chain_cnt);
+            if (chain_sc < KP_MIN_CHAIN_SCORE) {
+                chain_cnt = 0;
+                results[(size_t)cls * task_cap + i].score = 0;
+            }
+        } else {
+            chain_sc = min(KP_K * cnt, t.qmax - t.qmin + KP_K);
+        }
+        t.n_anchors = chain_cnt;
+        t.chain_score = chain_sc;
+    }
+}
+
 // ---- task order: counting sort of each width class by the rows the fill kernel will compute, most first ---------------------
+// (rejected tasks, n_anchors == 0, are left out; ordered[cls] = how many the order holds)
 // Tasks of one wave run in lock step for as many steps as the longest of them needs, so neighbours in the processing
 // order should have similar lengths; starting with the long ones also keeps the tail of the launch short.
 __device__ __forceinline__ int length_bucket(int rows) {
@@ -299,15 +312,18 @@ __global__ __launch_bounds__(256) void kp_task_hist_kernel(KpBatchView b, KpGene
     if (n > task_cap) n = task_cap;
     if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        atomicAdd(&s_h[length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]))], 1u);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const KpTask &t = tasks[(size_t)cls * task_cap + i];
+        if (t.n_anchors) atomicAdd(&s_h[length_bucket(task_rows(b, genes, t))], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[cls * 64 + threadIdx.x], s_h[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                               const uint32_t *__restrict__ task_count, uint32_t task_cap,
-                                                              uint32_t *__restrict__ hist, uint32_t *__restrict__ order) {
+                                                              uint32_t *__restrict__ hist, uint32_t *__restrict__ order,
+                                                              uint32_t *__restrict__ ordered) {
     __shared__ uint32_t s_start[64], s_h[64], s_base[64];
     const int cls = blockIdx.y;
     uint32_t n = task_count[cls];
@@ -315,14 +331,17 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpBatchView b, KpG
     if (threadIdx.x == 0) {  // bucket starts from the finished histogram (64 entries: not worth a scan)
         uint32_t acc = 0;
         for (int k = 0; k < 64; ++k) { s_start[k] = acc; acc += hist[cls * 64 + k]; }
+        if (blockIdx.x == 0) ordered[cls] = acc;
     }
     if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
     __syncthreads();
     // each block handles one contiguous chunk so that it can reserve its slots with one atomic per bucket
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-        atomicAdd(&s_h[length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]))], 1u);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const KpTask &t = tasks[(size_t)cls * task_cap + i];
+        if (t.n_anchors) atomicAdd(&s_h[length_bucket(task_rows(b, genes, t))], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {
         s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[KP_N_CLASSES * 64 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
@@ -330,18 +349,24 @@ __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpBatchView b, KpG
     }
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int k = length_bucket(task_rows(b, genes, tasks[(size_t)cls * task_cap + i]));
+        const KpTask &t = tasks[(size_t)cls * task_cap + i];
+        if (!t.n_anchors) continue;
+        const int k = length_bucket(task_rows(b, genes, t));
         order[(size_t)cls * task_cap + s_start[k] + s_base[k] + atomicAdd(&s_h[k], 1u)] = i;
     }
 }
 
 }  // namespace
 
-void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
-                          uint32_t *hist, uint32_t *order, hipStream_t stream) {
+void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t cap, KpKeyBits key_bits,
+                          KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
+                          uint32_t *order, hipStream_t stream) {
     const dim3 grid(128, KP_N_CLASSES), block(256);
+    hipLaunchKernelGGL(kp_chain_score_kernel, dim3(512, KP_N_CLASSES), block, 0, stream, sorted_anchors, cap, key_bits, tasks, task_count,
+                       task_cap, results);
     hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist);
-    hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist, order);
+    hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist, order,
+                       hist + 2 * KP_N_CLASSES * 64);
 }
 
 void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,

@@ -193,16 +193,21 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
                      hipStream_t stream);
-// kp_sw.hip: banded Smith-Waterman of every task; class c (16/32/64/128 diagonals) has its tasks, order, ends and
-// results at c * task_cap and its count at task_count[c]; one fill launch covers all four, one traceback launch follows.
+// kp_sw.hip: banded Smith-Waterman of every ORDERED task; class c (16/32/64/128 diagonals) has its tasks, order, ends and
+// results at c * task_cap and the length of its order at ordered_count[c]; one fill launch covers all four, one traceback launch follows.
 // `trace` holds trace_cap_units 16-byte units; *trace_top (zeroed by the caller) ends up as the units the pass needs.
-void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
+void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *ordered_count,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
                   uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
                   hipEvent_t after_fill);
-// kp_chain.hip: per width class, a permutation of the task list ordered by query length (longest first)
-void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count, uint32_t task_cap,
-                          uint32_t *hist /*[KP_N_CLASSES * 128] zeroed*/, uint32_t *order, hipStream_t stream);
+// kp_chain.hip: settles the provisional tasks (chain score and anchor count of every cluster, or rejection: kp_spec.h), then
+// builds, per width class, a permutation of the surviving tasks ordered by query length (longest first).  `hist` is
+// KP_ORDER_HEAD zeroed words: histogram, cursors and, at KP_ORDER_COUNTS, how many tasks each class's order holds.
+#define KP_ORDER_COUNTS (2 * KP_N_CLASSES * 64)
+#define KP_ORDER_HEAD (KP_ORDER_COUNTS + KP_N_CLASSES)
+void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t cap, KpKeyBits key_bits,
+                          KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
+                          uint32_t *order, hipStream_t stream);
 // kp_prot.hip
 // kp_reduce.hip: assembly a's hits with gene in [gene_lo, gene_hi) (one run: hits are sorted by gene) -> out rows, gene
 // indices relative to gene_lo; out_n[a] = how many

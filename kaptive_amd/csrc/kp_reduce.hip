@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
             t = tasks[(size_t)cls * task_cap + i];
             r = results[(size_t)cls * task_cap + i];
             qlen = gene_len[t.gs >> 1];
-            my_cells += (unsigned long long)qlen * (unsigned)t.width;
+            if (t.n_anchors) my_cells += (unsigned long long)qlen * (unsigned)t.width;  // (0: rejected by the chaining)
         }
         const bool hit = i < n && r.score >= KP_MIN_DP_SCORE;
         uint32_t slot = 0;

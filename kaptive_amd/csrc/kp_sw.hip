@@ -767,7 +767,7 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
 
 }  // namespace
 
-void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count,
+void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count /* of each class's order */,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
                   uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
                   hipEvent_t after_fill) {
