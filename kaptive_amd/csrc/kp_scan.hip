@@ -219,16 +219,19 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, KP_SCAN_WAVES_PER_SIMD) void kp_s
 #pragma unroll
         for (int i = 0; i < 67; ++i) d2[i] = max3u(d1[i], d1[i + 2], d1[i + 4]);
         const bool owner = lane >= 1 && lane <= SCAN_OWN && u < n_units;
+        const uint32_t lane64 = 64u * (uint32_t)lane;
+        const unsigned long long owner_mask = __builtin_amdgcn_ballot_w64(owner);
 #pragma unroll
         for (int p0 = 0; p0 < 64; p0 += 8) {
 #pragma unroll
             for (int p = p0; p < p0 + 8; ++p) {
-                const bool sel = owner && max(d2[p], d2[p + 3]) == X[9 + p];  // over the windows that start in [p - 9, p]
-                const unsigned long long ballot = __ballot(sel);
-                if (sel) {
-                    const uint32_t at = listed + (uint32_t)__builtin_popcountll(ballot & below);
+                // selected: the maximum over the windows that start in [p - 9, p] is x(p) itself; the comparison lands in a scalar
+                // register pair, the owner mask is applied there, and the same pair predicates the two stores
+                const unsigned long long ballot = __builtin_amdgcn_ballot_w64(max(d2[p], d2[p + 3]) == X[9 + p]) & owner_mask;
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, listed));
+                if (__builtin_amdgcn_inverse_ballot_w64(ballot)) {
                     lx[at] = X[9 + p];
-                    lp[at] = (uint16_t)(64 * lane + p);
+                    lp[at] = (uint16_t)(lane64 + p);
                 }
                 listed += (uint32_t)__builtin_popcountll(ballot);
             }
