@@ -199,6 +199,72 @@ def ingest_rate(seed0: int, length: float) -> dict:
                     "outside every timed leg above"}
 
 
+def _write_fasta(job):
+    seed, length, path = job
+    from kaptive_amd.synth import make_assembly
+
+    also = (_DBS["also"],) if _DBS["also"] is not None else ()
+    data = make_assembly(_DBS["main"], seed=seed, length=length, also=also, name=Path(path).name.split(".")[0], **_WL["asm_kw"]).contigs.to_fasta()
+    Path(path).write_bytes(data)
+    return len(data)
+
+
+def cli_prepare(seed0: int, length: float, workers: int, n_files: int = 192) -> dict:
+    """FASTA files for the command-line leg, written to tmpfs before any GPU state exists (forked workers)."""
+    import tempfile
+
+    root = Path(tempfile.mkdtemp(prefix="kaptive_amd_cli_", dir="/dev/shm" if Path("/dev/shm").is_dir() else None))
+    paths = [str(root / f"cli{i:04d}.fasta") for i in range(n_files)]
+    jobs = [(seed0 + 50_000 + i, length, p) for i, p in enumerate(paths)]
+    if workers > 1:
+        pool = get_context("fork").Pool(workers)
+        try:
+            sizes = pool.map(_write_fasta, jobs, chunksize=2)
+        finally:
+            pool.close()
+            pool.join()
+    else:
+        sizes = [_write_fasta(j) for j in jobs]
+    return {"root": root, "paths": paths, "nbytes": sum(sizes), "db_path": _DBS["main"].save(root / "db.npz")}
+
+
+def cli_from_fasta(prep: dict, repeats: int = 32, batch: int = 512) -> dict:
+    """`python -m kaptive_amd assembly DB FILES... -o out.tsv` as a user runs it, in a process of its own: FASTA files on
+    tmpfs -> reader threads -> pinned shards -> the batched typing -> TSV bytes (kaptive_amd/cli.py::_TypingPipeline).
+    The distinct 5 Mbp assemblies of `prep` are listed `repeats` times (the page cache serves them, as it would a second
+    pass over a directory), so the command runs for seconds while tmpfs holds a gigabyte.  Two rates: the whole command
+    (interpreter start, database load, context creation and buffer sizing included) and the steady state between the
+    second chunk's rows and the last one's."""
+    import shutil
+    import subprocess
+
+    root, paths, n_files = prep["root"], prep["paths"], len(prep["paths"])
+    try:
+        out, timing = root / "out.tsv", root / "timing.json"
+        env = dict(os.environ, KAPTIVE_AMD_CLI_TIMING=str(timing), PYTHONPATH=str(Path(__file__).resolve().parent))
+        argv = [sys.executable, "-m", "kaptive_amd", "assembly", str(prep["db_path"]), *(paths * repeats), "-o", str(out), "--batch-size", str(batch)]
+        t = time.perf_counter()
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        tm = json.loads(timing.read_text())
+        marks = tm["rows_written_at"]
+        rows = out.read_bytes().count(b"\n") - 1
+        steady = None
+        if len(marks) >= 4:
+            (n0, t0), (n1, t1) = marks[1], marks[-1]
+            steady = (n1 - n0) / (t1 - t0)
+        return {"assemblies": n_files * repeats, "rows": rows, "distinct_files": n_files,
+                "fasta_MB_per_assembly": round(prep["nbytes"] / n_files / 1e6, 2), "batch_size": batch, "wall_s": round(wall, 2),
+                "assemblies_per_s_whole_command": round(n_files * repeats / wall, 1),
+                "assemblies_per_s_steady": None if steady is None else round(steady, 1), "first_rows_after_s": round(marks[0][1], 2),
+                "database": "K-locus only (the CLI types one database per run, as the reference's does)",
+                "note": "files on tmpfs; steady = assemblies per second between the second chunk's rows and the last chunk's"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def usable_cores() -> tuple[int, str]:
     """Cores this process may actually keep busy: the affinity mask, cut down to the cgroup's CPU quota when there is one
     (a container that sees 256 CPUs but is given 16 CPUs' worth of time runs 256 busy processes at 1/16 speed each)."""
@@ -328,6 +394,7 @@ def main() -> None:
                          "loci identical to the database, the common case in real collections)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTA files on tmpfs -> `kaptive_amd assembly` -> TSV)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="steps per end-to-end leg (back to back: the pipeline fills and drains once per leg)")
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
@@ -373,10 +440,12 @@ def main() -> None:
     t_gen = time.perf_counter()
     ids, packed = build_workload(args.assemblies, seed0, length, workers)
     t_gen = time.perf_counter() - t_gen
-    cpu = ingest = None
+    cpu = ingest = cli_prep = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(seed0, length)
         ingest = ingest_rate(seed0, length)
+    if world == 1 and rank == 0 and not args.no_e2e and not args.no_cli:
+        cli_prep = cli_prepare(seed0, length, workers)
 
     import torch
     import torch.distributed as dist
@@ -635,6 +704,8 @@ def main() -> None:
                        "with_tsv adds the KaptiveRow bytes of every assembly and database"}  # fmt: skip
         for pb in pins:
             pb.close()
+        if cli_prep is not None:
+            e2e["cli_from_fasta"] = cli_from_fasta(cli_prep)
 
     if rank == 0:
         n_total = args.assemblies * world * args.steps

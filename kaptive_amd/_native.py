@@ -117,17 +117,19 @@ def _host_inflate(data: bytes, compression) -> bytes:
     return (bz2.decompress if compression == "bz2" else lzma.decompress)(data)
 
 
-def fasta_ingest(data: bytes, gzipped: "bool | str | None" = False):
+def fasta_ingest(data: bytes, gzipped: "bool | str | None" = False, keep_text: bool = True):
     """A FASTA file's bytes -> (PackedAssembly, contig names, sequence text uint8, contig lengths int32) in one native
     pass (kp_fasta_ingest: inflate -- `gzipped` is True / "gz", "bz2" or "xz" --, split records, strip whitespace, pack;
-    no GPU needed)."""
+    no GPU needed).  ``keep_text=False`` leaves the sequence text out (empty array): a run that only writes the TSV
+    report never looks at it."""
     h = lib()
     h.kp_fasta_free.restype = None
     out = C.POINTER(PackedFasta)()
-    rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(FASTA_FLAGS[gzipped] | 2), C.byref(out))
+    text = 2 if keep_text else 0
+    rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(FASTA_FLAGS[gzipped] | text), C.byref(out))
     if rc == ENOTSUP:
         data = _host_inflate(data, gzipped)
-        rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(2), C.byref(out))
+        rc = h.kp_fasta_ingest(data, C.c_int64(len(data)), C.c_int32(text), C.byref(out))
     if rc != 0:
         raise ValueError(f"kp_fasta_ingest failed ({rc}): not a readable FASTA / gzip stream, or longer than KP_MAX_ASM_LEN")
     record = _FastaRecord(out)  # frees the native record when the arrays below are gone

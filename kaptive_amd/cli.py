@@ -3,7 +3,8 @@
 Same positionals and flags as the reference's ``kaptive type`` (alias ``assembly``) and ``kaptive convert``
 (src/kaptive/serotyping/cli.py:118-267, shared output flags src/kaptive/cli.py:424-504), minus the plot output.  What
 differs underneath: genomes are read and packed by a thread pool (``--threads`` is honoured; the reference parses and
-ignores it), typed in batches on the GPU(s) (``--devices``, ``--batch-size``), and written in input order.
+ignores it) while earlier ones are being typed, in batches, on the GPU(s) (``--devices``: one process per
+device; ``--batch-size``), and written in input order (``_TypingPipeline``).
 DATABASE is a ``.npz`` blob written by ``Database.save`` or a GenBank file with its ``.toml`` next to it.
 """
 
@@ -122,7 +123,7 @@ def build_parser() -> argparse.ArgumentParser:
     o.add_argument("-t", "--threads", type=int, default=0, metavar="", help="Threads for reading/packing genomes, 0 = all")
     o.add_argument("--partial-edge-tolerance", type=int, default=5, metavar="", help="Bases from contig edge to call a partial gene")
     o.add_argument("--devices", default="0", metavar="", help="Comma-separated GPU indices (default: 0)")
-    o.add_argument("--batch-size", type=int, default=256, metavar="", help="Assemblies per device submission (default: 256)")
+    o.add_argument("--batch-size", type=int, default=512, metavar="", help="Assemblies per device submission (default: 512)")
     o.add_argument("-V", "--verbose", action="store_true")
     t.set_defaults(func=run_type)
     v = sub.add_parser("convert", help="Convert JSON-lines results to other formats")
@@ -143,89 +144,238 @@ def load_database(path: str):
     return Database.load(p)
 
 
-def run_type(args: argparse.Namespace) -> int:
-    import os
+class _TypingPipeline:
+    """One device's share of ``kaptive assembly``: files -> reader pool -> pinned shard -> ``Engine.type_stream`` -> bytes.
 
-    from kaptive_amd.core.genome import GenomeAssembly
-    from kaptive_amd.serotyping.core import Serotyper
+    The stages run beside each other: while the GPU types chunk k, the reader threads parse and pack chunk k + 1 .. k + 2
+    (``kp_fasta_ingest`` releases the interpreter lock), their packed words are copied into page-locked memory and
+    uploaded on the copy stream, and chunk k - 1's rows are formatted.  When only the TSV report is asked for, no
+    per-assembly object is ever built: the rows come from ``BatchTyping.tsv()`` (``kp_format_rows``, byte for byte what
+    ``KaptiveRow.from_result`` gives) and the files' sequence text is not even kept.  Every other output (``-j``, ``-l``,
+    ``-g``, ``-p``, ``--pha4ge``) goes through ``SerotypingResult`` objects, as the reference's writers do
+    (src/kaptive/serotyping/cli.py:20-114)."""
 
-    db = load_database(args.database)
-    devices = [int(d) for d in str(args.devices).split(",") if d != ""]
-    typers = [
-        Serotyper(db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
-                  allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance, device=d)
-        for d in devices
-    ]  # fmt: skip
-    exporter = ResultExporter(args)
-    threads = args.threads or os.cpu_count() or 1
-    chunks = [args.genomes[i : i + args.batch_size] for i in range(0, len(args.genomes), args.batch_size)]
+    PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
 
-    def load(path):
-        g = GenomeAssembly.from_file(path)
+    def __init__(self, args: argparse.Namespace, device: int) -> None:
+        import os
+
+        from kaptive_amd.serotyping.core import Serotyper
+
+        self.args = args
+        self.db = load_database(args.database)
+        self.typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
+                               allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
+                               device=device)  # fmt: skip
+        self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
+        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins", "pha4ge"))
+        self.want_tsv = bool(getattr(args, "out", None))
+        self.threads = max(1, args.threads or (os.cpu_count() or 1))
+        self.readers = ThreadPoolExecutor(max_workers=self.threads)
+        self._pins: list = []  # recycled page-locked buffers
+
+    def close(self) -> None:
+        self.readers.shutdown(wait=True, cancel_futures=True)
+        if self.typer._engine is not None:
+            self.typer._engine.close()
+        for pb in self._pins:
+            pb.close()
+
+    # -- stage 1: files -> packed assemblies (reader threads) --------------------------------------------------------------------
+    def _load(self, path):
+        from kaptive_amd.core.genome import GenomeAssembly
+
+        g = GenomeAssembly.from_file(path, keep_text=self.objects)
         g.packed()
         return g
 
-    for t in typers:
-        _ = t.engine  # contexts are created here, on the main thread, before any worker runs
+    # -- stage 2: one chunk's packed words -> page-locked memory -> device (asynchronous upload) ---------------------------------
+    def _pinned(self, n_words: int):
+        from kaptive_amd import _native
 
-    # One worker thread per device, bound to it for the whole run: a context is only ever driven by its own thread
-    # (include/kaptive_amd.h: calls on one context are serialised).  Workers take the next chunk off a shared queue;
-    # results are written in input order.
-    import queue
-    import threading
+        for i, pb in enumerate(self._pins):
+            if len(pb.array) >= n_words:
+                return self._pins.pop(i)
+        return _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
 
-    todo: "queue.Queue" = queue.Queue()
-    for job in enumerate(chunks):
-        todo.put(job)
-    finished: dict = {}
-    cond = threading.Condition()
+    def _make_batch(self, genomes):
+        packed = [g.packed() for g in genomes]
+        sizes = [len(pa.words) for pa in packed]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        pb = self._pinned(int(offs[-1]))
 
-    def worker(typer):
-        with ThreadPoolExecutor(max_workers=max(1, threads // len(devices))) as readers:
-            while True:
-                try:
-                    k, paths = todo.get_nowait()
-                except queue.Empty:
-                    return
-                try:
-                    out = typer.type_many(list(readers.map(load, paths)))
-                except BaseException as e:  # handed to the main thread, which re-raises it in input order
-                    out = e
-                with cond:
-                    finished[k] = out
-                    cond.notify_all()
+        def copy(i):
+            pb.array[offs[i] : offs[i + 1]] = packed[i].words
 
-    workers = [threading.Thread(target=worker, args=(t,), daemon=True) for t in typers]
-    done = 0
-    try:
-        for w in workers:
-            w.start()
-        for k in range(len(chunks)):
-            with cond:
-                cond.wait_for(lambda: k in finished)
-                results = finished.pop(k)
-            if isinstance(results, BaseException):
-                raise results
-            for r in results:
-                exporter(r)
-            done += len(results)
-            if args.verbose:
-                print(f"\r{done}/{len(args.genomes)}", end="", file=sys.stderr, flush=True)
-    finally:
-        while True:  # nothing more is started after a failure
+        list(self.readers.map(copy, range(len(packed))))  # (numpy copies of this size run without the interpreter lock)
+        batch = self.engine.ctx.batch(packed, pinned_words=pb.array[: int(offs[-1])])
+        batch._pin = pb
+        return batch
+
+    def _source(self, chunks):
+        """(batch, ids, genomes) per chunk; files of the next PREFETCH chunks are already being read and their batches
+        created (uploads enqueued) when a chunk is handed on."""
+        from collections import deque
+
+        reading: deque = deque()
+        ready: deque = deque()
+        it = iter(chunks)
+
+        def start_read():
             try:
-                todo.get_nowait()
-            except queue.Empty:
-                break
-        for w in workers:
-            if w.is_alive() or w.ident is not None:
-                w.join()
-        exporter.close()
-        for t in typers:
-            if t._engine is not None:
-                t._engine.close()
+                k, paths = next(it)
+            except StopIteration:
+                return False
+            reading.append((k, [self.readers.submit(self._load, p) for p in paths]))
+            return True
+
+        for _ in range(self.PREFETCH + 1):
+            start_read()
+        while reading or ready:
+            while reading and len(ready) < self.PREFETCH:
+                k, futures = reading.popleft()
+                genomes = [f.result() for f in futures]
+                start_read()
+                ready.append((self._make_batch(genomes), k, genomes))
+            batch, k, genomes = ready.popleft()
+            self._order.append(k)
+            yield batch, [g.id for g in genomes], genomes if self.objects else None
+
+    # -- stage 3: records -> bytes ------------------------------------------------------------------------------------------------
+    def run(self, chunks):
+        """Yields ``(k, outputs)`` for every ``(k, paths)`` of ``chunks``, in order; ``outputs`` maps "tsv" / "pha4ge" /
+        "json" to the bytes this chunk adds to that stream (per-assembly fasta files are written here)."""
+        from kaptive_amd.serotyping.io import Pha4geRow
+
+        args = self.args
+        self._order: list = []
+        done = 0
+        for bt, batch in self.engine.type_stream(self.typer, self._source(chunks)):
+            out = {}
+            if self.want_tsv:
+                out["tsv"] = bt.tsv()
+            if self.objects:
+                results = bt.results()
+                if getattr(args, "pha4ge", None):
+                    out["pha4ge"] = b"".join(bytes(Pha4geRow.from_result(r)) for r in results)
+                if getattr(args, "json", None):
+                    out["json"] = b"".join(result_to_json(r) for r in results)
+                for flag, attr, ext in (("loci", "locus_seqs", "fna"), ("genes", "gene_seqs", "ffn"), ("proteins", "translations", "faa")):
+                    if d := getattr(args, flag, None):
+                        d = Path(d)
+                        d.mkdir(parents=True, exist_ok=True)
+                        for r in results:
+                            (d / f"{r.genome}_{FILE_SUFFIX}.{ext}").write_bytes(getattr(r, attr).to_fasta())
+            pb = batch._pin
+            batch.close()  # (waits for whatever of the batch is still in flight: the pinned words are free after it)
+            self._pins.append(pb)
+            yield self._order[done], out
+            done += 1
+
+
+def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) -> None:
+    """One process per device (``--devices a,b,...``): types its chunks and sends ``(k, outputs)`` up the pipe; an
+    exception travels the same way and ends the worker."""
+    import kaptive_amd
+
+    kaptive_amd.tune_runtime()
+    pipe = None
+    try:
+        pipe = _TypingPipeline(args, device)
+        for k, out in pipe.run(chunks):
+            conn.send((k, out))
+        conn.send(None)
+    except BaseException as e:  # noqa: BLE001 - handed to the parent, which re-raises it
+        conn.send(e)
+    finally:
+        if pipe is not None:
+            pipe.close()
+        conn.close()
+
+
+def run_type(args: argparse.Namespace) -> int:
+    devices = [int(d) for d in str(args.devices).split(",") if d != ""] or [0]
+    chunks = [(k, args.genomes[i : i + args.batch_size]) for k, i in enumerate(range(0, len(args.genomes), args.batch_size))]
+    for p in args.genomes:  # the reference fails before it types anything (src/kaptive/cli.py:287-289)
+        if not Path(p).is_file():
+            raise FileNotFoundError(f"{p} does not exist")
+    from kaptive_amd.serotyping.io import KaptiveRow, Pha4geRow
+
+    handles = {}
+
+    def stream(path):
+        return sys.stdout.buffer if str(path) in ("-", "stdout") else open(path, "wb")
+
+    if tsv := getattr(args, "out", None):
+        handles["tsv"] = stream(tsv)
+        handles["tsv"].write(KaptiveRow.header())
+    if p := getattr(args, "pha4ge", None):
+        handles["pha4ge"] = stream(p)
+        handles["pha4ge"].write(Pha4geRow.header())
+    if j := getattr(args, "json", None):
+        handles["json"] = stream(j)
+    done = 0
+    import os
+    import time
+
+    timing_path = os.environ.get("KAPTIVE_AMD_CLI_TIMING")  # bench.py: when each chunk's rows were written
+    t_start, chunk_times = time.perf_counter(), []
+
+    def write(out, n):
+        nonlocal done
+        for key, blob in out.items():
+            handles[key].write(blob)
+        done += n
+        chunk_times.append((done, time.perf_counter() - t_start))
+        if args.verbose:
+            print(f"\r{done}/{len(args.genomes)}", end="", file=sys.stderr, flush=True)
+
+    try:
+        if len(devices) == 1:
+            pipe = _TypingPipeline(args, devices[0])
+            try:
+                for k, out in pipe.run(chunks):
+                    write(out, len(chunks[k][1]))
+            finally:
+                pipe.close()
+        else:
+            # chunk k goes to device k mod n; rows come back through pipes and are written in input order
+            import multiprocessing as mp
+
+            ctx = mp.get_context("spawn")
+            conns, procs = [], []
+            for i, d in enumerate(devices):
+                parent, child = ctx.Pipe(duplex=False)
+                proc = ctx.Process(target=_device_worker, args=(args, d, chunks[i :: len(devices)], child), daemon=True)
+                proc.start()
+                child.close()
+                conns.append(parent)
+                procs.append(proc)
+            try:
+                for k in range(len(chunks)):
+                    msg = conns[k % len(devices)].recv()
+                    if isinstance(msg, BaseException):
+                        raise msg
+                    if msg is None or msg[0] != k:
+                        raise RuntimeError(f"device worker {devices[k % len(devices)]} ended early or out of order")
+                    write(msg[1], len(chunks[k][1]))
+            finally:
+                for proc in procs:
+                    proc.join(timeout=30)
+                    if proc.is_alive():
+                        proc.terminate()
+    finally:
+        for h in handles.values():
+            if h is not sys.stdout.buffer:
+                h.close()
+            else:
+                h.flush()
     if args.verbose:
         print(file=sys.stderr)
+    if timing_path:
+        Path(timing_path).write_text(json.dumps({"assemblies": len(args.genomes), "seconds": time.perf_counter() - t_start,
+                                                 "batch_size": args.batch_size, "devices": devices,
+                                                 "rows_written_at": chunk_times}) + "\n")  # fmt: skip
     return 0
 
 

@@ -119,7 +119,7 @@ class GenomeAssembly:
         return cls.from_stream(genome)
 
     @classmethod
-    def from_file(cls, filepath: str | Path) -> "GenomeAssembly":
+    def from_file(cls, filepath: str | Path, keep_text: bool = True) -> "GenomeAssembly":
         filepath = Path(filepath)
         m = _FASTA_NAME.search(filepath.name)
         if not m:
@@ -129,7 +129,9 @@ class GenomeAssembly:
         from kaptive_amd import _native
 
         comp = m.group("compression")  # None, "gz", "bz2" or "xz": all inflated natively (zlib; libbz2 / liblzma of the host)
-        return cls._from_ingest(filepath.name.removesuffix(m.group()), _native.fasta_ingest(filepath.read_bytes(), gzipped=comp))
+        # (keep_text=False: contig names, lengths and the packed form only -- enough for typing and the TSV report)
+        return cls._from_ingest(filepath.name.removesuffix(m.group()),
+                                _native.fasta_ingest(filepath.read_bytes(), gzipped=comp, keep_text=keep_text))
 
     @classmethod
     def _from_ingest(cls, id_: str, ingested) -> "GenomeAssembly":

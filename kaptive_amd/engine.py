@@ -168,6 +168,53 @@ class Engine:
             collect(pending)
         return out
 
+    def type_stream(self, typer, source):
+        """``type_batches`` for a stream whose length is not known in advance (the CLI: batches are made while files are
+        still being read).  ``source`` yields ``(batch, ids, genomes_or_None)``; what comes out, in the same order, is
+        ``(BatchTyping, batch)`` -- the caller closes the batch.  Same sliding window: at most ``_native.WORK_SLOTS``
+        batches are between "alignment enqueued" and "records collected", the next batch is only pulled from ``source``
+        (created and uploaded) when a work set is free for it, and batch i's records are collected after batch i + 1's
+        reduction has been enqueued."""
+        from collections import deque
+
+        from kaptive_amd.serotyping import batch as B
+
+        depth = _native.WORK_SLOTS
+        it = iter(source)
+        live: deque = deque()  # aligned, not yet scored
+        pending = None  # reduction enqueued, records not yet collected
+        exhausted = False
+
+        def fill() -> None:
+            nonlocal exhausted
+            while not exhausted and len(live) + (1 if pending is not None else 0) < depth:
+                try:
+                    item = next(it)
+                except StopIteration:
+                    exhausted = True
+                    return
+                item[0].align_async()
+                live.append(item)
+
+        def collect(item):
+            batch, ids, genomes, scores, best = item
+            sums, kept, pieces = batch.typing(self.group)
+            return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes), batch
+
+        fill()
+        while live:
+            batch, ids, genomes = live.popleft()
+            scores, counts = batch.score(typer.min_gene_coverage, self.group)
+            best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
+            batch.reduce_async(best, self.typing_params(typer), self.group)
+            if pending is not None:
+                done, pending = pending, None
+                yield collect(done)
+            pending = (batch, ids, genomes, scores, best)
+            fill()
+        if pending is not None:
+            yield collect(pending)
+
     def reduce_batches(self, typer, batches: Sequence, aligned: bool = False) -> list:
         """Scores back, best loci chosen (numpy), reductions enqueued, for up to WORK_SLOTS batches at once.  Returns what
         ``collect_batches`` needs; callers driving several databases put the other database's host work in between

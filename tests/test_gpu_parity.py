@@ -682,6 +682,38 @@ def test_cli_types_fasta_files_like_the_reference(tmp_path):
     assert main(["assembly", str(tmp_path / "missing.npz"), paths[0], "-o", str(out)]) == 1
 
 
+def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_path):
+    """`kaptive assembly -o` alone streams `BatchTyping.tsv()` (no per-assembly objects, no sequence text kept); with any
+    other output the rows come from SerotypingResult objects.  Both must give the same bytes; so must two device
+    processes (`--devices 0,0`: two contexts on the one GPU of the box, chunks dealt round-robin, rows gathered in input
+    order) and a batch size that leaves a ragged last chunk."""
+    from kaptive_amd.cli import main
+
+    db = make_db("kpsc_k", seed=7, n_loci=9)
+    db_path = db.save(tmp_path / "db.npz")
+    paths = []
+    for i in range(11):
+        g = make_assembly(db, seed=900 + i, name=f"asm{i:02d}", length=60_000 + 3_000 * i, median_contigs=3 + i % 4,
+                          n_run=10 * (i % 3), locus=-1 if i == 4 else None)
+        p = tmp_path / f"asm{i:02d}.fasta{'.gz' if i % 5 == 0 else ''}"
+        data = g.contigs.to_fasta()
+        if i % 5 == 0:
+            import gzip
+
+            data = gzip.compress(data)
+        p.write_bytes(data)
+        paths.append(str(p))
+    fast, slow, two = tmp_path / "fast.tsv", tmp_path / "slow.tsv", tmp_path / "two.tsv"
+    assert main(["assembly", str(db_path), *paths, "-o", str(fast), "--batch-size", "4", "-t", "3"]) == 0
+    assert main(["assembly", str(db_path), *paths, "-o", str(slow), "-j", str(tmp_path / "r.jsonl"), "--batch-size", "3"]) == 0
+    assert main(["assembly", str(db_path), *paths, "-o", str(two), "--batch-size", "2", "--devices", "0,0", "-t", "2"]) == 0
+    rows = fast.read_bytes().splitlines(keepends=True)
+    assert len(rows) == 1 + len(paths) and [r.split(b"\t")[3] for r in rows[1:]] == [f"asm{i:02d}".encode() for i in range(11)]
+    assert fast.read_bytes() == slow.read_bytes() == two.read_bytes()
+    assert len((tmp_path / "r.jsonl").read_bytes().splitlines()) == len(paths)
+    assert main(["assembly", str(db_path), paths[0], str(tmp_path / "nope.fasta"), "-o", str(fast)]) == 1
+
+
 # ---- BASELINE.json configs at their real shape --------------------------------------------------------------------------
 def _oracle_typer(db, oracle):
     """Host reduction (the golden-pinned statement) fed by the oracle's aligner and protein DP: the expected rows."""
