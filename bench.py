@@ -394,6 +394,9 @@ def main() -> None:
                          "loci identical to the database, the common case in real collections)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
+    ap.add_argument("--upload-ahead", type=int, default=2,
+                    help="end-to-end legs: uploads enqueued this many shards beyond the alignment passes in flight (the copy "
+                         "engine must never wait for the driving thread, which spends most of its time waiting for results)")
     ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTA files on tmpfs -> `kaptive_amd assembly` -> TSV)")
     ap.add_argument("--e2e-steps", type=int, default=3, help="steps per end-to-end leg (back to back: the pipeline fills and drains once per leg)")
     ap.add_argument("--workers", type=int, default=0, help="processes for workload generation (0 = auto, 1 = inline)")
@@ -660,10 +663,10 @@ def main() -> None:
 
             total = n_batches * args.e2e_steps  # the leg is one stream of shards: step s re-sends shard i as number s * n + i
 
-            def get(i):  # uploads run two shards ahead of the alignment pass that reads them: a pass enqueued behind an
-                # upload that is still running holds up whatever shares its hardware queue
+            def get(i):  # uploads run --upload-ahead shards ahead of the alignment passes: the copy engine's queue is never
+                # empty while the driving thread waits for scores and records (profiles/r4_h2d_timeline.md)
                 t_c = time.perf_counter()
-                for j in range(i, i + args.ahead + 2):
+                for j in range(i, i + args.ahead + args.upload_ahead):
                     if j < total and j not in ahead:
                         ahead[j] = make_batches(j % n_batches, pins[j % n_batches].array)
                 host_create[0] += time.perf_counter() - t_c

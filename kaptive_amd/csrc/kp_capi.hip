@@ -133,6 +133,8 @@ struct KpOptions {
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
     int no_lds_filter = 0;       // tests compare the two filter tiers
     int library_sort = 0;        // anchors through kp_anchor_compact + rocPRIM's segmented radix sort instead of kp_bsort.hip
+    uint32_t upload_piece_mb = 4096;  // H2D copies of a batch's words are enqueued in pieces of this size (batch_make)
+    int readback_copy_engine = 0;   // results read back with hipMemcpyAsync instead of the read-back kernel (see Fetch)
 };
 
 // Page-locked host memory the library holds (kp_host_alloc and the batches' table staging), for kp_host_pinned_bytes.
@@ -235,10 +237,12 @@ struct KpWork {
     }
 };
 
-#define KP_INPUT_POOL 6
+#define KP_INPUT_POOL 16  /* recycled device copies of batch inputs: uploads run several shards ahead of the passes that read them */
 
 struct kp_ctx {
     int device = 0;
+    uint8_t *bounce = nullptr;     // page-locked landing area of result read-backs (Fetch)
+    size_t bounce_bytes = 0;
     int gs_bits = 18;              // bits of the gene/strand field of an anchor key this database can set
     int max_gene_len = 0;
     hipStream_t stream = nullptr;  // database uploads, stand-alone protein alignments (alignment passes: KpWork::astream)
@@ -341,6 +345,8 @@ void options_from_env(KpOptions &o) {
     o.scan_mode = (int)env_u32("KAPTIVE_AMD_SCAN_ABLATE", 0);
     o.no_lds_filter = (int)env_u32("KAPTIVE_AMD_NO_LDS_FILTER", 0);
     o.library_sort = (int)env_u32("KAPTIVE_AMD_LIBRARY_SORT", 0);
+    o.upload_piece_mb = std::max<uint32_t>(1, env_u32("KAPTIVE_AMD_UPLOAD_PIECE_MB", 4096));
+    { const char *rb = getenv("KAPTIVE_AMD_READBACK"); o.readback_copy_engine = rb && std::string(rb) == "copy"; }
 }
 
 // BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
@@ -380,6 +386,50 @@ void fill_blosum(int8_t *m) {
 }
 
 struct HostPosting { uint32_t key, gene, pos, z; };  // a gene seed: x, gene, first base on the forward strand, strand bit
+
+// Results come back to the host through the shader, not through a copy engine: kernels of the stream write them into a
+// page-locked landing area, the host waits for the stream and copies them out.  A read-back handed to the copy engines
+// (hipMemcpyAsync) queued up behind the shard that was being uploaded -- 1.25 GB, 22 ms -- so that every kp_batch_score
+// of a host-fed stream returned only when the upload in flight had landed (tools/experiments/h2d_interference.py: 20 ms
+// per batch alone, 140 ms beside a continuous upload; profiles/r4_h2d_timeline.md).  KAPTIVE_AMD_READBACK=copy restores
+// the copy-engine path for comparison.
+struct Fetch {
+    kp_ctx *ctx;
+    hipStream_t stream;
+    struct Item { void *dst; size_t off, bytes; };
+    std::vector<Item> items;
+    size_t used = 0;
+    bool by_copy_engine;
+    Fetch(kp_ctx *c, hipStream_t s) : ctx(c), stream(s), by_copy_engine(c->opt.readback_copy_engine != 0) {}
+    // total bytes of everything that will be added before finish()
+    int begin(size_t total) {
+        if (by_copy_engine) return KP_OK;
+        total += 64 * 8;
+        if (total > ctx->bounce_bytes) {
+            if (ctx->bounce) pinned_free(ctx->bounce);
+            ctx->bounce = nullptr; ctx->bounce_bytes = 0;
+            const size_t want = total + total / 4 + (1u << 20);
+            KP_HIP_CHECK(ctx, pinned_alloc((void **)&ctx->bounce, want));
+            ctx->bounce_bytes = want;
+        }
+        return KP_OK;
+    }
+    int add(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return KP_OK;
+        if (by_copy_engine || (bytes & 3u)) { KP_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); return KP_OK; }
+        if (used + bytes > ctx->bounce_bytes) return kp_fail(ctx, KP_ESTATE, "read-back larger than announced");
+        kp_launch_read_back(src, ctx->bounce + used, bytes, stream);
+        items.push_back(Item{dst, used, bytes});
+        used = (used + bytes + 63) & ~(size_t)63;
+        return KP_OK;
+    }
+    int finish() {
+        KP_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+        for (const Item &it : items) std::memcpy(it.dst, ctx->bounce + it.off, it.bytes);
+        items.clear(); used = 0;
+        return KP_OK;
+    }
+};
 
 template <class T>
 int upload(kp_ctx *ctx, DevBuf<T> &buf, const T *src, size_t n, hipStream_t stream = nullptr) {
@@ -506,7 +556,11 @@ int batch_make(kp_ctx *ctx, int32_t n_asm, const uint32_t *words, bool words_on_
         const size_t nw = (size_t)asm_word_off[n_asm];
         hipError_t e = b->in->d_words.reserve(std::max<size_t>(nw, 4));
         if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_ENOMEM, std::string("hipMalloc(words): ") + hipGetErrorString(e)); }
-        if (nw) e = hipMemcpyAsync(b->in->d_words.p, words, nw * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy);
+        // (optionally in pieces -- `upload_piece_mb` --: tried so that result read-backs could slip in between them on the
+        // copy engines; they did not, see Fetch)
+        const size_t piece = (size_t)ctx->opt.upload_piece_mb << 18;  // words
+        for (size_t at = 0; at < nw && e == hipSuccess; at += piece)
+            e = hipMemcpyAsync(b->in->d_words.p + at, words + at, std::min(piece, nw - at) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy);
         if (e != hipSuccess) { kp_batch_destroy(b); return kp_fail(ctx, KP_EHIP, std::string("H2D words: ") + hipGetErrorString(e)); }
         b->d_words = b->in->d_words.p;
     }
@@ -575,6 +629,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     for (KpInput *in : ctx->free_inputs) { in->release(); delete in; }
     ctx->free_inputs.clear();
     for (auto &w : ctx->work) w.release();
+    if (ctx->bounce) { pinned_free(ctx->bounce); ctx->bounce = nullptr; ctx->bounce_bytes = 0; }
     ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release(); ctx->d_gene_prof.release(); ctx->d_gene_has_n.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_ln.release();
@@ -620,6 +675,7 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
     else if (n == "scan_mode") o.scan_mode = (int)value;
     else if (n == "no_lds_filter") o.no_lds_filter = value != 0;
     else if (n == "library_sort") o.library_sort = value != 0;
+    else if (n == "upload_piece_mb") o.upload_piece_mb = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else return kp_fail(ctx, KP_EINVAL, "unknown option: " + n);
     return KP_OK;
 }
@@ -955,10 +1011,13 @@ static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         KP_HIP_CHECK(ctx, hipGetLastError());
         w->h_hit_counts.resize(2 * n_asm);
         unsigned long long cells = 0;
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_hit_counts.data(), w->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t),
-                                         hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&cells, w->d_cells.p, sizeof cells, hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+        {
+            Fetch f(ctx, ctx->post);
+            int frc;
+            if ((frc = f.begin(2 * n_asm * sizeof(uint32_t) + sizeof cells)) || (frc = f.add(w->h_hit_counts.data(), w->d_hit_counts.p, 2 * n_asm * sizeof(uint32_t))) ||
+                (frc = f.add(&cells, w->d_cells.p, sizeof cells)) || (frc = f.finish()))
+                return frc;
+        }
         uint32_t max_raw = 0;
         for (size_t a = 0; a < n_asm; ++a) max_raw = std::max(max_raw, w->h_hit_counts[a]);
         if (max_raw <= w->hit_cap) { w->stats[2] = (int64_t)cells; break; }
@@ -983,12 +1042,16 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         // the post stream picks up where this batch's alignment pass ends; later passes on ctx->stream are not waited for
         KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->post, w->ev[3 + KP_N_CLASSES], 0));
         w->h_counts.resize(2 * n_asm + KP_N_CLASSES);
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t),
-                                         hipMemcpyDeviceToHost, ctx->post));
         unsigned long long n_cand2[2] = {0, 0}, trace_need = 0;
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(n_cand2, w->d_cand_count.p, sizeof n_cand2, hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(&trace_need, w->d_trace_top.p, sizeof trace_need, hipMemcpyDeviceToHost, ctx->post));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+        {
+            Fetch f(ctx, ctx->post);
+            int frc;
+            if ((frc = f.begin((2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t) + sizeof n_cand2 + sizeof trace_need)) ||
+                (frc = f.add(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t))) ||
+                (frc = f.add(n_cand2, w->d_cand_count.p, sizeof n_cand2)) || (frc = f.add(&trace_need, w->d_trace_top.p, sizeof trace_need)) ||
+                (frc = f.finish()))
+                return frc;
+        }
         const unsigned long long n_cand = n_cand2[0] + n_cand2[1];
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
@@ -1297,11 +1360,13 @@ int kp_batch_score(kp_ctx *ctx, kp_batch *b, double min_gene_coverage, double *l
     kp_launch_score(b->view, R.hits, R.hit_n, w->hit_cap, T.typing, min_gene_coverage,
                     R.d_scores.p, R.d_lcounts.p, R.stream);
     KP_HIP_CHECK(ctx, hipGetLastError());
-    if (n) {
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_scores, R.d_scores.p, n * sizeof(double), hipMemcpyDeviceToHost, R.stream));
-        KP_HIP_CHECK(ctx, hipMemcpyAsync(locus_counts, R.d_lcounts.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, R.stream));
+    {
+        Fetch f(ctx, R.stream);
+        int frc;
+        if ((frc = f.begin(n * (sizeof(double) + sizeof(int32_t)))) || (frc = f.add(locus_scores, R.d_scores.p, n * sizeof(double))) ||
+            (frc = f.add(locus_counts, R.d_lcounts.p, n * sizeof(int32_t))) || (frc = f.finish()))
+            return frc;
     }
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
     R.prm.min_gene_coverage = min_gene_coverage;
     R.scored = true;
     return KP_OK;
@@ -1358,7 +1423,19 @@ int kp_batch_reduce(kp_ctx *ctx, kp_batch *b, const int32_t *best_locus, const k
     for (int a = 0; a < b->n_asm; ++a)
         if (best_locus[a] < 0 || best_locus[a] >= Tp->typing.n_loci) return kp_fail(ctx, KP_EINVAL, "best_locus out of range");
     R.prm = *prm;
-    int rc = upload(ctx, R.d_best, best_locus, (size_t)b->n_asm, R.stream);
+    int rc;
+    if (ctx->opt.readback_copy_engine) {
+        rc = upload(ctx, R.d_best, best_locus, (size_t)b->n_asm, R.stream);
+    } else {  // through the landing area and a kernel, like the read-backs: a copy-engine upload queues behind the shard in flight
+        Fetch f(ctx, R.stream);
+        const size_t bytes = (size_t)b->n_asm * sizeof(int32_t);
+        if ((rc = f.begin(bytes))) return rc;
+        KP_HIP_CHECK(ctx, R.d_best.reserve((size_t)b->n_asm));
+        if (bytes) {
+            std::memcpy(ctx->bounce, best_locus, bytes);
+            kp_launch_read_back(ctx->bounce, R.d_best.p, bytes, R.stream);
+        }
+    }
     if (rc == KP_OK && hipStreamSynchronize(R.stream) != hipSuccess) rc = kp_fail(ctx, KP_EHIP, "H2D best loci failed");
     if (rc) return rc;
     rc = enqueue_reduce(ctx, b, w);
@@ -1375,10 +1452,13 @@ static int fetch_summaries(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     const size_t n_asm = (size_t)b->n_asm;
     R.h_sums.resize(n_asm);
     for (int attempt = 0;; ++attempt) {
-        if (n_asm)
-            KP_HIP_CHECK(ctx, hipMemcpyAsync(R.h_sums.data(), R.d_summary.p, n_asm * sizeof(KpAsmSummary),
-                                             hipMemcpyDeviceToHost, R.stream));
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
+        {
+            Fetch f(ctx, R.stream);
+            int frc;
+            if ((frc = f.begin(n_asm * sizeof(KpAsmSummary))) || (frc = f.add(R.h_sums.data(), R.d_summary.p, n_asm * sizeof(KpAsmSummary))) ||
+                (frc = f.finish()))
+                return frc;
+        }
         int flags = 0;
         for (const auto &s : R.h_sums) flags |= s.overflow;
         if (flags & 4) return kp_fail(ctx, KP_EINVAL, "a locus has more genes than KP_MAX_LOCUS_GENES");
@@ -1447,10 +1527,12 @@ int kp_batch_typing(kp_ctx *ctx, kp_batch *b, kp_asm_summary *summaries, kp_kept
                         (size_t)kept_stride * sizeof(KpKept) / 4, kw, (int)n_asm, R.stream);
     kp_launch_pack_rows(reinterpret_cast<const uint32_t *>(R.d_pieces.p), (size_t)R.piece_cap * sizeof(KpPiece) / 4, pp,
                         (size_t)piece_stride * sizeof(KpPiece) / 4, pw, (int)n_asm, R.stream);
-    KP_HIP_CHECK(ctx, hipMemcpyAsync(kept, pk, n_asm * (size_t)kept_stride * sizeof(KpKept), hipMemcpyDeviceToHost, R.stream));
-    KP_HIP_CHECK(ctx, hipMemcpyAsync(pieces, pp, n_asm * (size_t)piece_stride * sizeof(KpPiece), hipMemcpyDeviceToHost,
-                                     R.stream));
-    KP_HIP_CHECK(ctx, hipStreamSynchronize(R.stream));
+    {
+        Fetch f(ctx, R.stream);
+        int frc;
+        const size_t kb = n_asm * (size_t)kept_stride * sizeof(KpKept), pb = n_asm * (size_t)piece_stride * sizeof(KpPiece);
+        if ((frc = f.begin(kb + pb)) || (frc = f.add(kept, pk, kb)) || (frc = f.add(pieces, pp, pb)) || (frc = f.finish())) return frc;
+    }
     // identity sums use numpy's float32 association; a few dozen adds per assembly, done here on the copied rows
     std::vector<float> vals;
     for (size_t a = 0; a < n_asm; ++a) {

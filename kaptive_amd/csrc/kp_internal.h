@@ -213,6 +213,8 @@ void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint
 // indices relative to gene_lo; out_n[a] = how many
 void kp_launch_hit_split(const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap, int32_t gene_lo, int32_t gene_hi,
                          kp_hit *out, uint32_t *out_n, int32_t n_asm, hipStream_t stream);
+// kp_reduce.hip: `bytes` (a multiple of 4) of device memory into page-locked host memory, written by a kernel
+void kp_launch_read_back(const void *src, void *dst_pinned, size_t bytes, hipStream_t stream);
 void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, size_t dst_pitch, size_t width, int rows,
                          hipStream_t stream);  // kp_reduce.hip: row-wise copy between pitched word matrices
 #define KP_PROT_ROWBUF_FIELDS 8  // ints per column of the strip kernel's row buffer (scratch: fields x (longest target + 1))

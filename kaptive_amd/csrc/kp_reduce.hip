@@ -7,6 +7,8 @@
 // this file decides who runs what: one 64-lane wave per assembly, lanes in parallel over hits for the quadratic parts
 // (rank sorts) and over the kept list / codons for the rest, lane 0 for the short sequential tails.  Assemblies are
 // independent, so a batch of N assemblies keeps N waves busy; no step needs more than one wave's worth of LDS.
+#include <algorithm>
+
 #include "kp_internal.h"
 #include "kp_reduce_core.h"
 
@@ -469,7 +471,20 @@ __global__ __launch_bounds__(256) void kp_pack_rows_kernel(const uint32_t *__res
     for (size_t i = threadIdx.x; i < dst_pitch; i += blockDim.x) d[i] = i < width ? s[i] : 0u;
 }
 
+// device memory -> page-locked host memory by the shader instead of a copy engine (kp_capi.hip: Fetch)
+__global__ __launch_bounds__(256) void kp_read_back_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
+
+void kp_launch_read_back(const void *src, void *dst_pinned, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;  // (callers read whole 32-bit words)
+    if (n == 0) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 512);
+    hipLaunchKernelGGL(kp_read_back_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(src),
+                       reinterpret_cast<uint32_t *>(dst_pinned), n);
+}
 
 void kp_launch_hit_split(const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap, int32_t gene_lo, int32_t gene_hi,
                          kp_hit *out, uint32_t *out_n, int32_t n_asm, hipStream_t stream) {
