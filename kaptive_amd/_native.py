@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import os
 import threading
 import weakref
 from pathlib import Path
@@ -313,6 +314,11 @@ def lib() -> C.CDLL:
                         f"{LIB_PATH} is missing: build it with `python -m kaptive_amd.build` (hipcc, gfx950). "
                         "kaptive_amd has no CPU fallback."
                     )
+                # The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises, i.e. when the library below pulls it in: a
+                # context drives a dozen streams and the default of 4 hardware queues costs a host-fed stream a fifth of
+                # its throughput (kaptive_amd.tune_runtime).  Library users who never call an entry point get it here;
+                # an explicit setting in the environment wins.
+                os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
                 h = C.CDLL(str(LIB_PATH))
                 h.kp_last_error.restype = C.c_char_p
                 h.kp_ctx_stream.restype = C.c_void_p

@@ -135,6 +135,7 @@ struct KpOptions {
     int library_sort = 0;        // anchors through kp_anchor_compact + rocPRIM's segmented radix sort instead of kp_bsort.hip
     uint32_t upload_piece_mb = 4096;  // H2D copies of a batch's words are enqueued in pieces of this size (batch_make)
     int readback_copy_engine = 0;   // results read back with hipMemcpyAsync instead of the read-back kernel (see Fetch)
+    int spin_wait = 0;              // host waits spin on the stream (the runtime's default) instead of blocking on an interrupt
 };
 
 // Page-locked host memory the library holds (kp_host_alloc and the batches' table staging), for kp_host_pinned_bytes.
@@ -347,6 +348,7 @@ void options_from_env(KpOptions &o) {
     o.library_sort = (int)env_u32("KAPTIVE_AMD_LIBRARY_SORT", 0);
     o.upload_piece_mb = std::max<uint32_t>(1, env_u32("KAPTIVE_AMD_UPLOAD_PIECE_MB", 4096));
     { const char *rb = getenv("KAPTIVE_AMD_READBACK"); o.readback_copy_engine = rb && std::string(rb) == "copy"; }
+    o.spin_wait = (int)env_u32("KAPTIVE_AMD_SPIN_WAIT", 0);
 }
 
 // BLOSUM62 as the reference lays it out: 256x256 bytes, -128 outside ARNDCQEGHILKMFPSTWYVBJZX*
@@ -594,7 +596,11 @@ int kp_ctx_create(int device_id, kp_ctx **out) {
     if (!ctx) return kp_fail(nullptr, KP_ENOMEM, "out of host memory");
     ctx->device = device_id;
     options_from_env(ctx->opt);
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+    // The driving thread spends most of its time waiting for the device (scores, records): blocked on an interrupt it
+    // leaves its core to the readers that feed the next shard (eight ranks and their ingest share one host); the
+    // runtime's default spins.  (A device-wide flag: it has to be set before the device's streams exist.)
+    if ((e = hipSetDevice(device_id)) == hipSuccess && !ctx->opt.spin_wait) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    if (e != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking)) != hipSuccess ||
         (e = create_priority_stream(&ctx->post)) != hipSuccess || (e = create_priority_stream(&ctx->aux)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
