@@ -46,37 +46,55 @@ __constant__ uint8_t c_chain_pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
 
 // minimap2's chaining of a small cluster (kp_spec.h), by one lane: keys[0..n) are the cluster's anchors (compact keys,
 // sorted by diagonal then query position), n <= KP_CHAIN_DP_MAX.  Returns the chain's score, *cnt = its anchor count.
-__device__ int chain_small(const uint64_t *__restrict__ keys, int n, KpKeyBits kb, int *cnt) {
-    int32_t t[KP_CHAIN_DP_MAX], q[KP_CHAIN_DP_MAX];
-    int16_t f[KP_CHAIN_DP_MAX];
-    int8_t p[KP_CHAIN_DP_MAX];
-    for (int i = 0; i < n; ++i) {  // insertion sort by (target, query)
+// The lane's working arrays live in LDS, slot-major (`at(i)` = slot i of this lane: consecutive lanes hit consecutive
+// banks): with private arrays every dynamically indexed access was a trip through scratch memory (1.44 ms per 1000
+// assemblies for what is a few dozen operations per cluster).
+constexpr int CS_THREADS = 64;
+struct ChainScratch {
+    int32_t t[KP_CHAIN_DP_MAX][CS_THREADS], q[KP_CHAIN_DP_MAX][CS_THREADS];
+    int16_t f[KP_CHAIN_DP_MAX][CS_THREADS];
+    int8_t p[KP_CHAIN_DP_MAX][CS_THREADS];
+};
+
+__device__ __forceinline__ int chain_small(const uint64_t *__restrict__ keys, int n, KpKeyBits kb, ChainScratch &cs, int me, int *cnt) {
+    for (int i = 0; i < n; ++i) {  // (independent loads: all of the cluster's keys are in flight together)
         const uint64_t key = keys[i];
-        const int32_t qi = (int32_t)kp_ckey_qpos(key, kb), ti = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + qi;
-        int j = i;
-        while (j > 0 && (t[j - 1] > ti || (t[j - 1] == ti && q[j - 1] > qi))) { t[j] = t[j - 1]; q[j] = q[j - 1]; --j; }
-        t[j] = ti; q[j] = qi;
+        const int32_t qi = (int32_t)kp_ckey_qpos(key, kb);
+        cs.q[i][me] = qi;
+        cs.t[i][me] = (int32_t)kp_ckey_diag(key, kb) - KP_DIAG_BIAS + qi;
     }
-    int best = 0;
+    for (int i = 1; i < n; ++i) {  // insertion sort by (target, query); a cluster on one diagonal arrives sorted
+        const int32_t ti = cs.t[i][me], qi = cs.q[i][me];
+        int j = i;
+        while (j > 0) {
+            const int32_t tp = cs.t[j - 1][me], qp = cs.q[j - 1][me];
+            if (!(tp > ti || (tp == ti && qp > qi))) break;
+            cs.t[j][me] = tp; cs.q[j][me] = qp;
+            --j;
+        }
+        if (j != i) { cs.t[j][me] = ti; cs.q[j][me] = qi; }
+    }
+    int best = 0, f_best = 0;
     for (int i = 0; i < n; ++i) {
+        const int32_t ti = cs.t[i][me], qi = cs.q[i][me];
         int max_f = KP_K, max_j = -1;
         for (int j = i - 1; j >= 0; --j) {
-            const int dq = q[i] - q[j], dr = t[i] - t[j];
+            const int dq = qi - cs.q[j][me], dr = ti - cs.t[j][me];
             if (dq <= 0 || dq > KP_CHAIN_MAX_DIST || dr == 0) continue;
             const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
             int sc = dg < KP_K ? dg : KP_K;
             if (dd || dg > KP_K) sc -= c_chain_pen[dd < KP_CHAIN_PEN_SIZE ? dd : KP_CHAIN_PEN_SIZE - 1];
-            sc += f[j];
+            sc += cs.f[j][me];
             if (sc > max_f) { max_f = sc; max_j = j; }
         }
-        f[i] = (int16_t)max_f; p[i] = (int8_t)max_j;
-        if (f[i] >= f[best]) best = i;  // the largest f, the later anchor on ties
+        cs.f[i][me] = (int16_t)max_f; cs.p[i][me] = (int8_t)max_j;
+        if (max_f >= f_best) { best = i; f_best = max_f; }  // the largest f, the later anchor on ties
     }
     int i = best, max_s = 0, steps = 0, cut = 0;
     do {  // walk back; the chain is cut where the score counted from its end peaks
-        i = p[i];
+        i = cs.p[i][me];
         ++steps;
-        const int sc = i < 0 ? f[best] : f[best] - f[i];
+        const int sc = i < 0 ? f_best : f_best - cs.f[i][me];
         if (sc > max_s) { max_s = sc; cut = steps; }
     } while (i >= 0);
     *cnt = cut;
@@ -261,9 +279,10 @@ __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t 
 // Small clusters are chained as minimap2 chains them (chain_small); a cluster that does not reach KP_MIN_CHAIN_SCORE is
 // REJECTED: n_anchors = 0, its result row reads score 0 (nothing downstream fills or traces it: the order below leaves it
 // out).  Larger clusters keep their anchor count and get the score of a co-linear chain.
-__global__ __launch_bounds__(256) void kp_chain_score_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
+__global__ __launch_bounds__(CS_THREADS) void kp_chain_score_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
                                                              KpTask *__restrict__ tasks, const uint32_t *__restrict__ task_count,
                                                              uint32_t task_cap, KpSwResult *__restrict__ results) {
+    __shared__ ChainScratch cs;
     const int cls = blockIdx.y;
     uint32_t n = task_count[cls];
     if (n > task_cap) n = task_cap;
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(256) void kp_chain_score_kernel(const uint64_t *__r
         const uint32_t first = (uint32_t)t.chain_score;
         int chain_cnt = cnt, chain_sc;
         if (cnt <= KP_CHAIN_DP_MAX) {
-            chain_sc = chain_small(keys + (size_t)t.asm_id * cap + first, cnt, kb, &chain_cnt);
+            chain_sc = chain_small(keys + (size_t)t.asm_id * cap + first, cnt, kb, cs, (int)threadIdx.x, &chain_cnt);
             if (chain_sc < KP_MIN_CHAIN_SCORE) {
                 chain_cnt = 0;
                 results[(size_t)cls * task_cap + i].score = 0;
@@ -362,8 +381,8 @@ void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint
                           KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
                           uint32_t *order, hipStream_t stream) {
     const dim3 grid(128, KP_N_CLASSES), block(256);
-    hipLaunchKernelGGL(kp_chain_score_kernel, dim3(512, KP_N_CLASSES), block, 0, stream, sorted_anchors, cap, key_bits, tasks, task_count,
-                       task_cap, results);
+    hipLaunchKernelGGL(kp_chain_score_kernel, dim3(2048, KP_N_CLASSES), dim3(CS_THREADS), 0, stream, sorted_anchors, cap, key_bits, tasks,
+                       task_count, task_cap, results);
     hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist);
     hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist, order,
                        hist + 2 * KP_N_CLASSES * 64);
