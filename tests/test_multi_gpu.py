@@ -81,7 +81,7 @@ def test_eight_ranks_rehearse_config5_on_one_gpu():
         # (a buffer may still grow ahead of need in these 16-assembly batches: a sub-slice's fill depends on the order in
         # which the scan's waves flushed, at this size by more than the 25 % of headroom that triggers growth; the default
         # run reports 0 -- profiles/r3_bench_line.json)
-        assert h["device_reallocations_in_timed_steps"] >= 0, h
+        assert 0 <= h["device_reallocations_in_timed_steps"] <= 4, h  # (a handful at most: growth ahead of need, never a rerun)
         assert h["process_cpu_s"] > 0 and h["driving_thread_cpu_s"] > 0 and h["max_rss_MB"] > 0 and h["pinned_host_MB"] >= 0
     for rank in (0, 3, 7):  # the same seeds in a process of their own
         one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--assemblies", "32", "--as-rank", str(rank), *common],
