@@ -1201,7 +1201,7 @@ int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out8, int64
             if (t.asm_id != a || t.n_anchors == 0) continue;  // (n_anchors == 0: a cluster the chaining rejected)
             if (out8 && n < cap) {
                 int32_t *o = out8 + 8 * n;
-                o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = t.qmin; o[6] = t.qmax; o[7] = t.chain_score;
+                o[0] = t.gs; o[1] = t.contig; o[2] = t.lo; o[3] = t.width; o[4] = t.n_anchors; o[5] = (int32_t)(t.qspan & 0xFFFFu); o[6] = (int32_t)(t.qspan >> 16); o[7] = t.chain_score;
             }
             ++n;
         }

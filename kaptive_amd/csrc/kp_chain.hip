@@ -119,7 +119,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     KpTask t;
     t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = (int32_t)first;
     t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
-    t.qmin = (int32_t)qmin; t.qmax = (int32_t)qmax;
+    t.qspan = qmin | (qmax << 16);
     const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
     if (s < TaskStage::room(cls)) {
         st.list(cls)[s] = t;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(CS_THREADS) void kp_chain_score_kernel(const uint64
                 results[(size_t)cls * task_cap + i].score = 0;
             }
         } else {
-            chain_sc = min(KP_K * cnt, t.qmax - t.qmin + KP_K);
+            chain_sc = min(KP_K * cnt, (int)(t.qspan >> 16) - (int)(t.qspan & 0xFFFFu) + KP_K);
         }
         t.n_anchors = chain_cnt;
         t.chain_score = chain_sc;

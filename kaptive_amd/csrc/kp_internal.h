@@ -132,9 +132,10 @@ struct KpTask {
     int32_t lo;         // lowest diagonal of the band (tpos - qpos, assembly coordinates)
     int32_t width;      // 16 / 32 / 64 / 128
     int32_t n_anchors;  // anchors of the cluster's chain (kp_spec.h)
-    int32_t qmin, qmax;
+    uint32_t qspan;     // qmin | qmax << 16: query extent of the cluster's anchors (positions fit 16 bits, kp_spec.h)
     int32_t chain_score;
-};
+};  // 32 bytes: the fill kernel takes the first half with one 16-byte load
+static_assert(sizeof(KpTask) == 32, "KpTask is read as two 16-byte halves");
 
 // Raw result of one task (before the score filter), same meaning as the oracle's kpo_sw rows.
 struct KpSwResult {

@@ -350,7 +350,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             have[h] = slot < n_tasks;
             ti[h] = have[h] ? order[slot] : 0u;
             tk[h].asm_id = 0; tk[h].gs = 0; tk[h].contig = 0; tk[h].lo = 0;
-            if (have[h]) tk[h] = tasks[ti[h]];
+            if (have[h]) {  // the first four fields are all the fill needs (one 16-byte load; the whole record is nine words)
+                const int4 head = *reinterpret_cast<const int4 *>(&tasks[ti[h]]);
+                tk[h].asm_id = head.x; tk[h].gs = head.y; tk[h].contig = head.z; tk[h].lo = head.w;
+            }
             const int gene = tk[h].gs >> 1;
             qlen[h] = have[h] ? genes.len[gene] : 0;
             q_off[h] = (uint32_t)genes.word_off[(tk[h].gs & 1) ? genes.n_genes + gene : gene];
