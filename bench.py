@@ -363,8 +363,8 @@ FILL_CLOCK_HZ = 2.26e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/r2
 
 def offline_pmc(args) -> dict | None:
     """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
-    collection of this same command (profiles/scan_pmc_r3.json) and are reported only for the workload it ran."""
-    path = ROOT / "profiles" / "scan_pmc_r3.json"
+    collection of this same command (profiles/scan_pmc_r4.json) and are reported only for the workload it ran."""
+    path = ROOT / "profiles" / "scan_pmc_r4.json"
     try:
         pmc = json.loads(path.read_text())
     except OSError:
@@ -717,6 +717,10 @@ def main() -> None:
         scan_bytes = float(np.mean([p["bytes_scanned"] for p in prof[0]]))
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
         pmc = offline_pmc(args)
+        if pmc and pmc.get("tcc_req_per_launch"):
+            l2_req, l2_src = float(pmc["tcc_req_per_launch"]), "TCC_REQ_sum of the offline PMC collection (all of the kernel's L2 requests)"
+        else:
+            l2_req, l2_src = scan_bytes * 4.0 * 2.0 / 11.0, "estimate: one probe per seed, 2 / 11 of the bases"
         scan_alone_ms = float(np.mean([p["scan"] for p in alone]))
         fill_alone_ms = float(np.mean([p["sw16"] for p in alone]))
         # per database: kernel milliseconds per step (sum over the step's batches, mean over steps)
@@ -792,10 +796,11 @@ def main() -> None:
                         "passes; `alone` = the same launch with nothing else running (untimed, after the steps)",
                 "alone": {"ms_per_launch": scan_alone_ms, "achieved": scan_bytes / (scan_alone_ms * 1e-3) / 1e9,
                           "frac": scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                # one 8-byte presence-filter probe per selected position (a quarter of the bases): the kernel's real
-                # roof is the rate at which the L2s serve independent requests (tools/microbench/l2_gather.hip)
-                "l2_requests": {"per_launch": scan_bytes, "rate_alone_G_per_s": scan_bytes / (scan_alone_ms * 1e-3) / 1e9,
-                                "measured_roof_G_per_s": L2_GATHER_ROOF_G, "frac_alone": scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / L2_GATHER_ROOF_G,
+                # one 8-byte presence-filter probe per seed (minimizers: 2 / 11 of the bases; round 3's rule selected a
+                # quarter): that request rate against the rate at which the L2s serve independent requests
+                # (tools/microbench/l2_gather.hip).  Since round 4 the kernel is bound by vector issue first.
+                "l2_requests": {"per_launch": l2_req, "per_launch_source": l2_src, "rate_alone_G_per_s": l2_req / (scan_alone_ms * 1e-3) / 1e9,
+                                "measured_roof_G_per_s": L2_GATHER_ROOF_G, "frac_alone": l2_req / (scan_alone_ms * 1e-3) / 1e9 / L2_GATHER_ROOF_G,
                                 "roof_source": "profiles/l2_gather_r2.txt (2 MB table, 8 loads in flight per lane)"},
             },
             "dp": {
