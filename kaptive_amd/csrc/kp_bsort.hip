@@ -19,6 +19,8 @@
 //      thousands of anchors: a 15 kb gene, or a gene present hundreds of times -- is ranked by the whole block at the end.
 // No memory access sits inside a sorting loop: an LDS read per comparison ran at the LDS's latency (4.6 ms of a 6 ms first
 // version), and a guard per unrolled comparison cost a scalar branch each.
+#include <atomic>
+
 #include "kp_internal.h"
 
 namespace {
@@ -360,19 +362,29 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
 
 size_t kp_bsort_lds_bytes(uint32_t n_bins) { return (size_t)n_bins * sizeof(uint32_t); }
 
+// The bucket counters are dynamic LDS on top of ~19 KB of static LDS (s_tile, s_big, s_part, s_huge, s_off); gfx950 has
+// 160 KB per CU.  BS_DYN_MAX = 128 KB of counters = 32768 values of the top key field = 16384 genes: the Kaptive-shaped
+// databases (a few thousand genes: 15-30 KB, three or more blocks per CU) are unaffected, a context that holds several
+// large databases at once runs one block per CU instead of falling back to the library's radix sort.
+constexpr size_t BS_DYN_MAX = 128u * 1024u;
+
 // true when the bucket path can take a database with n_bins = 2 * genes values of the top key field
-// (48 KB of counters + 35 KB of staging: two blocks per CU for the Kaptive-shaped databases, one for the largest taken)
-bool kp_bsort_fits(uint32_t n_bins) { return n_bins > 0 && kp_bsort_lds_bytes(n_bins) <= 48u * 1024u; }
+bool kp_bsort_fits(uint32_t n_bins) { return n_bins > 0 && kp_bsort_lds_bytes(n_bins) <= BS_DYN_MAX; }
 
 void kp_launch_anchor_bsort(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                             uint64_t *grouped, uint64_t *out, uint32_t *count, uint32_t *need, uint32_t n_bins,
                             KpKeyBits kb, hipStream_t stream) {
     if (b.n_asm == 0) return;
-    static bool raised = false;  // more than 64 KB of LDS per block has to be asked for once per process
-    if (!raised) {
+    // more than 64 KB of LDS per block has to be asked for, per device (the attribute belongs to the device's copy of the
+    // kernel): once per device and process, whichever thread comes first
+    static std::atomic<uint64_t> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp_anchor_bsort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  64 * 1024);
-        raised = true;
+                                  (int)BS_DYN_MAX);
+        raised.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kp_anchor_bsort_kernel, dim3(b.n_asm), dim3(BS_THREADS), kp_bsort_lds_bytes(n_bins), stream, sliced,
                        sub_count, sub_cap, grouped, out, count, need, n_bins, kb.qb + kb.db);

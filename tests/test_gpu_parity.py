@@ -236,6 +236,35 @@ def test_anchor_task_hit_stages_match_oracle(ctx, small_setup, small_db):
     batch.close()
 
 
+def test_twelve_thousand_genes_stay_on_the_bucket_sort(oracle):
+    """A 540-locus database (about 12 400 genes: 24 800 values of the anchor key's gene/strand field, 97 KB of LDS counters)
+    goes through kp_bsort.hip, not the library's radix sort: sorted anchors, tasks and hits equal the oracle's, and the
+    library path (`library_sort`) gives the same bytes."""
+    db = make_db("ab_k", seed=102, n_loci=540)
+    assert len(db.genes) > 12_000
+    odb = oracle.OracleDB(*pack_sequences_flat(db.genes))
+    asms = [make_assembly(db, seed=3100 + i, length=250_000, median_contigs=40, min_contig=200, force_split=i % 2 == 0) for i in range(3)]
+    packed = [a.packed() for a in asms]
+    c = _native.Context(0)
+    c.load_genes(*pack_sequences_flat(db.genes))
+    batch = c.batch(packed)
+    hits, off = batch.align()
+    for i, pa in enumerate(packed):
+        assert np.array_equal(batch.anchors(i), odb.anchors(pa)), asms[i].id
+        _same_records(np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names)),
+                      np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names)), f"tasks of {asms[i].id}")
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert len(hits) > 500
+    c.set_option("library_sort", 1)
+    lib = c.batch(packed)
+    hits_lib, off_lib = lib.align()
+    assert np.array_equal(off, off_lib)
+    _same_records(hits, hits_lib, "bucket sort vs library sort, 12 k genes")
+    for b in (batch, lib):
+        b.close()
+    c.close()
+
+
 def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
     """A small database is scanned with its presence filter in LDS; KAPTIVE_AMD_NO_LDS_FILTER=1 sends the same batch
     through the L2 tier.  The filter only prunes, so anchors and hits must be identical."""
