@@ -77,7 +77,9 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
     key = key ^ key >> 28;
     return key; /* the last step, key + (key << 31), adds nothing below bit 30 */
 }
-#define KP_MAX_GENE_LEN 15800 /* q positions fit 16 bits; biased scores (<= 2 * length + 14) stay below 0x7C00 (kp_sw.hip) */
+#define KP_MAX_GENE_LEN 65535       /* query positions are 16-bit fields of the anchor key and of the hit order's keys */
+#define KP_FILL16_MAX_GENE_LEN 15800 /* longest gene the packed 16-bit fill kernel takes: biased scores (<= 2 * length + 14) stay below
+                                        0x7C00 (kp_sw.hip); tasks of longer genes are filled with 32-bit scores (kp_sw_long_kernel) */
 #define KP_MAX_GENES 131071   /* (gene*2+strand) is stored in 18 bits */
 #define KP_MAX_ASM_LEN ((1u << 30) - 65536u)
 

@@ -13,7 +13,8 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "libkaptive_amd.so"
-MAX_GENE_LEN = 15800  # KP_MAX_GENE_LEN of include/kp_spec.h (tests/test_native_abi.py compares the two)
+MAX_GENE_LEN = 65535  # KP_MAX_GENE_LEN of include/kp_spec.h (tests/test_native_abi.py compares the two)
+FILL16_MAX_GENE_LEN = 15800  # KP_FILL16_MAX_GENE_LEN: longer genes are filled with 32-bit scores
 WORK_SLOTS = 3  # KP_WORK_SLOTS of include/kaptive_amd.h: alignment results a context keeps resident
 
 HIT_DTYPE = np.dtype(

@@ -947,7 +947,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, w->d_task_order.p + KP_ORDER_COUNTS, w->task_cap, w->d_task_order.p + ORDER_HEAD,
-                 w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p,
+                 w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->max_gene_len > KP_FILL16_MAX_GENE_LEN,
                  stream, ev[4]);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());

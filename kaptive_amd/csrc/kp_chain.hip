@@ -313,6 +313,8 @@ __device__ __forceinline__ int length_bucket(int rows) {
     const int b = rows >> 5;
     return 63 - (b > 63 ? 63 : b);
 }
+constexpr int NB = KP_ORDER_BUCKETS;  // 64 length buckets + the bucket of long genes' tasks (last in the order)
+__device__ __forceinline__ int task_bucket(const KpBatchView &b, const KpGenes &genes, const KpTask &t);
 // rows of the gene the task's band can reach inside its contig (kp_task_rows: a gene at a contig end is not filled beyond it)
 __device__ __forceinline__ int task_rows(const KpBatchView &b, const KpGenes &genes, const KpTask &t) {
     const int c_abs = b.asm_first_ctg[t.asm_id] + t.contig;
@@ -322,55 +324,62 @@ __device__ __forceinline__ int task_rows(const KpBatchView &b, const KpGenes &ge
     return r_hi - r_lo;
 }
 
+__device__ __forceinline__ int task_bucket(const KpBatchView &b, const KpGenes &genes, const KpTask &t) {
+    return genes.len[t.gs >> 1] > KP_FILL16_MAX_GENE_LEN ? NB - 1 : length_bucket(task_rows(b, genes, t));
+}
+
 __global__ __launch_bounds__(256) void kp_task_hist_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                            const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                            uint32_t *__restrict__ hist) {
-    __shared__ uint32_t s_h[64];
+    __shared__ uint32_t s_h[NB];
     const int cls = blockIdx.y;
     uint32_t n = task_count[cls];
     if (n > task_cap) n = task_cap;
-    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    if (threadIdx.x < NB) s_h[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const KpTask &t = tasks[(size_t)cls * task_cap + i];
-        if (t.n_anchors) atomicAdd(&s_h[length_bucket(task_rows(b, genes, t))], 1u);
+        if (t.n_anchors) atomicAdd(&s_h[task_bucket(b, genes, t)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[cls * 64 + threadIdx.x], s_h[threadIdx.x]);
+    if (threadIdx.x < NB && s_h[threadIdx.x]) atomicAdd(&hist[cls * NB + threadIdx.x], s_h[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void kp_task_scatter_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                               const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                               uint32_t *__restrict__ hist, uint32_t *__restrict__ order,
                                                               uint32_t *__restrict__ ordered) {
-    __shared__ uint32_t s_start[64], s_h[64], s_base[64];
+    __shared__ uint32_t s_start[NB], s_h[NB], s_base[NB];
     const int cls = blockIdx.y;
     uint32_t n = task_count[cls];
     if (n > task_cap) n = task_cap;
-    if (threadIdx.x == 0) {  // bucket starts from the finished histogram (64 entries: not worth a scan)
+    if (threadIdx.x == 0) {  // bucket starts from the finished histogram (65 entries: not worth a scan)
         uint32_t acc = 0;
-        for (int k = 0; k < 64; ++k) { s_start[k] = acc; acc += hist[cls * 64 + k]; }
-        if (blockIdx.x == 0) ordered[cls] = acc;
+        for (int k = 0; k < NB; ++k) { s_start[k] = acc; acc += hist[cls * NB + k]; }
+        if (blockIdx.x == 0) {
+            ordered[cls] = s_start[NB - 1];                    // ordinary tasks: the packed fill kernel's
+            ordered[KP_N_CLASSES + cls] = acc - s_start[NB - 1];  // tasks of long genes, behind them
+        }
     }
-    if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
+    if (threadIdx.x < NB) s_h[threadIdx.x] = 0;
     __syncthreads();
     // each block handles one contiguous chunk so that it can reserve its slots with one atomic per bucket
     const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const KpTask &t = tasks[(size_t)cls * task_cap + i];
-        if (t.n_anchors) atomicAdd(&s_h[length_bucket(task_rows(b, genes, t))], 1u);
+        if (t.n_anchors) atomicAdd(&s_h[task_bucket(b, genes, t)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[KP_N_CLASSES * 64 + cls * 64 + threadIdx.x], s_h[threadIdx.x]) : 0u;
+    if (threadIdx.x < NB) {
+        s_base[threadIdx.x] = s_h[threadIdx.x] ? atomicAdd(&hist[KP_N_CLASSES * NB + cls * NB + threadIdx.x], s_h[threadIdx.x]) : 0u;
         s_h[threadIdx.x] = 0;
     }
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const KpTask &t = tasks[(size_t)cls * task_cap + i];
         if (!t.n_anchors) continue;
-        const int k = length_bucket(task_rows(b, genes, t));
+        const int k = task_bucket(b, genes, t);
         order[(size_t)cls * task_cap + s_start[k] + s_base[k] + atomicAdd(&s_h[k], 1u)] = i;
     }
 }
@@ -385,7 +394,7 @@ void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint
                        task_count, task_cap, results);
     hipLaunchKernelGGL(kp_task_hist_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist);
     hipLaunchKernelGGL(kp_task_scatter_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, hist, order,
-                       hist + 2 * KP_N_CLASSES * 64);
+                       hist + KP_ORDER_COUNTS);
 }
 
 void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t *seg_begin, uint32_t *seg_end,

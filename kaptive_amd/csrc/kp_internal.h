@@ -199,13 +199,17 @@ void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const
 // `trace` holds trace_cap_units 16-byte units; *trace_top (zeroed by the caller) ends up as the units the pass needs.
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *ordered_count,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
-                  uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
+                  uint64_t trace_cap_units, KpSwResult *results, bool has_long_genes, hipStream_t stream,
                   hipEvent_t after_fill);
 // kp_chain.hip: settles the provisional tasks (chain score and anchor count of every cluster, or rejection: kp_spec.h), then
 // builds, per width class, a permutation of the surviving tasks ordered by query length (longest first).  `hist` is
 // KP_ORDER_HEAD zeroed words: histogram, cursors and, at KP_ORDER_COUNTS, how many tasks each class's order holds.
-#define KP_ORDER_COUNTS (2 * KP_N_CLASSES * 64)
-#define KP_ORDER_HEAD (KP_ORDER_COUNTS + KP_N_CLASSES)
+// (65 buckets per class: 64 by length for the packed fill kernel, the 65th holds the tasks of genes longer than
+// KP_FILL16_MAX_GENE_LEN, which come last in the order and are filled by kp_sw_long_kernel; counts: [KP_N_CLASSES] ordinary,
+// then [KP_N_CLASSES] long)
+#define KP_ORDER_BUCKETS 65
+#define KP_ORDER_COUNTS (2 * KP_N_CLASSES * KP_ORDER_BUCKETS)
+#define KP_ORDER_HEAD (KP_ORDER_COUNTS + 2 * KP_N_CLASSES)
 void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t cap, KpKeyBits key_bits,
                           KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
                           uint32_t *order, hipStream_t stream);

@@ -47,7 +47,7 @@
 //     candidates are compared two below their value (d - 2 is the predecessor's H - open - ext plus the score + 4; e - 2
 //     and f - 2 are the cell's own E - ext and F - ext), so H itself is never formed.  The smallest value the recurrence can
 //     produce is -(open + 2 ext) = -8, and "no gap yet" is represented by exactly that (it loses every maximum it takes
-//     part in, like -inf), so everything is >= 0; the largest is 2 * length + 12 < 32768 (KP_MAX_GENE_LEN).
+//     part in, like -inf), so everything is >= 0; the largest is 2 * length + 12 < 32768 (KP_FILL16_MAX_GENE_LEN).
 //   * the restart at 0 costs nothing: the gap state a cell hands to its right neighbour is floored at 0 inside the
 //     three-way maximum that forms it, so one of a cell's three candidates is always >= 0 (dp_cell).
 //   * best cell: per lane and task the running maximum of its cells, the PAIR of steps in which it last rose and the eight
@@ -68,7 +68,7 @@ constexpr int OE = KP_GAP_OPEN + KP_GAP_EXT;
 constexpr int EX = KP_GAP_EXT;
 static_assert(KP_SC_MATCH == 2 && KP_SC_MISMATCH == -4 && KP_SC_N == -1 && OE == 6 && EX == 2,
               "the profile fields and the biases below encode these scores");
-static_assert(2 * KP_MAX_GENE_LEN + 14 < 0x7C00, "biased scores must stay below the half-precision infinity pattern (pk_max3) "
+static_assert(2 * KP_FILL16_MAX_GENE_LEN + 14 < 0x7C00, "biased scores must stay below the half-precision infinity pattern (pk_max3) "
                                                  "and leave bit 15 of a half-word free for the guard");
 
 constexpr unsigned K1 = 0x00010001u;                        // a value in both halves: x * K1
@@ -146,7 +146,7 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
 // Three-way maximum of both halves in one instruction: v_pk_maximum3_f16 (new in gfx950).  Positive half-precision bit
 // patterns below 0x7C00 order like unsigned integers and the instruction returns the winning operand's bits unchanged,
 // denormal patterns included (tools/microbench/pk_max3.hip: all 6.0e9 checked triples exact, same issue cost as
-// v_pk_max_u16) -- and every biased score of this kernel is in [0, 2 * KP_MAX_GENE_LEN + 14] < 0x7C00.
+// v_pk_max_u16) -- and every biased score of this kernel is in [0, 2 * KP_FILL16_MAX_GENE_LEN + 14] < 0x7C00.
 __device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c) {
     unsigned r;
 #ifdef KP_SW_NO_MAX3  // (A/B builds: KAPTIVE_AMD_EXTRA_FLAGS=-DKP_SW_NO_MAX3)
@@ -615,6 +615,157 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, next_quad, s_prof, s_t, s_tw, s_spread);
 }
 
+
+// ---- fill with 32-bit scores: the tasks of genes longer than KP_FILL16_MAX_GENE_LEN ------------------------------------------
+// The reference compiles any CDS (src/kaptive/db/core.py:402-404, 478); the packed kernel above holds scores in 16 bits.
+// The rare longer gene's tasks are left out of its order (kp_chain.hip) and filled here instead: the same band mapping (P
+// lanes per task, lane l holds diagonals 4l .. 4l + 3 and works on row m - l at step m), the recurrence of kp_spec.h
+// written out in plain 32-bit arithmetic, ONE task per lane group, sequences read straight from the packed words --
+// several times slower per cell, on a handful of tasks.  It leaves what kp_sw_kernel leaves: the best cell (KpSwEnd) and the
+// direction words in the same layout (a cell's word: eight steps, per four steps a byte of [not D, E opened] pairs above a
+// byte of [not L, F opened] pairs), so the traceback kernel does not know which kernel filled a task.
+constexpr int LONG_NEG = -(1 << 29);
+
+template <int P>
+__device__ __forceinline__ void sw_long_class(const KpBatchView &b, const KpGenes &genes, const KpTask *__restrict__ tasks,
+                                              const uint32_t *__restrict__ order, uint32_t n_tasks, KpSwEnd *__restrict__ ends,
+                                              uint4 *__restrict__ trace, unsigned long long *__restrict__ trace_top, uint64_t trace_cap,
+                                              uint32_t block, uint32_t n_blocks) {
+    constexpr int G = 64 / P;
+    const int lane = threadIdx.x, g = lane / P, l = lane % P;
+    for (uint32_t quad = block; (uint64_t)quad * G < n_tasks; quad += n_blocks) {
+        const uint32_t slot = quad * G + g;
+        const bool have = slot < n_tasks;
+        const uint32_t ti = have ? order[slot] : 0u;
+        KpTask tk;
+        tk.asm_id = 0; tk.gs = 0; tk.contig = 0; tk.lo = 0;
+        if (have) tk = tasks[ti];
+        const int gene = tk.gs >> 1;
+        const int qlen = have ? genes.len[gene] : 0;
+        const uint32_t *qnib = genes.nib + genes.word_off[(tk.gs & 1) ? genes.n_genes + gene : gene];
+        const uint32_t *asm_words = b.words + b.asm_word_off[tk.asm_id];
+        const int c_abs = b.asm_first_ctg[tk.asm_id] + tk.contig;
+        const int cstart = b.ctg_start[c_abs], cend = cstart + b.ctg_len[c_abs];
+        const int r0n = b.asm_first_nrun[tk.asm_id], n_runs = b.asm_first_nrun[tk.asm_id + 1] - r0n;
+        const int32_t *runs = b.n_runs + 2 * (size_t)r0n;
+        int q0, r_hi;
+        kp_task_rows(tk.lo, 4 * P, cstart, cend, qlen, &q0, &r_hi);
+        const int steps = have ? (r_hi - q0) + P - 1 : 0;
+        const int n_chunks = (((steps + 7) >> 3) + 3) & ~3;
+        int max_steps = steps;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) max_steps = max(max_steps, __shfl_xor(max_steps, o));
+        const unsigned long long want = (unsigned long long)P * (unsigned)(have ? n_chunks : 0);
+        unsigned long long toff = 0;
+        if (have && l == 0) toff = atomicAdd(trace_top, want);
+        toff = ((unsigned long long)__shfl((unsigned)(toff >> 32), g * P) << 32) | __shfl((unsigned)toff, g * P);
+        const bool fits = have && toff + want <= trace_cap;
+        uint4 *trace_x = trace + toff + TG * l;
+
+        auto target_code = [&](int t) -> int {  // 0..3, 4 = N, 5 = outside the contig
+            if (t < cstart || t >= cend) return 5;
+            int code = (int)((asm_words[t >> 4] >> (2 * (t & 15))) & 3u);
+            if (n_runs > 0) {
+                int a = 0, z = n_runs;
+                while (a < z) {
+                    const int mid = (a + z) >> 1;
+                    if (runs[2 * mid + 1] <= t) a = mid + 1; else z = mid;
+                }
+                if (a < n_runs && runs[2 * a] <= t) code = 4;
+            }
+            return code;
+        };
+        int H[4] = {0, 0, 0, 0}, E[4], F[4], tc[4];
+        bool saw_n = have && genes.has_n[gene] != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { E[k] = F[k] = LONG_NEG; tc[k] = 5; }
+        int best = 0, best_r = 0, best_b = 4 * l;
+        uint32_t word[4] = {0, 0, 0, 0};
+        const int steps8 = (max_steps + 7) & ~7;
+        for (int m = 0; m < steps8; ++m) {
+            const int r = q0 + m - l;  // this lane's row
+            const bool row_ok = have && r >= q0 && r < r_hi;
+            const int qc = row_ok ? (int)nibble(qnib[r >> 3], r & 7) : 4;
+            // columns of the lane's cells: t0 + k, t0 = lo + r + 4l
+            const int t0 = tk.lo + r + 4 * l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tc[k] = row_ok ? target_code(t0 + k) : 5;
+            // left neighbour of A: lane l - 1's D as the previous step left it; upper neighbour of D: lane l + 1's A of this step
+            int hl = __shfl_up(H[3], 1), el = __shfl_up(E[3], 1);
+            if (l == 0) { hl = 0; el = LONG_NEG; }
+            const int oldH[4] = {H[0], H[1], H[2], H[3]}, oldF[4] = {F[0], F[1], F[2], F[3]};
+            const int sh = 2 * (m & 3) + 16 * ((m >> 2) & 1);
+            int hu_d = 0, fu_d = LONG_NEG;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 3) {  // (every lane has computed its A by now)
+                    hu_d = __shfl_down(H[0], 1); fu_d = __shfl_down(F[0], 1);
+                    if (l == P - 1) { hu_d = 0; fu_d = LONG_NEG; }
+                }
+                const int hleft = k == 0 ? hl : H[k - 1], eleft = k == 0 ? el : E[k - 1];
+                const int hup = k == 3 ? hu_d : oldH[k + 1], fup = k == 3 ? fu_d : oldF[k + 1];
+                const int hd = oldH[k];
+                const int code = tc[k];
+                const bool inside = row_ok && code < 5;
+                saw_n |= inside && code == 4;
+                const int e_open = hleft - OE, e_ext = eleft - EX, f_open = hup - OE, f_ext = fup - EX;
+                const int e = e_open >= e_ext ? e_open : e_ext, f = f_open >= f_ext ? f_open : f_ext;
+                const int s = (qc > 3 || code > 3) ? KP_SC_N : (qc == code ? KP_SC_MATCH : KP_SC_MISMATCH);
+                int bv = hd + s, tb = 0;
+                if (e > bv) { bv = e; tb = 1; }
+                if (f > bv) { bv = f; tb = 2; }
+                const uint32_t not_d = tb != 0, not_l = tb == 0 ? (hd == 0) : (tb == 2);
+                const uint32_t eo = e_open >= e_ext, fo = f_open >= f_ext;
+                word[k] |= ((not_d << 9) | (eo << 8) | (not_l << 1) | fo) << sh;
+                if (inside) {
+                    E[k] = e; F[k] = f;
+                    H[k] = bv > 0 ? bv : 0;
+                    if (bv > best) { best = bv; best_r = r; best_b = 4 * l + k; }
+                } else {
+                    H[k] = 0; E[k] = LONG_NEG; F[k] = LONG_NEG;
+                }
+            }
+            if ((m & 7) == 7) {
+                const int j = m >> 3;
+                if (fits && j < n_chunks) trace_x[(size_t)(j / TG) * (TG * P) + (j % TG)] = make_uint4(word[0], word[1], word[2], word[3]);
+                word[0] = word[1] = word[2] = word[3] = 0;
+            }
+        }
+        // best cell of the task: the largest score, then the first row, then the first column
+        bool sn = saw_n;
+#pragma unroll
+        for (int o = 1; o < P; o <<= 1) {
+            const int s2 = __shfl_xor(best, o), r2 = __shfl_xor(best_r, o), b2 = __shfl_xor(best_b, o);
+            if (s2 > best || (s2 == best && (r2 < best_r || (r2 == best_r && b2 < best_b)))) { best = s2; best_r = r2; best_b = b2; }
+            sn |= __shfl_xor((int)sn, o) != 0;
+        }
+        if (have && l == 0) {
+            KpSwEnd out;
+            out.score = fits ? best : 0;
+            out.er = best > 0 ? best_r : q0;
+            out.eb = (best > 0 ? best_b : 0) | (sn ? KP_SWEND_HAS_N : 0);
+            out.trace_off = (uint32_t)toff;
+            ends[ti] = out;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void kp_sw_long_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
+                                                        const uint32_t *__restrict__ order_counts, uint32_t task_cap,
+                                                        const uint32_t *__restrict__ order, KpSwEnd *__restrict__ ends,
+                                                        uint4 *__restrict__ trace, unsigned long long *__restrict__ trace_top,
+                                                        uint64_t trace_cap) {
+    // class c's long tasks follow its ordinary ones in the order: [counts[c], counts[c] + counts[KP_N_CLASSES + c])
+    const int c = blockIdx.y;
+    const uint32_t first = order_counts[c], n = order_counts[KP_N_CLASSES + c];
+    if (n == 0) return;
+    const size_t off = (size_t)c * task_cap;
+    if (c == 3) sw_long_class<32>(b, genes, tasks + off, order + off + first, n, ends + off, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
+    else if (c == 2) sw_long_class<16>(b, genes, tasks + off, order + off + first, n, ends + off, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
+    else if (c == 1) sw_long_class<8>(b, genes, tasks + off, order + off + first, n, ends + off, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
+    else sw_long_class<4>(b, genes, tasks + off, order + off + first, n, ends + off, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
+}
+
 // ---- traceback: one lane per task -------------------------------------------------------------------------------------------
 // Cell (row r, band index bi) sits on target position lo + r + bi; a diagonal step keeps bi, a step to the left (E, gap
 // in the query) lowers it, a step up (F, gap in the target) raises it.  The nibble of (r, bi) is in lane stream bi / 4,
@@ -644,7 +795,7 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
                                                               const uint32_t *__restrict__ trace,
                                                               KpSwResult *__restrict__ results) {
     const int cls = blockIdx.y;
-    uint32_t n = task_count[cls];
+    uint32_t n = task_count[cls] + task_count[KP_N_CLASSES + cls];  // the class's order: ordinary tasks, then those of long genes
     if (n > task_cap) n = task_cap;
     const int P = 4 << cls;
     const uint32_t n_iter = (n + 63u) & ~63u;  // whole waves iterate together
@@ -772,11 +923,14 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
 
 void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *tasks, const uint32_t *task_count /* of each class's order */,
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
-                  uint64_t trace_cap_units, KpSwResult *results, hipStream_t stream,
+                  uint64_t trace_cap_units, KpSwResult *results, bool has_long_genes, hipStream_t stream,
                   hipEvent_t after_fill) {
     const dim3 grid(3 * WIDE_BLOCKS + 256u * NARROW_BLOCKS_PER_CU), block(64);
     hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, ends,
                        reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
+    if (has_long_genes)  // (a database property: the Kaptive-shaped ones have none and never launch it)
+        hipLaunchKernelGGL(kp_sw_long_kernel, dim3(256, KP_N_CLASSES), block, 0, stream, b, genes, tasks, task_count, task_cap, order, ends,
+                           reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
     if (after_fill) (void)hipEventRecord(after_fill, stream);
     hipLaunchKernelGGL(kp_sw_traceback_kernel, dim3(2048, KP_N_CLASSES), dim3(TB_THREADS), 0, stream, b, genes, tasks, task_count,
                        task_cap, order, ends, reinterpret_cast<const uint32_t *>(trace), results);

@@ -36,7 +36,7 @@ class Engine:
         self.group = 0
         self.device = device
         self.ctx = _native.Context(device)
-        for d in dbs:  # KP_MAX_GENE_LEN (include/kp_spec.h): the fill kernel's packed 16-bit scores cover genes this long
+        for d in dbs:  # KP_MAX_GENE_LEN (include/kp_spec.h): query positions are 16-bit fields of the anchor and hit keys
             too_long = np.flatnonzero(np.asarray(d.genes.lengths) > _native.MAX_GENE_LEN)
             if len(too_long):
                 g = int(too_long[0])

@@ -491,7 +491,7 @@ def test_empty_batch_and_errors(ctx, small_setup):
     assert len(hits) == 0 and off.tolist() == [0]
     batch.close()
     with pytest.raises(ValueError):
-        ctx.load_genes(np.zeros(40000, np.uint8), np.array([0, 40000], np.int32))  # gene longer than KP_MAX_GENE_LEN
+        ctx.load_genes(np.zeros(70000, np.uint8), np.array([0, 70000], np.int32))  # gene longer than KP_MAX_GENE_LEN
 
 
 # ---- whole typing results against the reference's goldens ---------------------------------------------------------------
@@ -926,13 +926,13 @@ def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, oracle, sm
 
 
 def test_longest_genes_reach_the_packed_score_range(oracle):
-    """Genes at KP_MAX_GENE_LEN: the fill kernel's biased 16-bit scores (2 * length + 12) come within a few hundred of the
+    """Genes at KP_FILL16_MAX_GENE_LEN: the fill kernel's biased 16-bit scores (2 * length + 12) come within a few hundred of the
     half-precision infinity pattern 0x7C00 its three-way maxima (v_pk_maximum3_f16 on integer bit patterns) must stay below.  Exact copies, copies with substitutions, with an insertion and a deletion (wide bands), with an N run,
-    on both strands, and a gene one base too long (rejected at load)."""
+    on both strands.  (Longer genes: test_genes_beyond_the_packed_score_range.)"""
     from kaptive_amd.synth import revcomp
 
     rng = np.random.default_rng(4242)
-    max_len = _native.MAX_GENE_LEN
+    max_len = _native.FILL16_MAX_GENE_LEN
     g1, g2, g3 = (random_dna(rng, n, 0.5) for n in (max_len, max_len - 1, 15000))
     genes = Sequences.from_records([SeqRecord("g1", g1.tobytes()), SeqRecord("g2", g2.tobytes()), SeqRecord("g3", g3.tobytes())])
     codes, off = pack_sequences_flat(genes)
@@ -959,7 +959,49 @@ def test_longest_genes_reach_the_packed_score_range(oracle):
     _same_records(hits, want, "hits of the longest genes")
     assert hits["score"].max() == 2 * max_len and len(hits) >= 5
     batch.close()
-    too_long = Sequences.from_records([SeqRecord("g", random_dna(rng, max_len + 1, 0.5).tobytes())])
+    ctx.close()
+
+
+def test_genes_beyond_the_packed_score_range(oracle):
+    """The reference compiles any CDS (src/kaptive/db/core.py:402-404, 478).  Genes longer than KP_FILL16_MAX_GENE_LEN do
+    not fit the packed 16-bit fill kernel: their tasks are filled with 32-bit scores (kp_sw_long_kernel), everything else
+    in the same pass the usual way.  A 20 kb and a 41 kb gene -- exact, with substitutions, with an insertion and a
+    deletion, with an N run, reverse strand, running off a contig end -- beside ordinary genes: hits equal the oracle's.
+    Only genes beyond KP_MAX_GENE_LEN (16-bit query positions) are rejected at load."""
+    from kaptive_amd.synth import revcomp
+
+    rng = np.random.default_rng(777)
+    big, huge = random_dna(rng, 20_000, 0.5), random_dna(rng, 41_003, 0.5)
+    small = [random_dna(rng, n, 0.5) for n in (900, 1500, 15_800)]
+    genes = Sequences.from_records([SeqRecord("big", big.tobytes()), SeqRecord("s0", small[0].tobytes()), SeqRecord("huge", huge.tobytes()),
+                                    SeqRecord("s1", small[1].tobytes()), SeqRecord("s2", small[2].tobytes())])  # fmt: skip
+    codes, off = pack_sequences_flat(genes)
+    ctx = _native.Context(0)
+    ctx.load_genes(codes, off)
+    odb = oracle.OracleDB(codes, off)
+    sub = big.copy()
+    at = rng.choice(len(sub), 1200, replace=False)
+    sub[at] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, len(at))]
+    indel = np.concatenate([huge[:9000], random_dna(rng, 7, 0.5), huge[9000:30000], huge[30011:]])
+    with_n = big.copy()
+    with_n[12_000:12_025] = ord("N")
+    pad = lambda n: random_dna(rng, n, 0.5)  # noqa: E731
+    recs = [SeqRecord("exact", np.concatenate([pad(300), big, pad(200), small[0], pad(50)]).tobytes()),
+            SeqRecord("rc_sub", np.concatenate([pad(100), revcomp(sub), pad(50), small[2], pad(20)]).tobytes()),
+            SeqRecord("indel", np.concatenate([pad(64), indel, pad(64)]).tobytes()),
+            SeqRecord("n_run", np.concatenate([pad(10), with_n, pad(10), revcomp(small[1])]).tobytes()),
+            SeqRecord("tail_only", huge[25_000:].tobytes()),
+            SeqRecord("head_only", np.concatenate([pad(5), revcomp(huge[:17_000])]).tobytes())]  # fmt: skip
+    asm = GenomeAssembly("longer_genes", Sequences.from_records(recs))
+    pa = asm.packed()
+    batch = ctx.batch([pa, pa])
+    hits, hoff = batch.align()
+    want = odb.align(pa)
+    for i in range(2):
+        _same_records(hits[hoff[i] : hoff[i + 1]], want, "hits of genes beyond the packed range")
+    assert (want["score"] == 2 * 20_000).any() and want["score"].max() > 80_000 and (want["gene"] == 2).sum() >= 3 and (want["gene"] == 4).any()
+    batch.close()
+    too_long = Sequences.from_records([SeqRecord("g", random_dna(rng, _native.MAX_GENE_LEN + 1, 0.5).tobytes())])
     c2, o2 = pack_sequences_flat(too_long)
     with pytest.raises(ValueError):
         ctx.load_genes(c2, o2)

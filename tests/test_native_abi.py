@@ -36,6 +36,7 @@ def test_binding_constants_match_header():
     assert int(re.search(r"#define\s+KP_WORK_SLOTS\s+(\d+)", text).group(1)) == _native.WORK_SLOTS
     spec = (ROOT / "include" / "kp_spec.h").read_text()
     assert int(re.search(r"#define\s+KP_MAX_GENE_LEN\s+(\d+)", spec).group(1)) == _native.MAX_GENE_LEN
+    assert int(re.search(r"#define\s+KP_FILL16_MAX_GENE_LEN\s+(\d+)", spec).group(1)) == _native.FILL16_MAX_GENE_LEN
 
 
 def test_no_gpu_means_loud_failure():
