@@ -18,7 +18,10 @@
  *                       wheel (call sites src/kaptive/core/genome.py:188-189, src/kaptive/serotyping/core.py:147-155;
  *                       consumer src/kaptive/core/alignment.py:409-446); its source is not in the reference tree and
  *                       no reference test pins any alignment.  PARITY UNPINNED for this stage: the specification is
- *                       include/kp_spec.h, and this file is its executable statement.
+ *                       include/kp_spec.h (kp-align v3: minimap2's (10, 15) minimizer sampling, chain-score test and
+ *                       mapping quality restated), and this file is its executable statement.  Its seeds are checked
+ *                       against an independent restatement of mm_sketch (oracle/mm2_model.c) and its report rows
+ *                       against that model's (tests/test_mm2_concordance.py, profiles/concordance_r4.md).
  */
 #include <stdint.h>
 #include <stdlib.h>
