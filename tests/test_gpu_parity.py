@@ -323,6 +323,87 @@ def test_genes_with_ambiguous_bases_match_oracle(oracle, small_db):
     c.close()
 
 
+def test_seeds_at_contig_ends_n_runs_and_repeats_match_oracle(oracle):
+    """The streaming kernel decides seeds by a window rule, the edge kernel by mm_sketch's state machine next to contig ends
+    and N runs (kp_seed_is_interior).  Contigs built from pieces of the genes so that every seed is an anchor, with
+    everything that makes the two meet: contigs of 1 to 80 bases, N runs of every length 1..40 at every distance 0..60
+    from a contig end and from each other, N at the first and last base, homopolymer and short-period stretches (equal
+    15-mers inside a window: ties) in the interior, across the interior/edge boundary and at the very ends, genes cut in
+    the middle of a window.  Anchors (and hits) must equal the oracle's, contig by contig."""
+    rng = np.random.default_rng(20260929)
+    db = make_db("kpsc_k", seed=7, n_loci=4)
+    codes, off = pack_sequences_flat(db.genes)
+    odb = oracle.OracleDB(codes, off)
+    c = _native.Context(0)
+    c.load_genes(codes, off)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    gene = lambda: db.genes.seqs[int(db.genes.offsets[g := int(rng.integers(0, len(db.genes)))]):][: int(db.genes.lengths[g])]  # noqa: E731
+
+    def piece(n):
+        g = gene()
+        a = int(rng.integers(0, max(1, len(g) - n)))
+        return g[a : a + n].copy()
+
+    def periodic(n):
+        unit = acgt[rng.integers(0, 4, int(rng.integers(1, 9)))]
+        return np.tile(unit, n // len(unit) + 1)[:n]
+
+    asms = []
+    for a in range(6):
+        recs = []
+        for k in range(90):
+            kind = k % 9
+            if kind == 0:  # short contigs, down to one base
+                seq = piece(int(rng.integers(1, 81)))
+            elif kind == 1:  # an N run near the start / the end / both
+                seq = piece(int(rng.integers(60, 400)))
+                for _ in range(int(rng.integers(1, 3))):
+                    at = int(rng.integers(0, 61)) if rng.random() < 0.5 else len(seq) - 1 - int(rng.integers(0, 61))
+                    at = min(max(at, 0), len(seq) - 1)
+                    seq[at : at + int(rng.integers(1, 41))] = ord("N")
+            elif kind == 2:  # two N runs a few bases apart in the interior
+                seq = piece(int(rng.integers(200, 600)))
+                at = int(rng.integers(40, len(seq) - 120))
+                seq[at : at + int(rng.integers(1, 30))] = ord("N")
+                at += int(rng.integers(1, 61))
+                seq[at : at + int(rng.integers(1, 30))] = ord("N")
+            elif kind == 3:  # ties at the very start or end
+                seq = np.concatenate([periodic(int(rng.integers(16, 60))), piece(int(rng.integers(40, 200)))])
+                if rng.random() < 0.5:
+                    seq = seq[::-1].copy()
+            elif kind == 4:  # ties in the interior and across the interior / edge boundary
+                seq = piece(int(rng.integers(150, 500)))
+                at = int(rng.integers(0, len(seq) - 60))
+                n = int(rng.integers(16, 60))
+                seq[at : at + n] = periodic(n)
+            elif kind == 5:  # a whole contig of one base / one short unit
+                seq = periodic(int(rng.integers(15, 200)))
+            elif kind == 6:  # N at the first and the last base, IUPAC and lower case in between
+                seq = piece(int(rng.integers(30, 300)))
+                seq[0] = seq[-1] = ord("N")
+                seq[len(seq) // 2] = ord("r")
+            elif kind == 7:  # exactly the lengths around k, k + w - 1 and k + 2w
+                seq = piece(int(rng.choice([14, 15, 16, 23, 24, 25, 26, 33, 34, 35, 36, 44, 45, 59, 60, 61, 73, 74, 75])))
+            else:  # ordinary
+                seq = piece(int(rng.integers(300, 2000)))
+            recs.append(SeqRecord(f"c{k}", seq.tobytes()))
+        asms.append(GenomeAssembly(f"edges{a}", Sequences.from_records(recs)))
+    packed = [a.packed() for a in asms]
+    batch = c.batch(packed)
+    hits, hoff = batch.align()
+    n_anchors = 0
+    for i, pa in enumerate(packed):
+        want = odb.anchors(pa)
+        got = batch.anchors(i)
+        n_anchors += len(want)
+        assert np.array_equal(got, want), f"{asms[i].id}: {len(got)} anchors vs {len(want)}; first difference at " \
+            f"{int(np.flatnonzero(got[: min(len(got), len(want))] != want[: min(len(got), len(want))])[0]) if len(got) and len(want) and (got[: min(len(got), len(want))] != want[: min(len(got), len(want))]).any() else min(len(got), len(want))}"
+        _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert n_anchors > 20_000
+    batch.close()
+    c.close()
+
+
 def test_bucket_sort_and_library_sort_give_the_same_anchors(oracle):
     """kp_bsort.hip against rocPRIM's segmented radix sort (`library_sort`) and the oracle, on an assembly built to hit
     every bucket size class of the bucket sort: single anchors, a few (sorting network in one lane), tens (wave ranking),
