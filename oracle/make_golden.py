@@ -311,16 +311,41 @@ def gen_typing() -> None:
         exp["typer_kwargs_json"] = np.frombuffer(json.dumps(kwargs).encode(), np.uint8)
         save_case(f"k_divergent_{tag}", "k", genome, hits, exp, chain)
         index.append(f"k_divergent_{tag}")
+    # Full-size cases (BASELINE.json configs 2 and 4 at their real shape): the inputs are DESCRIBED, not stored -- database
+    # and assembly are regenerated from the seeds by kaptive_amd.synth (tests/golden_util.py) -- and everything expected is
+    # what the reference's Serotyper returned for them here.
+    for name, key, db_args, kw in FULL_SIZE_CASES:
+        t0 = time.time()
+        db = make_db(*db_args[:1], seed=db_args[1])
+        genome = make_assembly(db, name=name, **kw)
+        ref_db = to_ref_db(db)
+        hits, chain = O.OracleDB(*pack_sequences_flat(db.genes)).align(genome.packed(), with_chain=True)
+        exp = run_reference_typing(ref_db, RefSerotyper(ref_db), genome, hits)
+        save_case(name, key, genome, hits, exp, chain, synth=dict(db=list(db_args), assembly=kw))
+        index.append(name)
+        print(f"typing {name}: {len(hits)} hits -> {bytes(exp['kaptive_row'])[:90]!r} ({time.time() - t0:.1f}s)")
     (OUT / "typing_index.json").write_text(json.dumps(index, indent=1) + "\n")
 
 
-def save_case(name, key, genome, hits, exp, chain=None) -> None:
+FULL_SIZE_CASES = [
+    ("k_fullsize", "kfull", ("kpsc_k", 100), dict(seed=20_001)),                                                   # config 2: 5 Mbp, ~120 contigs
+    ("ab_fullsize", "abfull", ("ab_k", 102), dict(seed=40_001, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True)),  # config 4
+]
+
+
+def save_case(name, key, genome, hits, exp, chain=None, synth=None) -> None:
     """``chain``: the chain score behind every hit (aligner tables only) -- an input of the hit's mapq that the record does
     not keep; the hit-finalisation test needs it to recompute the recorded mapq."""
+    inputs = dict(contig_ids=np.array(list(genome.contigs.ids), dtype="U"), contig_seqs=genome.contigs.seqs,
+                  contig_lengths=genome.contigs.lengths)
+    if synth is not None:  # regenerated from seeds by the loader; a digest of the sequence text guards the generator
+        import hashlib
+
+        inputs = dict(synth_json=np.frombuffer(json.dumps(synth).encode(), np.uint8),
+                      contig_sha1=np.array(hashlib.sha1(genome.contigs.seqs.tobytes()).hexdigest()))
     np.savez_compressed(
         OUT / f"typing_{name}.npz",
-        db_key=np.array(key), genome_id=np.array(genome.id), contig_ids=np.array(list(genome.contigs.ids), dtype="U"),
-        contig_seqs=genome.contigs.seqs, contig_lengths=genome.contigs.lengths, hits=hits,
+        db_key=np.array(key), genome_id=np.array(genome.id), hits=hits, **inputs,
         hit_chain_scores=np.zeros(len(hits), np.int32) if chain is None else np.asarray(chain, np.int32),
         **{f"exp.{k}": v for k, v in exp.items()},
     )  # fmt: skip

@@ -20,19 +20,37 @@ def case_names() -> list[str]:
     return json.loads((GOLDEN / "typing_index.json").read_text())
 
 
+# databases of the full-size cases: regenerated from their seeds (kaptive_amd.synth), not stored
+SYNTH_DBS = {"kfull": ("kpsc_k", 100), "abfull": ("ab_k", 102)}
+
+
 @lru_cache(maxsize=None)
 def load_db(key: str) -> Database:
+    if key in SYNTH_DBS:
+        from kaptive_amd.synth import make_db
+
+        kind, seed = SYNTH_DBS[key]
+        return make_db(kind, seed=seed)
     return Database.load(GOLDEN / f"db_{key}.npz")
 
 
 def load_case(name: str):
     z = np.load(GOLDEN / f"typing_{name}.npz", allow_pickle=False)
-    lengths = z["contig_lengths"]
-    offsets = np.zeros(len(lengths), np.int32)
-    if len(lengths) > 1:
-        np.cumsum(lengths[:-1], out=offsets[1:])
-    contigs = Sequences(tuple(str(s) for s in z["contig_ids"]), z["contig_seqs"], offsets, lengths)
-    genome = GenomeAssembly(str(z["genome_id"]), contigs)
+    if "synth_json" in z.files:  # a full-size case: the assembly is regenerated from its seeds
+        import hashlib
+
+        from kaptive_amd.synth import make_assembly
+
+        synth = json.loads(bytes(z["synth_json"]).decode())
+        genome = make_assembly(load_db(str(z["db_key"])), name=str(z["genome_id"]), **synth["assembly"])
+        assert hashlib.sha1(genome.contigs.seqs.tobytes()).hexdigest() == str(z["contig_sha1"]), "the generator has changed"
+    else:
+        lengths = z["contig_lengths"]
+        offsets = np.zeros(len(lengths), np.int32)
+        if len(lengths) > 1:
+            np.cumsum(lengths[:-1], out=offsets[1:])
+        contigs = Sequences(tuple(str(s) for s in z["contig_ids"]), z["contig_seqs"], offsets, lengths)
+        genome = GenomeAssembly(str(z["genome_id"]), contigs)
     exp = {k[4:]: z[k] for k in z.files if k.startswith("exp.")}
     scalars = json.loads(bytes(exp.pop("scalars_json")).decode())
     kwargs = json.loads(bytes(exp.pop("typer_kwargs_json")).decode()) if "typer_kwargs_json" in exp else {}
