@@ -816,7 +816,13 @@ def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_p
     fast, slow, two = tmp_path / "fast.tsv", tmp_path / "slow.tsv", tmp_path / "two.tsv"
     assert main(["assembly", str(db_path), *paths, "-o", str(fast), "--batch-size", "4", "-t", "3"]) == 0
     assert main(["assembly", str(db_path), *paths, "-o", str(slow), "-j", str(tmp_path / "r.jsonl"), "--batch-size", "3"]) == 0
-    assert main(["assembly", str(db_path), *paths, "-o", str(two), "--batch-size", "2", "--devices", "0,0", "-t", "2"]) == 0
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "kaptive_amd", "assembly", str(db_path), *paths, "-o", str(two), "--batch-size", "2",
+                        "--devices", "0,0", "-t", "2"], capture_output=True, text=True, timeout=600,
+                       cwd=str(__import__("pathlib").Path(__file__).resolve().parent.parent))  # (as a user runs it: the device processes re-import __main__)
+    assert r.returncode == 0, r.stderr[-2000:]
     rows = fast.read_bytes().splitlines(keepends=True)
     assert len(rows) == 1 + len(paths) and [r.split(b"\t")[3] for r in rows[1:]] == [f"asm{i:02d}".encode() for i in range(11)]
     assert fast.read_bytes() == slow.read_bytes() == two.read_bytes()
