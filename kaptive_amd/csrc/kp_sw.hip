@@ -588,7 +588,9 @@ constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride ove
 constexpr uint32_t NARROW_BLOCKS_PER_CU = KP_SW_NARROW_BLOCKS_PER_CU;  // blocks of the 16-diagonal class (they take quads off a counter)
 
 #ifndef KP_SW_WAVES
-#define KP_SW_WAVES 4  // waves per SIMD the register budget is set for (two tasks per register: 128 VGPRs)
+#define KP_SW_WAVES 3  // waves per SIMD the register budget is set for: 145 VGPRs, nothing spilled to scratch (at 4 -- 128 VGPRs --
+                       // the per-quad set-up spilled 17 VGPRs; round 4, same box: 46.8-47.0 k assemblies/s at 3 against 46.2-46.4 k at 4,
+                       // fill alone 7.36 ms either way: the kernel is bound by vector issue, not by latency)
 #endif
 __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
