@@ -177,6 +177,10 @@ def ingest_rate(seed0: int, length: float) -> dict:
     for x in texts:
         _native.fasta_ingest(x)
     one = nbytes / (time.perf_counter() - t) / 1e6
+    t = time.perf_counter()
+    for x in texts:
+        _native.fasta_ingest(x, keep_text=False)  # what a TSV-only run of the CLI asks for
+    one_packed_only = nbytes / (time.perf_counter() - t) / 1e6
     cores = os.cpu_count() or 1
     chunk = [texts[i % len(texts)] for i in range(cores)]  # a chunk is parsed, used and dropped, as a reader feeding a GPU
     rounds = 6                                             # does: the buffers of one chunk serve the next (block pool)
@@ -192,7 +196,9 @@ def ingest_rate(seed0: int, length: float) -> dict:
         _native.fasta_ingest_many(chunk)  # one call, the library's own thread per core (GenomeAssembly.from_files)
     box = rounds * sum(len(x) for x in chunk) / (time.perf_counter() - t) / 1e6
     best = max(box, box_py)
-    return {"MBps_per_core": round(one, 1), "MBps_per_box": round(best, 1),
+    return {"MBps_per_core": round(one, 1), "MBps_per_core_without_text": round(one_packed_only, 1),
+            "text_path": {0: "table look-ups", 1: "AVX2 + BMI2", 2: "AVX-512 (BW, VBMI2) + BMI2"}[_native.lib().kp_fasta_simd(-1)],
+            "MBps_per_box": round(best, 1),
             "MBps_per_box_python_thread_per_file": round(box_py, 1), "MBps_per_box_one_native_call": round(box, 1), "cores": cores,
             "assemblies_per_s_per_box": round(best * 1e6 / (nbytes / len(texts)), 1),
             "note": "plain FASTA bytes through kp_fasta_ingest (sequence text kept, as GenomeAssembly.from_file needs it); "

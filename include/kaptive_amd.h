@@ -37,6 +37,7 @@ extern "C" {
 #define KP_ESTATE (-4)    /* call out of order (no database loaded, no batch aligned, ...) */
 #define KP_EOVERFLOW (-5) /* an internal device buffer overflowed and the automatic retry also failed */
 #define KP_ENOTSUP (-6)   /* the host lacks what the call needs (kp_fasta_ingest: no libbz2 / liblzma to load) */
+#define KP_EIO (-7)       /* a file could not be opened or mapped (kp_fasta_ingest_file) */
 
 typedef struct kp_ctx kp_ctx;     /* one GPU + stream + resident database */
 typedef struct kp_batch kp_batch; /* a set of packed assemblies resident in HBM, plus its results */
@@ -105,12 +106,21 @@ KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
 #define KP_FASTA_BZ2 4 /* bzip2 stream(s): libbz2 of the host, looked up at first use; KP_ENOTSUP when the host has none */
 #define KP_FASTA_XZ 8  /* .xz stream(s): liblzma of the host, likewise (the reference opens .gz / .bz2 / .xz by suffix) */
 KP_API int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out);
+/* The same from the file itself (GenomeAssembly.from_file, src/kaptive/core/genome.py:194-214, reads the whole file into a
+ * bytes object first): the file is mapped and parsed where the page cache holds it -- no copy of the text is made.
+ * `flags` as above (the caller picks the compression from the suffix, as the reference does); KP_EIO when the path
+ * cannot be opened or is not a regular file. */
+KP_API int kp_fasta_ingest_file(const char *path, int32_t flags, kp_packed_fasta **out);
 /* Many files in one call, on `threads` host threads of the library's own (0 = one per core, at most n_files): file i is
  * data[i][0 .. n[i]) with flags[i]; out[i] and rc[i] are what kp_fasta_ingest would have returned for it.  A reader that
  * feeds a GPU has to turn tens of GB/s of text into packed words; a Python thread per file spends too much of each call
  * holding the interpreter lock.  Returns KP_OK when the arguments were usable (look at rc[] for the files). */
 KP_API int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int32_t *flags, int32_t n_files,
                                 int32_t threads, kp_packed_fasta **out, int32_t *rc);
+/* Which text path the ingest runs on this host: 2 = 64 bytes at a time with AVX-512 (BW, VBMI2) + BMI2, 1 = AVX2 + BMI2,
+ * 0 = table look-ups; settled from cpuid at first use (environment KAPTIVE_AMD_FASTA_SIMD caps it).  cap >= 0 lowers it
+ * for the calls that follow (tests compare the paths), cap < 0 only asks.  All paths give the same bytes. */
+KP_API int kp_fasta_simd(int32_t cap);
 /* The same layout from contigs already in memory (Sequences.seqs / offsets / lengths of the reference's containers,
  * src/kaptive/core/seq.py:307-325): contig c is seqs[offsets[c] .. offsets[c] + lengths[c]).  names / name_off of the
  * result are empty. */

@@ -32,7 +32,7 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_pack_contigs",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
@@ -109,6 +109,7 @@ def pack_contigs(seqs: np.ndarray, offsets: np.ndarray, lengths: np.ndarray):
 
 FASTA_FLAGS = {None: 0, "": 0, False: 0, True: 1, "gz": 1, "bz2": 4, "xz": 8}  # KP_FASTA_GZIP / _BZ2 / _XZ
 ENOTSUP = -6
+EIO = -7
 
 
 def _host_inflate(data: bytes, compression) -> bytes:
@@ -135,6 +136,30 @@ def fasta_ingest(data: bytes, gzipped: "bool | str | None" = False, keep_text: b
     if rc != 0:
         raise ValueError(f"kp_fasta_ingest failed ({rc}): not a readable FASTA / gzip stream, or longer than KP_MAX_ASM_LEN")
     record = _FastaRecord(out)  # frees the native record when the arrays below are gone
+    pa, names = _packed_from(out, True, record)
+    p = out.contents
+    seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)
+    return pa, names, seqs, pa.ctg_len.copy()
+
+
+def fasta_ingest_file(path, gzipped: "bool | str | None" = False, keep_text: bool = True):
+    """``fasta_ingest`` of a file by its path (kp_fasta_ingest_file): the library maps the file, so its text is never
+    copied into a Python bytes object.  Falls back to reading the file here when the path is not a regular file or the
+    host lacks the decompression library."""
+    import os
+
+    h = lib()
+    h.kp_fasta_free.restype = None
+    out = C.POINTER(PackedFasta)()
+    text = 2 if keep_text else 0
+    rc = h.kp_fasta_ingest_file(os.fsencode(path), C.c_int32(FASTA_FLAGS[gzipped] | text), C.byref(out))
+    if rc in (ENOTSUP, EIO):
+        with open(path, "rb") as f:
+            return fasta_ingest(f.read(), gzipped, keep_text)
+    if rc != 0:
+        raise ValueError(f"kp_fasta_ingest_file failed ({rc}) for {path}: not a readable FASTA / compressed stream, or longer "
+                         "than KP_MAX_ASM_LEN")
+    record = _FastaRecord(out)
     pa, names = _packed_from(out, True, record)
     p = out.contents
     seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)

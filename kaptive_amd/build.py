@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     def compile_one(name: str) -> Path:
         src, obj = CSRC / name, objdir / (name + ".o")
         if force or _stale(obj, [src, *headers]):
-            flags = FLAGS if name.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+            # host-only sources are compiled as plain C++ (hipcc would run a device pass over them as well)
+            flags = FLAGS if name.endswith(".hip") else [*(f for f in FLAGS if not f.startswith("--offload-arch")), "-x", "c++"]
             cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)

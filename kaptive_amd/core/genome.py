@@ -124,14 +124,15 @@ class GenomeAssembly:
         m = _FASTA_NAME.search(filepath.name)
         if not m:
             raise NotImplementedError(f"Unsupported format: {filepath}")
-        # One native pass from the file's bytes to contigs + packed form (kp_fasta_ingest; zlib inflates .gz there).  The
+        # One native pass from the file (mapped by the library, never copied into a bytes object) to contigs + packed form
+        # (kp_fasta_ingest_file; zlib inflates .gz there).  The
         # reference opens by suffix, reads everything and hands the bytes to rammappy's parser (genome.py:194-214, 35-46).
         from kaptive_amd import _native
 
         comp = m.group("compression")  # None, "gz", "bz2" or "xz": all inflated natively (zlib; libbz2 / liblzma of the host)
         # (keep_text=False: contig names, lengths and the packed form only -- enough for typing and the TSV report)
         return cls._from_ingest(filepath.name.removesuffix(m.group()),
-                                _native.fasta_ingest(filepath.read_bytes(), gzipped=comp, keep_text=keep_text))
+                                _native.fasta_ingest_file(filepath, gzipped=comp, keep_text=keep_text))
 
     @classmethod
     def _from_ingest(cls, id_: str, ingested) -> "GenomeAssembly":

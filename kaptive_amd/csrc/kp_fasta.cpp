@@ -6,6 +6,11 @@
 // whitespace removed; A C G T/U (either case) -> 0..3, anything else is an N run.  No GPU involved; ctypes releases the
 // GIL, so callers pack many files from a thread pool.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <immintrin.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -245,6 +250,9 @@ int unxz_all(const uint8_t *data, int64_t n, std::vector<uint8_t> &out) {
 }
 
 int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **out);
+int detect_simd();
+int simd_level();
+extern std::atomic<int> g_simd;
 
 }  // namespace
 
@@ -269,6 +277,41 @@ int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fas
     return pack_text(data, n, (flags & KP_FASTA_KEEP_TEXT) != 0, out);
 }
 
+// The file itself: mapped, not read -- a read() would copy the text once more (as much time as the parse takes on the
+// vector paths), and a Python caller would do that copy into a freshly allocated bytes object, page faults included.
+int kp_fasta_ingest_file(const char *path, int32_t flags, kp_packed_fasta **out) {
+    if (!out || !path) return KP_EINVAL;
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return KP_EIO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {  // (a pipe or a device: the caller reads it and passes the bytes)
+        close(fd);
+        return KP_EIO;
+    }
+    int rc;
+    if (st.st_size == 0) {
+        rc = kp_fasta_ingest(reinterpret_cast<const uint8_t *>(""), 0, flags, out);
+    } else {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m == MAP_FAILED) {
+            close(fd);
+            return KP_EIO;
+        }
+        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        rc = kp_fasta_ingest(static_cast<const uint8_t *>(m), (int64_t)st.st_size, flags, out);
+        munmap(m, (size_t)st.st_size);
+    }
+    close(fd);
+    return rc;
+}
+
+int kp_fasta_simd(int32_t cap) {
+    const int have = detect_simd();
+    if (cap >= 0) g_simd.store(std::min(have, (int)cap), std::memory_order_relaxed);
+    return simd_level();
+}
+
 int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int32_t *flags, int32_t n_files, int32_t threads,
                          kp_packed_fasta **out, int32_t *rc) {
     if (n_files < 0 || (n_files > 0 && (!data || !n || !flags || !out || !rc))) return KP_EINVAL;
@@ -290,45 +333,289 @@ int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int
 
 namespace {
 
+// ---- the sequence lines of one record ----------------------------------------------------------------------------------
+// 64 bytes of text at a time: every byte is classed at once -- base (A C G T U, either case), whitespace, anything else --
+// and the 2-bit codes of the bases come out of the bytes' own bits: code = (bit 1 ^ bit 2) + 2 * (bit 2 ^ bit 3) of the
+// ASCII value ('A' 0x41 -> 0, 'C' 0x43 -> 1, 'G' 0x47 -> 2, 'T' 0x54 / 'U' 0x55 -> 3; bit 5, the case, takes no part).  The
+// two bit planes leave the vector as 64-bit masks; whitespace is squeezed out of the MASKS (pext), not out of the bytes,
+// and the planes are interleaved into packed words (pdep).  Line ends are not looked for at all: a chunk stops at the
+// first byte that is neither base nor whitespace, which is looked at on its own (an N-run symbol, or the '>' of the next
+// header when the byte before it ended a line).  One core turns ~9 GB/s of plain FASTA into words this way (scalar table
+// look-ups: 2.9); which path runs is settled once from cpuid (kp_fasta_simd).
+struct Masks { uint64_t base, ws, nl, b0, b1; };  // per byte of the chunk: is a base / whitespace / '\n'; code bit 0 / 1
+
+#define KP_T512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,avx2,bmi,bmi2,popcnt,lzcnt")))
+#define KP_T256 __attribute__((target("avx2,bmi,bmi2,popcnt,lzcnt")))
+
+alignas(16) const uint8_t BASE_BY_NIBBLE[16] = {0xFF, 'A', 0xFF, 'C', 'T', 'U', 0xFF, 'G', 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+
+KP_T512 inline Masks classify512(__m512i v) {
+    const __m512i lut = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i *)BASE_BY_NIBBLE));
+    // the upper-case letter a base with this low nibble would be (bytes >= 0x80 look up 0): equal to the byte's own
+    // upper case exactly for the ten base symbols
+    const __m512i up = _mm512_and_si512(v, _mm512_set1_epi8((char)0xDF));
+    const __m512i t = _mm512_xor_si512(v, _mm512_srli_epi16(v, 1));  // bits 1 and 2: the code (bit 7 takes a neighbour's bit: unused)
+    Masks m;
+    m.base = _mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(lut, v), up);
+    m.ws = _mm512_cmple_epu8_mask(_mm512_sub_epi8(v, _mm512_set1_epi8(9)), _mm512_set1_epi8(4)) | _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8(32));
+    m.nl = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('\n'));
+    m.b0 = _mm512_test_epi8_mask(t, _mm512_set1_epi8(2));
+    m.b1 = _mm512_test_epi8_mask(t, _mm512_set1_epi8(4));
+    return m;
+}
+
+KP_T256 inline void classify256(__m256i v, uint32_t &base, uint32_t &ws, uint32_t &nl, uint32_t &b0, uint32_t &b1) {
+    const __m256i lut = _mm256_broadcastsi128_si256(_mm_load_si128((const __m128i *)BASE_BY_NIBBLE));
+    const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
+    const __m256i t = _mm256_xor_si256(v, _mm256_srli_epi16(v, 1));
+    const __m256i d = _mm256_sub_epi8(v, _mm256_set1_epi8(9));  // 9..13 -> 0..4: (d min 4) == d
+    base = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, v), up));
+    ws = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(_mm256_min_epu8(d, _mm256_set1_epi8(4)), d),
+                                                        _mm256_cmpeq_epi8(v, _mm256_set1_epi8(32))));
+    nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('\n')));
+    b0 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 6));  // bit 1 of every byte -> its bit 7
+    b1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 5));
+}
+
+// 2-bit writer for the vector paths: up to 32 bases per call through a 64-bit accumulator, 64 bits leave it at a time
+struct Packer64 {
+    uint32_t *wp;
+    uint64_t acc = 0;
+    int nb = 0;       // bits waiting in acc (even, < 64)
+    int64_t pos = 0;  // bases written (padded space)
+    explicit Packer64(uint32_t *w) : wp(w) {}
+    inline void put_n(uint64_t bits, int n_bases) {  // bits: 2 * n_bases valid bits, zero above; n_bases <= 32
+        acc |= bits << nb;
+        int tot = nb + 2 * n_bases;
+        if (tot >= 64) {
+            std::memcpy(wp, &acc, 8);
+            wp += 2;
+            acc = nb ? bits >> (64 - nb) : 0;
+            tot -= 64;
+        }
+        nb = tot;
+        pos += n_bases;
+    }
+    inline void put(uint32_t code) { put_n(code, 1); }
+    inline void pad_to(int64_t align) {
+        for (int64_t k = (align - pos % align) % align; k > 0;) {
+            const int t = k > 32 ? 32 : (int)k;
+            put_n(0, t);
+            k -= t;
+        }
+    }
+    inline void flush() {  // (pos is a multiple of 16 here)
+        if (nb) { std::memcpy(wp, &acc, 4); wp += 1; acc = 0; nb = 0; }
+    }
+};
+
+struct Body {  // what the body loops share with pack_text
+    Packer64 &pk;
+    std::vector<int32_t> &runs;
+    uint8_t *&dp;  // sequence text kept (nullptr: not kept)
+    bool in_run = false;
+};
+
+// one symbol that is not a base (nor whitespace): part of an N run
+inline void put_other(Body &b, uint8_t c) {
+    if (!b.in_run) { b.runs.push_back((int32_t)b.pk.pos); b.runs.push_back((int32_t)b.pk.pos); b.in_run = true; }
+    b.runs.back() = (int32_t)b.pk.pos + 1;
+    b.pk.put(0);
+    if (b.dp) *b.dp++ = c;
+}
+
+// the first `take` bytes of a classified chunk (all of them bases or whitespace) -> packed words (+ text)
+KP_T256 inline void emit_bits(Body &b, const Masks &m, int take) {
+    const uint64_t keep = m.base & (take >= 64 ? ~0ull : ((1ull << take) - 1ull));
+    const int n_bases = (int)_mm_popcnt_u64(keep);
+    if (!n_bases) return;
+    b.in_run = false;
+    const uint64_t c0 = _pext_u64(m.b0, keep), c1 = _pext_u64(m.b1, keep);
+    const uint64_t lo = _pdep_u64(c0, 0x5555555555555555ull) | _pdep_u64(c1, 0xAAAAAAAAAAAAAAAAull);
+    if (n_bases <= 32) {
+        b.pk.put_n(lo, n_bases);
+    } else {
+        b.pk.put_n(lo, 32);
+        b.pk.put_n(_pdep_u64(c0 >> 32, 0x5555555555555555ull) | _pdep_u64(c1 >> 32, 0xAAAAAAAAAAAAAAAAull), n_bases - 32);
+    }
+}
+
+// Sequence lines from data[i] (a line start) up to the next line that starts with '>' or the end of the text; returns
+// the index it stopped at.  LEVEL 2: AVX-512 (BW, VBMI2), 1: AVX2; both need BMI2.
+template <int LEVEL>
+KP_T256 inline int64_t scalar_stretch(Body &b, const uint8_t *data, int64_t i, int64_t n, bool &line_start, bool &header) {
+    // symbols that are not bases, and the whitespace between them, one at a time: until a base or a header turns up
+    header = false;
+    while (i < n) {
+        const uint8_t c = data[i], code = T.code[c];
+        if (code == 8) { line_start = c == '\n'; ++i; continue; }
+        if (c == '>' && line_start) { header = true; break; }
+        if (code < 4) break;
+        put_other(b, c);
+        line_start = false;
+        ++i;
+    }
+    return i;
+}
+
+KP_T512 int64_t body512(Body &b, const uint8_t *data, int64_t i, int64_t n) {
+    bool line_start = true, header = false;
+    while (i < n) {
+        if (b.pk.pos > (int64_t)KP_MAX_ASM_LEN) return -1;
+        const int64_t left = n - i;
+        const __mmask64 in = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        const __m512i v = _mm512_maskz_loadu_epi8(in, data + i);
+        const Masks m = classify512(v);
+        const uint64_t bad = ~(m.base | m.ws);  // (bytes past the end of the text read as 0: bad)
+        const int take = bad ? (int)_tzcnt_u64(bad) : 64;
+        if (take) {
+            if (b.dp) {
+                const uint64_t keep = m.base & (take >= 64 ? ~0ull : ((1ull << take) - 1ull));
+                _mm512_storeu_si512((void *)b.dp, _mm512_maskz_compress_epi8(keep, v));  // (the block has 64 bytes of slack)
+                b.dp += _mm_popcnt_u64(keep);
+            }
+            emit_bits(b, m, take);
+            line_start = (m.nl >> (take - 1)) & 1u;
+            i += take;
+        }
+        if (take < 64 && i < n) {
+            i = scalar_stretch<2>(b, data, i, n, line_start, header);
+            if (header) break;
+        }
+    }
+    return i;
+}
+
+KP_T256 int64_t body256(Body &b, const uint8_t *data, int64_t i, int64_t n) {
+    bool line_start = true, header = false;
+    while (i < n) {
+        if (b.pk.pos > (int64_t)KP_MAX_ASM_LEN) return -1;
+        int take = 0;
+        if (n - i >= 64) {
+            Masks m;
+            uint32_t a[5], c[5];
+            classify256(_mm256_loadu_si256((const __m256i *)(data + i)), a[0], a[1], a[2], a[3], a[4]);
+            classify256(_mm256_loadu_si256((const __m256i *)(data + i + 32)), c[0], c[1], c[2], c[3], c[4]);
+            m.base = a[0] | (uint64_t)c[0] << 32; m.ws = a[1] | (uint64_t)c[1] << 32; m.nl = a[2] | (uint64_t)c[2] << 32;
+            m.b0 = a[3] | (uint64_t)c[3] << 32; m.b1 = a[4] | (uint64_t)c[4] << 32;
+            const uint64_t bad = ~(m.base | m.ws);
+            take = bad ? (int)_tzcnt_u64(bad) : 64;
+            if (take) {
+                if (b.dp) {  // the text without its whitespace: runs of bases copied as they lie
+                    uint64_t keep = m.base & (take >= 64 ? ~0ull : ((1ull << take) - 1ull));
+                    while (keep) {
+                        const int s = (int)_tzcnt_u64(keep);
+                        const uint64_t rest = ~(keep >> s);
+                        const int len = rest ? (int)_tzcnt_u64(rest) : 64 - s;
+                        std::memcpy(b.dp, data + i + s, (size_t)len);
+                        b.dp += len;
+                        keep = s + len >= 64 ? 0 : keep & ~((1ull << (s + len)) - 1ull);
+                    }
+                }
+                emit_bits(b, m, take);
+                line_start = (m.nl >> (take - 1)) & 1u;
+                i += take;
+            }
+            if (take == 64) continue;
+        }
+        if (i < n) {
+            // the chunk's first odd symbol, or the last bytes of the text: a base goes through the packer on its own
+            const uint8_t ch = data[i], code = T.code[ch];
+            if (code < 4) {
+                b.in_run = false;
+                b.pk.put(code);
+                if (b.dp) *b.dp++ = ch;
+                line_start = false;
+                ++i;
+                continue;
+            }
+            i = scalar_stretch<1>(b, data, i, n, line_start, header);
+            if (header) break;
+        }
+    }
+    return i;
+}
+
+int64_t body_scalar(Body &b, const uint8_t *data, int64_t i, int64_t n) {
+    auto slow = [&](const uint8_t *p, const uint8_t *e) {  // symbol by symbol: whitespace dropped, N runs recorded
+        for (; p < e; ++p) {
+            const uint8_t c = T.code[*p];
+            if (c == 8) continue;
+            if (c == 4) { put_other(b, *p); continue; }
+            b.in_run = false;
+            b.pk.put(c);
+            if (b.dp) *b.dp++ = *p;
+        }
+    };
+    while (i < n && data[i] != '>') {
+        const uint8_t *nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
+        const uint8_t *p = data + i, *e = nl ? nl : data + n;
+        i = nl ? (nl - data) + 1 : n;
+        for (; e - p >= 16; p += 16) {  // 16 symbols at a time while they are plain bases
+            uint32_t w = 0, seen = 0;
+#pragma GCC unroll 16
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t c = T.code[p[k]];
+                seen |= c;
+                w |= (c & 3u) << (2 * k);
+            }
+            if (seen & 12u) slow(p, p + 16);
+            else {
+                b.in_run = false;
+                b.pk.put_n(w, 16);
+                if (b.dp) { std::memcpy(b.dp, p, 16); b.dp += 16; }
+            }
+        }
+        slow(p, e);
+        if (b.pk.pos > (int64_t)KP_MAX_ASM_LEN) return -1;
+    }
+    return i;
+}
+
+int detect_simd() {
+    __builtin_cpu_init();
+    if (!__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("popcnt")) return 0;
+    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+        __builtin_cpu_supports("avx512vbmi2"))
+        return 2;
+    return 1;
+}
+std::atomic<int> g_simd{-1};
+int simd_level() {
+    int l = g_simd.load(std::memory_order_relaxed);
+    if (l < 0) {
+        l = detect_simd();
+        if (const char *e = std::getenv("KAPTIVE_AMD_FASTA_SIMD")) l = std::min(l, std::max(0, std::atoi(e)));
+        g_simd.store(l, std::memory_order_relaxed);
+    }
+    return l;
+}
+
 int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **out) {
-    // every '>' may open a contig (32-base alignment: at most two more words each); sequence bytes give <= n bases
-    size_t marks = 0;
-    for (const uint8_t *p = data, *e = data + n; p < e && (p = (const uint8_t *)std::memchr(p, '>', (size_t)(e - p))); ++p) ++marks;
-    const size_t n_words_max = (size_t)n / 16 + 2 * marks + 8;
+    // Room for the words: every symbol is at most one base and every contig starts on a 32-base boundary (two words at
+    // most).  The contigs are not counted ahead (that would be a pass over the text of its own): the block starts with
+    // room for one contig per 2 KB and, should a file have more, the '>' of the rest are counted then and the block grows.
+    int64_t marks_left = -1;  // '>' from the current header on; -1: not counted yet
+    size_t n_words_max = (size_t)n / 16 + 2 * (256 + (size_t)n / 2048) + 16;
     size_t words_cap = 0, seqs_cap = 0;
     uint32_t *words = (uint32_t *)g_pool.take(n_words_max * 4, &words_cap);
-    uint8_t *dense = keep_text ? (uint8_t *)g_pool.take((size_t)n + 16, &seqs_cap) : nullptr;  // the contigs' symbols as written
+    uint8_t *dense = keep_text ? (uint8_t *)g_pool.take((size_t)n + 80, &seqs_cap) : nullptr;  // the contigs' symbols as written
     uint8_t *dp = dense;                                                                          // (whitespace removed), back to back
     struct Guard {  // blocks go back to the pool on every early return
         uint32_t *&w; size_t &wc; uint8_t *&d; size_t &dc; bool armed = true;
         ~Guard() { if (armed) { g_pool.give(w, wc); g_pool.give(d, dc); } }
     } guard{words, words_cap, dense, seqs_cap};
     if (!words || (keep_text && !dense)) return KP_ENOMEM;
-    std::memset(words, 0, n_words_max * 4);
     std::vector<int32_t> ctg_start, ctg_len, runs, name_off;
     std::string names;
-    Packer pk(words);
+    Packer64 pk(words);
+    Body body{pk, runs, dp};
+    const int level = simd_level();
     int64_t i = 0;
     while (i < n && data[i] != '>') {  // text before the first header is ignored
         const uint8_t *nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
         i = nl ? (nl - data) + 1 : n;
     }
-    bool in_run = false;
-    auto slow = [&](const uint8_t *p, const uint8_t *e) {  // symbol by symbol: whitespace dropped, N runs recorded
-        for (; p < e; ++p) {
-            const uint8_t c = T.code[*p];
-            if (c == 8) continue;
-            if (keep_text) *dp++ = *p;
-            if (c == 4) {
-                if (!in_run) { runs.push_back((int32_t)pk.pos); runs.push_back((int32_t)pk.pos); in_run = true; }
-                runs.back() = (int32_t)pk.pos + 1;
-                pk.put(0);
-            } else {
-                in_run = false;
-                pk.put(c);
-            }
-        }
-    };
     while (i < n) {
         // header line: the record's name is its first word
         int64_t j = i + 1;
@@ -336,40 +623,40 @@ int pack_text(const uint8_t *data, int64_t n, bool keep_text, kp_packed_fasta **
         name_off.push_back((int32_t)names.size());
         names.append((const char *)data + i + 1, (size_t)(j - i - 1));
         const uint8_t *nl = (const uint8_t *)std::memchr(data + j, '\n', (size_t)(n - j));
+        const int64_t header_at = i;
         i = nl ? (nl - data) + 1 : n;
         // sequence lines up to the next line that starts with '>'
         pk.pad_to(KP_CONTIG_ALIGN);
         if (pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
-        const int64_t start = pk.pos;
-        in_run = false;
-        while (i < n && data[i] != '>') {
-            nl = (const uint8_t *)std::memchr(data + i, '\n', (size_t)(n - i));
-            const uint8_t *p = data + i, *e = nl ? nl : data + n;
-            i = nl ? (nl - data) + 1 : n;
-            for (; e - p >= 16; p += 16) {  // 16 symbols at a time while they are plain bases
-                uint32_t w = 0, seen = 0;
-#pragma GCC unroll 16
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t c = T.code[p[k]];
-                    seen |= c;
-                    w |= (c & 3u) << (2 * k);
-                }
-                if (seen & 12u) slow(p, p + 16);
-                else {
-                    in_run = false;
-                    pk.put16(w);
-                    if (keep_text) { std::memcpy(dp, p, 16); dp += 16; }
-                }
+        if (marks_left > 0) --marks_left;
+        const size_t need = (size_t)(pk.pos + (n - i) + 64) / 16 + 8 + (marks_left > 0 ? 2 * (size_t)marks_left : 0);
+        if (need > n_words_max) {
+            if (marks_left < 0) {
+                marks_left = 0;
+                for (const uint8_t *p = data + header_at + 1, *e = data + n; p < e && (p = (const uint8_t *)std::memchr(p, '>', (size_t)(e - p))); ++p) ++marks_left;
             }
-            slow(p, e);
-            if (pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
+            const size_t grown = need + 2 * (size_t)marks_left + 64;
+            size_t cap2 = 0;
+            uint32_t *w2 = (uint32_t *)g_pool.take(grown * 4, &cap2);
+            if (!w2) return KP_ENOMEM;
+            const size_t done = (size_t)(pk.wp - words);
+            std::memcpy(w2, words, done * 4);
+            g_pool.give(words, words_cap);
+            words = w2; words_cap = cap2; n_words_max = grown;
+            pk.wp = words + done;
         }
+        const int64_t start = pk.pos;
+        body.in_run = false;
+        i = level == 2 ? body512(body, data, i, n) : level == 1 ? body256(body, data, i, n) : body_scalar(body, data, i, n);
+        if (i < 0 || pk.pos > (int64_t)KP_MAX_ASM_LEN) return KP_EINVAL;
         ctg_start.push_back((int32_t)start);
         ctg_len.push_back((int32_t)(pk.pos - start));
     }
     name_off.push_back((int32_t)names.size());
     pk.pad_to(KP_ASM_ALIGN);
+    pk.flush();
     const int64_t pos = pk.pos;
+    std::memset(pk.wp, 0, 16);  // (nothing reads past padded_len / 16 words; a zeroed line's worth for good measure)
 
     Owned *r = new (std::nothrow) Owned();
     if (!r) return KP_ENOMEM;

@@ -67,6 +67,12 @@ def pack_contigs(contigs: Sequences) -> PackedAssembly:
     edges = np.flatnonzero(n_mask[1:] != n_mask[:-1]) + 1
     if n_mask[0]:
         edges = np.r_[0, edges]
+    # a run never spans two contigs (kp_fasta_ingest / kp_pack_contigs start a new one with every contig): where a contig
+    # that fills its slot ends in an ambiguous base and the next one starts with one, the run is cut at the boundary
+    inner = np.unique(starts[1:])  # (empty contigs share their start with the next one)
+    cut = inner[n_mask[inner - 1] & n_mask[inner]] if len(inner) else inner
+    if len(cut):
+        edges = np.sort(np.r_[edges, cut, cut], kind="stable")
     runs = edges.reshape(-1, 2).astype(np.int32) if len(edges) else np.empty((0, 2), np.int32)
     return PackedAssembly(
         codes_to_words(codes) if padded else np.empty(0, np.uint32),

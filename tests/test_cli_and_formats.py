@@ -55,46 +55,61 @@ def test_fasta_parsers_and_native_pack_agree(tmp_path):
         assert len(nm) == len(parse_fasta_bytes(blob)) and pa.padded_len % 64 == 0
 
 
-def test_native_pack_fuzz_against_the_python_packer():
-    """Random FASTA text -- line widths around the packer's 16-symbol blocks, lower case, U, IUPAC / N runs that cross
-    line ends, blanks and tabs inside lines, CR LF, empty records, no final newline -- packs to what the numpy path
-    (parse_fasta_bytes + pack_contigs) gives."""
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_native_pack_fuzz_against_the_python_packer(level):
+    """Random FASTA text -- line widths around the packer's 16-symbol blocks and 64-byte chunks, lower case, U, IUPAC / N
+    runs that cross line ends, '>' inside a line, bytes above 0x7F, blanks and tabs inside lines, CR LF, empty records, no
+    final newline -- packs to what the numpy path (parse_fasta_bytes + pack_contigs) gives, on every text path of the
+    ingest (kp_fasta_simd: table look-ups, AVX2, AVX-512), with and without the sequence text kept."""
     from kaptive_amd.core.seq import SeqRecord, Sequences
     from kaptive_amd.pack import pack_contigs
 
-    rng = np.random.default_rng(99)
-    alphabet = np.frombuffer(b"ACGTacgtUuNnRYKM-*", np.uint8)
-    for trial in range(60):
-        lines, eol = [], (b"\r\n" if trial % 3 == 0 else b"\n")
-        if trial % 4 == 0:
-            lines.append(b"leading junk line")
-        for r in range(int(rng.integers(0, 6))):
-            n = int(rng.choice([0, 1, 15, 16, 17, 31, 33, 200, 1000]))
-            p_odd = float(rng.choice([0.0, 0.02, 0.3]))
-            seq = np.where(rng.random(n) < p_odd, alphabet[rng.integers(8, len(alphabet), n)], alphabet[rng.integers(0, 8, n)])
-            seq = seq.astype(np.uint8).tobytes()
-            lines.append(b">rec%d_%d %s" % (trial, r, b"desc here" if r % 2 else b""))
-            width = int(rng.choice([1, 7, 16, 17, 32, 60, 61, 80]))
-            for j in range(0, n, width):
-                chunk = seq[j : j + width]
-                if rng.random() < 0.1 and len(chunk) > 2:
-                    k = int(rng.integers(1, len(chunk)))
-                    chunk = chunk[:k] + (b" " if rng.random() < 0.5 else b"\t") + chunk[k:]
-                lines.append(chunk)
-            if rng.random() < 0.3:
-                lines.append(b"")
-        text = eol.join(lines) + (eol if trial % 5 else b"")
-        recs = parse_fasta_bytes(text)
-        want = pack_contigs(Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs]))
-        got, names = _native.fasta_pack(text)
-        seqs = Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs])
-        direct = _native.pack_contigs(seqs.seqs, seqs.offsets, seqs.lengths)  # the same contigs, already in memory
-        assert direct.padded_len == want.padded_len and all(
-            np.array_equal(getattr(direct, f), getattr(want, f)) for f in ("words", "ctg_start", "ctg_len", "n_runs")), trial
-        assert list(names) == [nm for nm, _ in recs], trial
-        assert got.padded_len == want.padded_len, trial
-        for f in ("words", "ctg_start", "ctg_len", "n_runs"):
-            assert np.array_equal(getattr(got, f), getattr(want, f)), (trial, f)
+    h = _native.lib()
+    if h.kp_fasta_simd(level) != level:
+        h.kp_fasta_simd(99)
+        pytest.skip(f"this host's CPU has no level-{level} path")
+    try:
+        rng = np.random.default_rng(99)
+        alphabet = np.frombuffer(b"ACGTacgtUuNnRYKM-*>\x80\xff\x00\x7f@`", np.uint8)
+        for trial in range(90):
+            lines, eol = [], (b"\r\n" if trial % 3 == 0 else b"\n")
+            if trial % 4 == 0:
+                lines.append(b"leading junk line")
+            n_rec = int(rng.integers(0, 6)) if trial % 10 else 700  # (700 short records: the word block has to grow)
+            for r in range(n_rec):
+                n = int(rng.choice([0, 1, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 1000, 5000]))
+                p_odd = float(rng.choice([0.0, 0.02, 0.3, 0.95]))
+                seq = np.where(rng.random(n) < p_odd, alphabet[rng.integers(8, len(alphabet), n)], alphabet[rng.integers(0, 8, n)])
+                seq = seq.astype(np.uint8).tobytes()
+                lines.append(b">rec%d_%d %s" % (trial, r, b"desc here" if r % 2 else b""))
+                width = int(rng.choice([1, 7, 16, 17, 32, 60, 61, 63, 64, 65, 80, 127, 128, 4000]))
+                for j in range(0, n, width):
+                    chunk = seq[j : j + width]
+                    if chunk[:1] == b">":  # (at a line start that would be a header: the reference parser's reading too)
+                        chunk = b"N" + chunk[1:]
+                    if rng.random() < 0.1 and len(chunk) > 2:
+                        k = int(rng.integers(1, len(chunk)))
+                        chunk = chunk[:k] + (b" " if rng.random() < 0.5 else b"\t") + chunk[k:]
+                    lines.append(chunk)
+                if rng.random() < 0.3:
+                    lines.append(b"")
+            text = eol.join(lines) + (eol if trial % 5 else b"")
+            recs = parse_fasta_bytes(text)
+            want = pack_contigs(Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs]))
+            got, names = _native.fasta_pack(text)
+            seqs = Sequences.from_records([SeqRecord(nm, sq) for nm, sq in recs])
+            direct = _native.pack_contigs(seqs.seqs, seqs.offsets, seqs.lengths)  # the same contigs, already in memory
+            assert direct.padded_len == want.padded_len and all(
+                np.array_equal(getattr(direct, f), getattr(want, f)) for f in ("words", "ctg_start", "ctg_len", "n_runs")), trial
+            assert list(names) == [nm for nm, _ in recs], trial
+            assert got.padded_len == want.padded_len, trial
+            for f in ("words", "ctg_start", "ctg_len", "n_runs"):
+                assert np.array_equal(getattr(got, f), getattr(want, f)), (trial, f)
+            pa, names2, kept, lengths = _native.fasta_ingest(text, keep_text=True)
+            assert list(names2) == list(names) and np.array_equal(pa.words, want.words) and np.array_equal(pa.n_runs, want.n_runs)
+            assert kept.tobytes() == b"".join(sq for _, sq in recs) and lengths.tolist() == [len(sq) for _, sq in recs], trial
+    finally:
+        h.kp_fasta_simd(99)
 
 
 @pytest.mark.parametrize("kind", ["kpsc_k", "kpsc_o"])
