@@ -117,6 +117,27 @@ KP_API int kp_fasta_ingest_file(const char *path, int32_t flags, kp_packed_fasta
  * holding the interpreter lock.  Returns KP_OK when the arguments were usable (look at rc[] for the files). */
 KP_API int kp_fasta_ingest_many(const uint8_t *const *data, const int64_t *n, const int32_t *flags, int32_t n_files,
                                 int32_t threads, kp_packed_fasta **out, int32_t *rc);
+/* A chunk of files -> the tables of one batch, for a reader that feeds a GPU from FASTA files (the reference reads, parses
+ * and indexes one file at a time on its worker threads, src/kaptive/serotyping/cli.py:183-210, core/genome.py:177-214).
+ * kp_fasta_ingest_shard parses the files (kp_fasta_ingest_file, sequence text not kept) on `threads` threads of the library
+ * (0 = one per core) and lays the tables out exactly as kp_batch_create* takes them; a file that failed is an empty
+ * assembly here, rc[i] holds its code (n_failed / first_failed say whether to look).  kp_shard_words_into then copies the
+ * packed words of all assemblies back to back into `dst` (total_words of them; page-locked memory the caller sized after
+ * the first call) and releases the per-file buffers; the tables stay valid until kp_shard_free. */
+typedef struct kp_packed_shard {
+    int32_t n_asm, n_failed, first_failed;
+    int64_t total_words;
+    int64_t *asm_word_off;                /* n_asm + 1 */
+    int32_t *ctg_start, *ctg_len;         /* asm_first_ctg[n_asm] each */
+    int32_t *asm_first_ctg;               /* n_asm + 1 */
+    int32_t *n_runs;                      /* 2 * asm_first_nrun[n_asm] */
+    int32_t *asm_first_nrun;              /* n_asm + 1 */
+    int32_t *rc;                          /* n_asm */
+} kp_packed_shard;
+KP_API int kp_fasta_ingest_shard(const char *const *paths, const int32_t *flags, int32_t n_files, int32_t threads,
+                                 kp_packed_shard **out);
+KP_API int kp_shard_words_into(kp_packed_shard *shard, uint32_t *dst, int64_t dst_words, int32_t threads);
+KP_API void kp_shard_free(kp_packed_shard *shard);
 /* Which text path the ingest runs on this host: 2 = 64 bytes at a time with AVX-512 (BW, VBMI2) + BMI2, 1 = AVX2 + BMI2,
  * 0 = table look-ups; settled from cpuid at first use (environment KAPTIVE_AMD_FASTA_SIMD caps it).  cap >= 0 lowers it
  * for the calls that follow (tests compare the paths), cap < 0 only asks.  All paths give the same bytes. */

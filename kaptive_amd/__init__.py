@@ -24,6 +24,28 @@ def tune_runtime(hw_queues: int = 16) -> bool:
     return not _native.is_loaded()
 
 
+def usable_cpus() -> int:
+    """CPUs this process may keep busy: the affinity mask cut down to the cgroup's CPU quota (a container that sees 256
+    CPUs and is granted 16 CPUs' worth of time runs 256 reader threads no faster than 16, and slower for the switching)."""
+    n = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 __version__ = "0.1.0"
 # Version string written into TSV/JSON rows where the reference writes kaptive.__version__
 # (reference: src/kaptive/serotyping/core.py:463).

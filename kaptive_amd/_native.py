@@ -32,7 +32,7 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_simd", "kp_pack_contigs",
+    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
@@ -164,6 +164,70 @@ def fasta_ingest_file(path, gzipped: "bool | str | None" = False, keep_text: boo
     p = out.contents
     seqs = record.view(p.seqs, int(p.n_seq_bytes), C.c_uint8, np.uint8)
     return pa, names, seqs, pa.ctg_len.copy()
+
+
+class _PackedShard(C.Structure):  # kp_packed_shard
+    _fields_ = [("n_asm", C.c_int32), ("n_failed", C.c_int32), ("first_failed", C.c_int32), ("total_words", C.c_int64),
+                ("asm_word_off", C.POINTER(C.c_int64)), ("ctg_start", C.POINTER(C.c_int32)), ("ctg_len", C.POINTER(C.c_int32)),
+                ("asm_first_ctg", C.POINTER(C.c_int32)), ("n_runs", C.POINTER(C.c_int32)), ("asm_first_nrun", C.POINTER(C.c_int32)),
+                ("rc", C.POINTER(C.c_int32))]  # fmt: skip
+
+
+class FastaShard:
+    """A chunk of FASTA files parsed and packed by the library's own threads (kp_fasta_ingest_shard), held as the tables
+    of one batch: no per-file Python work at all -- with a Python call per file, names and arrays included, the interpreter
+    lock capped a reader pool at ~6.5 k files/s whatever the parser did.  ``words_into`` copies the packed words into
+    page-locked memory (kp_shard_words_into); ``Batch(ctx, tables=shard.tables(), pinned_words=...)`` uploads them."""
+
+    def __init__(self, paths, compressions, threads: int = 0) -> None:
+        import os
+
+        h = lib()
+        h.kp_shard_free.restype = None
+        n = len(paths)
+        self._paths = [os.fsencode(p) for p in paths]
+        arr = (C.c_char_p * max(n, 1))(*self._paths)
+        fl = (C.c_int32 * max(n, 1))(*[FASTA_FLAGS[c] for c in compressions])
+        self._h = C.POINTER(_PackedShard)()
+        rc = h.kp_fasta_ingest_shard(arr, fl, C.c_int32(n), C.c_int32(threads), C.byref(self._h))
+        if rc != 0:
+            raise MemoryError(f"kp_fasta_ingest_shard failed ({rc})")
+        sh = self._h.contents
+        self.n_asm, self.total_words = n, int(sh.total_words)
+        self.failed = []
+        if sh.n_failed:
+            self.failed = [(i, int(sh.rc[i])) for i in range(n) if sh.rc[i] != 0]
+
+    def tables(self) -> tuple:
+        """(asm_word_off, ctg_start, ctg_len, asm_first_ctg, n_runs, asm_first_nrun): views of the library's arrays, valid
+        while this object lives."""
+        sh, n = self._h.contents, self.n_asm
+
+        def view(ptr, k, dt):
+            return np.ctypeslib.as_array(ptr, shape=(k,)) if k else np.empty(0, dt)
+
+        first_ctg = view(sh.asm_first_ctg, n + 1, np.int32)
+        first_run = view(sh.asm_first_nrun, n + 1, np.int32)
+        nc, nr = (int(first_ctg[-1]), int(first_run[-1])) if n else (0, 0)
+        return (view(sh.asm_word_off, n + 1, np.int64), view(sh.ctg_start, nc, np.int32), view(sh.ctg_len, nc, np.int32),
+                first_ctg, view(sh.n_runs, 2 * nr, np.int32), first_run)
+
+    def words_into(self, dst: np.ndarray, threads: int = 0) -> None:
+        if dst.dtype != np.uint32 or not dst.flags.c_contiguous or len(dst) < self.total_words:
+            raise ValueError("words_into needs a contiguous uint32 array of at least total_words")
+        rc = lib().kp_shard_words_into(self._h, _p(dst), C.c_int64(len(dst)), C.c_int32(threads))
+        if rc != 0:
+            raise RuntimeError(f"kp_shard_words_into failed ({rc})")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            try:
+                lib().kp_shard_free(self._h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
 
 
 def compression_is_native() -> bool:
@@ -459,36 +523,43 @@ class Context:
         return out
 
     def batch(self, packed: list, device_words: int | None = None, pinned_words: "np.ndarray | None" = None,
-              after: "Batch | None" = None) -> "Batch":
-        return Batch(self, packed, device_words, pinned_words, after)
+              after: "Batch | None" = None, tables: "tuple | None" = None) -> "Batch":
+        return Batch(self, packed, device_words, pinned_words, after, tables)
 
 
 class Batch:
     """Packed assemblies resident on the device (kp_batch). ``packed`` is a list of PackedAssembly; with
     ``device_words`` (a device pointer to the concatenated words) nothing but the small tables is copied."""
 
-    def __init__(self, ctx: Context, packed: list, device_words: int | None = None,
-                 pinned_words: "np.ndarray | None" = None, after: "Batch | None" = None) -> None:
+    def __init__(self, ctx: Context, packed: "list | None", device_words: int | None = None,
+                 pinned_words: "np.ndarray | None" = None, after: "Batch | None" = None, tables: "tuple | None" = None) -> None:
         """``after``: the batch (of another context on the same GPU) whose device words this one adopts while their
         upload may still be in flight.  ``pinned_words``: the concatenated words of ``packed`` in page-locked memory (``pinned_array``); the upload
         is then enqueued asynchronously (kp_batch_create_async) and the array must stay alive until ``upload_wait`` or
-        the first ``wait``/``score`` of the batch."""
+        the first ``wait``/``score`` of the batch.  ``tables`` (instead of ``packed``): the batch's tables as they go to
+        the library -- ``FastaShard.tables()`` -- next to ``pinned_words`` or ``device_words``."""
         self.ctx = ctx
-        self.n_asm = len(packed)
-        word_off = np.zeros(self.n_asm + 1, np.int64)
-        first_ctg = np.zeros(self.n_asm + 1, np.int32)
-        first_run = np.zeros(self.n_asm + 1, np.int32)
-        for i, pa in enumerate(packed):
-            word_off[i + 1] = word_off[i] + pa.padded_len // 16
-            first_ctg[i + 1] = first_ctg[i] + len(pa.ctg_start)
-            first_run[i + 1] = first_run[i] + len(pa.n_runs)
 
         def cat(xs, dt):
             return np.ascontiguousarray(np.concatenate(xs), dtype=dt) if xs else np.empty(0, dt)
 
-        ctg_start = cat([pa.ctg_start for pa in packed], np.int32)
-        ctg_len = cat([pa.ctg_len for pa in packed], np.int32)
-        n_runs = cat([pa.n_runs.reshape(-1) for pa in packed], np.int32)
+        if tables is not None:
+            if packed is not None or (pinned_words is None and device_words is None):
+                raise ValueError("tables come with pinned_words or device_words, not with packed assemblies")
+            word_off, ctg_start, ctg_len, first_ctg, n_runs, first_run = tables
+            self.n_asm = len(word_off) - 1
+        else:
+            self.n_asm = len(packed)
+            word_off = np.zeros(self.n_asm + 1, np.int64)
+            first_ctg = np.zeros(self.n_asm + 1, np.int32)
+            first_run = np.zeros(self.n_asm + 1, np.int32)
+            for i, pa in enumerate(packed):
+                word_off[i + 1] = word_off[i] + pa.padded_len // 16
+                first_ctg[i + 1] = first_ctg[i] + len(pa.ctg_start)
+                first_run[i + 1] = first_run[i] + len(pa.n_runs)
+            ctg_start = cat([pa.ctg_start for pa in packed], np.int32)
+            ctg_len = cat([pa.ctg_len for pa in packed], np.int32)
+            n_runs = cat([pa.n_runs.reshape(-1) for pa in packed], np.int32)
         self._h = C.c_void_p()
         self._pinned = pinned_words
         if pinned_words is not None:

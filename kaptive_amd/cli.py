@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -170,7 +171,9 @@ class _TypingPipeline:
         self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
         self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins", "pha4ge"))
         self.want_tsv = bool(getattr(args, "out", None))
-        self.threads = max(1, args.threads or (os.cpu_count() or 1))
+        from kaptive_amd import usable_cpus
+
+        self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
         self._pins: list = []  # recycled page-locked buffers
 
@@ -189,6 +192,28 @@ class _TypingPipeline:
         g.packed()
         return g
 
+    def _load_shard(self, paths):
+        """A whole chunk in one native call (TSV-only runs: nothing but the packed form and the assembly names is needed):
+        the library's threads map, parse and pack the files and lay out the batch's tables (kp_fasta_ingest_shard); the
+        interpreter does nothing per file but derive the assembly's name from the path.  A chunk with a file the library
+        could not take goes the per-file way, which knows the fall-backs and raises the reference's errors."""
+        from kaptive_amd import _native
+        from kaptive_amd.core.genome import _FASTA_NAME
+
+        ids, comps = [], []
+        for path in paths:
+            name = os.path.basename(os.fspath(path))
+            m = _FASTA_NAME.search(name)
+            if not m:
+                raise NotImplementedError(f"Unsupported format: {path}")
+            ids.append(name.removesuffix(m.group()))
+            comps.append(m.group("compression"))
+        shard = _native.FastaShard(paths, comps, self.threads)
+        if shard.failed:
+            shard.close()
+            return [self._load(path) for path in paths]
+        return shard, ids
+
     # -- stage 2: one chunk's packed words -> page-locked memory -> device (asynchronous upload) ---------------------------------
     def _pinned(self, n_words: int):
         from kaptive_amd import _native
@@ -199,6 +224,14 @@ class _TypingPipeline:
         return _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
 
     def _make_batch(self, genomes):
+        if isinstance(genomes, tuple):  # (FastaShard, ids): the words go to page-locked memory on the library's threads
+            shard = genomes[0]
+            pb = self._pinned(shard.total_words)
+            shard.words_into(pb.array, self.threads)
+            batch = self.engine.ctx.batch(None, pinned_words=pb.array[: shard.total_words], tables=shard.tables())
+            shard.close()  # (the library has copied the tables)
+            batch._pin = pb
+            return batch
         packed = [g.packed() for g in genomes]
         sizes = [len(pa.words) for pa in packed]
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -226,7 +259,10 @@ class _TypingPipeline:
                 k, paths = next(it)
             except StopIteration:
                 return False
-            reading.append((k, [self.readers.submit(self._load, p) for p in paths]))
+            if self.objects:
+                reading.append((k, [self.readers.submit(self._load, p) for p in paths]))
+            else:
+                reading.append((k, self.readers.submit(self._load_shard, paths)))
             return True
 
         for _ in range(self.PREFETCH + 1):
@@ -234,12 +270,13 @@ class _TypingPipeline:
         while reading or ready:
             while reading and len(ready) < self.PREFETCH:
                 k, futures = reading.popleft()
-                genomes = [f.result() for f in futures]
+                genomes = [f.result() for f in futures] if isinstance(futures, list) else futures.result()
                 start_read()
-                ready.append((self._make_batch(genomes), k, genomes))
-            batch, k, genomes = ready.popleft()
+                ids = genomes[1] if isinstance(genomes, tuple) else [g.id for g in genomes]
+                ready.append((self._make_batch(genomes), k, ids, genomes if self.objects else None))
+            batch, k, ids, genomes = ready.popleft()
             self._order.append(k)
-            yield batch, [g.id for g in genomes], genomes if self.objects else None
+            yield batch, ids, genomes
 
     # -- stage 3: records -> bytes ------------------------------------------------------------------------------------------------
     def run(self, chunks):

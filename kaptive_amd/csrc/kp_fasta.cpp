@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -304,6 +305,92 @@ int kp_fasta_ingest_file(const char *path, int32_t flags, kp_packed_fasta **out)
     }
     close(fd);
     return rc;
+}
+
+// ---- a chunk of files -> the tables of one batch ---------------------------------------------------------------------
+// What a reader that feeds a GPU does per chunk, in two calls that never hold the interpreter lock: parse the files on
+// the library's threads and lay their tables out as kp_batch_create* wants them; then copy the packed words of all of
+// them, back to back, into the (page-locked) buffer the caller chose once it knew the size.
+struct Shard : kp_packed_shard {
+    std::vector<kp_packed_fasta *> parts;
+};
+
+static void run_on_threads(int32_t n_items, int32_t threads, const std::function<void(int32_t)> &item) {
+    int t = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    t = std::max(1, std::min(t, (int)n_items));
+    std::atomic<int32_t> next{0};
+    auto work = [&]() {
+        for (int32_t i = next.fetch_add(1); i < n_items; i = next.fetch_add(1)) item(i);
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)t - 1);
+    for (int k = 1; k < t; ++k) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
+int kp_fasta_ingest_shard(const char *const *paths, const int32_t *flags, int32_t n_files, int32_t threads, kp_packed_shard **out) {
+    if (!out || n_files < 0 || (n_files > 0 && (!paths || !flags))) return KP_EINVAL;
+    *out = nullptr;
+    Shard *sh = new (std::nothrow) Shard();
+    if (!sh) return KP_ENOMEM;
+    std::memset(static_cast<kp_packed_shard *>(sh), 0, sizeof(kp_packed_shard));
+    sh->parts.assign((size_t)n_files, nullptr);
+    sh->n_asm = n_files;
+    sh->rc = (int32_t *)std::calloc((size_t)n_files + 1, 4);
+    sh->asm_word_off = (int64_t *)std::calloc((size_t)n_files + 1, 8);
+    sh->asm_first_ctg = (int32_t *)std::calloc((size_t)n_files + 1, 4);
+    sh->asm_first_nrun = (int32_t *)std::calloc((size_t)n_files + 1, 4);
+    if (!sh->rc || !sh->asm_word_off || !sh->asm_first_ctg || !sh->asm_first_nrun) { kp_shard_free(sh); return KP_ENOMEM; }
+    run_on_threads(n_files, threads, [&](int32_t i) {
+        sh->rc[i] = kp_fasta_ingest_file(paths[i], flags[i] & ~KP_FASTA_KEEP_TEXT, &sh->parts[(size_t)i]);
+    });
+    for (int32_t i = 0; i < n_files; ++i) {
+        const kp_packed_fasta *f = sh->parts[(size_t)i];
+        if (sh->rc[i] != KP_OK && sh->n_failed++ == 0) sh->first_failed = i;
+        sh->asm_word_off[i + 1] = sh->asm_word_off[i] + (f ? f->padded_len / 16 : 0);
+        sh->asm_first_ctg[i + 1] = sh->asm_first_ctg[i] + (f ? f->n_contigs : 0);
+        sh->asm_first_nrun[i + 1] = sh->asm_first_nrun[i] + (f ? f->n_runs : 0);
+    }
+    sh->total_words = sh->asm_word_off[n_files];
+    const size_t nc = (size_t)sh->asm_first_ctg[n_files], nr = (size_t)sh->asm_first_nrun[n_files];
+    sh->ctg_start = (int32_t *)std::malloc(4 * nc + 4);
+    sh->ctg_len = (int32_t *)std::malloc(4 * nc + 4);
+    sh->n_runs = (int32_t *)std::malloc(8 * nr + 4);
+    if (!sh->ctg_start || !sh->ctg_len || !sh->n_runs) { kp_shard_free(sh); return KP_ENOMEM; }
+    for (int32_t i = 0; i < n_files; ++i) {
+        const kp_packed_fasta *f = sh->parts[(size_t)i];
+        if (!f) continue;
+        std::memcpy(sh->ctg_start + sh->asm_first_ctg[i], f->ctg_start, 4 * (size_t)f->n_contigs);
+        std::memcpy(sh->ctg_len + sh->asm_first_ctg[i], f->ctg_len, 4 * (size_t)f->n_contigs);
+        std::memcpy(sh->n_runs + 2 * (size_t)sh->asm_first_nrun[i], f->n_run_pairs, 8 * (size_t)f->n_runs);
+    }
+    *out = sh;
+    return KP_OK;
+}
+
+int kp_shard_words_into(kp_packed_shard *shard, uint32_t *dst, int64_t dst_words, int32_t threads) {
+    if (!shard || (shard->total_words > 0 && !dst) || dst_words < shard->total_words) return KP_EINVAL;
+    Shard *sh = static_cast<Shard *>(shard);
+    if (sh->parts.empty() && sh->n_asm > 0) return KP_ESTATE;  // the words were handed over already
+    run_on_threads(sh->n_asm, threads, [&](int32_t i) {
+        kp_packed_fasta *&f = sh->parts[(size_t)i];
+        if (!f) return;
+        std::memcpy(dst + sh->asm_word_off[i], f->words, 4 * (size_t)(sh->asm_word_off[i + 1] - sh->asm_word_off[i]));
+        kp_fasta_free(f);  // (its blocks go back to the pool for the next chunk's files)
+        f = nullptr;
+    });
+    sh->parts.clear();
+    return KP_OK;
+}
+
+void kp_shard_free(kp_packed_shard *shard) {
+    if (!shard) return;
+    Shard *sh = static_cast<Shard *>(shard);
+    for (kp_packed_fasta *f : sh->parts) kp_fasta_free(f);
+    std::free(sh->rc); std::free(sh->asm_word_off); std::free(sh->asm_first_ctg); std::free(sh->asm_first_nrun);
+    std::free(sh->ctg_start); std::free(sh->ctg_len); std::free(sh->n_runs);
+    delete sh;
 }
 
 int kp_fasta_simd(int32_t cap) {

@@ -112,6 +112,52 @@ def test_native_pack_fuzz_against_the_python_packer(level):
         h.kp_fasta_simd(99)
 
 
+def test_shard_ingest_equals_file_by_file(tmp_path):
+    """kp_fasta_ingest_shard + kp_shard_words_into (a chunk of files -> the tables and words of one batch, on the
+    library's threads) against kp_fasta_ingest of every file: plain, gzip, an empty file, one with N runs, many contigs;
+    a missing file is reported, not fatal; the words can be handed over only once."""
+    rng = np.random.default_rng(5)
+    paths, comps = [], []
+    for k in range(9):
+        lines = []
+        for c in range(int(rng.integers(0, 40)) if k != 3 else 0):
+            n = int(rng.integers(0, 3000))
+            seq = np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, n, p=[0.245, 0.245, 0.245, 0.245, 0.02])].tobytes()
+            lines.append(b">c%d_%d some words" % (k, c))
+            lines += [seq[j : j + 70] for j in range(0, n, 70)]
+        text = b"\n".join(lines) + b"\n" if lines else b""
+        if k % 3 == 1:
+            path, comp = tmp_path / f"asm{k}.fna.gz", "gz"
+            path.write_bytes(gzip.compress(text))
+        else:
+            path, comp = tmp_path / f"asm{k}.fasta", None
+            path.write_bytes(text)
+        paths.append(str(path))
+        comps.append(comp)
+    shard = _native.FastaShard(paths, comps, threads=3)
+    assert shard.n_asm == 9 and not shard.failed
+    word_off, ctg_start, ctg_len, first_ctg, n_runs, first_run = [a.copy() for a in shard.tables()]
+    dst = np.full(shard.total_words + 5, 0xDEADBEEF, np.uint32)
+    shard.words_into(dst, threads=2)
+    with pytest.raises(RuntimeError):
+        shard.words_into(dst)
+    assert (dst[shard.total_words :] == 0xDEADBEEF).all()
+    for i, (path, comp) in enumerate(zip(paths, comps)):
+        pa, _, _, _ = _native.fasta_ingest_file(path, gzipped=comp, keep_text=False)
+        assert word_off[i + 1] - word_off[i] == pa.padded_len // 16
+        assert np.array_equal(dst[word_off[i] : word_off[i + 1]], pa.words), i
+        assert np.array_equal(ctg_start[first_ctg[i] : first_ctg[i + 1]], pa.ctg_start)
+        assert np.array_equal(ctg_len[first_ctg[i] : first_ctg[i + 1]], pa.ctg_len)
+        assert np.array_equal(n_runs[2 * first_run[i] : 2 * first_run[i + 1]].reshape(-1, 2), pa.n_runs)
+    shard.close()
+    bad = _native.FastaShard([paths[0], str(tmp_path / "missing.fasta"), str(tmp_path / "asm1.fna.gz")], [None, None, None])
+    assert [i for i, _ in bad.failed] == [1] and bad.n_asm == 3  # (a gzip file read as text parses -- as junk -- like any bytes)
+    bad.close()
+    empty = _native.FastaShard([], [])
+    assert empty.total_words == 0 and len(empty.tables()[0]) == 1
+    empty.words_into(np.empty(0, np.uint32))
+
+
 @pytest.mark.parametrize("kind", ["kpsc_k", "kpsc_o"])
 def test_genbank_round_trip(kind, tmp_path):
     db = make_db(kind, seed=5, n_loci=6 if kind == "kpsc_k" else None)
