@@ -107,7 +107,7 @@ KP_API int kp_fasta_pack(const uint8_t *data, int64_t n, kp_packed_fasta **out);
 #define KP_FASTA_XZ 8  /* .xz stream(s): liblzma of the host, likewise (the reference opens .gz / .bz2 / .xz by suffix) */
 KP_API int kp_fasta_ingest(const uint8_t *data, int64_t n, int32_t flags, kp_packed_fasta **out);
 /* The same from the file itself (GenomeAssembly.from_file, src/kaptive/core/genome.py:194-214, reads the whole file into a
- * bytes object first): the file is mapped and parsed where the page cache holds it -- no copy of the text is made.
+ * bytes object first): the library reads it into a recycled buffer of its own and parses it there.
  * `flags` as above (the caller picks the compression from the suffix, as the reference does); KP_EIO when the path
  * cannot be opened or is not a regular file. */
 KP_API int kp_fasta_ingest_file(const char *path, int32_t flags, kp_packed_fasta **out);

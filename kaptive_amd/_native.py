@@ -143,8 +143,8 @@ def fasta_ingest(data: bytes, gzipped: "bool | str | None" = False, keep_text: b
 
 
 def fasta_ingest_file(path, gzipped: "bool | str | None" = False, keep_text: bool = True):
-    """``fasta_ingest`` of a file by its path (kp_fasta_ingest_file): the library maps the file, so its text is never
-    copied into a Python bytes object.  Falls back to reading the file here when the path is not a regular file or the
+    """``fasta_ingest`` of a file by its path (kp_fasta_ingest_file): the library reads the file into a recycled buffer of its
+    own, so its text never becomes a Python bytes object.  Falls back to reading the file here when the path is not a regular file or the
     host lacks the decompression library."""
     import os
 

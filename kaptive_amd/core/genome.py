@@ -124,7 +124,7 @@ class GenomeAssembly:
         m = _FASTA_NAME.search(filepath.name)
         if not m:
             raise NotImplementedError(f"Unsupported format: {filepath}")
-        # One native pass from the file (mapped by the library, never copied into a bytes object) to contigs + packed form
+        # One native pass from the file (read by the library into a recycled buffer, never a bytes object) to contigs + packed form
         # (kp_fasta_ingest_file; zlib inflates .gz there).  The
         # reference opens by suffix, reads everything and hands the bytes to rammappy's parser (genome.py:194-214, 35-46).
         from kaptive_amd import _native
