@@ -299,6 +299,9 @@ def cli_from_fasta(prep: dict, repeats: int = 96, batch: int = 512) -> dict:
         shutil.rmtree(root, ignore_errors=True)
 
 
+_GRANTED = {"cores": None}  # what the affinity mask and the cgroup quota grant, before the spin check below may lower it
+
+
 def usable_cores() -> tuple[int, str]:
     """Cores this process may actually keep busy: the affinity mask, cut down to the cgroup's CPU quota when there is one
     (a container that sees 256 CPUs but is given 16 CPUs' worth of time runs 256 busy processes at 1/16 speed each)."""
@@ -318,6 +321,7 @@ def usable_cores() -> tuple[int, str]:
             break
         except (OSError, ValueError, IndexError):
             continue
+    _GRANTED["cores"] = n
     if n > 1:  # ... and to what the box really gives: n spinning processes get sum(CPU seconds) / wall cores between them
         ctx = get_context("fork")
         with ctx.Pool(n, initializer=_cpu_init, initargs=(ctx.Barrier(n),)) as pool:
@@ -375,6 +379,10 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
                   f"together on a barrier after input generation: CPU oracle (oracle/kp_oracle.c aligner + protein DP built "
                   f"{flags}, one seed index shared by all processes, numpy reduction); {n_all} assemblies in {wall:.1f} s",
         "cores_note": cores_why,
+        # (a noisy box lowers `cores`, and with it the process count of this leg: the granted figure and the rate scaled to it
+        # -- an extrapolation at the measured per-core rate -- stand beside the measured one)
+        "cores_granted": _GRANTED["cores"],
+        "value_scaled_to_granted_cores": None if not _GRANTED["cores"] else round(rate_all * _GRANTED["cores"] / cores, 2),
         "parallel_efficiency": round(rate_all / (cores * rate_one), 3),
         "cpu_seconds_per_assembly_all_cores": round(cpu_s / n_all, 3),
         "aligner_share_all_cores": round(align_s / max(sum(p[2] - p[1] for p in parts), 1e-9), 3),

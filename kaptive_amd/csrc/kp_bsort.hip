@@ -29,8 +29,14 @@ constexpr int BS_THREADS = 512, BS_WAVES = BS_THREADS / 64;
 constexpr int BS_STAGE = 512;     // keys one wave ranks in registers (8 per lane)
 constexpr int BS_RANK_MAX = 24;   // buckets up to this size are ranked against lane broadcasts, larger ones go through a bitonic network
 constexpr int BS_TILE = 1024;     // keys per LDS tile of the block-wide pass
-constexpr int BS_BIG_LIST = 1024; // buckets of BS_RANK_MAX + 1 .. BS_STAGE keys remembered for the shared pass (more: sorted where they are met)
-constexpr int BS_HUGE_LIST = 64;  // buckets larger than BS_STAGE remembered for the block-wide pass (more: ranked in place, slowly)
+#ifndef KP_BS_BIG_LIST  // (both list lengths can be cut down at build time so that a test run meets their overflow paths:
+#define KP_BS_BIG_LIST 1024  //  tools/gpu_bsort_overflow.sh)
+#endif
+#ifndef KP_BS_HUGE_LIST
+#define KP_BS_HUGE_LIST 64
+#endif
+constexpr int BS_BIG_LIST = KP_BS_BIG_LIST; // buckets of BS_RANK_MAX + 1 .. BS_STAGE keys remembered for the shared pass (more: sorted where they are met)
+constexpr int BS_HUGE_LIST = KP_BS_HUGE_LIST;  // buckets larger than BS_STAGE remembered for the block-wide pass (more: ranked in place, slowly)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -254,7 +260,10 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
                 for (uint32_t j = 0; j < bm[u]; ++j) {
                     const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)klo, (int)j);
                     const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)khi, (int)j);
-                    rank += (((uint64_t)ohi << 32) | olo) < key[u] ? 1u : 0u;
+                    // (keys are unique -- one posting per gene seed, one candidate per contig position, the streaming and the
+                    // edge kernel own disjoint positions -- but equal keys would still get slots of their own: source order)
+                    const uint64_t other = ((uint64_t)ohi << 32) | olo;
+                    rank += (other < key[u] || (other == key[u] && j < (uint32_t)lane)) ? 1u : 0u;
                 }
                 if ((uint32_t)lane < bm[u]) dst[bs[u] + rank] = key[u];
             }
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
                     for (uint32_t i = 0; i < bm; ++i) {
                         const uint64_t key = grp[bs + i];
                         uint32_t rank = 0;
-                        for (uint32_t j = 0; j < bm; ++j) rank += grp[bs + j] < key ? 1u : 0u;
+                        for (uint32_t j = 0; j < bm; ++j) rank += (grp[bs + j] < key || (grp[bs + j] == key && j < i)) ? 1u : 0u;
                         dst[bs + rank] = key;
                     }
                 }
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
                 for (uint32_t j = tid; j < tn; j += BS_THREADS) tile[j] = grp[bs + t0 + j];
                 __syncthreads();
                 if (i < bm)
-                    for (uint32_t j = 0; j < tn; ++j) rank += tile[j] < key ? 1u : 0u;
+                    for (uint32_t j = 0; j < tn; ++j) rank += (tile[j] < key || (tile[j] == key && t0 + j < i)) ? 1u : 0u;
             }
             if (i < bm) dst[bs + rank] = key;
         }
