@@ -22,22 +22,12 @@ import numpy as np
 FILE_SUFFIX = "kaptive_results"
 
 
-def _json_default(o):
-    if isinstance(o, np.ndarray):
-        return o.tolist()
-    if isinstance(o, np.generic):
-        return o.item()
-    if isinstance(o, (bytes, np.bytes_)):
-        return o.decode("utf-8", "replace")
-    if isinstance(o, tuple):
-        return list(o)
-    raise TypeError(type(o))
-
-
 def result_to_json(result) -> bytes:
-    d = result.to_dict()
-    d["problems"] = int(d["problems"])
-    return (json.dumps(d, default=_json_default, allow_nan=True) + "\n").encode()
+    """One JSON line per result, laid out as the reference's ``orjson.dumps(result.to_dict(), OPT_SERIALIZE_NUMPY |
+    OPT_APPEND_NEWLINE)`` lays it out (src/kaptive/serotyping/cli.py:67-76): ``serotyping/jsonl.py``."""
+    from kaptive_amd.serotyping.jsonl import dumps_line
+
+    return dumps_line(result.to_dict())
 
 
 class ResultExporter:

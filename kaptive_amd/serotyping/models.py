@@ -236,8 +236,12 @@ class SerotypingResult:
 
     @classmethod
     def from_dict(cls, data: dict[str, Any]) -> "SerotypingResult":
+        scalars = {k: data[k] for k in _SCALARS}
+        for k in ("best_locus_score", "best_locus_completeness", "length_discrepancy", "percent_identity", "percent_coverage"):
+            if scalars[k] is None:  # (the JSON writer, like orjson, has no NaN: null stands for it)
+                scalars[k] = float("nan")
         return cls(
-            **{k: data[k] for k in _SCALARS},
+            **scalars,
             missing_expected_genes=tuple(data.get("missing_expected_genes", [])),
             locus_pieces=LocusPieces.from_dict(data["locus_pieces"]),
             gene_hits=GeneHits.from_dict(data["gene_hits"]),

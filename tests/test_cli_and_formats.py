@@ -207,6 +207,29 @@ def test_jsonl_round_trip_and_convert(tmp_path, oracle):
     assert rows[2] == bytes(KaptiveRow.from_result(res2)) and b"\tn/a\t" in rows[2]
 
 
+def test_json_lines_follow_orjson_conventions():
+    """serotyping/jsonl.py restates what orjson.dumps(..., OPT_SERIALIZE_NUMPY | OPT_APPEND_NEWLINE) writes (the wheel is
+    absent here): compact, insertion order, raw UTF-8, numpy values in their own precision, Ryu's number layout, NaN as
+    null.  The digits must read back as the same float (float32: as the same float32)."""
+    from kaptive_amd.serotyping.jsonl import dumps_line, format_f32, format_f64
+
+    assert [format_f64(x) for x in (1.0, 100.0, 99.5, 0.1, 1e-5, 1e-6, 1.5e-7, 1e15, 1e16, 1.234e20, -2.5, 5e-324, 0.0, -0.0)] == [
+        "1.0", "100.0", "99.5", "0.1", "0.00001", "1e-6", "1.5e-7", "1000000000000000.0", "1e16", "1.234e20", "-2.5", "5e-324",
+        "0.0", "-0.0"]  # fmt: skip
+    assert [format_f32(x) for x in (0.1, 99.5, 1e-6, 1e-7, 16777216.0, 1e13, 3.4028235e38)] == [
+        "0.1", "99.5", "0.000001", "1e-7", "16777216.0", "1e13", "3.4028235e38"]
+    assert format_f64(float("nan")) == format_f64(float("inf")) == format_f32(np.float32("nan")) == "null"
+    rng = np.random.default_rng(4)
+    for x in np.concatenate([rng.random(300) * 100, 10.0 ** rng.uniform(-30, 30, 300), rng.standard_normal(100) * 1e-3]):
+        assert float(format_f64(float(x))) == float(x)
+        assert np.float32(format_f32(np.float32(x))) == np.float32(x)
+        assert len(format_f32(np.float32(x))) <= len(format_f64(float(np.float32(x))))  # never the widened digits
+    line = dumps_line({"a": np.float32(0.1), "b": np.array([1, -2], np.int8), "c": np.array([True, False]), "d": 'h\u00e9 "q"\n',
+                       "e": (1, 2.0), "f": np.array([[0.1, 2.5]], np.float32), "g": float("nan"), "h": None, "i": np.uint32(7)})
+    assert line == '{"a":0.1,"b":[1,-2],"c":[true,false],"d":"h\u00e9 \\"q\\"\\n","e":[1,2.0],"f":[[0.1,2.5]],"g":null,"h":null,"i":7}\n'.encode()
+    assert json.loads(line)["d"] == 'h\u00e9 "q"\n'
+
+
 def test_cli_parser_matches_reference_flags():
     ap = build_parser()
     a = ap.parse_args(["assembly", "db.npz", "a.fasta", "b.fna.gz", "-o", "out.tsv", "-j", "out.jsonl", "--max-other-genes",
