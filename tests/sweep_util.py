@@ -1,0 +1,58 @@
+"""Workers of the full-size parity sweep (tests/test_gpu_parity.py::test_parity_sweep_at_full_size): the CPU oracle's hit
+tables for seeded synthetic assemblies, computed in spawned processes (the test's own process holds a HIP context, which
+does not survive a fork).  TEST INFRASTRUCTURE: imports oracle/."""
+
+from __future__ import annotations
+
+import numpy as np
+
+_STATE: dict = {}
+
+# (database of the assembly's main locus, seed of that database, databases typed against)
+CONFIGS = {
+    "kpsc": dict(main=("kpsc_k", 100), also=("kpsc_o", 101), asm={}),
+    "ab_k": dict(main=("ab_k", 102), also=None, asm=dict(length=4.0e6, median_contigs=1500, min_contig=200, force_split=True)),
+}
+
+
+def assembly_kwargs(config: str, i: int) -> dict:
+    """Deterministic variety: divergence from 0 to 12 %, indels, N runs, a second locus, a tandem gene copy."""
+    kw = dict(CONFIGS[config]["asm"])
+    kw["sub_rate"] = [None, 0.0, 0.01, 0.03, 0.06, 0.09, 0.12, None][i % 8]
+    if i % 5 == 1:
+        kw["indel_rate"] = 2e-3
+    if i % 6 == 2:
+        kw["n_run"] = 3
+    if i % 7 == 3 and config == "kpsc":
+        kw["second_locus"] = (i * 13) % 100
+    if i % 9 == 4:
+        kw["tandem_gene"] = 1
+    return kw
+
+
+def make(config: str, i: int):
+    from kaptive_amd.synth import make_assembly, make_db
+
+    if ("dbs", config) not in _STATE:
+        c = CONFIGS[config]
+        _STATE["dbs", config] = (make_db(*[c["main"][0]], seed=c["main"][1]),
+                                 make_db(c["also"][0], seed=c["also"][1]) if c["also"] else None)
+    main, also = _STATE["dbs", config]
+    return make_assembly(main, seed=31_000 + 97 * i, also=(also,) if also is not None else (), **assembly_kwargs(config, i)), main, also
+
+
+def oracle_hits(job):
+    """(config, i) -> [hit table per database] from the oracle's aligner."""
+    from kaptive_amd.pack import pack_sequences_flat
+    from oracle import oracle as O
+
+    config, i = job
+    g, main, also = make(config, i)
+    out = []
+    for k, db in enumerate((main, also)):
+        if db is None:
+            continue
+        if ("odb", config, k) not in _STATE:
+            _STATE["odb", config, k] = O.OracleDB(*pack_sequences_flat(db.genes))
+        out.append(np.array(_STATE["odb", config, k].align(g.packed())))
+    return out

@@ -925,6 +925,56 @@ def test_config4_acinetobacter_at_full_size(oracle):
     eng.close()
 
 
+def test_parity_sweep_at_full_size(oracle):
+    """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 6: BASELINE configs 2/3 -- 5 Mbp, K
+    and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
+    second loci and tandem copies: the device's hit tables equal the oracle's record for record, for every assembly and
+    database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
+    import json
+    import multiprocessing as mp
+    import os
+
+    from kaptive_amd.engine import Engine
+    from tests import sweep_util as S
+
+    n = int(os.environ.get("KAPTIVE_AMD_SWEEP", "6"))
+    summary = {}
+    with mp.get_context("spawn").Pool(min(16, max(2, (os.cpu_count() or 2) // 2))) as pool:
+        for config in S.CONFIGS:
+            jobs = [(config, i) for i in range(n)]
+            pending = pool.map_async(S.oracle_hits, jobs, chunksize=1)
+            made = [S.make(config, i) for i in range(n)]
+            genomes, dbs = [m[0] for m in made], [d for d in made[0][1:] if d is not None]
+            packed = [g.packed() for g in genomes]
+            engines = [Engine(db) for db in dbs]
+            compared = 0
+            for lo in range(0, n, 64):
+                part = packed[lo : lo + 64]
+                first = engines[0].ctx.batch(part)
+                batches = [first] + [e.ctx.batch(part, device_words=first.device_words, after=first) for e in engines[1:]]
+                for b in batches:
+                    b.align_async()
+                got = []
+                for b in batches:
+                    b.wait()
+                    got.append(b.hits())
+                if lo == 0:
+                    want = pending.get(timeout=3600)
+                for k, (hits, off) in enumerate(got):
+                    for i in range(len(part)):
+                        _same_records(hits[off[i] : off[i + 1]], want[lo + i][k], f"{config} database {k}, assembly {lo + i} {S.assembly_kwargs(config, lo + i)}")
+                        compared += int(off[i + 1] - off[i])
+                for b in reversed(batches):
+                    b.close()
+            for e in engines:
+                e.close()
+            summary[config] = {"assemblies": n, "databases": len(dbs), "hit_records_equal": compared, "differing": 0}
+    if out := os.environ.get("KAPTIVE_AMD_SWEEP_OUT"):
+        with open(out, "w") as f:
+            json.dump(summary, f, indent=1)
+    assert all(v["hit_records_equal"] > 100 * n for v in summary.values())
+
+
 def test_many_hit_stress_forces_every_fallback(oracle):
     """A full-size assembly carrying five K loci: more hits than the LDS sort stage holds (SORT_LDS = 4096), with hit,
     kept, piece and protein buffers started far too small, so every grow-and-rerun path runs at full size."""
