@@ -279,29 +279,72 @@ __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t 
 // Small clusters are chained as minimap2 chains them (chain_small); a cluster that does not reach KP_MIN_CHAIN_SCORE is
 // REJECTED: n_anchors = 0, its result row reads score 0 (nothing downstream fills or traces it: the order below leaves it
 // out).  Larger clusters keep their anchor count and get the score of a co-linear chain.
+// A lane's work grows with the square of its cluster's anchor count and a wave runs at the pace of its largest cluster, so a
+// block does not take its tasks as they lie in the list (appended by thousands of waves: sizes mixed at random): it takes a
+// tile of CS_TILE of them, ranks the tile by anchor count (counting sort over the 26 possible sizes, largest first, in LDS)
+// and hands each round of 64 lanes neighbours in that order.
+#ifndef KP_CS_TILE
+#define KP_CS_TILE 512
+#endif
+constexpr int CS_TILE = KP_CS_TILE;
 __global__ __launch_bounds__(CS_THREADS) void kp_chain_score_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
                                                              KpTask *__restrict__ tasks, const uint32_t *__restrict__ task_count,
                                                              uint32_t task_cap, KpSwResult *__restrict__ results) {
     __shared__ ChainScratch cs;
-    const int cls = blockIdx.y;
+    __shared__ uint32_t s_bin[KP_CHAIN_DP_MAX + 2];
+    __shared__ uint16_t s_order[CS_TILE];
+    static_assert(CS_TILE % CS_THREADS == 0 && CS_TILE <= 65536, "whole rounds, 16-bit tile indices");
+    const int cls = blockIdx.y, lane = (int)threadIdx.x;
     uint32_t n = task_count[cls];
     if (n > task_cap) n = task_cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        KpTask &t = tasks[(size_t)cls * task_cap + i];
-        const int cnt = t.n_anchors;
-        const uint32_t first = (uint32_t)t.chain_score;
-        int chain_cnt = cnt, chain_sc;
-        if (cnt <= KP_CHAIN_DP_MAX) {
-            chain_sc = chain_small(keys + (size_t)t.asm_id * cap + first, cnt, kb, cs, (int)threadIdx.x, &chain_cnt);
-            if (chain_sc < KP_MIN_CHAIN_SCORE) {
-                chain_cnt = 0;
-                results[(size_t)cls * task_cap + i].score = 0;
+    KpTask *list = tasks + (size_t)cls * task_cap;
+    for (uint32_t tile0 = blockIdx.x * (uint32_t)CS_TILE; tile0 < n; tile0 += gridDim.x * (uint32_t)CS_TILE) {
+        const uint32_t m = min((uint32_t)CS_TILE, n - tile0);
+        if (lane < KP_CHAIN_DP_MAX + 2) s_bin[lane] = 0;
+        __syncthreads();
+        int bin[CS_TILE / CS_THREADS];
+        uint32_t rank[CS_TILE / CS_THREADS];
+#pragma unroll
+        for (int r = 0; r < CS_TILE / CS_THREADS; ++r) {
+            const uint32_t i = (uint32_t)(r * CS_THREADS + lane);
+            bin[r] = 0; rank[r] = 0;
+            if (i < m) {
+                const int c = list[tile0 + i].n_anchors;
+                bin[r] = c > KP_CHAIN_DP_MAX ? 0 : KP_CHAIN_DP_MAX + 1 - c;  // bin 0: nothing to chain; then 24, 23, ... anchors
+                rank[r] = atomicAdd(&s_bin[bin[r]], 1u);
             }
-        } else {
-            chain_sc = min(KP_K * cnt, (int)(t.qspan >> 16) - (int)(t.qspan & 0xFFFFu) + KP_K);
         }
-        t.n_anchors = chain_cnt;
-        t.chain_score = chain_sc;
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t acc = 0;
+            for (int b = 0; b < KP_CHAIN_DP_MAX + 2; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CS_TILE / CS_THREADS; ++r) {
+            const uint32_t i = (uint32_t)(r * CS_THREADS + lane);
+            if (i < m) s_order[s_bin[bin[r]] + rank[r]] = (uint16_t)i;
+        }
+        __syncthreads();
+        for (uint32_t k = (uint32_t)lane; k < m; k += CS_THREADS) {
+            const uint32_t i = tile0 + s_order[k];
+            KpTask &t = list[i];
+            const int cnt = t.n_anchors;
+            const uint32_t first = (uint32_t)t.chain_score;
+            int chain_cnt = cnt, chain_sc;
+            if (cnt <= KP_CHAIN_DP_MAX) {
+                chain_sc = chain_small(keys + (size_t)t.asm_id * cap + first, cnt, kb, cs, lane, &chain_cnt);
+                if (chain_sc < KP_MIN_CHAIN_SCORE) {
+                    chain_cnt = 0;
+                    results[(size_t)cls * task_cap + i].score = 0;
+                }
+            } else {
+                chain_sc = min(KP_K * cnt, (int)(t.qspan >> 16) - (int)(t.qspan & 0xFFFFu) + KP_K);
+            }
+            t.n_anchors = chain_cnt;
+            t.chain_score = chain_sc;
+        }
+        __syncthreads();
     }
 }
 
