@@ -165,7 +165,10 @@ class _TypingPipeline:
 
         self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
+        import threading
+
         self._pins: list = []  # recycled page-locked buffers
+        self._pin_lock = threading.Lock()
 
     def close(self) -> None:
         self.readers.shutdown(wait=True, cancel_futures=True)
@@ -202,24 +205,29 @@ class _TypingPipeline:
         if shard.failed:
             shard.close()
             return [self._load(path) for path in paths]
-        return shard, ids
+        # the words go to page-locked memory here, on the reader's side of the pipeline (the driving thread only creates the
+        # batch): 0.6 GB per chunk of 512 assemblies, copied by the library's threads
+        pb = self._pinned(shard.total_words)
+        shard.words_into(pb.array, self.threads)
+        tables = tuple(np.array(t) for t in shard.tables())
+        total = shard.total_words
+        shard.close()
+        return (tables, total, pb), ids
 
     # -- stage 2: one chunk's packed words -> page-locked memory -> device (asynchronous upload) ---------------------------------
     def _pinned(self, n_words: int):
         from kaptive_amd import _native
 
-        for i, pb in enumerate(self._pins):
-            if len(pb.array) >= n_words:
-                return self._pins.pop(i)
+        with self._pin_lock:  # (reader threads take buffers, the driving thread gives them back)
+            for i, pb in enumerate(self._pins):
+                if len(pb.array) >= n_words:
+                    return self._pins.pop(i)
         return _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
 
     def _make_batch(self, genomes):
-        if isinstance(genomes, tuple):  # (FastaShard, ids): the words go to page-locked memory on the library's threads
-            shard = genomes[0]
-            pb = self._pinned(shard.total_words)
-            shard.words_into(pb.array, self.threads)
-            batch = self.engine.ctx.batch(None, pinned_words=pb.array[: shard.total_words], tables=shard.tables())
-            shard.close()  # (the library has copied the tables)
+        if isinstance(genomes, tuple):  # ((tables, words, pinned buffer), ids) of _load_shard
+            tables, total, pb = genomes[0]
+            batch = self.engine.ctx.batch(None, pinned_words=pb.array[:total], tables=tables)
             batch._pin = pb
             return batch
         packed = [g.packed() for g in genomes]
@@ -295,7 +303,8 @@ class _TypingPipeline:
                             (d / f"{r.genome}_{FILE_SUFFIX}.{ext}").write_bytes(getattr(r, attr).to_fasta())
             pb = batch._pin
             batch.close()  # (waits for whatever of the batch is still in flight: the pinned words are free after it)
-            self._pins.append(pb)
+            with self._pin_lock:
+                self._pins.append(pb)
             yield self._order[done], out
             done += 1
 
