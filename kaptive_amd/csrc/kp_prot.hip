@@ -93,20 +93,19 @@ template <bool ROW_MAJOR = true>  // false: the lane does not visit its cells in
 __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, int j, unsigned c1, unsigned c2,
                                           const int8_t *s_mat, int lm, int li, Pay lpm, Pay lpi, int um, int ud, Pay upm,
                                           Pay upd) {
-    // D: gap arriving from above (a path would start at a neighbour whose M is 0)
-    upm = pick(um == 0, Pay{0, 0}, upm);
+    // D: gap arriving from above.  (A path starts at a cell whose M is 0: such a cell keeps the payload of its M state at
+    // zero -- the last statement below --, so none of its three readers has to ask.)
     const int d_open = um - GO, d_ext = ud - GE;
     int ndv = max(d_open, d_ext);
     Pay npd = pick(d_open >= d_ext, upm, upd);
     npd.g += GAP_ROW;
     // I: gap arriving from the left
-    lpm = pick(lm == 0, Pay{0, 0}, lpm);
     const int i_open = lm - GO, i_ext = li - GE;
     int niv = max(i_open, i_ext);
     Pay npi = pick(i_open >= i_ext, lpm, lpi);
     npi.g += GAP_COL;
     // M: diagonal first, then D, then I, each only if strictly better
-    Pay npm = pick(c.m == 0, Pay{0, 0}, c.pm);
+    Pay npm = c.pm;
     const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
     const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[(x1 * 32 + x2) & 1023u];  // 32: byte outside the alphabet
     int bv = c.m + sc;
@@ -124,7 +123,7 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
         r.best = nm; r.bi = i; r.bj = j; r.bp = npm;
     }
     c.m = nm; c.dv = in ? ndv : NEGP; c.iv = in ? niv : NEGP;
-    c.pm = npm; c.pd = npd; c.pi = npi;
+    c.pm = pick(nm == 0, Pay{0, 0}, npm); c.pd = npd; c.pi = npi;
 }
 
 // NC adjacent diagonals per lane: 4 covers any band of up to 64 diagonals; 3 covers 48, which is enough for the default band
