@@ -61,7 +61,7 @@ struct Result {
 // works on row i = m - l + 1 at step m, so a wave aligns four pairs side by side.  With that skew the first cell's left
 // neighbour is lane l-1's last cell of the previous step, the last cell's upper neighbour is lane l+1's first cell of
 // the same step, everything else is one of the lane's own registers (DPP row shifts; a group of 16 lanes is a DPP row).
-// s_seq1/s_seq2: residues as (raw byte << 8 | BLOSUM index 0..24, 32 = outside the alphabet); s_mat: 32x32 scores.
+// s_seq1/s_seq2: residues as (raw byte << 8 | BLOSUM index 0..24, 31 = outside the alphabet); s_mat: 32x32 scores.
 constexpr int QP = 16;  // lanes per pair
 
 __device__ __forceinline__ int row_lower(int v) {  // lane b <- lane b-1 within the group's DPP row
@@ -107,7 +107,7 @@ __device__ __forceinline__ void prot_cell(PCell &c, Result &r, bool in, int i, i
     // M: diagonal first, then D, then I, each only if strictly better
     Pay npm = c.pm;
     const unsigned x1 = c1 & 255u, x2 = c2 & 255u;
-    const int sc = (x1 | x2) >= 32u ? KP_PROT_FILL : (int)s_mat[(x1 * 32 + x2) & 1023u];  // 32: byte outside the alphabet
+    const int sc = (int)s_mat[x1 * 32 + x2];  // (index 31 = a byte outside the alphabet: its row and column hold KP_PROT_FILL)
     int bv = c.m + sc;
     npm.a += ((c1 >> 8) == (c2 >> 8)) ? 0x10000u : 1u;
     const bool take_d = ndv > bv;
@@ -391,10 +391,10 @@ __device__ __forceinline__ void store_result(Result r, int lane_in_group, int32_
     }
 }
 
-// compact substitution table in LDS: s_idx = index of each byte in ARNDCQEGHILKMFPSTWYVBJZX* (32 for everything else),
+// compact substitution table in LDS: s_idx = index of each byte in ARNDCQEGHILKMFPSTWYVBJZX* (31 for everything else),
 // s_mat = the 32 x 32 corner of the reference's 256 x 256 lookup those indices address
 __device__ __forceinline__ void stage_blosum(const int8_t *__restrict__ blosum, int8_t *s_mat, uint8_t *s_idx, int lane) {
-    for (int c = lane; c < 256; c += 64) s_idx[c] = 32;
+    for (int c = lane; c < 256; c += 64) s_idx[c] = 31;
     __syncthreads();
     if (lane < 25) s_idx[(uint8_t)"ARNDCQEGHILKMFPSTWYVBJZX*"[lane]] = (uint8_t)lane;
     __syncthreads();
