@@ -148,16 +148,21 @@ class _TypingPipeline:
 
     PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
 
-    def __init__(self, args: argparse.Namespace, device: int) -> None:
+    def __init__(self, args: argparse.Namespace, device: int, typer=None) -> None:
+        """``typer``: a ``Serotyper`` the caller already holds (``Serotyper.tsv_from_files``); otherwise one is made from the
+        command line's database and thresholds."""
         import os
 
         from kaptive_amd.serotyping.core import Serotyper
 
         self.args = args
-        self.db = load_database(args.database)
-        self.typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
-                               allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
-                               device=device)  # fmt: skip
+        self._own_typer = typer is None
+        if typer is None:
+            self.db = load_database(args.database)
+            typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
+                              allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
+                              device=device)  # fmt: skip
+        self.typer = typer
         self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
         self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins", "pha4ge"))
         self.want_tsv = bool(getattr(args, "out", None))
@@ -172,7 +177,7 @@ class _TypingPipeline:
 
     def close(self) -> None:
         self.readers.shutdown(wait=True, cancel_futures=True)
-        if self.typer._engine is not None:
+        if self._own_typer and self.typer._engine is not None:
             self.typer._engine.close()
         for pb in self._pins:
             pb.close()

@@ -14,7 +14,7 @@ vectors produced by the reference (tests/golden). Phase markers below cite the r
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Any, Callable, Sequence
+from typing import Iterator, Any, Callable, Sequence
 
 import numpy as np
 
@@ -115,6 +115,25 @@ class Serotyper:
         if self._aligner is not None:
             return [self.reduce(g, self._aligner(g)) for g in loaded]
         return self.engine.type_many(self, loaded)
+
+    def tsv_from_files(self, paths: Sequence[str | Path], batch_size: int = 512, threads: int = 0) -> "Iterator[bytes]":
+        """The ``kaptive assembly ... -o`` pipeline for library callers (not in the reference, whose batch entry is its CLI,
+        src/kaptive/serotyping/cli.py:183-210): FASTA files -> chunks of ``batch_size`` parsed by the library's threads ->
+        pinned shards -> the batched typing -> the ``KaptiveRow`` bytes of every chunk, in input order, without a Python
+        object per assembly.  Yields one ``bytes`` per chunk (no header line: ``KaptiveRow.header()``)."""
+        import argparse
+
+        from kaptive_amd.cli import _TypingPipeline
+
+        args = argparse.Namespace(out="-", threads=threads, json=None, loci=None, genes=None, proteins=None, pha4ge=None)
+        paths = [str(p) for p in paths]
+        chunks = [(k, paths[i : i + batch_size]) for k, i in enumerate(range(0, len(paths), batch_size))]
+        pipe = _TypingPipeline(args, 0, typer=self)  # (the device is the one this Serotyper was made for)
+        try:
+            for _, out in pipe.run(chunks):
+                yield out["tsv"]
+        finally:
+            pipe.close()
 
     # -- reduction ------------------------------------------------------------------------------------------------
     def score_loci(self, alns: Alignments, gene_idx: np.ndarray) -> tuple[np.ndarray, np.ndarray, int]:

@@ -828,6 +828,14 @@ def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_p
     assert fast.read_bytes() == slow.read_bytes() == two.read_bytes()
     assert len((tmp_path / "r.jsonl").read_bytes().splitlines()) == len(paths)
     assert main(["assembly", str(db_path), paths[0], str(tmp_path / "nope.fasta"), "-o", str(fast)]) == 1
+    # the same pipeline for a library caller: Serotyper.tsv_from_files, a typer that goes on typing afterwards
+    from kaptive_amd.serotyping.io import KaptiveRow
+
+    typer = Serotyper(db)
+    chunks = list(typer.tsv_from_files(paths, batch_size=4, threads=2))
+    assert len(chunks) == 3 and KaptiveRow.header() + b"".join(chunks) == fast.read_bytes()
+    again = typer.type_many(paths[:2])
+    assert [bytes(KaptiveRow.from_result(r)) for r in again] == rows[1:3]
 
 
 # ---- BASELINE.json configs at their real shape --------------------------------------------------------------------------
