@@ -446,7 +446,7 @@ def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
     try:
         return args.func(args)
-    except (DatabaseError, FileNotFoundError, PermissionError, NotImplementedError) as e:
+    except (DatabaseError, FileNotFoundError, PermissionError, NotImplementedError, ValueError) as e:  # (ValueError: an unreadable FASTA / compressed stream)
         print(f"error: {e}", file=sys.stderr)
         return 1
     except KeyboardInterrupt:
