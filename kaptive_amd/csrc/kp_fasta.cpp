@@ -483,7 +483,7 @@ namespace {
 // first byte that is neither base nor whitespace, which is looked at on its own (an N-run symbol, or the '>' of the next
 // header when the byte before it ended a line).  One core turns ~9 GB/s of plain FASTA into words this way (scalar table
 // look-ups: 2.9); which path runs is settled once from cpuid (kp_fasta_simd).
-struct Masks { uint64_t base, ws, nl, b0, b1; };  // per byte of the chunk: is a base / whitespace / '\n'; code bit 0 / 1
+struct Masks { uint64_t base, ws, b0, b1; };  // per byte of the chunk: is a base / whitespace; code bit 0 / 1
 
 #define KP_T512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,avx2,bmi,bmi2,popcnt,lzcnt")))
 #define KP_T256 __attribute__((target("avx2,bmi,bmi2,popcnt,lzcnt")))
@@ -499,13 +499,12 @@ KP_T512 inline Masks classify512(__m512i v) {
     Masks m;
     m.base = _mm512_cmpeq_epi8_mask(_mm512_shuffle_epi8(lut, v), up);
     m.ws = _mm512_cmple_epu8_mask(_mm512_sub_epi8(v, _mm512_set1_epi8(9)), _mm512_set1_epi8(4)) | _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8(32));
-    m.nl = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('\n'));
     m.b0 = _mm512_test_epi8_mask(t, _mm512_set1_epi8(2));
     m.b1 = _mm512_test_epi8_mask(t, _mm512_set1_epi8(4));
     return m;
 }
 
-KP_T256 inline void classify256(__m256i v, uint32_t &base, uint32_t &ws, uint32_t &nl, uint32_t &b0, uint32_t &b1) {
+KP_T256 inline void classify256(__m256i v, uint32_t &base, uint32_t &ws, uint32_t &b0, uint32_t &b1) {
     const __m256i lut = _mm256_broadcastsi128_si256(_mm_load_si128((const __m128i *)BASE_BY_NIBBLE));
     const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
     const __m256i t = _mm256_xor_si256(v, _mm256_srli_epi16(v, 1));
@@ -513,7 +512,6 @@ KP_T256 inline void classify256(__m256i v, uint32_t &base, uint32_t &ws, uint32_
     base = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(lut, v), up));
     ws = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(_mm256_min_epu8(d, _mm256_set1_epi8(4)), d),
                                                         _mm256_cmpeq_epi8(v, _mm256_set1_epi8(32))));
-    nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('\n')));
     b0 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 6));  // bit 1 of every byte -> its bit 7
     b1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 5));
 }
@@ -583,29 +581,29 @@ KP_T256 inline void emit_bits(Body &b, const Masks &m, int take) {
 
 // Sequence lines from data[i] (a line start) up to the next line that starts with '>' or the end of the text; returns
 // the index it stopped at.  LEVEL 2: AVX-512 (BW, VBMI2), 1: AVX2; both need BMI2.
-template <int LEVEL>
-KP_T256 inline int64_t scalar_stretch(Body &b, const uint8_t *data, int64_t i, int64_t n, bool &line_start, bool &header) {
-    // symbols that are not bases, and the whitespace between them, one at a time: until a base or a header turns up
+// symbols that are not bases, and the whitespace between them, one at a time: until a base or a header turns up.  A '>' opens
+// a header iff it is the first byte of a line: the body's first byte (`from`), or the byte after a '\n'.
+inline int64_t scalar_stretch(Body &b, const uint8_t *data, int64_t i, int64_t n, int64_t from, bool &header) {
     header = false;
     while (i < n) {
         const uint8_t c = data[i], code = T.code[c];
-        if (code == 8) { line_start = c == '\n'; ++i; continue; }
-        if (c == '>' && line_start) { header = true; break; }
+        if (code == 8) { ++i; continue; }
+        if (c == '>' && (i == from || data[i - 1] == '\n')) { header = true; break; }
         if (code < 4) break;
         put_other(b, c);
-        line_start = false;
         ++i;
     }
     return i;
 }
 
 KP_T512 int64_t body512(Body &b, const uint8_t *data, int64_t i, int64_t n) {
-    bool line_start = true, header = false;
+    const int64_t from = i;
+    bool header = false;
     while (i < n) {
         if (b.pk.pos > (int64_t)KP_MAX_ASM_LEN) return -1;
         const int64_t left = n - i;
-        const __mmask64 in = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-        const __m512i v = _mm512_maskz_loadu_epi8(in, data + i);
+        const __m512i v = left >= 64 ? _mm512_loadu_si512((const void *)(data + i))
+                                     : _mm512_maskz_loadu_epi8((1ull << left) - 1ull, data + i);
         const Masks m = classify512(v);
         const uint64_t bad = ~(m.base | m.ws);  // (bytes past the end of the text read as 0: bad)
         const int take = bad ? (int)_tzcnt_u64(bad) : 64;
@@ -616,11 +614,10 @@ KP_T512 int64_t body512(Body &b, const uint8_t *data, int64_t i, int64_t n) {
                 b.dp += _mm_popcnt_u64(keep);
             }
             emit_bits(b, m, take);
-            line_start = (m.nl >> (take - 1)) & 1u;
             i += take;
         }
         if (take < 64 && i < n) {
-            i = scalar_stretch<2>(b, data, i, n, line_start, header);
+            i = scalar_stretch(b, data, i, n, from, header);
             if (header) break;
         }
     }
@@ -628,17 +625,18 @@ KP_T512 int64_t body512(Body &b, const uint8_t *data, int64_t i, int64_t n) {
 }
 
 KP_T256 int64_t body256(Body &b, const uint8_t *data, int64_t i, int64_t n) {
-    bool line_start = true, header = false;
+    const int64_t from = i;
+    bool header = false;
     while (i < n) {
         if (b.pk.pos > (int64_t)KP_MAX_ASM_LEN) return -1;
         int take = 0;
         if (n - i >= 64) {
             Masks m;
-            uint32_t a[5], c[5];
-            classify256(_mm256_loadu_si256((const __m256i *)(data + i)), a[0], a[1], a[2], a[3], a[4]);
-            classify256(_mm256_loadu_si256((const __m256i *)(data + i + 32)), c[0], c[1], c[2], c[3], c[4]);
-            m.base = a[0] | (uint64_t)c[0] << 32; m.ws = a[1] | (uint64_t)c[1] << 32; m.nl = a[2] | (uint64_t)c[2] << 32;
-            m.b0 = a[3] | (uint64_t)c[3] << 32; m.b1 = a[4] | (uint64_t)c[4] << 32;
+            uint32_t a[4], c[4];
+            classify256(_mm256_loadu_si256((const __m256i *)(data + i)), a[0], a[1], a[2], a[3]);
+            classify256(_mm256_loadu_si256((const __m256i *)(data + i + 32)), c[0], c[1], c[2], c[3]);
+            m.base = a[0] | (uint64_t)c[0] << 32; m.ws = a[1] | (uint64_t)c[1] << 32;
+            m.b0 = a[2] | (uint64_t)c[2] << 32; m.b1 = a[3] | (uint64_t)c[3] << 32;
             const uint64_t bad = ~(m.base | m.ws);
             take = bad ? (int)_tzcnt_u64(bad) : 64;
             if (take) {
@@ -654,7 +652,6 @@ KP_T256 int64_t body256(Body &b, const uint8_t *data, int64_t i, int64_t n) {
                     }
                 }
                 emit_bits(b, m, take);
-                line_start = (m.nl >> (take - 1)) & 1u;
                 i += take;
             }
             if (take == 64) continue;
@@ -666,11 +663,10 @@ KP_T256 int64_t body256(Body &b, const uint8_t *data, int64_t i, int64_t n) {
                 b.in_run = false;
                 b.pk.put(code);
                 if (b.dp) *b.dp++ = ch;
-                line_start = false;
                 ++i;
                 continue;
             }
-            i = scalar_stretch<1>(b, data, i, n, line_start, header);
+            i = scalar_stretch(b, data, i, n, from, header);
             if (header) break;
         }
     }
