@@ -169,6 +169,10 @@ class _TypingPipeline:
         from kaptive_amd import usable_cpus
 
         self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
+        # PREFETCH + 1 chunks are being parsed at any time, each by one native call: the thread budget is shared out among them
+        # (measured on the 16-CPU box, threads per call 4 / 6 / 8 / 12 / 16 / 24 / 32: 12.5 / 15.2 / 12.1 / 11.0 / 11.0 / 7.4 / 6.5 k
+        # assemblies/s -- a cgroup throttles what oversubscribes its quota)
+        self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
         import threading
 
@@ -206,14 +210,14 @@ class _TypingPipeline:
                 raise NotImplementedError(f"Unsupported format: {path}")
             ids.append(name.removesuffix(m.group()))
             comps.append(m.group("compression"))
-        shard = _native.FastaShard(paths, comps, self.threads)
+        shard = _native.FastaShard(paths, comps, self.shard_threads)
         if shard.failed:
             shard.close()
             return [self._load(path) for path in paths]
         # the words go to page-locked memory here, on the reader's side of the pipeline (the driving thread only creates the
         # batch): 0.6 GB per chunk of 512 assemblies, copied by the library's threads
         pb = self._pinned(shard.total_words)
-        shard.words_into(pb.array, self.threads)
+        shard.words_into(pb.array, self.shard_threads)
         tables = tuple(np.array(t) for t in shard.tables())
         total = shard.total_words
         shard.close()
