@@ -389,6 +389,10 @@ def run_type(args: argparse.Namespace) -> int:
 
             ctx = mp.get_context("spawn")
             conns, procs = [], []
+            from kaptive_amd import usable_cpus
+
+            # the device processes share the host: each gets its part of the reader-thread budget
+            args.threads = max(1, (args.threads or usable_cpus()) // len(devices))
             for i, d in enumerate(devices):
                 parent, child = ctx.Pipe(duplex=False)
                 proc = ctx.Process(target=_device_worker, args=(args, d, chunks[i :: len(devices)], child), daemon=True)
