@@ -946,6 +946,7 @@ def test_parity_sweep_at_full_size(oracle):
     from tests import sweep_util as S
 
     n = int(os.environ.get("KAPTIVE_AMD_SWEEP", "6"))
+    per_batch = int(os.environ.get("KAPTIVE_AMD_SWEEP_BATCH", "64"))  # (1024 x 5 Mbp: batch-wide base positions beyond 2^32)
     summary = {}
     with mp.get_context("spawn").Pool(min(16, max(2, (os.cpu_count() or 2) // 2))) as pool:
         for config in S.CONFIGS:
@@ -956,8 +957,8 @@ def test_parity_sweep_at_full_size(oracle):
             packed = [g.packed() for g in genomes]
             engines = [Engine(db) for db in dbs]
             compared = 0
-            for lo in range(0, n, 64):
-                part = packed[lo : lo + 64]
+            for lo in range(0, n, per_batch):
+                part = packed[lo : lo + per_batch]
                 first = engines[0].ctx.batch(part)
                 batches = [first] + [e.ctx.batch(part, device_words=first.device_words, after=first) for e in engines[1:]]
                 for b in batches:
@@ -976,7 +977,8 @@ def test_parity_sweep_at_full_size(oracle):
                     b.close()
             for e in engines:
                 e.close()
-            summary[config] = {"assemblies": n, "databases": len(dbs), "hit_records_equal": compared, "differing": 0}
+            summary[config] = {"assemblies": n, "assemblies_per_batch": min(n, per_batch), "databases": len(dbs),
+                               "hit_records_equal": compared, "differing": 0}
     if out := os.environ.get("KAPTIVE_AMD_SWEEP_OUT"):
         with open(out, "w") as f:
             json.dump(summary, f, indent=1)
