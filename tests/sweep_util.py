@@ -42,17 +42,29 @@ def make(config: str, i: int):
 
 
 def oracle_hits(job):
-    """(config, i) -> [hit table per database] from the oracle's aligner."""
+    """(config, i) -> ([hit table per database] from the oracle's aligner, [KaptiveRow bytes per database] from the host
+    reduction -- the statement the reference goldens pin -- fed by those hits and the oracle's protein DP)."""
+    from kaptive_amd.core.pairwise import PairwiseAlignments
     from kaptive_amd.pack import pack_sequences_flat
+    from kaptive_amd.serotyping.core import Serotyper
+    from kaptive_amd.serotyping.io import KaptiveRow
     from oracle import oracle as O
+    from tests.golden_util import hits_to_alignments
 
     config, i = job
     g, main, also = make(config, i)
-    out = []
+    hits, rows = [], []
     for k, db in enumerate((main, also)):
         if db is None:
             continue
         if ("odb", config, k) not in _STATE:
             _STATE["odb", config, k] = O.OracleDB(*pack_sequences_flat(db.genes))
-        out.append(np.array(_STATE["odb", config, k].align(g.packed())))
-    return out
+        h = np.array(_STATE["odb", config, k].align(g.packed()))
+        hits.append(h)
+        typer = Serotyper(
+            db, aligner=lambda genome, db=db, h=h: hits_to_alignments(db, genome, h),
+            protein_aligner=lambda q, t: PairwiseAlignments.from_table(
+                O.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)),
+        )  # fmt: skip
+        rows.append(bytes(KaptiveRow.from_result(typer(g))))
+    return hits, rows

@@ -936,8 +936,8 @@ def test_config4_acinetobacter_at_full_size(oracle):
 def test_parity_sweep_at_full_size(oracle):
     """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 6: BASELINE configs 2/3 -- 5 Mbp, K
     and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
-    second loci and tandem copies: the device's hit tables equal the oracle's record for record, for every assembly and
-    database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
+    second loci and tandem copies: the device's hit tables equal the oracle's record for record and its report rows equal the
+    host reduction's byte for byte, for every assembly and database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
     import json
     import multiprocessing as mp
     import os
@@ -956,7 +956,12 @@ def test_parity_sweep_at_full_size(oracle):
             genomes, dbs = [m[0] for m in made], [d for d in made[0][1:] if d is not None]
             packed = [g.packed() for g in genomes]
             engines = [Engine(db) for db in dbs]
-            compared = 0
+            typers = []
+            for db, e in zip(dbs, engines):
+                t = Serotyper(db)
+                t._engine = e
+                typers.append(t)
+            compared = rows_equal = 0
             for lo in range(0, n, per_batch):
                 part = packed[lo : lo + per_batch]
                 first = engines[0].ctx.batch(part)
@@ -971,14 +976,20 @@ def test_parity_sweep_at_full_size(oracle):
                     want = pending.get(timeout=3600)
                 for k, (hits, off) in enumerate(got):
                     for i in range(len(part)):
-                        _same_records(hits[off[i] : off[i + 1]], want[lo + i][k], f"{config} database {k}, assembly {lo + i} {S.assembly_kwargs(config, lo + i)}")
+                        _same_records(hits[off[i] : off[i + 1]], want[lo + i][0][k], f"{config} database {k}, assembly {lo + i} {S.assembly_kwargs(config, lo + i)}")
                         compared += int(off[i + 1] - off[i])
+                    # ... and the rows of the device's reduction equal the host reduction's on the oracle's hits
+                    ids = [g.id for g in genomes[lo : lo + per_batch]]
+                    rows = engines[k].type_batch(typers[k], batches[k], ids, aligned=True).rows()
+                    for i, row in enumerate(rows):
+                        assert row == want[lo + i][1][k], f"{config} database {k}, row of assembly {lo + i} {S.assembly_kwargs(config, lo + i)}"
+                    rows_equal += len(rows)
                 for b in reversed(batches):
                     b.close()
             for e in engines:
                 e.close()
             summary[config] = {"assemblies": n, "assemblies_per_batch": min(n, per_batch), "databases": len(dbs),
-                               "hit_records_equal": compared, "differing": 0}
+                               "hit_records_equal": compared, "report_rows_equal": rows_equal, "differing": 0}
     if out := os.environ.get("KAPTIVE_AMD_SWEEP_OUT"):
         with open(out, "w") as f:
             json.dump(summary, f, indent=1)
