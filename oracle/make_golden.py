@@ -327,9 +327,34 @@ def gen_typing() -> None:
     (OUT / "typing_index.json").write_text(json.dumps(index, indent=1) + "\n")
 
 
+def gen_typing_full_missing() -> None:
+    index = json.loads((OUT / "typing_index.json").read_text())
+    for name, key, db_args, kw in FULL_SIZE_CASES:
+        if (OUT / f"typing_{name}.npz").exists() and name in index:
+            continue
+        t0 = time.time()
+        db = make_db(*db_args[:1], seed=db_args[1])
+        genome = make_assembly(db, name=name, **kw)
+        ref_db = to_ref_db(db)
+        hits, chain = O.OracleDB(*pack_sequences_flat(db.genes)).align(genome.packed(), with_chain=True)
+        exp = run_reference_typing(ref_db, RefSerotyper(ref_db), genome, hits)
+        save_case(name, key, genome, hits, exp, chain, synth=dict(db=list(db_args), assembly=kw))
+        if name not in index:
+            index.append(name)
+        print(f"typing {name}: {len(hits)} hits -> {bytes(exp['kaptive_row'])[:90]!r} ({time.time() - t0:.1f}s)")
+    (OUT / "typing_index.json").write_text(json.dumps(index, indent=1) + "\n")
+
+
 FULL_SIZE_CASES = [
     ("k_fullsize", "kfull", ("kpsc_k", 100), dict(seed=20_001)),                                                   # config 2: 5 Mbp, ~120 contigs
     ("ab_fullsize", "abfull", ("ab_k", 102), dict(seed=40_001, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True)),  # config 4
+    # (round 4, later) the shapes the parity sweep varies, each once through the reference's own reduction at full size
+    ("k_full_div9", "kfull", ("kpsc_k", 100), dict(seed=20_002, sub_rate=0.09)),
+    ("k_full_indel", "kfull", ("kpsc_k", 100), dict(seed=20_003, indel_rate=2e-3)),
+    ("k_full_nrun_second", "kfull", ("kpsc_k", 100), dict(seed=20_004, n_run=3, second_locus=17)),
+    ("k_full_tandem", "kfull", ("kpsc_k", 100), dict(seed=20_005, tandem_gene=1)),
+    ("o_fullsize", "ofull", ("kpsc_o", 101), dict(seed=20_006)),                                                   # config 3's O half
+    ("ab_full_div6", "abfull", ("ab_k", 102), dict(seed=40_002, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True, sub_rate=0.06)),
 ]
 
 
@@ -465,6 +490,8 @@ def main() -> None:
         gen_seqs(np.random.default_rng(3))
     if "typing" in what:
         gen_typing()
+    if "typing_full" in what:  # only the full-size cases that are not there yet (the index gains their names)
+        gen_typing_full_missing()
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ def case_names() -> list[str]:
 
 
 # databases of the full-size cases: regenerated from their seeds (kaptive_amd.synth), not stored
-SYNTH_DBS = {"kfull": ("kpsc_k", 100), "abfull": ("ab_k", 102)}
+SYNTH_DBS = {"kfull": ("kpsc_k", 100), "abfull": ("ab_k", 102), "ofull": ("kpsc_o", 101)}
 
 
 @lru_cache(maxsize=None)
