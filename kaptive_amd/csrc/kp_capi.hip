@@ -143,7 +143,9 @@ static std::mutex g_pin_mutex;
 static std::unordered_map<void *, size_t> g_pin_sizes;
 static size_t g_pin_bytes = 0;
 static hipError_t pinned_alloc(void **out, size_t bytes) {
-    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    // portable: usable by every device's context whichever thread (and current device) allocates it -- a reader thread of
+    // the CLI takes page-locked buffers while the driving thread holds the context
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_pin_mutex);
         g_pin_sizes[*out] = bytes;
