@@ -156,15 +156,20 @@ class _TypingPipeline:
 
         from kaptive_amd.serotyping.core import Serotyper
 
+        import time
+
         self.args = args
+        self.marks = {"pipeline_start": time.perf_counter()}  # (KAPTIVE_AMD_CLI_TIMING: where the time before the first rows goes)
         self._own_typer = typer is None
         if typer is None:
             self.db = load_database(args.database)
+            self.marks["database_loaded"] = time.perf_counter()
             typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
                               allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
                               device=device)  # fmt: skip
         self.typer = typer
         self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
+        self.marks["context_ready"] = time.perf_counter()
         self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins", "pha4ge"))
         self.want_tsv = bool(getattr(args, "out", None))
         from kaptive_amd import usable_cpus
@@ -281,7 +286,9 @@ class _TypingPipeline:
                 genomes = [f.result() for f in futures] if isinstance(futures, list) else futures.result()
                 start_read()
                 ids = genomes[1] if isinstance(genomes, tuple) else [g.id for g in genomes]
+                self.marks.setdefault("first_chunk_parsed", __import__("time").perf_counter())
                 ready.append((self._make_batch(genomes), k, ids, genomes if self.objects else None))
+                self.marks.setdefault("first_batch_created", __import__("time").perf_counter())
             batch, k, ids, genomes = ready.popleft()
             self._order.append(k)
             yield batch, ids, genomes
@@ -373,7 +380,7 @@ def run_type(args: argparse.Namespace) -> int:
     import time
 
     timing_path = os.environ.get("KAPTIVE_AMD_CLI_TIMING")  # bench.py: when each chunk's rows were written
-    t_start, chunk_times = time.perf_counter(), []
+    t_start, chunk_times, phases = time.perf_counter(), [], {}
 
     def write(out, n):
         nonlocal done
@@ -391,6 +398,7 @@ def run_type(args: argparse.Namespace) -> int:
                 for k, out in pipe.run(chunks):
                     write(out, len(chunks[k][1]))
             finally:
+                phases = {name: round(t - t_start, 3) for name, t in pipe.marks.items()}
                 pipe.close()
         else:
             # chunk k goes to device k mod n; rows come back through pipes and are written in input order
@@ -433,7 +441,7 @@ def run_type(args: argparse.Namespace) -> int:
     if timing_path:
         Path(timing_path).write_text(json.dumps({"assemblies": len(args.genomes), "seconds": time.perf_counter() - t_start,
                                                  "batch_size": args.batch_size, "devices": devices,
-                                                 "rows_written_at": chunk_times}) + "\n")  # fmt: skip
+                                                 "rows_written_at": chunk_times, "phases_s": phases}) + "\n")  # fmt: skip
     return 0
 
 

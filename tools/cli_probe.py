@@ -57,12 +57,13 @@ def main() -> int:
                 if r.returncode != 0:
                     print(r.stderr[-600:])
                     return 1
-                marks = json.loads(timing.read_text())["rows_written_at"]
+                tm = json.loads(timing.read_text())
+                marks = tm["rows_written_at"]
                 (n0, t0), (n1, t1) = marks[min(4, len(marks) - 2)], marks[-1]
                 print(json.dumps({"files": len(paths) * args.repeats, "gz": args.gz, "threads": threads, "batch": batch,
                                   "text_MB_per_file": round(sum(sizes) / len(sizes) / 1e6, 2),
                                   "MB_per_file_on_disk": round(sum(os.path.getsize(p) for p in paths) / len(paths) / 1e6, 2), "wall_s": round(wall, 2),
-                                  "first_rows_after_s": round(marks[0][1], 2), "assemblies_per_s_steady": round((n1 - n0) / (t1 - t0), 1)}), flush=True)
+                                  "first_rows_after_s": round(marks[0][1], 2), "phases_s": tm.get("phases_s"), "assemblies_per_s_steady": round((n1 - n0) / (t1 - t0), 1)}), flush=True)
         return 0
     finally:
         shutil.rmtree(root, ignore_errors=True)
