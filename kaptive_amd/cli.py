@@ -141,10 +141,10 @@ class _TypingPipeline:
 
     The stages run beside each other: while the GPU types chunk k, the reader threads parse and pack chunk k + 1 .. k + 2
     (``kp_fasta_ingest`` releases the interpreter lock), their packed words are copied into page-locked memory and
-    uploaded on the copy stream, and chunk k - 1's rows are formatted.  When only the TSV report is asked for, no
-    per-assembly object is ever built: the rows come from ``BatchTyping.tsv()`` (``kp_format_rows``, byte for byte what
-    ``KaptiveRow.from_result`` gives) and the files' sequence text is not even kept.  Every other output (``-j``, ``-l``,
-    ``-g``, ``-p``, ``--pha4ge``) goes through ``SerotypingResult`` objects, as the reference's writers do
+    uploaded on the copy stream, and chunk k - 1's rows are formatted.  When only the TSV and / or PHA4GE reports are asked for,
+    no per-assembly object is ever built: the rows come from ``BatchTyping.tsv()`` (``kp_format_rows``, byte for byte what
+    ``KaptiveRow.from_result`` gives) and ``BatchTyping.pha4ge()``, and the files' sequence text is not even kept.  The
+    other outputs (``-j``, ``-l``, ``-g``, ``-p``) go through ``SerotypingResult`` objects, as the reference's writers do
     (src/kaptive/serotyping/cli.py:20-114)."""
 
     PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
@@ -170,7 +170,7 @@ class _TypingPipeline:
         self.typer = typer
         self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
         self.marks["context_ready"] = time.perf_counter()
-        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins", "pha4ge"))
+        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins"))
         self.want_tsv = bool(getattr(args, "out", None))
         from kaptive_amd import usable_cpus
 
@@ -297,8 +297,6 @@ class _TypingPipeline:
     def run(self, chunks):
         """Yields ``(k, outputs)`` for every ``(k, paths)`` of ``chunks``, in order; ``outputs`` maps "tsv" / "pha4ge" /
         "json" to the bytes this chunk adds to that stream (per-assembly fasta files are written here)."""
-        from kaptive_amd.serotyping.io import Pha4geRow
-
         args = self.args
         self._order: list = []
         done = 0
@@ -306,10 +304,10 @@ class _TypingPipeline:
             out = {}
             if self.want_tsv:
                 out["tsv"] = bt.tsv()
+            if getattr(args, "pha4ge", None):
+                out["pha4ge"] = bt.pha4ge()
             if self.objects:
                 results = bt.results()
-                if getattr(args, "pha4ge", None):
-                    out["pha4ge"] = b"".join(bytes(Pha4geRow.from_result(r)) for r in results)
                 if getattr(args, "json", None):
                     out["json"] = b"".join(result_to_json(r) for r in results)
                 for flag, attr, ext in (("loci", "locus_seqs", "fna"), ("genes", "gene_seqs", "ffn"), ("proteins", "translations", "faa")):

@@ -217,6 +217,34 @@ class BatchTyping:
                           self.percent_identity, self.percent_coverage, self.length_discrepancy)  # fmt: skip
 
 
+    def pha4ge(self) -> bytes:
+        """The PHA4GE lines of the whole batch (``--pha4ge``), from the batch's columns: byte for byte what
+        ``Pha4geRow.from_result(result(i))`` gives (reference: src/kaptive/serotyping/io.py, ``Pha4geRow``) without an object
+        per assembly."""
+        from kaptive_amd import KAPTIVE_COMPAT_VERSION
+        from kaptive_amd.serotyping.io import _PHA4GE_PROBLEMS, Pha4geRow
+
+        db = self.typer._db
+        md = db.metadata
+        fixed = dict(genotyping_schema_taxon=b"%s [NCBITaxon:%d]" % (md.organism.encode(), md.taxon),
+                     genotyping_database_name=md.name.encode(), genotyping_database_version=md.version.encode(),
+                     genotyping_software_version=KAPTIVE_COMPAT_VERSION.encode())  # fmt: skip
+        notes = [(int(flag), text) for flag, text in _PHA4GE_PROBLEMS]
+        out = []
+        for i, genome in enumerate(self.ids):
+            locus = db.loci.ids[int(self.best_locus[i])].encode()
+            p = int(self.problems[i])
+            if p:
+                said = [(b"match broken into %d pieces" % int(self.n_pieces[i])) if text is None else text for flag, text in notes if p & flag]
+                details = b"Best locus match: %b. Problems: %b" % (locus, b", ".join(said))
+            else:
+                details = b"Best locus match: %b." % locus
+            out.append(bytes(Pha4geRow(sample=genome.encode(), genotype=locus, genotyping_details=details,
+                                       genotype_confidence_value=b"Typeable" if self.typeable[i] else b"Untypeable",
+                                       genotype_predicted_phenotype=self.phenotype[i].encode(), **fixed)))  # fmt: skip
+        return b"".join(out)
+
+
 class _HitsView:
     """The one attribute ``Serotyper._phenotype`` reads off a GeneHits."""
 
