@@ -14,6 +14,7 @@ import argparse
 import json
 import os
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
@@ -156,8 +157,6 @@ class _TypingPipeline:
 
         from kaptive_amd.serotyping.core import Serotyper
 
-        import time
-
         self.args = args
         self.marks = {"pipeline_start": time.perf_counter()}  # (KAPTIVE_AMD_CLI_TIMING: where the time before the first rows goes)
         self._own_typer = typer is None
@@ -286,9 +285,9 @@ class _TypingPipeline:
                 genomes = [f.result() for f in futures] if isinstance(futures, list) else futures.result()
                 start_read()
                 ids = genomes[1] if isinstance(genomes, tuple) else [g.id for g in genomes]
-                self.marks.setdefault("first_chunk_parsed", __import__("time").perf_counter())
+                self.marks.setdefault("first_chunk_parsed", time.perf_counter())
                 ready.append((self._make_batch(genomes), k, ids, genomes if self.objects else None))
-                self.marks.setdefault("first_batch_created", __import__("time").perf_counter())
+                self.marks.setdefault("first_batch_created", time.perf_counter())
             batch, k, ids, genomes = ready.popleft()
             self._order.append(k)
             yield batch, ids, genomes
@@ -374,9 +373,6 @@ def run_type(args: argparse.Namespace) -> int:
     if j := getattr(args, "json", None):
         handles["json"] = stream(j)
     done = 0
-    import os
-    import time
-
     timing_path = os.environ.get("KAPTIVE_AMD_CLI_TIMING")  # bench.py: when each chunk's rows were written
     t_start, chunk_times, phases = time.perf_counter(), [], {}
 
