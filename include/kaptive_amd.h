@@ -43,6 +43,9 @@ typedef struct kp_ctx kp_ctx;     /* one GPU + stream + resident database */
 typedef struct kp_batch kp_batch; /* a set of packed assemblies resident in HBM, plus its results */
 
 /* ---- context -------------------------------------------------------------------------------------------------- */
+/* GPUs the process sees (>= 0), or a negative KP_E* code: `kaptive assembly --devices all` shards over all of them, one
+ * process each (the reference has no device notion; its unit of parallelism is the worker thread, cli.py:183-210). */
+KP_API int kp_device_count(void);
 KP_API int kp_ctx_create(int device_id, kp_ctx **out);
 KP_API void kp_ctx_destroy(kp_ctx *ctx);
 /* Message of the last failed call on ctx (ctx may be NULL for a failed kp_ctx_create). Never NULL. */

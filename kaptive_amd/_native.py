@@ -32,7 +32,7 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
+    "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
@@ -228,6 +228,14 @@ class FastaShard:
             self._h = None
 
     __del__ = close
+
+
+def device_count() -> int:
+    """GPUs this process sees (kp_device_count)."""
+    n = lib().kp_device_count()
+    if n < 0:
+        raise NativeError(f"kp_device_count failed ({n}): {lib().kp_last_error(None).decode()}")
+    return int(n)
 
 
 def compression_is_native() -> bool:

@@ -112,9 +112,9 @@ def build_parser() -> argparse.ArgumentParser:
     c.add_argument("--min-completeness", type=float, default=0.5, metavar="", help="Typeable if >= completeness (default: 0.5)")
     c.add_argument("--below-threshold", action="store_true", help="Typeable if any genes in locus are below threshold")
     o = t.add_argument_group("Other options")
-    o.add_argument("-t", "--threads", type=int, default=0, metavar="", help="Threads for reading/packing genomes, 0 = all")
+    o.add_argument("-t", "--threads", type=int, default=0, metavar="", help="Threads for reading/packing genomes (0 = the CPUs this process is granted)")
     o.add_argument("--partial-edge-tolerance", type=int, default=5, metavar="", help="Bases from contig edge to call a partial gene")
-    o.add_argument("--devices", default="0", metavar="", help="Comma-separated GPU indices (default: 0)")
+    o.add_argument("--devices", default="0", metavar="", help="Comma-separated GPU indices, or 'all' (default: 0)")
     o.add_argument("--batch-size", type=int, default=0, metavar="",
                    help="Assemblies per device submission (default: 64, 128, 256, then 512 -- first rows early, large batches later)")
     o.add_argument("-V", "--verbose", action="store_true")
@@ -344,7 +344,12 @@ def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) ->
 
 
 def run_type(args: argparse.Namespace) -> int:
-    devices = [int(d) for d in str(args.devices).split(",") if d != ""] or [0]
+    if str(args.devices).strip().lower() == "all":
+        from kaptive_amd import _native
+
+        devices = list(range(max(1, _native.device_count())))
+    else:
+        devices = [int(d) for d in str(args.devices).split(",") if d != ""] or [0]
     # Chunks: of --batch-size when given; otherwise small ones first (the first rows are out after 0.6 s instead of 1.5 s:
     # page-locking and device buffers of a 512-assembly chunk take a second to set up) and 512 from the fourth chunk of a
     # device on, where the steady rate is highest.

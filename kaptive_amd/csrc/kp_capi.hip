@@ -586,6 +586,13 @@ const char *const NO_RESULTS = "this batch has no resident alignment results (no
 
 extern "C" {
 
+int kp_device_count(void) {
+    int n_dev = 0;
+    const hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess) return kp_fail(nullptr, KP_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n_dev;
+}
+
 int kp_ctx_create(int device_id, kp_ctx **out) {
     if (!out) return kp_fail(nullptr, KP_EINVAL, "out is null");
     *out = nullptr;

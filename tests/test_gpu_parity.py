@@ -828,6 +828,8 @@ def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_p
     assert fast.read_bytes() == slow.read_bytes() == two.read_bytes()
     assert len((tmp_path / "r.jsonl").read_bytes().splitlines()) == len(paths)
     assert main(["assembly", str(db_path), paths[0], str(tmp_path / "nope.fasta"), "-o", str(fast)]) == 1
+    assert main(["assembly", str(db_path), *paths, "-o", str(tmp_path / "all.tsv"), "--devices", "all"]) == 0  # every GPU the box has
+    assert (tmp_path / "all.tsv").read_bytes() == fast.read_bytes() and _native.device_count() >= 1
     # --pha4ge rides on the batch's columns too (BatchTyping.pha4ge); with -j beside it the rows come from result objects
     ph_fast, ph_slow = tmp_path / "fast.pha4ge", tmp_path / "slow.pha4ge"
     assert main(["assembly", str(db_path), *paths, "-o", str(tmp_path / "f2.tsv"), "--pha4ge", str(ph_fast), "--batch-size", "4"]) == 0
