@@ -119,13 +119,24 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
 #define KP_MIN_SEED_SPAN 40
 #define KP_CHAIN_DP_MAX 24
 #define KP_CHAIN_MAX_DIST 5000 /* minimap2's max_gap */
-#define KP_CHAIN_PEN_SIZE 128
+#define KP_CHAIN_PEN_SIZE 512 /* dd 0..500 (minimap2's bw), padded */
 #define KP_CHAIN_PEN_TABLE                                                                                            \
-    {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 6, 6,                     \
-     6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 10, 10, 10, 10, 10,                 \
-     10, 10, 10, 11, 11, 11, 11, 11, 11, 11, 11, 12, 12, 12, 12, 12, 12, 12, 13, 13, 13, 13, 13, 13, 13, 13, 14, 14, 14,  \
-     14, 14, 14, 14, 14, 15, 15, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 17, 17, 17,  \
-     18, 18, 18, 18, 18, 18}
+    {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 6, 6, \
+     6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 10, 10, 10, 10, 10, \
+     10, 10, 10, 11, 11, 11, 11, 11, 11, 11, 11, 12, 12, 12, 12, 12, 12, 12, 13, 13, 13, 13, 13, 13, 13, 13, 14, 14, 14, 14, 14, 14, \
+     14, 14, 15, 15, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, \
+     18, 18, 19, 19, 19, 19, 19, 19, 19, 19, 20, 20, 20, 20, 20, 20, 20, 20, 21, 21, 21, 21, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, \
+     22, 22, 23, 23, 23, 23, 23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 24, 25, 25, 25, 25, 25, 25, 25, 25, 26, 26, 26, 26, 26, 26, \
+     26, 26, 27, 27, 27, 27, 27, 27, 27, 27, 28, 28, 28, 28, 28, 28, 28, 28, 29, 29, 29, 29, 29, 29, 29, 29, 30, 30, 30, 30, 30, 30, \
+     30, 30, 31, 31, 31, 31, 31, 31, 31, 31, 32, 32, 32, 32, 32, 32, 32, 32, 33, 33, 33, 33, 33, 33, 33, 33, 33, 34, 34, 34, 34, 34, \
+     34, 34, 34, 35, 35, 35, 35, 35, 35, 35, 35, 36, 36, 36, 36, 36, 36, 36, 36, 37, 37, 37, 37, 37, 37, 37, 37, 38, 38, 38, 38, 38, \
+     38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, \
+     42, 42, 42, 42, 43, 43, 43, 43, 43, 43, 43, 43, 44, 44, 44, 44, 44, 44, 44, 44, 45, 45, 45, 45, 45, 45, 45, 45, 45, 46, 46, 46, \
+     46, 46, 46, 46, 46, 47, 47, 47, 47, 47, 47, 47, 47, 48, 48, 48, 48, 48, 48, 48, 48, 49, 49, 49, 49, 49, 49, 49, 49, 50, 50, 50, \
+     50, 50, 50, 50, 50, 50, 51, 51, 51, 51, 51, 51, 51, 51, 52, 52, 52, 52, 52, 52, 52, 52, 53, 53, 53, 53, 53, 53, 53, 53, 54, 54, \
+     54, 54, 54, 54, 54, 54, 55, 55, 55, 55, 55, 55, 55, 55, 55, 56, 56, 56, 56, 56, 56, 56, 56, 57, 57, 57, 57, 57, 57, 57, 57, 58, \
+     58, 58, 58, 58, 58, 58, 58, 59, 59, 59, 59, 59, 59, 59, 59, 59, 60, 60, 60, 60, 60, 60, 60, 60, 61, 61, 61, 61, 61, 61, 61, 61, \
+     62, 62, 62, 62, 62, 62, 62, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64}
 
 /* ---- banded local alignment (Smith-Waterman-Gotoh; scores <= 2 * KP_MAX_GENE_LEN) ----------------------------------------------------------
  * H = max(0, Hdiag + s, E, F);  E (gap in query, moves along the target) = max(Hleft - (O+X), Eleft - X);
@@ -152,6 +163,77 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
 #define KP_MASK_LEVEL_NUM 1   /* a hit is secondary to a better hit of its gene that covers more than */
 #define KP_MASK_LEVEL_DEN 2   /* KP_MASK_LEVEL_NUM / KP_MASK_LEVEL_DEN of the shorter one's query span (minimap2 -M 0.5) */
 #define KP_NEG_INF (-(1 << 29))
+
+/* ---- kp-align v4: chains across diagonal jumps of up to KP_JOIN_BW (minimap2's bw = 500) -----------------------------------
+ * minimap2 chains anchors whose diagonals differ by up to bw = 500 and aligns through the gap (global fill between the
+ * flanking anchors under min(4 + 2n, 24 + n)); a gene with an insertion or deletion of 33-500 bases is ONE hit there.  The
+ * clusters above stop at KP_DIAG_GAP; v4 puts the JOIN on top of them and leaves everything else as it was: every accepted
+ * cluster is still a band task with a hit of its own, and a joined alignment that passes the tests below REPLACES the hits of
+ * the pieces it runs through.
+ *
+ * GROUPS.  A cluster is PROVISIONAL when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases (it may
+ * still be rejected by its chain score).  Walking an assembly's provisional clusters in the order of the sorted anchors,
+ * a cluster joins the group of the provisional cluster before it iff both have the same gene/strand, its lowest diagonal is
+ * at most KP_JOIN_BW above the highest diagonal of that cluster, and the group holds fewer than KP_JOIN_GROUP_MAX clusters;
+ * otherwise it starts a new group.  (Diagonals are in the assembly's padded coordinates: near a contig boundary clusters of
+ * two contigs interleave, so a group may hold clusters of several contigs.)  Groups of one are nothing.
+ *
+ * CHAINS OF CLUSTERS.  Nodes are the group's ACCEPTED clusters (chain score >= KP_MIN_CHAIN_SCORE; cs = that score, n = its
+ * anchor count).  HEAD of a cluster = its anchor with the smallest (query position, diagonal), TAIL = the one with the
+ * largest; t = q + diagonal.  Nodes are ordered by (head t, head q, order of the sorted anchors).  minimap2's chaining DP on
+ * that order:  f[i] = cs[i] + max(0, max over earlier j of f[j] + link(j, i)), the FIRST maximum met going backwards from
+ * i - 1 (a predecessor is taken only if it beats "none"), with, for dq = head_q[i] - tail_q[j], dr = head_t[i] - tail_t[j],
+ * dd = |dr - dq|:  link = invalid unless i and j lie on the same contig, 0 < dq <= KP_CHAIN_MAX_DIST, 0 < dr <= KP_CHAIN_MAX_DIST and dd <= KP_JOIN_BW;
+ * link = min(KP_K, dq, dr) - KP_K - kp_chain_pen[dd]  (what mm_chain_dp gives the first anchor of i after the last of j,
+ * relative to starting afresh).  Backtracking as mg_chain_backtrack: repeatedly take the unused node with the largest f
+ * (the later one on ties) and walk the predecessors until a used node, the start, or KP_JOIN_MAX_PIECES nodes; the walked
+ * nodes are a chain with score f[end] - f[node the walk stopped at] (f[end] at the start) and the sum of their anchor
+ * counts.  Chains of >= 2 nodes that score >= KP_MIN_CHAIN_SCORE are JOINS; their pieces are numbered in query order (0 = first).
+ *
+ * JOINED FILL.  All pieces get the band width W of the widest piece's task; a narrower task's band is widened evenly
+ * (lo - (W - width) / 2).  Piece 0 is filled as a band task (the recurrence above).  Piece k > 0 is filled by the same
+ * recurrence with two more candidates for H, the CROSS gaps from piece k - 1: when piece k lies on higher diagonals
+ * (lo[k] > lo[k-1]; an insertion in the contig) a gap along row r from a cell (r, t') of piece k - 1 with H > 0 and
+ * t' < lo[k] + r (left of piece k's band in that row):
+ *     X1 = max (H(r, t') + 2 t') - 4 - 2 t        X2 = max (H(r, t') + t') - 24 - t         (first piece / second piece of the gap cost)
+ * otherwise (a deletion) a gap down column t from a cell (r', t) of piece k - 1 with H > 0 on a diagonal above piece k's band
+ * (t - r' > lo[k] + W - 1):   X1 = max (H(r', t) + 2 r') - 4 - 2 r,   X2 = max (H(r', t) + r') - 24 - r.
+ * The source cell of a maximum is the first one in increasing t' (r').  H = max(0, diagonal, E, F, X1, X2) with ties in that
+ * order (a cross gap must beat everything before it).  Every state carries a flag CROSSED: set by X1 / X2, inherited along
+ * diagonal, E and F moves, cleared by a restart.  The END of piece k > 0 is its first maximum of H over CROSSED cells in rows
+ * >= qmax + KP_K - 1 (qmax: the largest query position of the piece's anchors -- a joined path runs through the piece's
+ * anchors, as minimap2's does).
+ *
+ * JOINED HITS.  For k = last piece down to 1, unless piece k lies on a joined path reported before: if piece k has an END
+ * with H >= KP_MIN_DP_SCORE, walk back from it (through cross gaps into earlier pieces, as far as it goes).  On the way:
+ * suf = score of the part of the path behind the current cell, sufmax = its largest value at a cell in state H so far; at
+ * a cross gap, if sufmax - suf > KP_JOIN_DROP the path is REJECTED (minimap2's z-drop of 400 against the open cost of the
+ * second gap piece: behind the gap the path fell that far below where it arrived, so minimap2 would have split there).  An
+ * accepted path is a hit: score = H(END) + the long-gap credit of its in-band gaps, coordinates from its first and last
+ * cell, columns = cells + gap columns, matches counted base by base, n_seeds and chain score those of the join; the hits of
+ * the band tasks of every piece it visited are dropped, and those pieces report no joined path of their own. */
+#define KP_JOIN_BW 500
+/* ORDER SCORE.  minimap2 orders a query's hits, filters them (-s) and computes mapping qualities with dp_max -- the best
+ * running score of the path when a gap of n columns is charged KP_GAP_OPEN + 2 log2(1 + n) -- not with the alignment score.
+ * For band tasks the two are as good as equal; a joined path's cross gaps make them differ by hundreds.  A joined hit
+ * therefore carries a BONUS = sum over its cross gaps of (cost charged - (KP_GAP_OPEN + kp_log2x2(n))), floored at 0 per
+ * gap and capped at KP_HIT_BONUS_MAX; order score = score + bonus takes the place of the score in the emission order
+ * and in the mapping quality.  Until a hit's mapping quality is set the bonus rides in the bits of `score` from
+ * KP_HIT_BONUS_SHIFT up; finished hit records hold the plain score. */
+#define KP_HIT_BONUS_SHIFT 20
+#define KP_HIT_BONUS_MAX 2047
+#define KP_HIT_SCORE(field) ((int32_t)((uint32_t)(field) & ((1u << KP_HIT_BONUS_SHIFT) - 1u)))
+#define KP_HIT_OSCORE(field) (KP_HIT_SCORE(field) + (int32_t)((uint32_t)(field) >> KP_HIT_BONUS_SHIFT))
+KP_SPEC_FN int kp_log2x2(uint32_t n) { /* 2 log2(1 + n) to the nearest integer or so: exponent + the top mantissa bits, integers only */
+    const uint32_t m = n + 1u;
+    int e = 0;
+    while ((m >> e) > 1u) ++e;
+    const uint32_t mant = e >= 4 ? (m >> (e - 4)) & 15u : (m << (4 - e)) & 15u;
+    return 2 * e + (mant >= 3u) + (mant >= 11u);
+}
+#define KP_JOIN_GROUP_MAX 16
+#define KP_JOIN_MAX_PIECES 8
+#define KP_JOIN_DROP (400 - KP_GAP_OPEN2)
 
 /* ---- protein alignment (restates src/kaptive/core/pairwise.py:395-584) ------------------------------------------------ */
 #define KP_PROT_GAP_OPEN 11

@@ -26,12 +26,18 @@ TASK_DTYPE = np.dtype(
      ("qmax", "<i4"), ("chain_score", "<i4")]
 )  # fmt: skip
 
+JOIN_MAX_PIECES = 8  # KP_JOIN_MAX_PIECES
+JOIN_DTYPE = np.dtype(
+    [("gs", "<i4"), ("contig", "<i4"), ("n_pieces", "<i4"), ("n_anchors", "<i4"), ("chain_score", "<i4"), ("width", "<i4"),
+     ("lo", "<i4", (JOIN_MAX_PIECES,)), ("piece", "<i4", (JOIN_MAX_PIECES, 11))]
+)  # fmt: skip (kp_batch_joins: per piece state, visited mask, cell score, q_start, q_end, t_start, t_end, matches, block_len, score, bonus)
+
 EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
     "kp_host_free", "kp_host_pinned_bytes", "kp_device_allocations", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
-    "kp_batch_tasks", "kp_batch_task_results", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
+    "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
@@ -420,7 +426,7 @@ def lib() -> C.CDLL:
                 h = C.CDLL(str(LIB_PATH))
                 h.kp_last_error.restype = C.c_char_p
                 h.kp_ctx_stream.restype = C.c_void_p
-                for f in ("kp_db_n_postings", "kp_batch_anchors", "kp_batch_tasks", "kp_batch_task_results"):
+                for f in ("kp_db_n_postings", "kp_batch_anchors", "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins"):
                     getattr(h, f).restype = C.c_int64
                 h.kp_ctx_destroy.restype = None
                 h.kp_batch_destroy.restype = None
@@ -709,6 +715,15 @@ class Batch:
         self.ctx._check(n, "kp_batch_task_results")
         out = np.zeros((n, 7), np.int32)
         lib().kp_batch_task_results(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
+        return out
+
+
+    def joins(self, asm_index: int) -> np.ndarray:
+        """The joins of one assembly (kp_spec.h, kp-align v4) as JOIN_DTYPE rows, in device order (kp_batch_joins)."""
+        n = lib().kp_batch_joins(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))
+        self.ctx._check(n, "kp_batch_joins")
+        out = np.zeros(n, JOIN_DTYPE)
+        lib().kp_batch_joins(self.ctx._h, self._h, C.c_int32(asm_index), _p(out), C.c_int64(n))
         return out
 
 

@@ -19,7 +19,7 @@
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells, const float *ln_half,
-                            const float *ln_int, hipStream_t stream);
+                            const float *ln_int, const KpJoin *joins, const uint32_t *join_count, uint32_t join_cap, hipStream_t stream);
 void kp_launch_score(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
                      const KpTypingDb &db, double min_cov, double *scores, int32_t *counts, hipStream_t stream);
 void kp_launch_reduce(const KpBatchView &b, const kp_hit *hits, const uint32_t *n_hits, uint32_t hit_cap,
@@ -209,6 +209,13 @@ struct KpWork {
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     DevBuf<uint32_t> d_task_order;  // [ORDER_HEAD] histogram + cursors, then [KP_N_CLASSES * task_cap] permutation
+    // kp-align v4 (kp_join.hip): groups of provisional clusters, joins per band class, their counts ([0] groups, [1 + c] joins)
+    DevBuf<KpGroup> d_groups;
+    DevBuf<KpJoin> d_joins;
+    DevBuf<uint32_t> d_join_counts;
+    uint32_t group_cap = 0, join_cap = 0;
+    uint32_t h_join_counts[1 + KP_N_CLASSES] = {};
+    std::vector<KpJoin> h_joins;  // fetched on first use (kp_batch_joins: stage tests only)
     // device-side hit tables (per-assembly regions of hit_cap rows)
     DevBuf<kp_hit> d_hits_raw, d_hits;
     DevBuf<uint32_t> d_hit_counts;  // [n_asm] raw, then [n_asm] final
@@ -228,6 +235,7 @@ struct KpWork {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
         d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_order.release();
         d_ends.release(); d_trace_top.release(); d_trace.release();
+        d_groups.release(); d_joins.release(); d_join_counts.release();
         if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
         if (astream) { (void)hipStreamSynchronize(astream); (void)hipStreamDestroy(astream); astream = nullptr; }
         d_hits_raw.release(); d_hits.release(); d_hit_counts.release(); d_keys.release(); d_cells.release();
@@ -262,6 +270,7 @@ struct kp_ctx {
     int64_t words_hw = 0;        // most packed words any batch of this context held: candidate lists are sized for that, so a
                                  // work set that meets a slightly larger batch than before does not re-allocate (and stall)
     uint64_t trace_units_per_asm = 0;  // trace buffer of a pass = n_asm * this many 16-byte units
+    uint32_t group_cap = 0, join_cap = 0;  // group / join lists of a pass (entries; joins per band class)
     // resident database
     bool has_db = false;
     int32_t n_genes = 0;
@@ -918,6 +927,9 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
     KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
+    KP_HIP_CHECK(ctx, w->d_groups.reserve(w->group_cap));
+    KP_HIP_CHECK(ctx, w->d_joins.reserve(KP_N_CLASSES * (size_t)w->join_cap));
+    KP_HIP_CHECK(ctx, w->d_join_counts.reserve(1 + KP_N_CLASSES));
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->in->ready, 0));  // the batch's H2D copies
     if (b->after && b->after->in) KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, b->after->in->ready, 0));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_counts.p, 0, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t), stream));
@@ -925,6 +937,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, 2 * sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_join_counts.p, 0, (1 + KP_N_CLASSES) * sizeof(uint32_t), stream));
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
     // compact anchor keys: as many bits per field as this batch and database can set
@@ -949,15 +962,21 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     }
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
-                    d_task_count, w->task_cap, stream);
+                    d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
     kp_launch_task_order(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, d_task_count, w->task_cap,
                          w->d_results.p, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD, stream);
+    // kp-align v4: chains of clusters across diagonal jumps (needs the chain scores the task order has just settled)
+    kp_launch_join_chain(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, w->task_cap, w->d_groups.p,
+                         w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, w->d_task_order.p + KP_ORDER_COUNTS, w->task_cap, w->d_task_order.p + ORDER_HEAD,
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->max_gene_len > KP_FILL16_MAX_GENE_LEN,
                  stream, ev[4]);
+    // ... and their joined alignment; it marks the band tasks a joined path replaces, so it follows their traceback
+    kp_launch_join_sw(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_trace_top.p,
+                      w->trace_cap, w->d_results.p, stream);
     for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
@@ -977,6 +996,9 @@ static void size_work(kp_ctx *ctx, const kp_batch *b, KpWork *w) {
     w->hit_cap = ctx->hit_cap;
     if (ctx->trace_units_per_asm == 0) ctx->trace_units_per_asm = (uint64_t)ctx->opt.trace_kb_per_asm * 64;
     w->trace_cap = std::max<uint64_t>(4096, (uint64_t)std::max(b->n_asm, 1) * ctx->trace_units_per_asm);
+    if (ctx->group_cap == 0) ctx->group_cap = 1024;
+    if (ctx->join_cap == 0) ctx->join_cap = 1024;
+    w->group_cap = ctx->group_cap; w->join_cap = ctx->join_cap;
 }
 
 int kp_batch_align(kp_ctx *ctx, kp_batch *b) {
@@ -1022,7 +1044,8 @@ static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
         kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, w->d_tasks.p, w->d_results.p, w->d_counts.p + n_asm,
                                w->task_cap, w->d_hits_raw.p, w->d_hit_counts.p, w->hit_cap, w->d_keys.p, w->d_hits.p,
-                               w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->d_ln.p, ctx->d_ln.p + KP_MAPQ_LN_HALF_SIZE, ctx->post);
+                               w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->d_ln.p, ctx->d_ln.p + KP_MAPQ_LN_HALF_SIZE, w->d_joins.p,
+                               w->d_join_counts.p + 1, w->join_cap, ctx->post);
         KP_HIP_CHECK(ctx, hipGetLastError());
         w->h_hit_counts.resize(2 * n_asm);
         unsigned long long cells = 0;
@@ -1061,18 +1084,22 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         {
             Fetch f(ctx, ctx->post);
             int frc;
-            if ((frc = f.begin((2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t) + sizeof n_cand2 + sizeof trace_need)) ||
+            if ((frc = f.begin((2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t) + sizeof n_cand2 + sizeof trace_need + sizeof w->h_join_counts)) ||
                 (frc = f.add(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t))) ||
                 (frc = f.add(n_cand2, w->d_cand_count.p, sizeof n_cand2)) || (frc = f.add(&trace_need, w->d_trace_top.p, sizeof trace_need)) ||
-                (frc = f.finish()))
+                (frc = f.add(w->h_join_counts, w->d_join_counts.p, sizeof w->h_join_counts)) || (frc = f.finish()))
                 return frc;
         }
+        uint32_t max_join = 0;
+        for (int c = 0; c < KP_N_CLASSES; ++c) max_join = std::max(max_join, w->h_join_counts[1 + c]);
+        const uint32_t n_group = w->h_join_counts[0];
         const unsigned long long n_cand = n_cand2[0] + n_cand2[1];
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);
         const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
-        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap) {
+        if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap &&
+            n_group <= w->group_cap && max_join <= w->join_cap) {
             // Everything fitted.  What came close makes room for the passes after this one: the sub-slice an anchor
             // lands in depends on the order in which the scan's waves flushed, so the fullest slice varies from pass to
             // pass on the same input, and a rerun costs a whole pass.
@@ -1086,6 +1113,8 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
                                                         (uint32_t)(((uint64_t)max_task + max_task / 4 + n_asm - 1) / std::max<size_t>(n_asm, 1)));
             if (n_cand + n_cand / 16 > w->cand_cap)
                 ctx->cand_frac = std::max(ctx->cand_frac, (double)(n_cand + n_cand / 4) / ((double)b->view.total_words * 4.0));
+            if (n_group + n_group / 4 > w->group_cap) ctx->group_cap = std::max(ctx->group_cap, 2 * n_group);
+            if (max_join + max_join / 4 > w->join_cap) ctx->join_cap = std::max(ctx->join_cap, 2 * max_join);
             break;
         }
         if (attempt >= 4) return kp_fail(ctx, KP_EOVERFLOW, "anchor/task buffers overflowed repeatedly");
@@ -1104,6 +1133,8 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
             w->trace_cap = std::min<uint64_t>(trace_need + trace_need / 4, 1ull << 32);  // later batches differ by a few per cent
             ctx->trace_units_per_asm = std::max<uint64_t>(ctx->trace_units_per_asm, (w->trace_cap + n_asm - 1) / std::max<size_t>(n_asm, 1));
         }
+        if (n_group > w->group_cap) { w->group_cap = n_group + n_group / 4 + 64; ctx->group_cap = std::max(ctx->group_cap, w->group_cap); }
+        if (max_join > w->join_cap) { w->join_cap = max_join + max_join / 4 + 64; ctx->join_cap = std::max(ctx->join_cap, w->join_cap); }
         if (max_task > w->task_cap) {
             w->task_cap = (max_task + max_task / 8 + 1023u) & ~1023u;
             ctx->tasks_per_asm = std::max<uint32_t>(ctx->tasks_per_asm, (uint32_t)((w->task_cap + n_asm - 1) / std::max<size_t>(n_asm, 1)));
@@ -1116,6 +1147,7 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
     for (size_t a = 0; a < n_asm; ++a) n_anchor += w->h_counts[a];
     for (int c = 0; c < KP_N_CLASSES; ++c) n_task += w->h_counts[n_asm + c];
     for (auto &v : w->h_tasks) v.clear();
+    w->h_joins.clear();
     int rc = finalise_hits_on_device(ctx, b, w);
     if (rc) return rc;
     w->stats[0] = n_anchor; w->stats[1] = n_task; w->stats[3] = w->hit_off[n_asm];
@@ -1235,10 +1267,46 @@ int64_t kp_batch_task_results(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7
             if (out7 && n < cap) {
                 const KpSwResult &r = res[i];
                 int32_t *o = out7 + 7 * n;
-                o[0] = r.score; o[1] = r.q_start; o[2] = r.q_end; o[3] = r.t_start; o[4] = r.t_end; o[5] = r.matches; o[6] = r.block_len;
+                // (a negative score marks a band task whose hit a joined path replaced, kp_join.hip: the task's own result stands)
+                o[0] = r.score < 0 ? -r.score : r.score; o[1] = r.q_start; o[2] = r.q_end; o[3] = r.t_start; o[4] = r.t_end; o[5] = r.matches; o[6] = r.block_len;
             }
             ++n;
         }
+    }
+    return n;
+}
+
+int64_t kp_batch_joins(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out, int64_t cap) {
+    if (!ctx || !b || b->ctx != ctx || a < 0 || a >= b->n_asm) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    size_t total = 0;
+    for (int c = 0; c < KP_N_CLASSES; ++c) total += w->h_join_counts[1 + c];
+    if (w->h_joins.size() != total) {  // fetched on first use: only the stage tests look at joins
+        w->h_joins.resize(total);
+        size_t at = 0;
+        for (int c = 0; c < KP_N_CLASSES; ++c) {
+            const size_t nj = w->h_join_counts[1 + c];
+            if (nj && hipMemcpy(w->h_joins.data() + at, w->d_joins.p + (size_t)c * w->join_cap, nj * sizeof(KpJoin), hipMemcpyDeviceToHost) != hipSuccess)
+                return kp_fail(ctx, KP_EHIP, "D2H joins failed");
+            at += nj;
+        }
+    }
+    int64_t n = 0;
+    for (const KpJoin &J : w->h_joins) {
+        if (J.asm_id != a) continue;
+        if (out && n < cap) {
+            int32_t *o = out + KP_JOIN_ROW_INTS * n;
+            std::memset(o, 0, KP_JOIN_ROW_INTS * sizeof(int32_t));
+            o[0] = J.gs; o[1] = J.contig; o[2] = J.n_pieces; o[3] = J.n_anchors; o[4] = J.chain_score; o[5] = J.width;
+            for (int k = 0; k < J.n_pieces; ++k) {
+                o[6 + k] = J.lo[k];
+                int32_t *pr = o + 6 + KP_JOIN_MAX_PIECES + 11 * k;
+                pr[0] = J.state[k]; pr[1] = J.visited[k];
+                if (J.state[k] == 1) std::memcpy(pr + 2, J.res[k], 9 * sizeof(int32_t));
+            }
+        }
+        ++n;
     }
     return n;
 }

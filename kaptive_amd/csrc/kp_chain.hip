@@ -101,25 +101,28 @@ __device__ __forceinline__ int chain_small(const uint64_t *__restrict__ keys, in
     return max_s;
 }
 
-// called by one lane.  A cluster whose anchors cover fewer than KP_MIN_SEED_SPAN query bases cannot chain to
-// KP_MIN_CHAIN_SCORE (a chain scores at most its query extent) and is dropped here; the rest become PROVISIONAL tasks
-// -- n_anchors = the cluster's anchor count, chain_score = the index of its first anchor in the assembly's sorted list --
-// which kp_chain_score_kernel settles (kp_spec.h: chain score and anchor count, or rejection).
-__device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
-                                              uint32_t qmax, int cnt, uint32_t first, KpTask *tasks, uint32_t *task_count,
-                                              uint32_t task_cap, TaskStage &st) {
-    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
-    int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16, cls = 0;
-    if (need > 16) {
-        margin = KP_BAND_MARGIN;
-        need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
-        w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
-        cls = w == 32 ? 1 : (w == 64 ? 2 : 3);
-    }
-    KpTask t;
-    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = (int32_t)first;
-    t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
-    t.qspan = qmin | (qmax << 16);
+// ---- kp-align v4: groups of provisional clusters (kp_spec.h) --------------------------------------------------------------------
+// Lane 0 of a wave meets its clusters in the order of the sorted anchors, so it can tell which provisional clusters of one
+// gene/strand follow each other within KP_JOIN_BW diagonals.  One cluster is held back (PENDING) until the next provisional
+// cluster shows whether the two belong to a group: a lone cluster then goes to the block's stage as before, a member of a
+// group is appended to the global list at once -- its slot is what the group record refers to -- and the finished group
+// record (tasks, anchor ranges) goes to the group list.  Groups are rare; the stage keeps serving nearly every task.
+struct JoinWave {
+    KpTask pend;
+    uint32_t pend_first, pend_cnt, pend_dmax;
+    int pend_valid, pend_in_group;
+    KpGroup grp;
+};
+struct GroupOut {
+    KpGroup *groups;
+    uint32_t *count;
+    uint32_t cap;
+};
+
+__device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w == 32 ? 1 : (w == 64 ? 2 : 3)); }
+
+__device__ __forceinline__ void emit_staged(const KpTask &t, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, TaskStage &st) {
+    const int cls = class_of_width(t.width);
     const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
     if (s < TaskStage::room(cls)) {
         st.list(cls)[s] = t;
@@ -127,6 +130,59 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     }
     const uint32_t slot = atomicAdd(&task_count[cls], 1u);  // stage full: append directly
     if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = t;  // beyond cap: counted, not stored (host retries)
+}
+
+__device__ __forceinline__ void pending_to_group(JoinWave &J, KpTask *tasks, uint32_t *task_count, uint32_t task_cap) {
+    const int cls = class_of_width(J.pend.width);
+    const uint32_t slot = atomicAdd(&task_count[cls], 1u);
+    if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = J.pend;
+    const int n = J.grp.n;
+    J.grp.task[n] = KP_TASK_REF(cls, slot); J.grp.first[n] = J.pend_first; J.grp.cnt[n] = J.pend_cnt;
+    J.grp.n = n + 1;
+}
+
+__device__ __forceinline__ void pending_flush(JoinWave &J, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, TaskStage &st,
+                                              const GroupOut &go) {
+    if (!J.pend_valid) return;
+    if (J.pend_in_group) {
+        pending_to_group(J, tasks, task_count, task_cap);
+        const uint32_t g = atomicAdd(go.count, 1u);
+        if (g < go.cap) go.groups[g] = J.grp;  // beyond cap: counted, not stored (host retries)
+    } else {
+        emit_staged(J.pend, tasks, task_count, task_cap, st);
+    }
+    J.pend_valid = 0;
+}
+
+// called by one lane.  A cluster whose anchors cover fewer than KP_MIN_SEED_SPAN query bases cannot chain to
+// KP_MIN_CHAIN_SCORE (a chain scores at most its query extent) and is dropped here; the rest become PROVISIONAL tasks
+// -- n_anchors = the cluster's anchor count, chain_score = the index of its first anchor in the assembly's sorted list --
+// which kp_chain_score_kernel settles (kp_spec.h: chain score and anchor count, or rejection).
+__device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
+                                              uint32_t qmax, int cnt, uint32_t first, KpTask *tasks, uint32_t *task_count,
+                                              uint32_t task_cap, TaskStage &st, JoinWave &J, const GroupOut &go) {
+    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
+    int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
+    if (need > 16) {
+        margin = KP_BAND_MARGIN;
+        need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
+        w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+    }
+    KpTask t;
+    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = (int32_t)first;
+    t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
+    t.qspan = qmin | (qmax << 16);
+    // does it follow the pending cluster within the join bandwidth (kp_spec.h, GROUPS)?
+    const bool joins = J.pend_valid && J.pend.gs == t.gs && d0 - J.pend_dmax <= (uint32_t)KP_JOIN_BW &&
+                       (J.pend_in_group ? J.grp.n + 1 : 1) < KP_JOIN_GROUP_MAX;
+    if (joins) {
+        if (!J.pend_in_group) { J.grp.n = 0; J.grp.asm_id = a; }
+        pending_to_group(J, tasks, task_count, task_cap);
+    } else {
+        pending_flush(J, tasks, task_count, task_cap, st, go);
+    }
+    J.pend = t; J.pend_first = first; J.pend_cnt = (uint32_t)cnt; J.pend_dmax = dmax;
+    J.pend_valid = 1; J.pend_in_group = joins ? 1 : 0;
 }
 
 struct Cluster {  // wave-uniform
@@ -139,8 +195,10 @@ struct Cluster {  // wave-uniform
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView b, const uint64_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb,
                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
-                                                      uint32_t task_cap) {
+                                                      uint32_t task_cap, GroupOut go) {
     __shared__ TaskStage st;
+    __shared__ JoinWave s_jw[CHAIN_WAVES];
+    JoinWave &jw = s_jw[threadIdx.x >> 6];
     const int a = blockIdx.y, lane = threadIdx.x & 63;
     uint32_t n = count[a];
     if (n > cap) n = cap;
@@ -160,17 +218,34 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         return l - 1;
     };
     if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
+    if (lane == 0) { jw.pend_valid = 0; jw.pend_in_group = 0; jw.grp.n = 0; }
     __syncthreads();
-    if (!idle) {
+    // A wave owns the gene/strand GROUPS OF ANCHORS that start in its slice (kp-align v4: the clusters of one gene/strand must
+    // pass through one lane in order, see JoinWave): a slice that starts inside such a group leaves it to the wave before it
+    // -- it skips ahead to the first anchor of another gene/strand -- and a wave keeps going past its slice's end until the
+    // gene/strand changes.
+    uint32_t start = lo;
+    if (!idle && lo > 0) {
+        const uint32_t g_prev = kp_ckey_gs(k[lo - 1], kb);
+        for (;;) {
+            const uint32_t i = start + lane;
+            const unsigned long long other = __ballot(i < n && kp_ckey_gs(k[i], kb) != g_prev);
+            if (other) { start += (uint32_t)__builtin_ctzll(other); break; }
+            start += 64;
+            if (start >= n) break;
+        }
+    }
+    if (!idle && start < hi) {
+    const uint32_t g_hi = kp_ckey_gs(k[hi - 1], kb);  // anchors from `hi` on are this wave's while they carry it
     uint64_t prev_key = 0;  // the anchor before the round's first one
     int prev_ctg = -1;
-    bool have_prev = lo > 0;
-    if (have_prev) { prev_key = k[lo - 1]; prev_ctg = contig_of(prev_key); }
+    bool have_prev = start > 0;
+    if (have_prev) { prev_key = k[start - 1]; prev_ctg = contig_of(prev_key); }
     Cluster cur;
     cur.open = false; cur.gs = cur.d0 = cur.dprev = cur.qmin = cur.qmax = cur.first = 0; cur.ctg = 0; cur.cnt = 0;
     auto flush = [&]() {
         if (cur.open && lane == 0)
-            flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, cur.cnt, cur.first, tasks, task_count, task_cap, st);
+            flush_cluster(a, cur.gs, cur.ctg, cur.d0, cur.dprev, cur.qmin, cur.qmax, cur.cnt, cur.first, tasks, task_count, task_cap, st, jw, go);
         cur.open = false;
     };
 
@@ -203,15 +278,17 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         }
     };
 
-    uint64_t next_key = lo + lane < n ? k[lo + lane] : 0ull;  // the following round's anchors are fetched a round ahead
-    for (uint32_t w = lo; w < n; w += 64) {
-        const bool overrun = w >= hi;  // past the slice: only to finish the run that is still open
-        if (overrun && !cur.open) break;
+    uint64_t next_key = start + lane < n ? k[start + lane] : 0ull;  // the following round's anchors are fetched a round ahead
+    for (uint32_t w = start; w < n; w += 64) {
         const uint32_t i = w + lane;
-        const bool valid = i < n;
         const uint64_t key = next_key;
         next_key = i + 64 < n ? k[i + 64] : 0ull;
         const uint32_t gs = kp_ckey_gs(key, kb), d = kp_ckey_diag(key, kb), q = kp_ckey_qpos(key, kb);
+        // the round's anchors that are this wave's: a prefix (the list is sorted by gene/strand first)
+        const unsigned long long foreign = __ballot(!(i < n && (i < hi || gs == g_hi)));
+        const int n_valid = foreign ? (int)__builtin_ctzll(foreign) : 64;
+        if (n_valid == 0) break;
+        const bool valid = lane < n_valid;
         const int ctg = valid ? contig_of(key) : -1;
         uint64_t pk = ((uint64_t)__shfl_up((uint32_t)(key >> 32), 1) << 32) | __shfl_up((uint32_t)key, 1);
         int pc = __shfl_up(ctg, 1);
@@ -219,35 +296,36 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         if (lane == 0) { pk = prev_key; pc = prev_ctg; has_pred = have_prev; }
         const bool head = valid && (!has_pred || kp_ckey_gs(pk, kb) != gs || pc != ctg || d - kp_ckey_diag(pk, kb) > KP_DIAG_GAP);
         const unsigned long long heads = __ballot(head);
-        const int n_valid = (int)min(64u, n - w);
         prev_key = __shfl(key, n_valid - 1);
         prev_ctg = __shfl(ctg, n_valid - 1);
         have_prev = true;
         const int first = heads ? (int)__builtin_ctzll(heads) : n_valid;  // anchors before it continue the open run
-        if (first > 0 && cur.open) merge(0, first, d, q, w);  // (no open cluster: tail of a run the previous wave owns)
-        if (!heads) continue;
-        flush();  // the first break ends whatever was open
-        if (overrun) break;  // ... and what follows belongs to the next slice
-        // Most runs are stray seeds (fewer than KP_MIN_ANCHORS anchors) that can never become a task: every head lane
-        // measures its own run, and only runs that are long enough -- or reach the end of the round and may go on --
-        // are visited.
-        const unsigned long long later = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
-        const int my_end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
-        unsigned long long todo = __ballot(head && (my_end - lane >= KP_MIN_ANCHORS || my_end == n_valid));
-        while (todo) {
-            const int pos = (int)__builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int end = __shfl(my_end, pos);
-            cur.open = true;
-            cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
-            cur.d0 = cur.dprev = __shfl(d, pos);
-            cur.qmin = cur.qmax = __shfl(q, pos);
-            cur.cnt = 1; cur.first = w + (uint32_t)pos;
-            if (pos + 1 < end) merge(pos + 1, end, d, q, w);
-            if (end < n_valid) flush();  // the run ends inside the round; otherwise it stays open for the next one
+        if (first > 0 && cur.open) merge(0, first, d, q, w);
+        if (heads) {
+            flush();  // the first break ends whatever was open
+            // Most runs are stray seeds (fewer than KP_MIN_ANCHORS anchors) that can never become a task: every head lane
+            // measures its own run, and only runs that are long enough -- or reach the end of the round and may go on --
+            // are visited.
+            const unsigned long long later = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
+            const int my_end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
+            unsigned long long todo = __ballot(head && (my_end - lane >= KP_MIN_ANCHORS || my_end == n_valid));
+            while (todo) {
+                const int pos = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int end = __shfl(my_end, pos);
+                cur.open = true;
+                cur.gs = __shfl(gs, pos); cur.ctg = __shfl(ctg, pos);
+                cur.d0 = cur.dprev = __shfl(d, pos);
+                cur.qmin = cur.qmax = __shfl(q, pos);
+                cur.cnt = 1; cur.first = w + (uint32_t)pos;
+                if (pos + 1 < end) merge(pos + 1, end, d, q, w);
+                if (end < n_valid) flush();  // the run ends inside the round; otherwise it stays open for the next one
+            }
         }
+        if (n_valid < 64) break;  // the wave's last anchors
     }
     flush();
+    if (lane == 0) pending_flush(jw, tasks, task_count, task_cap, st, go);
     }
     __syncthreads();
     if (threadIdx.x < KP_N_CLASSES) {
@@ -448,8 +526,11 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
-                     KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, hipStream_t stream) {
+                     KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, KpGroup *groups,
+                     uint32_t *group_count, uint32_t group_cap, hipStream_t stream) {
     if (b.n_asm == 0) return;
+    GroupOut go;
+    go.groups = groups; go.count = group_count; go.cap = group_cap;
     hipLaunchKernelGGL(kp_chain_kernel, dim3(CHAIN_SLICES / CHAIN_WAVES, b.n_asm), dim3(64 * CHAIN_WAVES), 0, stream, b, sorted_anchors, anchor_count,
-                       cap, key_bits, tasks, task_count, task_cap);
+                       cap, key_bits, tasks, task_count, task_cap, go);
 }

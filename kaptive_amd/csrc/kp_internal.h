@@ -167,6 +167,35 @@ struct KpSwEnd {
 };
 #define KP_SWEND_HAS_N 0x100  // the gene or the task's target window holds an N (matches are then counted base by base)
 
+// ---- kp-align v4: joins (kp_spec.h) ------------------------------------------------------------------------------------------------
+// A task reference: band class in the top bits, slot in the class's list below.
+#define KP_TASK_REF(cls, slot) (((uint32_t)(cls) << 28) | (uint32_t)(slot))
+#define KP_REF_CLS(ref) ((ref) >> 28)
+#define KP_REF_SLOT(ref) ((ref) & 0x0FFFFFFFu)
+// A group of provisional clusters of one gene/strand (kp_chain.hip appends them as it meets them): their tasks and where
+// their anchors lie in the assembly's sorted list.
+struct KpGroup {
+    int32_t asm_id, n;
+    uint32_t task[KP_JOIN_GROUP_MAX];   // KP_TASK_REF
+    uint32_t first[KP_JOIN_GROUP_MAX];  // first anchor
+    uint32_t cnt[KP_JOIN_GROUP_MAX];    // anchors of the cluster (all of them, not the chain's)
+};
+// A join: a chain of two or more accepted clusters.  The chaining kernel fills the head, the joined fill the per-piece
+// bookkeeping, the walk-back the results (same meaning as the oracle's kpo_join).
+struct KpJoin {
+    int32_t asm_id, gs, contig, n_pieces, n_anchors, chain_score, width;
+    uint32_t task[KP_JOIN_MAX_PIECES];  // KP_TASK_REF of every piece's band task, query order
+    int32_t lo[KP_JOIN_MAX_PIECES];     // lowest diagonal of its (widened) band
+    int32_t qmax[KP_JOIN_MAX_PIECES];
+    // joined fill: where each piece's direction bytes and its exports towards the next piece are (16-byte units of the
+    // trace buffer; 0xFFFFFFFF = the buffer had no room: the host grows it and reruns the pass), its END cell
+    uint32_t trace_off[KP_JOIN_MAX_PIECES], export_off[KP_JOIN_MAX_PIECES];
+    int32_t end_s[KP_JOIN_MAX_PIECES], end_r[KP_JOIN_MAX_PIECES], end_b[KP_JOIN_MAX_PIECES];
+    // walk-back
+    int32_t state[KP_JOIN_MAX_PIECES], visited[KP_JOIN_MAX_PIECES];
+    int32_t res[KP_JOIN_MAX_PIECES][9];
+};
+
 #define KP_HIP_CHECK(ctx, expr)                                                                     \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
@@ -193,7 +222,7 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,
-                     hipStream_t stream);
+                     KpGroup *groups, uint32_t *group_count, uint32_t group_cap, hipStream_t stream);
 // kp_sw.hip: banded Smith-Waterman of every ORDERED task; class c (16/32/64/128 diagonals) has its tasks, order, ends and
 // results at c * task_cap and the length of its order at ordered_count[c]; one fill launch covers all four, one traceback launch follows.
 // `trace` holds trace_cap_units 16-byte units; *trace_top (zeroed by the caller) ends up as the units the pass needs.
@@ -213,6 +242,15 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
 void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t cap, KpKeyBits key_bits,
                           KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
                           uint32_t *order, hipStream_t stream);
+// kp_join.hip (kp-align v4): groups -> joins (one list per band class: joins[c * join_cap ..), join_count[c]); the joined fill and
+// walk-back of every join (direction bytes and exports come out of the same trace buffer as the band tasks'); band tasks
+// whose hit a joined path replaces get the sign of their result's score flipped.
+void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
+                          const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
+                          KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream);
+void kp_launch_join_sw(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                       uint32_t task_cap, void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, KpSwResult *results,
+                       hipStream_t stream);
 // kp_prot.hip
 // kp_reduce.hip: assembly a's hits with gene in [gene_lo, gene_hi) (one run: hits are sorted by gene) -> out rows, gene
 // indices relative to gene_lo; out_n[a] = how many

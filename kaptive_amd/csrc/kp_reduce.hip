@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
     if (my_cells) atomicAdd(cells, my_cells);
 }
 
+// ---- 1b. joined paths (kp-align v4, kp_join.hip) -> raw hits: one thread per join, an atomic per hit (joins are rare) --------
+__global__ __launch_bounds__(64) void kp_join_hits_kernel(KpBatchView b, const int32_t *__restrict__ gene_len, const KpJoin *__restrict__ joins,
+                                                          const uint32_t *__restrict__ join_count, uint32_t join_cap,
+                                                          kp_hit *__restrict__ raw, uint32_t *__restrict__ n_raw, uint32_t hit_cap,
+                                                          unsigned long long *__restrict__ cells) {
+    const int cls = blockIdx.y;
+    uint32_t n = join_count[cls];
+    if (n > join_cap) n = join_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const KpJoin &J = joins[(size_t)cls * join_cap + i];
+        const int qlen = gene_len[J.gs >> 1];
+        atomicAdd(cells, (unsigned long long)qlen * (unsigned)J.width * (unsigned)J.n_pieces);
+        for (int k = 1; k < J.n_pieces; ++k) {
+            if (J.state[k] != 1) continue;
+            const uint32_t slot = atomicAdd(&n_raw[J.asm_id], 1u);
+            if (slot >= hit_cap) continue;
+            const int32_t cs = b.ctg_start[b.asm_first_ctg[J.asm_id] + J.contig];
+            const int32_t *r = J.res[k];
+            raw[(size_t)J.asm_id * hit_cap + slot] =
+                kp_make_hit(J.gs, J.contig, cs, qlen, (int)((uint32_t)r[7] | ((uint32_t)r[8] << KP_HIT_BONUS_SHIFT)), r[1], r[2], r[3], r[4],
+                            r[5], r[6], J.n_anchors, J.chain_score);
+        }
+    }
+}
+
 // ---- 2. emission order, duplicates, mapq (kp_spec.h) -------------------------------------------------------------------
 // One block per assembly: rank sort (leading keys in LDS, every thread counts the hits that precede its own), then the
 // duplicate / mapq pass on neighbours of the sorted list (kp_same_span is an equivalence, so "equal to the last kept
@@ -502,10 +527,13 @@ void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, s
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells,
-                            const float *ln_half, const float *ln_int, hipStream_t stream) {
+                            const float *ln_half, const float *ln_int, const KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                            hipStream_t stream) {
     if (b.n_asm == 0) return;
     hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
                        task_cap, raw, n_raw, hit_cap, cells);
+    hipLaunchKernelGGL(kp_join_hits_kernel, dim3(16, KP_N_CLASSES), dim3(64), 0, stream, b, gene_len, joins, join_count, join_cap, raw,
+                       n_raw, hit_cap, cells);
     hipLaunchKernelGGL(kp_hit_sort_kernel, dim3(b.n_asm), dim3(SORT_THREADS), 0, stream, raw, n_raw, hit_cap, keys, hits,
                        n_hits, ln_half, ln_int);
 }

@@ -59,7 +59,7 @@ KP_HD kp_hit kp_make_hit(int gs, int contig, int32_t ctg_start, int qlen, int sc
 
 // emission order of kp_spec.h as three ascending 64-bit keys
 KP_HD void kp_hit_keys(const kp_hit &h, uint64_t k[3]) {
-    k[0] = ((uint64_t)(uint32_t)h.gene << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)h.score) << 20) | (uint32_t)h.contig;
+    k[0] = ((uint64_t)(uint32_t)h.gene << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)KP_HIT_OSCORE(h.score)) << 20) | (uint32_t)h.contig;
     k[1] = ((uint64_t)(uint32_t)h.t_start << 32) | ((uint64_t)(h.strand < 0 ? 1u : 0u) << 31) |
            ((uint64_t)(uint32_t)h.q_start << 16) | (uint32_t)h.q_end;
     k[2] = ((uint64_t)(uint32_t)h.t_end << 32) | ((uint64_t)(0xFFFFu - (uint32_t)h.matches) << 16) | (uint32_t)h.block_len;
@@ -121,8 +121,8 @@ KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *subsc, int
                 parent[i] = j;
                 if (sci > subsc[j]) subsc[j] = sci;
                 if (h[j].contig != h[i].contig || h[j].t_start != h[i].t_start || h[j].t_end != h[i].t_end || ol != mn) {
-                    if (h[i].score > dp2[j]) dp2[j] = h[i].score;
-                    if (h[j].score - h[i].score <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = true;
+                    if (KP_HIT_OSCORE(h[i].score) > dp2[j]) dp2[j] = KP_HIT_OSCORE(h[i].score);
+                    if (KP_HIT_OSCORE(h[j].score) - KP_HIT_OSCORE(h[i].score) <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = true;
                 }
                 if (cnt_sub) n_sub[j]++;
                 break;
@@ -133,9 +133,10 @@ KP_HD void kp_assign_mapq(kp_hit *h, int n, int32_t *parent, int32_t *subsc, int
         const int cs = kp_hit_chain_score(h[i]);
         h[i].pad_ = 0;
         h[i].mapq = parent[i] != i ? (uint8_t)0
-                                    : (uint8_t)kp_mapq_value(h[i].score, cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
+                                    : (uint8_t)kp_mapq_value(KP_HIT_OSCORE(h[i].score), cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
                                                              n_sub[i], ln_half, ln_int);
     }
+    for (int i = 0; i < n; ++i) h[i].score = KP_HIT_SCORE(h[i].score);  // (kp_spec.h, order score: the finished record holds the plain score)
 }
 
 KP_HD bool kp_same_span(const kp_hit &x, const kp_hit &y) {

@@ -161,9 +161,13 @@ def make_assembly(
     also: tuple = (),
     tandem_gene: int = 0,
     indel_rate: float = 2e-5,
+    mid_indels: tuple = (),
 ) -> GenomeAssembly:
     """One synthetic assembly holding a mutated copy of one database locus.
-    ``locus`` < 0 plants no locus at all."""
+    ``locus`` < 0 plants no locus at all.  ``mid_indels``: (size, "del" | "ins") pairs, each planted inside a gene of
+    the locus copy of its own (a deletion of ``size`` bases or an insertion of ``size`` random ones somewhere in the
+    gene's middle half) -- the 30-500 base events minimap2 chains across (bw = 500); drawn from a generator of their
+    own, so that the other draws of a seed do not move."""
     rng = np.random.default_rng(seed)
     gc = DB_SHAPES.get(db.metadata.keyword, {}).get("gc", 0.5) if gc is None else gc
     total = int(length * rng.uniform(0.95, 1.05))
@@ -192,6 +196,16 @@ def make_assembly(
                 stop = np.frombuffer(b"TAA", np.uint8)
                 copy[at : at + 3] = stop if db.gene_intervals.strands[gi] > 0 else revcomp(stop)
         copy = mutate(rng, copy, 0.0, indel_rate=indel_rate)
+        if mid_indels:
+            rng2 = np.random.default_rng([seed, 0x1DE1])
+            genes = rng2.choice(np.arange(g0, g1), size=min(len(mid_indels), g1 - g0), replace=False)
+            edits = []
+            for gi, (size, kind) in zip(genes, mid_indels):
+                s, e = int(db.gene_intervals.starts[gi]), int(db.gene_intervals.ends[gi])
+                at = s + int(rng2.integers((e - s) // 4, max((e - s) // 4 + 1, 3 * (e - s) // 4 - (size if kind == "del" else 0))))
+                edits.append((at, int(size), kind, random_dna(rng2, int(size), gc)))
+            for at, size, kind, ins in sorted(edits, key=lambda t: -t[0]):  # from the far end: earlier coordinates stay put
+                copy = np.delete(copy, slice(at, at + size)) if kind == "del" else np.concatenate([copy[:at], ins, copy[at:]])
         if tandem_gene:  # `tandem_gene` extra copies of one gene, head to tail, each mutated on its own (multi-copy stress)
             gi = int(rng.integers(g0, g1))
             s, e = int(db.gene_intervals.starts[gi]), min(int(db.gene_intervals.ends[gi]), len(copy))

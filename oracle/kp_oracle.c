@@ -505,14 +505,25 @@ static int contig_of(const kpo_asm *a, int64_t t) { /* largest c with ctg_start[
     return lo;
 }
 
-static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo_task **out) {
-    int64_t cap = 1024, nt = 0;
+/* a provisional cluster (kp_spec.h, v4): what the join stage needs of it */
+typedef struct kpo_pcl {
+    int32_t gs, contig;
+    int32_t d0, dmax;       /* lowest / highest anchor diagonal (true values) */
+    int32_t task;           /* index into the task list, -1 when its chain score rejected it */
+    int32_t hq, ht, tq, tt; /* head and tail anchor: query position, target position */
+    int32_t qmax;
+} kpo_pcl;
+
+static int64_t make_tasks_x(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo_task **out, kpo_pcl **pcl_out, int64_t *n_pcl_out) {
+    int64_t cap = 1024, nt = 0, pcap = 1024, np = 0;
     kpo_task *tasks = malloc((size_t)cap * sizeof(kpo_task));
+    kpo_pcl *pcl = malloc((size_t)pcap * sizeof(kpo_pcl));
     int64_t i = 0;
     while (i < n) {
         uint32_t gs = KP_KEY_GS(keys[i]), d0 = KP_KEY_DIAG(keys[i]), q = KP_KEY_QPOS(keys[i]);
         int ctg = contig_of(a, (int64_t)d0 - KP_DIAG_BIAS + q);
         uint32_t dprev = d0, dmax = d0, qmin = q, qmax = q;
+        uint32_t hq = q, hd = d0, tq = q, td = d0; /* head: smallest (q, diagonal); tail: largest */
         int cnt = 1;
         int64_t j = i + 1;
         for (; j < n; j++) {
@@ -522,7 +533,10 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
             dprev = d2; dmax = d2; cnt++;
             if (q2 < qmin) qmin = q2;
             if (q2 > qmax) qmax = q2;
+            if (q2 < hq) { hq = q2; hd = d2; }  /* (diagonals ascend: the first anchor with the smallest q has the smallest diagonal) */
+            if (q2 >= tq) { tq = q2; td = d2; }
         }
+        const int provisional = cnt >= KP_MIN_ANCHORS && (int)(qmax - qmin) + KP_K >= KP_MIN_SEED_SPAN;
         int chain_cnt = cnt, chain_sc = 0, ok;
         if (cnt <= KP_CHAIN_DP_MAX) {
             chain_sc = chain_small(keys + i, cnt, &chain_cnt);
@@ -531,6 +545,16 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
             const int span = (int)(qmax - qmin) + KP_K;
             ok = span >= KP_MIN_SEED_SPAN;
             chain_sc = KP_K * cnt < span ? KP_K * cnt : span;
+        }
+        if (provisional) {
+            if (np == pcap) { pcap *= 2; pcl = realloc(pcl, (size_t)pcap * sizeof(kpo_pcl)); }
+            kpo_pcl *c = &pcl[np++];
+            c->gs = (int32_t)gs; c->contig = ctg;
+            c->d0 = (int32_t)((int64_t)d0 - KP_DIAG_BIAS); c->dmax = (int32_t)((int64_t)dmax - KP_DIAG_BIAS);
+            c->task = ok ? (int32_t)nt : -1;
+            c->hq = (int32_t)hq; c->ht = (int32_t)((int64_t)hd - KP_DIAG_BIAS + hq);
+            c->tq = (int32_t)tq; c->tt = (int32_t)((int64_t)td - KP_DIAG_BIAS + tq);
+            c->qmax = (int32_t)qmax;
         }
         if (ok) {
             int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
@@ -548,7 +572,12 @@ static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo
         i = j;
     }
     *out = tasks;
+    if (pcl_out) { *pcl_out = pcl; *n_pcl_out = np; } else free(pcl);
     return nt;
+}
+
+static int64_t make_tasks(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo_task **out) {
+    return make_tasks_x(a, keys, n, out, NULL, NULL);
 }
 
 /* Banded local alignment of one task with stored traceback.  out: score, q_start, q_end, t_start, t_end (query in the
@@ -619,6 +648,240 @@ static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstar
     free(H); free(E); free(F); free(tH); free(tE); free(tF);
 }
 
+/* ---- kp-align v4: joins (kp_spec.h) ----------------------------------------------------------------------------------------- */
+typedef struct kpo_join {
+    int32_t gs, contig, n_pieces, n_anchors, chain_score, width;
+    int32_t task[KP_JOIN_MAX_PIECES]; /* task of every piece, query order */
+    int32_t lo[KP_JOIN_MAX_PIECES];   /* lowest diagonal of its (widened) band */
+    int32_t qmax[KP_JOIN_MAX_PIECES];
+    /* results, per piece k > 0: res[k] = cell score, q_start, q_end, t_start, t_end, matches, block_len, reported score;
+     * state[k]: 0 = no END / below the cut-off / on a path reported before, 1 = hit, 2 = rejected by the drop test;
+     * visited[k] = mask of the pieces the path of piece k runs through */
+    int32_t res[KP_JOIN_MAX_PIECES][9]; /* [8]: the bonus of the order score */
+    int32_t state[KP_JOIN_MAX_PIECES], visited[KP_JOIN_MAX_PIECES];
+} kpo_join;
+
+/* groups of provisional clusters -> chains of accepted clusters -> join records */
+static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks, kpo_join **out) {
+    static const uint8_t pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
+    int64_t cap = 64, nj = 0;
+    kpo_join *joins = malloc((size_t)cap * sizeof(kpo_join));
+    int64_t g0 = 0;
+    while (g0 < np) {
+        int64_t g1 = g0 + 1;
+        while (g1 < np && g1 - g0 < KP_JOIN_GROUP_MAX && pcl[g1].gs == pcl[g1 - 1].gs && pcl[g1].d0 - pcl[g1 - 1].dmax <= KP_JOIN_BW)
+            g1++;
+        int node[KP_JOIN_GROUP_MAX], m = 0;
+        for (int64_t c = g0; c < g1; c++)
+            if (pcl[c].task >= 0) node[m++] = (int)c;
+        if (m >= 2) {
+            for (int i = 1; i < m; i++) { /* order by (head t, head q, list order): insertion sort, stable */
+                const int x = node[i];
+                int j = i;
+                while (j > 0 && (pcl[node[j - 1]].ht > pcl[x].ht || (pcl[node[j - 1]].ht == pcl[x].ht && pcl[node[j - 1]].hq > pcl[x].hq))) { node[j] = node[j - 1]; j--; }
+                node[j] = x;
+            }
+            int f[KP_JOIN_GROUP_MAX], p[KP_JOIN_GROUP_MAX], used[KP_JOIN_GROUP_MAX];
+            for (int i = 0; i < m; i++) {
+                const kpo_pcl *ci = &pcl[node[i]];
+                int best = 0, bj = -1;
+                for (int j = i - 1; j >= 0; j--) {
+                    const kpo_pcl *cj = &pcl[node[j]];
+                    if (cj->contig != ci->contig) continue;
+                    const int dq = ci->hq - cj->tq, dr = ci->ht - cj->tt;
+                    if (dq <= 0 || dr <= 0 || dq > KP_CHAIN_MAX_DIST || dr > KP_CHAIN_MAX_DIST) continue;
+                    const int dd = dr > dq ? dr - dq : dq - dr;
+                    if (dd > KP_JOIN_BW) continue;
+                    const int dg = dr < dq ? dr : dq;
+                    const int link = (dg < KP_K ? dg : KP_K) - KP_K - (int)pen[dd];
+                    if (f[j] + link > best) { best = f[j] + link; bj = j; }
+                }
+                f[i] = tasks[ci->task].chain_score + best; p[i] = bj; used[i] = 0;
+            }
+            for (;;) {
+                int end = -1;
+                for (int i = 0; i < m; i++)
+                    if (!used[i] && (end < 0 || f[i] >= f[end])) end = i;
+                if (end < 0) break;
+                int chain[KP_JOIN_MAX_PIECES], len = 0, i = end;
+                while (i >= 0 && !used[i] && len < KP_JOIN_MAX_PIECES) { chain[len++] = i; used[i] = 1; i = p[i]; }
+                if (len < 2 || f[end] - (i >= 0 ? f[i] : 0) < KP_MIN_CHAIN_SCORE) continue; /* (a branch off a used node can fall below -m) */
+                if (nj == cap) { cap *= 2; joins = realloc(joins, (size_t)cap * sizeof(kpo_join)); }
+                kpo_join *J = &joins[nj++];
+                memset(J, 0, sizeof *J);
+                J->gs = pcl[node[end]].gs; J->contig = pcl[node[end]].contig; J->n_pieces = len;
+                J->chain_score = f[end] - (i >= 0 ? f[i] : 0);
+                for (int k = 0; k < len; k++) { /* the walk went backwards: piece 0 is the last node walked */
+                    const kpo_pcl *c = &pcl[node[chain[len - 1 - k]]];
+                    const kpo_task *t = &tasks[c->task];
+                    J->task[k] = c->task; J->qmax[k] = c->qmax;
+                    J->n_anchors += t->n_anchors;
+                    if (t->width > J->width) J->width = t->width;
+                }
+                for (int k = 0; k < len; k++) {
+                    const kpo_task *t = &tasks[J->task[k]];
+                    J->lo[k] = t->lo - (J->width - t->width) / 2;
+                }
+            }
+        }
+        g0 = g1;
+    }
+    *out = joins;
+    return nj;
+}
+
+/* Joined fill and walk-back of one join (kp_spec.h).  q: the gene in the join's orientation. */
+enum { XT_DIAG = 0, XT_E = 1, XT_F = 2, XT_RESTART = 3, XT_X1 = 4, XT_X2 = 5 };
+#define KPO_DEAD(v) ((v) < KP_NEG_INF / 2)
+typedef struct {
+    int32_t *H; uint8_t *tH, *tE, *tF; /* [qlen * w] */
+    int64_t *x1, *x2;                  /* exports towards the next piece: best key per row (or column), INT64_MIN = none */
+    int32_t *a1, *a2;                  /* ... and the coordinate (t' or r') of the cell that holds it */
+    int64_t xbase; int xlen, horizontal; /* index = row (horizontal) or t - xbase (vertical) */
+    int end_s, end_r, end_b;
+} kpo_xpiece;
+
+static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstart, int64_t cend) {
+    const int m = J->n_pieces, w = J->width;
+    const int oe = KP_GAP_OPEN + KP_GAP_EXT, ex = KP_GAP_EXT;
+    const size_t cells = (size_t)qlen * (size_t)w;
+    kpo_xpiece P[KP_JOIN_MAX_PIECES];
+    memset(P, 0, sizeof P);
+#define AT(r, b) ((size_t)(r) * (size_t)w + (size_t)(b))
+    for (int k = 0; k < m; k++) {
+        kpo_xpiece *X = &P[k];
+        const int lo = J->lo[k];
+        /* piece 0: local (H >= 0, restarts); later pieces: CONTINUATION -- no restart, cells that no path from piece k - 1
+         * reaches are dead (KP_NEG_INF), scores may be negative */
+        const int cont = k > 0, none = cont ? KP_NEG_INF : 0;
+        X->H = malloc(cells * 4); X->tH = malloc(cells); X->tE = malloc(cells); X->tF = malloc(cells);
+        int32_t *E = malloc(cells * 4), *F = malloc(cells * 4);
+        const kpo_xpiece *prev = k > 0 ? &P[k - 1] : NULL;
+        if (k + 1 < m) { /* this piece exports towards piece k + 1 */
+            X->horizontal = J->lo[k + 1] > lo;
+            X->xbase = lo; X->xlen = X->horizontal ? qlen : qlen + w;
+            X->x1 = malloc((size_t)X->xlen * 8); X->x2 = malloc((size_t)X->xlen * 8);
+            X->a1 = malloc((size_t)X->xlen * 4); X->a2 = malloc((size_t)X->xlen * 4);
+            for (int i = 0; i < X->xlen; i++) { X->x1[i] = X->x2[i] = INT64_MIN; X->a1[i] = X->a2[i] = 0; }
+        }
+        X->end_s = KP_NEG_INF; X->end_r = X->end_b = -1;
+#define VALID(r, b) ((r) >= 0 && (b) >= 0 && (b) < w && (int64_t)(r) + lo + (b) >= cstart && (int64_t)(r) + lo + (b) < cend)
+        for (int r = 0; r < qlen; r++) {
+            for (int b = 0; b < w; b++) {
+                const int64_t t = (int64_t)r + lo + b;
+                if (t < cstart || t >= cend) { X->H[AT(r, b)] = none; E[AT(r, b)] = F[AT(r, b)] = KP_NEG_INF; X->tH[AT(r, b)] = XT_RESTART; X->tE[AT(r, b)] = X->tF[AT(r, b)] = 0; continue; }
+                int hl = none, el = KP_NEG_INF, hu = none, fu = KP_NEG_INF, hd = none;
+                if (VALID(r, b - 1)) { hl = X->H[AT(r, b - 1)]; el = E[AT(r, b - 1)]; }
+                if (VALID(r - 1, b + 1)) { hu = X->H[AT(r - 1, b + 1)]; fu = F[AT(r - 1, b + 1)]; }
+                if (VALID(r - 1, b)) hd = X->H[AT(r - 1, b)];
+                const int e_open = hl - oe, e_ext = el - ex, f_open = hu - oe, f_ext = fu - ex;
+                int e = e_open >= e_ext ? e_open : e_ext, f = f_open >= f_ext ? f_open : f_ext;
+                X->tE[AT(r, b)] = e_open >= e_ext ? 0 : 1;
+                X->tF[AT(r, b)] = f_open >= f_ext ? 0 : 1;
+                if (KPO_DEAD(e)) e = KP_NEG_INF;
+                if (KPO_DEAD(f)) f = KP_NEG_INF;
+                E[AT(r, b)] = e; F[AT(r, b)] = f;
+                const uint8_t qc = q[r], cc = tc[t];
+                const int s = (qc > 3 || cc > 3) ? KP_SC_N : (qc == cc ? KP_SC_MATCH : KP_SC_MISMATCH);
+                int64_t best = (int64_t)hd + s; int tb = XT_DIAG;
+                if (e > best) { best = e; tb = XT_E; }
+                if (f > best) { best = f; tb = XT_F; }
+                if (prev) { /* cross gaps from piece k - 1 */
+                    const int64_t xi = prev->horizontal ? r : t - prev->xbase;
+                    if (xi >= 0 && xi < prev->xlen && prev->x1[xi] != INT64_MIN) {
+                        const int64_t pos = prev->horizontal ? t : r;
+                        const int64_t c1 = prev->x1[xi] - KP_GAP_OPEN - (int64_t)KP_GAP_EXT * pos;
+                        const int64_t c2 = prev->x2[xi] - KP_GAP_OPEN2 - (int64_t)KP_GAP_EXT2 * pos;
+                        if (c1 > best) { best = c1; tb = XT_X1; }
+                        if (c2 > best) { best = c2; tb = XT_X2; }
+                    }
+                }
+                int live;
+                if (cont) { live = !KPO_DEAD(best); if (!live) { X->H[AT(r, b)] = KP_NEG_INF; X->tH[AT(r, b)] = XT_RESTART; } }
+                else { live = best > 0; if (!live) { X->H[AT(r, b)] = 0; X->tH[AT(r, b)] = XT_RESTART; } }
+                if (live) {
+                    X->H[AT(r, b)] = (int)best; X->tH[AT(r, b)] = (uint8_t)tb;
+                    if (cont && r >= J->qmax[k] + KP_K - 1 && best > X->end_s) { X->end_s = (int)best; X->end_r = r; X->end_b = b; }
+                    if (X->x1) { /* export (cells of this piece that lie before / above the next piece's band) */
+                        const int lo_next = J->lo[k + 1];
+                        if (X->horizontal ? (b < lo_next - lo) : (lo + b > lo_next + w - 1)) {
+                            const int64_t xi = X->horizontal ? r : t - X->xbase, pos = X->horizontal ? t : r;
+                            const int64_t k1 = best + (int64_t)KP_GAP_EXT * pos, k2 = best + (int64_t)KP_GAP_EXT2 * pos;
+                            /* first maximum in increasing t' (rows are visited left to right) / r' (rows in increasing order) */
+                            if (k1 > X->x1[xi]) { X->x1[xi] = k1; X->a1[xi] = (int32_t)pos; }
+                            if (k2 > X->x2[xi]) { X->x2[xi] = k2; X->a2[xi] = (int32_t)pos; }
+                        }
+                    }
+                }
+            }
+        }
+#undef VALID
+        free(E); free(F);
+    }
+    /* joined paths, last piece first */
+    int on_path = 0; /* mask of pieces on a path reported before */
+    for (int k = m - 1; k >= 1; k--) {
+        J->state[k] = 0; J->visited[k] = 0;
+        if ((on_path >> k) & 1) continue;
+        const kpo_xpiece *X = &P[k];
+        if (X->end_r < 0 || X->end_s < KP_MIN_DP_SCORE) continue;
+        int pk = k, r = X->end_r, b = X->end_b, state = 0, matches = 0, cols = 0, gap = 0, credit = 0;
+        int sr = r, sb = b, spk = k;
+        int suf = 0, sufmax = 0, rejected = 0, visited = 1 << k, bonus = 0;
+        for (;;) {
+            const kpo_xpiece *Y = &P[pk];
+            const int lo = J->lo[pk];
+            if (state == 0) {
+                const int64_t t = (int64_t)r + lo + b;
+                if (r < 0 || b < 0 || b >= w || t < cstart || t >= cend) break;
+                const int tb = Y->tH[AT(r, b)];
+                if (tb == XT_RESTART) break;
+                if (suf > sufmax) sufmax = suf;
+                if (tb == XT_DIAG) {
+                    sr = r; sb = b; spk = pk; cols++;
+                    const uint8_t qc = q[r], cc = tc[t];
+                    if (qc <= 3 && qc == cc) matches++;
+                    suf += (qc > 3 || cc > 3) ? KP_SC_N : (qc == cc ? KP_SC_MATCH : KP_SC_MISMATCH);
+                    r--;
+                } else if (tb == XT_E || tb == XT_F) state = tb;
+                else { /* a cross gap: on to the cell of piece pk - 1 it came from */
+                    if (sufmax - suf > KP_JOIN_DROP) { rejected = 1; break; }
+                    const kpo_xpiece *Z = &P[pk - 1];
+                    const int64_t xi = Z->horizontal ? r : t - Z->xbase;
+                    const int32_t src = tb == XT_X1 ? Z->a1[xi] : Z->a2[xi];
+                    const int n = Z->horizontal ? (int)(t - src) : r - src;
+                    cols += n;
+                    const int cost = tb == XT_X1 ? KP_GAP_OPEN + KP_GAP_EXT * n : KP_GAP_OPEN2 + KP_GAP_EXT2 * n;
+                    suf -= cost;
+                    if (cost > KP_GAP_OPEN + kp_log2x2((uint32_t)n)) bonus += cost - (KP_GAP_OPEN + kp_log2x2((uint32_t)n));
+                    if (Z->horizontal) b = (int)(src - r - J->lo[pk - 1]);       /* same row, column src */
+                    else { b = (int)(t - src - J->lo[pk - 1]); r = src; }      /* same column, row src */
+                    pk--; visited |= 1 << pk;
+                }
+            } else if (state == XT_E) {
+                const int tb = Y->tE[AT(r, b)]; cols++; gap++; b--; suf -= ex;
+                if (tb == 0) { state = 0; suf -= KP_GAP_OPEN; if (gap > KP_GAP_LONG) credit += gap - KP_GAP_LONG; gap = 0; }
+            } else {
+                const int tb = Y->tF[AT(r, b)]; cols++; gap++; r--; b++; suf -= ex;
+                if (tb == 0) { state = 0; suf -= KP_GAP_OPEN; if (gap > KP_GAP_LONG) credit += gap - KP_GAP_LONG; gap = 0; }
+            }
+        }
+        J->visited[k] = visited;
+        if (rejected) { J->state[k] = 2; continue; }
+        J->state[k] = 1;
+        on_path |= visited;
+        J->res[k][0] = X->end_s; J->res[k][1] = sr; J->res[k][2] = X->end_r + 1;
+        J->res[k][3] = (int32_t)((int64_t)sr + J->lo[spk] + sb); J->res[k][4] = (int32_t)((int64_t)X->end_r + J->lo[k] + X->end_b + 1);
+        J->res[k][5] = matches; J->res[k][6] = cols; J->res[k][7] = X->end_s + credit;
+        J->res[k][8] = bonus < KP_HIT_BONUS_MAX ? bonus : KP_HIT_BONUS_MAX;
+    }
+#undef AT
+    for (int k = 0; k < m; k++) {
+        free(P[k].H); free(P[k].tH); free(P[k].tE); free(P[k].tF);
+        free(P[k].x1); free(P[k].x2); free(P[k].a1); free(P[k].a2);
+    }
+}
+
 static const float *ln_half_table(void) {
     static float *t = NULL;
     if (!t) {
@@ -673,8 +936,8 @@ static void assign_mapq(kp_hit *h, int n) {
                 parent[i] = j;
                 if (sci > subsc[j]) subsc[j] = sci;
                 if (h[j].contig != h[i].contig || h[j].t_start != h[i].t_start || h[j].t_end != h[i].t_end || ol != mn) {
-                    if (h[i].score > dp2[j]) dp2[j] = h[i].score;
-                    if (h[j].score - h[i].score <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = 1;
+                    if (KP_HIT_OSCORE(h[i].score) > dp2[j]) dp2[j] = KP_HIT_OSCORE(h[i].score);
+                    if (KP_HIT_OSCORE(h[j].score) - KP_HIT_OSCORE(h[i].score) <= 2 * KP_SC_MATCH - KP_SC_MISMATCH) cnt_sub = 1;
                 }
                 if (cnt_sub) n_sub[j]++;
                 break;
@@ -685,16 +948,17 @@ static void assign_mapq(kp_hit *h, int n) {
         const int cs = hit_chain_score(&h[i]);
         h[i].pad_ = 0;
         h[i].mapq = parent[i] != i ? 0
-                                    : (uint8_t)kp_mapq_value(h[i].score, cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
+                                    : (uint8_t)kp_mapq_value(KP_HIT_OSCORE(h[i].score), cs, h[i].n_seeds, h[i].matches, h[i].block_len, subsc[i], dp2[i],
                                                              n_sub[i], ln_half_table(), ln_int_table());
     }
+    for (int i = 0; i < n; i++) h[i].score = KP_HIT_SCORE(h[i].score); /* the finished record holds the plain score */
     free(parent); free(subsc); free(dp2); free(n_sub);
 }
 
 static int cmp_hit(const void *a, const void *b) {
     const kp_hit *x = a, *y = b;
     if (x->gene != y->gene) return x->gene < y->gene ? -1 : 1;
-    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    if (KP_HIT_OSCORE(x->score) != KP_HIT_OSCORE(y->score)) return KP_HIT_OSCORE(x->score) > KP_HIT_OSCORE(y->score) ? -1 : 1;
     if (x->contig != y->contig) return x->contig < y->contig ? -1 : 1;
     if (x->t_start != y->t_start) return x->t_start < y->t_start ? -1 : 1;
     if (x->strand != y->strand) return x->strand > y->strand ? -1 : 1;
@@ -761,6 +1025,46 @@ KPO_API int64_t kpo_sw(const kpo_db *db, const uint32_t *words, int64_t padded_l
     return n_tasks;
 }
 
+/* joins of one assembly, run: caller frees *out */
+static int64_t run_joins(const kpo_db *db, const kpo_asm *a, const kpo_pcl *pcl, int64_t np, const kpo_task *tasks, kpo_join **out) {
+    kpo_join *joins; const int64_t nj = make_joins(pcl, np, tasks, &joins);
+    for (int64_t j = 0; j < nj; j++) {
+        kpo_join *J = &joins[j];
+        const int g = J->gs >> 1, qlen = db->off[g + 1] - db->off[g];
+        const uint8_t *q = ((J->gs & 1) ? db->rc : db->codes) + db->off[g];
+        const int64_t cs = a->ctg_start[J->contig];
+        join_run(J, q, qlen, a->codes, cs, cs + a->ctg_len[J->contig]);
+    }
+    *out = joins;
+    return nj;
+}
+
+/* stage entry point: the joins of one assembly as rows of KPO_JOIN_ROW int32 --
+ * gs, contig, n_pieces, n_anchors, chain_score, width, lo[8], then per piece state, visited, res[9] */
+#define KPO_JOIN_ROW (6 + KP_JOIN_MAX_PIECES + 11 * KP_JOIN_MAX_PIECES)
+KPO_API int64_t kpo_joins(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
+                          const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, int32_t *out, int64_t cap) {
+    kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
+    uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
+    kpo_task *tasks; kpo_pcl *pcl; int64_t np = 0;
+    make_tasks_x(&a, keys, n, &tasks, &pcl, &np);
+    kpo_join *joins; const int64_t nj = run_joins(db, &a, pcl, np, tasks, &joins);
+    for (int64_t j = 0; j < nj && j < cap; j++) {
+        const kpo_join *J = &joins[j];
+        int32_t *o = out + KPO_JOIN_ROW * j;
+        memset(o, 0, KPO_JOIN_ROW * sizeof(int32_t));
+        o[0] = J->gs; o[1] = J->contig; o[2] = J->n_pieces; o[3] = J->n_anchors; o[4] = J->chain_score; o[5] = J->width;
+        for (int k = 0; k < J->n_pieces; k++) {
+            o[6 + k] = J->lo[k];
+            int32_t *pr = o + 6 + KP_JOIN_MAX_PIECES + 11 * k;
+            pr[0] = J->state[k]; pr[1] = J->visited[k];
+            if (J->state[k] == 1) memcpy(pr + 2, J->res[k], 9 * sizeof(int32_t));
+        }
+    }
+    free(joins); free(pcl); free(tasks); free(keys); free(a.codes);
+    return nj;
+}
+
 /* Full aligner for one assembly: hits in emission order.  Returns the number of hits (writes at most cap). */
 KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
                           const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, kp_hit *out,
@@ -768,8 +1072,19 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
                           int32_t *chain_out /* optional [cap]: the chain score behind every hit */) {
     kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
     uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
-    kpo_task *tasks; int64_t nt = make_tasks(&a, keys, n, &tasks);
-    kp_hit *hits = malloc((size_t)(nt > 0 ? nt : 1) * sizeof(kp_hit));
+    kpo_task *tasks; kpo_pcl *pcl; int64_t np = 0;
+    int64_t nt = make_tasks_x(&a, keys, n, &tasks, &pcl, &np);
+    kpo_join *joins; const int64_t nj = run_joins(db, &a, pcl, np, tasks, &joins);
+    uint8_t *dropped = calloc((size_t)(nt > 0 ? nt : 1), 1); /* band tasks whose hit a joined path replaces */
+    int64_t n_join_hits = 0;
+    for (int64_t j = 0; j < nj; j++)
+        for (int k = 1; k < joins[j].n_pieces; k++)
+            if (joins[j].state[k] == 1) {
+                n_join_hits++;
+                for (int v = 0; v < joins[j].n_pieces; v++)
+                    if ((joins[j].visited[k] >> v) & 1) dropped[joins[j].task[v]] = 1;
+            }
+    kp_hit *hits = malloc((size_t)(nt + n_join_hits > 0 ? nt + n_join_hits : 1) * sizeof(kp_hit));
     int64_t nh = 0, cells = 0;
     for (int64_t i = 0; i < nt; i++) {
         const kpo_task *t = &tasks[i];
@@ -779,7 +1094,7 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         int32_t r[8];
         sw_task(q, qlen, a.codes, cs, cs + ctg_len[t->contig], t->lo, t->width, r);
         cells += (int64_t)qlen * t->width;
-        if (r[0] < KP_MIN_DP_SCORE) continue;
+        if (r[0] < KP_MIN_DP_SCORE || dropped[i]) continue;
         kp_hit *h = &hits[nh++];
         memset(h, 0, sizeof *h);
         h->gene = g; h->contig = t->contig; h->strand = rev ? -1 : 1;
@@ -790,6 +1105,26 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         h->n_seeds = (uint8_t)(t->n_anchors < 255 ? t->n_anchors : 255);
         { const int cs = t->chain_score < 65535 ? t->chain_score : 65535; h->mapq = (uint8_t)(cs & 255); h->pad_ = (uint8_t)(cs >> 8); }
     }
+    for (int64_t j = 0; j < nj; j++) { /* the joined paths */
+        const kpo_join *J = &joins[j];
+        const int g = J->gs >> 1, rev = J->gs & 1, qlen = db->off[g + 1] - db->off[g];
+        const int64_t cs = ctg_start[J->contig];
+        cells += (int64_t)qlen * J->width * J->n_pieces;
+        for (int k = 1; k < J->n_pieces; k++) {
+            if (J->state[k] != 1) continue;
+            const int32_t *r = J->res[k];
+            kp_hit *h = &hits[nh++];
+            memset(h, 0, sizeof *h);
+            h->gene = g; h->contig = J->contig; h->strand = rev ? -1 : 1;
+            h->q_start = rev ? qlen - r[2] : r[1];
+            h->q_end = rev ? qlen - r[1] : r[2];
+            h->t_start = (int32_t)(r[3] - cs); h->t_end = (int32_t)(r[4] - cs);
+            h->score = (int32_t)((uint32_t)r[7] | ((uint32_t)r[8] << KP_HIT_BONUS_SHIFT)); h->matches = r[5]; h->block_len = r[6];
+            h->n_seeds = (uint8_t)(J->n_anchors < 255 ? J->n_anchors : 255);
+            { const int c2 = J->chain_score < 65535 ? J->chain_score : 65535; h->mapq = (uint8_t)(c2 & 255); h->pad_ = (uint8_t)(c2 >> 8); }
+        }
+    }
+    free(dropped); free(joins); free(pcl);
     qsort(hits, (size_t)nh, sizeof(kp_hit), cmp_hit);
     int64_t m = 0;
     for (int64_t i = 0; i < nh; i++) { /* hits with the same span are emitted once */

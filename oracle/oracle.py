@@ -26,6 +26,16 @@ TASK_DTYPE = np.dtype(
 )  # fmt: skip
 
 
+JOIN_MAX_PIECES = 8
+JOIN_DTYPE = np.dtype(
+    [("gs", "<i4"), ("contig", "<i4"), ("n_pieces", "<i4"), ("n_anchors", "<i4"), ("chain_score", "<i4"), ("width", "<i4"),
+     ("lo", "<i4", (JOIN_MAX_PIECES,)),
+     # per piece: state (0 nothing, 1 hit, 2 rejected by the drop test), mask of visited pieces, then the cell score,
+     # q_start, q_end, t_start, t_end, matches, block_len, the reported score of its joined path and its order-score bonus
+     ("piece", "<i4", (JOIN_MAX_PIECES, 11))]
+)  # fmt: skip
+
+
 def build(force: bool = False) -> Path:
     so = _HERE / "libkp_oracle.so"
     src = _HERE / "kp_oracle.c"
@@ -63,7 +73,7 @@ def _load(path: Path) -> None:
     _LIB = C.CDLL(str(path))
     _LIB.kpo_db_create.restype = C.c_void_p
     _LIB.kpo_db_n_postings.restype = C.c_int64
-    for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract", "kpo_seeds"):
+    for f in ("kpo_anchors", "kpo_tasks", "kpo_sw", "kpo_align", "kpo_translate", "kpo_extract", "kpo_seeds", "kpo_joins"):
         getattr(_LIB, f).restype = C.c_int64
 
 
@@ -205,6 +215,14 @@ class OracleDB:
         tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
         out = np.zeros((len(tasks), 7), np.int32)
         lib().kpo_sw(*args, _p(tasks), C.c_int64(len(tasks)), _p(out))
+        return out
+
+    def joins(self, pa) -> np.ndarray:
+        """Joins of the assembly (kp_spec.h, v4), one JOIN_DTYPE row each, in the order the oracle finds them."""
+        keep, args = self._asm_args(pa)
+        n = lib().kpo_joins(*args, None, C.c_int64(0))
+        out = np.zeros(n, JOIN_DTYPE)
+        lib().kpo_joins(*args, _p(out), C.c_int64(n))
         return out
 
     def align(self, pa, with_stats: bool = False, with_chain: bool = False):

@@ -16,7 +16,7 @@ CONFIGS = {
 
 
 def assembly_kwargs(config: str, i: int) -> dict:
-    """Deterministic variety: divergence from 0 to 12 %, indels, N runs, a second locus, a tandem gene copy."""
+    """Deterministic variety: divergence from 0 to 12 %, indels, N runs, a second locus, a tandem gene copy, mid-size indels."""
     kw = dict(CONFIGS[config]["asm"])
     kw["sub_rate"] = [None, 0.0, 0.01, 0.03, 0.06, 0.09, 0.12, None][i % 8]
     if i % 5 == 1:
@@ -27,6 +27,10 @@ def assembly_kwargs(config: str, i: int) -> dict:
         kw["second_locus"] = (i * 13) % 100
     if i % 9 == 4:
         kw["tandem_gene"] = 1
+    if i % 4 == 3:  # insertions / deletions of 33-480 bases inside genes: joined alignments (kp_spec.h, kp-align v4)
+        size = 33 + (41 * i) % 448
+        kind, other = ("del", "ins") if i % 8 == 3 else ("ins", "del")
+        kw["mid_indels"] = ((size, kind), (size + 1, kind), (33 + (size * 7) % 448, other))
     return kw
 
 

@@ -236,6 +236,74 @@ def test_anchor_task_hit_stages_match_oracle(ctx, small_setup, small_db):
     batch.close()
 
 
+def _join_assemblies(db):
+    """Genes with insertions and deletions of 33-480 bases (kp_spec.h, kp-align v4): planted by the generator in whole
+    assemblies, and hand-made contigs for what it does not reach -- three pieces in one gene, a short piece before a long
+    gap (the continuation starts below zero), both strands, an N run next to the junction, a junction at a contig end,
+    two copies of the edited gene on one contig, and a tail of unrelated sequence before a chance piece."""
+    from kaptive_amd.synth import revcomp
+
+    small = dict(length=90_000, median_contigs=5, min_contig=200, p_is=0, p_stop=0)
+    asms = []
+    for i, (size, kind) in enumerate(((33, "del"), (40, "ins"), (64, "del"), (100, "ins"), (150, "del"), (300, "ins"), (450, "del"), (480, "ins"))):
+        other = "ins" if kind == "del" else "del"
+        asms.append(make_assembly(db, seed=500 + i, mid_indels=((size, kind), (size + 1, kind), (size + 2, other)), **small))
+    asms.append(make_assembly(db, seed=520, length=90_000, median_contigs=60, min_contig=200, force_split=True, p_is=0, p_stop=0,
+                              mid_indels=((60, "del"), (90, "ins"), (200, "del"), (35, "ins"))))
+    rng = np.random.default_rng(99)
+    genes = [np.frombuffer(db.genes[i].seq, np.uint8) for i in (2, 5, 11, 17, 23)]
+    flank = lambda n: random_dna(rng, n, 0.5)  # noqa: E731
+
+    def edit(g, edits):  # (position, "del" | "ins", size), applied from the far end
+        for at, kind, size in sorted(edits, reverse=True):
+            g = np.delete(g, slice(at, at + size)) if kind == "del" else np.concatenate([g[:at], flank(size), g[at:]])
+        return g
+
+    g0, g1, g2, g3, g4 = genes
+    recs = [
+        SeqRecord("three_pieces", np.concatenate([flank(500), edit(g0, [(len(g0) // 3, "del", 40), (2 * len(g0) // 3, "ins", 90)]), flank(400)]).tobytes()),
+        SeqRecord("three_pieces_rc", revcomp(np.concatenate([flank(300), edit(g1, [(len(g1) // 3, "ins", 70), (2 * len(g1) // 3, "del", 36)]), flank(300)])).tobytes()),
+        SeqRecord("short_head", np.concatenate([flank(200), edit(g2, [(120, "del", 400)]), flank(200)]).tobytes()),
+        SeqRecord("short_tail", np.concatenate([flank(200), edit(g3, [(len(g3) - 110, "ins", 450)]), flank(200)]).tobytes()),
+        SeqRecord("two_copies", np.concatenate([flank(100), edit(g4, [(len(g4) // 2, "del", 80)]), flank(150), edit(g4, [(len(g4) // 2, "ins", 120)]), flank(100)]).tobytes()),
+        SeqRecord("at_contig_end", np.concatenate([flank(100), edit(g0, [(len(g0) // 2, "ins", 200)])[: len(g0) // 2 + 200 + 60]]).tobytes()),
+        SeqRecord("junk_tail", np.concatenate([flank(100), g1[:500], flank(260), g1[700:760], flank(100)]).tobytes()),
+        SeqRecord("more_junk", np.concatenate([flank(100), g3[:500], flank(760), g3[1200:], flank(100)]).tobytes()),
+    ]
+    with_n = np.concatenate([flank(200), edit(g2, [(len(g2) // 2, "del", 90)]), flank(200)])
+    with_n[200 + len(g2) // 2 - 30 : 200 + len(g2) // 2 - 22] = ord("N")
+    recs.append(SeqRecord("n_near_junction", with_n.tobytes()))
+    asms.append(GenomeAssembly("hand_made_joins", Sequences.from_records(recs)))
+    return asms
+
+
+def test_joins_across_mid_size_indels_match_oracle(ctx, small_setup, small_db):
+    """kp-align v4: groups, chains of clusters, the joined fill (local first piece, continuation pieces, cross gaps by
+    atomic maxima) and the walk-back with the drop test -- join records, band tasks and hit tables equal the oracle's."""
+    odb = small_setup
+    asms = _join_assemblies(small_db)
+    packed = [a.packed() for a in asms]
+    batch = ctx.batch(packed)
+    hits, off = batch.align()
+    n_joined = n_rejected = n_three = 0
+    for i, pa in enumerate(packed):
+        want_j, got_j = odb.joins(pa), batch.joins(i)
+        key = lambda j: np.lexsort((j["lo"][:, 0], j["contig"], j["gs"]))  # noqa: E731
+        want_j, got_j = want_j[key(want_j)] if len(want_j) else want_j, got_j[key(got_j)] if len(got_j) else got_j
+        assert len(want_j) == len(got_j), (asms[i].id, len(want_j), len(got_j))
+        for f in want_j.dtype.names:
+            assert np.array_equal(want_j[f], got_j[f]), (asms[i].id, f, want_j[f][:2], got_j[f][:2])
+        n_joined += int((want_j["piece"][:, :, 0] == 1).sum())
+        n_rejected += int((want_j["piece"][:, :, 0] == 2).sum())
+        n_three += int((want_j["n_pieces"] >= 3).sum())
+        want_t = np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names))
+        got_t = np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names))
+        _same_records(got_t, want_t, f"tasks of {asms[i].id}")
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert n_joined >= 25 and n_three >= 2 and n_rejected >= 1, (n_joined, n_rejected, n_three)  # the comparison above was not vacuous
+    batch.close()
+
+
 def test_twelve_thousand_genes_stay_on_the_bucket_sort(oracle):
     """A 540-locus database (about 12 400 genes: 24 800 values of the anchor key's gene/strand field, 97 KB of LDS counters)
     goes through kp_bsort.hip, not the library's radix sort: sorted anchors, tasks and hits equal the oracle's, and the

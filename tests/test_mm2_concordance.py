@@ -155,6 +155,37 @@ def test_locus_type_and_confidence_agree_with_the_minimap2_model(dbs, config):
     assert seeds_equal >= 0.999 * shared and mapq_equal >= 0.98 * shared, (shared, seeds_equal, mapq_equal)
 
 
+@pytest.mark.parametrize("kind", ["del", "ins"])
+def test_mid_size_indels_give_the_models_rows(dbs, kind):
+    """kp-align v4 (kp_spec.h): a gene with an insertion or deletion of 33-450 bases is ONE hit through the gap, as in the
+    minimap2 model (bw = 500), not two half-gene hits -- byte-identical report rows, and every joined hit of the oracle is
+    a hit of the model with the same span, score and anchor count."""
+    db, odb, typer = _db(dbs, "kpsc_k", 100)
+    joined = 0
+    for i, size in enumerate((33, 48, 64, 100, 150, 300, 450)):
+        genome = make_assembly(db, seed=7300 + 10 * i + (kind == "ins"), length=300_000, median_contigs=8, p_is=0, p_stop=0,
+                               mid_indels=((size, kind), (size + 1, kind)))
+        packed = genome.packed()
+        hk, hm = odb.align(packed), mm2.Mm2Index.from_contigs(genome.contigs).map(db.genes)
+        fk = bytes(KaptiveRow.from_result(typer.reduce(genome, hits_to_alignments(db, genome, hk)))).split(b"\t")
+        fm = bytes(KaptiveRow.from_result(typer.reduce(genome, hits_to_alignments(db, genome, hm)))).split(b"\t")
+        assert fk == fm, (size, kind, genome.id, [c for c in range(len(fk)) if fk[c] != fm[c]])
+        sm = {_span(h): h for h in hm}
+        for j in odb.joins(packed):
+            for k in range(1, int(j["n_pieces"])):
+                if j["piece"][k][0] != 1:
+                    continue
+                g, glen = int(j["gs"]) >> 1, int(db.genes.lengths[int(j["gs"]) >> 1])
+                qs, qe = int(j["piece"][k][3]), int(j["piece"][k][4])
+                cs = int(packed.ctg_start[int(j["contig"])])
+                span = (g, int(j["contig"]), -1 if j["gs"] & 1 else 1, glen - qe if j["gs"] & 1 else qs, glen - qs if j["gs"] & 1 else qe,
+                        int(j["piece"][k][5]) - cs, int(j["piece"][k][6]) - cs)
+                if span in sm:  # (divergent relatives of the edited gene may end a few bases apart)
+                    joined += 1
+                    assert int(sm[span]["score"]) == int(j["piece"][k][9]) and int(sm[span]["n_seeds"]) == min(255, int(j["n_anchors"]))
+    assert joined >= 14
+
+
 # ---- seeds: the oracle's state machine against the model's mm_sketch -----------------------------------------------------------
 _CODE = np.full(256, 4, np.uint8)
 for _i, _c in enumerate(b"ACGT"):

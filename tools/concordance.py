@@ -34,6 +34,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 FIELDS = ("Best match locus", "Best match type", "Match confidence", "Problems")
 
+MID_INDEL_SIZES = (33, 48, 64, 100, 150, 300, 450)
 _STATE: dict = {}
 
 
@@ -91,6 +92,17 @@ def cases(scale: float, full_size: int):
         out.append(("n_run", ["k"], "k", dict(seed=64_000 + i, n_run=40, p_is=0, **small), ()))
     for i in range(per):
         out.append(("no_locus", ["k"], "k", dict(seed=65_000 + i, locus=-1, **small), ()))
+    # insertions and deletions of 33-450 bases inside genes (minimap2 chains across them, bw = 500): three genes per
+    # assembly get one each -- the size itself, size + 1 (the other reading-frame class) and, of the opposite kind, size + 2
+    small_ab = dict(length=400_000, median_contigs=150, force_split=True, min_contig=200)
+    for di, (key, small_kw) in enumerate((("k", small), ("ab", small_ab))):
+        for zi, size in enumerate(MID_INDEL_SIZES):
+            for ki, kind in enumerate(("del", "ins")):
+                other = "ins" if kind == "del" else "del"
+                for i in range(max(1, per // 2)):
+                    kw = dict(seed=70_000 + 10_000 * di + 500 * zi + 100 * ki + i, p_is=0, p_stop=0,
+                              mid_indels=((size, kind), (size + 1, kind), (size + 2, other)), **small_kw)
+                    out.append((f"midindel_{size}_{kind}", [key], key, kw, ()))
     return out
 
 
@@ -168,7 +180,7 @@ def run_case(case):
 def summarise(records: list[dict]) -> str:
     by_tag: dict[str, list[dict]] = defaultdict(list)
     for r in records:
-        by_tag[r["tag"] + ("/" + r["db"] if r["tag"] == "config3" else "")].append(r)
+        by_tag[r["tag"] + ("/" + r["db"] if r["tag"] == "config3" or r["tag"].startswith("midindel") else "")].append(r)
     lines = []
     lines.append("| workload | rows | byte-identical rows | locus/type/confidence/problems identical | locus+type+confidence identical | final genes identical in coordinates | in state | raw hit spans shared / kp-only / mm2-only | scores equal on shared spans | mapq equal | chain anchors equal |")
     lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
@@ -199,7 +211,7 @@ def main() -> None:
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--procs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--full-size", type=int, default=6)
-    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r4"))
+    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r5"))
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     cs = cases(a.scale, a.full_size)
