@@ -32,7 +32,7 @@ __device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w =
 
 // ---- groups -> joins ---------------------------------------------------------------------------------------------------------------
 struct JNode {
-    int hq, ht, tq, tt, cs, cnt, ctg, qmax, lo, width;
+    int hq, ht, tq, tt, cs, cnt, ctg, qmax, lo, width, d0, dmax;
     uint32_t ref;
 };
 
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
             N.tq = (int)(tail >> 32); N.tt = (int)(uint32_t)tail - KP_DIAG_BIAS + N.tq;
             N.cs = t.chain_score; N.cnt = t.n_anchors; N.ctg = t.contig; N.qmax = (int)(t.qspan >> 16);
             N.lo = t.lo; N.width = t.width; N.ref = ref;
+            N.d0 = (int)kp_ckey_diag(k[0], kb); N.dmax = (int)kp_ckey_diag(k[G.cnt[c] - 1], kb);  // (sorted by diagonal first)
         }
         if (m < 2) continue;
         int ord[KP_JOIN_GROUP_MAX];
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
             for (int j = i - 1; j >= 0; --j) {
                 const JNode &cj = node[ord[j]];
                 if (cj.ctg != ci.ctg) continue;
+                if (ci.d0 - cj.dmax <= KP_DIAG_GAP && cj.d0 - ci.dmax <= KP_DIAG_GAP) continue;  // one run of diagonals, cut in two by another contig's anchors
                 const int dq = ci.hq - cj.tq, dr = ci.ht - cj.tt;
                 if (dq <= 0 || dr <= 0 || dq > KP_CHAIN_MAX_DIST || dr > KP_CHAIN_MAX_DIST) continue;
                 const int dd = dr > dq ? dr - dq : dq - dr;
@@ -148,23 +150,11 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
         const int qlen = have ? genes.len[gene] : 0;
         const uint32_t *qnib = genes.nib + genes.word_off[(gs & 1) ? genes.n_genes + gene : gene];
         const uint32_t *asm_words = b.words + b.asm_word_off[asm_id];
+        const int asm_n_words = (int)(b.asm_word_off[asm_id + 1] - b.asm_word_off[asm_id]);
         const int c_abs = b.asm_first_ctg[asm_id] + (have ? J->contig : 0);
         const int cstart = b.ctg_start[c_abs], cend = cstart + b.ctg_len[c_abs];
         const int r0n = b.asm_first_nrun[asm_id], n_runs = b.asm_first_nrun[asm_id + 1] - r0n;
         const int32_t *runs = b.n_runs + 2 * (size_t)r0n;
-        auto target_code = [&](int t) -> int {  // 0..3, 4 = N, 5 = outside the contig
-            if (t < cstart || t >= cend) return 5;
-            int code = (int)((asm_words[t >> 4] >> (2 * (t & 15))) & 3u);
-            if (n_runs > 0) {
-                int a = 0, z = n_runs;
-                while (a < z) {
-                    const int mid = (a + z) >> 1;
-                    if (runs[2 * mid + 1] <= t) a = mid + 1; else z = mid;
-                }
-                if (a < n_runs && runs[2 * a] <= t) code = 4;
-            }
-            return code;
-        };
         int max_pieces = n_pieces;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) max_pieces = max(max_pieces, __shfl_xor(max_pieces, o));
@@ -206,81 +196,107 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
 #pragma unroll
             for (int c = 0; c < 4; ++c) { H[c] = none; E[c] = F[c] = JNEG; }
             int best = JNEG, best_r = -1, best_b = 4 * l;
-            for (int m = 0; m < max_steps; ++m) {
-                const int r = q0 + m - l;  // this lane's row
-                const bool row_ok = fits && m < steps8 && r >= q0 && r < r_hi;
-                const int qc = row_ok ? (int)nib4(qnib[r >> 3], r & 7) : 4;
-                const int t0 = lo + r + 4 * l;
-                // left neighbour of cell 0: lane l - 1's cell 3 as the previous step left it; upper neighbour of cell 3: lane
-                // l + 1's cell 0 of this step
-                int hl = __shfl_up(H[3], 1), el = __shfl_up(E[3], 1);
-                if (l == 0) { hl = none; el = JNEG; }
-                const int oldH[4] = {H[0], H[1], H[2], H[3]}, oldF[4] = {F[0], F[1], F[2], F[3]};
-                // cross gaps: the keys of this row (horizontal) -- those of a column are fetched per cell
-                unsigned long long rk1 = 0ull, rk2 = 0ull;
-                if (row_ok && cont && imp && imp_horizontal && r < imp_len) {
-                    rk1 = __hip_atomic_load(&imp[2 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    rk2 = __hip_atomic_load(&imp[2 * r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Eight steps at a time: what they read -- the query rows, the target bases and the keys of the cross gaps -- does not
+            // depend on the cells before them, so it is all requested up front and the eight dependent steps then run from
+            // registers (a step that fetched its own operands waited for memory three times: 3.3 ms for a 1300-row piece).
+            for (int m0 = 0; m0 < max_steps; m0 += 8) {
+                const int r0 = q0 + m0 - l;  // this lane's row at the chunk's first step
+                const int tb0 = lo + r0 + 4 * l;  // ... and the column of its cell 0 there: step s, cell c sits on tb0 + s + c
+                uint64_t qwin, twin;
+                {
+                    const int w0 = r0 >> 3, nq = (qlen + 7) >> 3;  // (arithmetic shifts: rows before the gene read as N)
+                    const uint32_t lo_w = (fits && w0 >= 0 && w0 < nq) ? qnib[w0] : 0x44444444u;
+                    const uint32_t hi_w = (fits && w0 + 1 >= 0 && w0 + 1 < nq) ? qnib[w0 + 1] : 0x44444444u;
+                    qwin = (((uint64_t)hi_w << 32) | lo_w) >> (4 * (r0 & 7));
+                    const int v0 = tb0 >> 4;
+                    const uint32_t lo_t = (fits && v0 >= 0 && v0 < asm_n_words) ? asm_words[v0] : 0u;
+                    const uint32_t hi_t = (fits && v0 + 1 >= 0 && v0 + 1 < asm_n_words) ? asm_words[v0 + 1] : 0u;
+                    twin = (((uint64_t)hi_t << 32) | lo_t) >> (2 * (tb0 & 15));  // eleven bases: 22 of the 34 bits that are left
                 }
-                uint32_t word = 0;
-                int hu_d = none, fu_d = JNEG;
+                unsigned long long kx1[11], kx2[11];  // cross-gap keys: of rows r0 + s (horizontal) or of columns tb0 + j (vertical)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (c == 3) {  // (every lane has computed its cell 0 by now)
-                        hu_d = __shfl_down(H[0], 1); fu_d = __shfl_down(F[0], 1);
-                        if (l == P - 1) { hu_d = none; fu_d = JNEG; }
-                    }
-                    const int t = t0 + c;
-                    const int code = row_ok ? target_code(t) : 5;
-                    const bool inside = row_ok && code < 5;
-                    const int hleft = c == 0 ? hl : H[c - 1], eleft = c == 0 ? el : E[c - 1];
-                    const int hup = c == 3 ? hu_d : oldH[c + 1], fup = c == 3 ? fu_d : oldF[c + 1];
-                    const int hd = oldH[c];
-                    const int e_open = hleft - (KP_GAP_OPEN + KP_GAP_EXT), e_ext = eleft - KP_GAP_EXT;
-                    const int f_open = hup - (KP_GAP_OPEN + KP_GAP_EXT), f_ext = fup - KP_GAP_EXT;
-                    int e = e_open >= e_ext ? e_open : e_ext, f = f_open >= f_ext ? f_open : f_ext;
-                    const uint32_t e_extd = e_open >= e_ext ? 0u : 1u, f_extd = f_open >= f_ext ? 0u : 1u;
-                    if (dead(e)) e = JNEG;
-                    if (dead(f)) f = JNEG;
-                    const int s = (qc > 3 || code > 3) ? KP_SC_N : (qc == code ? KP_SC_MATCH : KP_SC_MISMATCH);
-                    int bv = hd + s;
-                    uint32_t tb = XT_DIAG;
-                    if (e > bv) { bv = e; tb = XT_E; }
-                    if (f > bv) { bv = f; tb = XT_F; }
-                    if (inside && cont && imp) {
-                        unsigned long long k1 = rk1, k2 = rk2;
-                        int pos = t - imp_lo;  // (the exporter's frame: columns count from its band's origin)
-                        if (!imp_horizontal) {
-                            const int xi = t - imp_lo;
-                            k1 = k2 = 0ull;
-                            if (xi >= 0 && xi < imp_len) {
-                                k1 = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                k2 = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            pos = r;
-                        }
-                        if (k1) {  // (a row / column with one key has both)
-                            const int c1 = (int)(k1 >> 32) - XBIAS - KP_GAP_OPEN - KP_GAP_EXT * pos;
-                            const int c2 = (int)(k2 >> 32) - XBIAS - KP_GAP_OPEN2 - KP_GAP_EXT2 * pos;
-                            if (c1 > bv) { bv = c1; tb = XT_X1; }
-                            if (c2 > bv) { bv = c2; tb = XT_X2; }
-                        }
-                    }
-                    const bool live = inside && (cont ? !dead(bv) : bv > 0);
-                    if (inside) { E[c] = e; F[c] = f; } else { E[c] = F[c] = JNEG; }
-                    H[c] = live ? bv : none;
-                    word |= ((live ? tb : (uint32_t)XT_RESTART) | (e_extd << 3) | (f_extd << 4)) << (8 * c);
-                    if (live) {
-                        if (cont && r >= rmin && bv > best) { best = bv; best_r = r; best_b = 4 * l + c; }
-                        if (exports && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
-                            const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
-                            const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
-                            atomicMax(&exp[2 * xi], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low);
-                            atomicMax(&exp[2 * xi + 1], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low);
+                for (int j = 0; j < 11; ++j) {
+                    kx1[j] = kx2[j] = 0ull;
+                    if (fits && cont && imp) {
+                        const int xi = imp_horizontal ? r0 + j : tb0 + j - imp_lo;
+                        if ((!imp_horizontal || j < 8) && xi >= 0 && xi < imp_len) {
+                            kx1[j] = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            kx2[j] = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
-                if (fits && m < steps8) tr[(size_t)m * P + l] = word;
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx) {
+                    const int m = m0 + sidx, r = r0 + sidx;
+                    const bool row_ok = fits && m < steps8 && r >= q0 && r < r_hi;
+                    const int qc = (int)((qwin >> (4 * sidx)) & 15u);
+                    // left neighbour of cell 0: lane l - 1's cell 3 as the previous step left it; upper neighbour of cell 3: lane
+                    // l + 1's cell 0 of this step
+                    int hl = __shfl_up(H[3], 1), el = __shfl_up(E[3], 1);
+                    if (l == 0) { hl = none; el = JNEG; }
+                    const int oldH[4] = {H[0], H[1], H[2], H[3]}, oldF[4] = {F[0], F[1], F[2], F[3]};
+                    uint32_t word = 0;
+                    int hu_d = none, fu_d = JNEG;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c == 3) {  // (every lane has computed its cell 0 by now)
+                            hu_d = __shfl_down(H[0], 1); fu_d = __shfl_down(F[0], 1);
+                            if (l == P - 1) { hu_d = none; fu_d = JNEG; }
+                        }
+                        const int t = tb0 + sidx + c;
+                        int code = 5;  // 0..3, 4 = N, 5 = outside the contig
+                        if (row_ok && t >= cstart && t < cend) {
+                            code = (int)((twin >> (2 * (sidx + c))) & 3u);
+                            if (n_runs > 0) {  // (rare: assemblies with scaffold gaps)
+                                int a2 = 0, z2 = n_runs;
+                                while (a2 < z2) {
+                                    const int mid = (a2 + z2) >> 1;
+                                    if (runs[2 * mid + 1] <= t) a2 = mid + 1; else z2 = mid;
+                                }
+                                if (a2 < n_runs && runs[2 * a2] <= t) code = 4;
+                            }
+                        }
+                        const bool inside = code < 5;
+                        const int hleft = c == 0 ? hl : H[c - 1], eleft = c == 0 ? el : E[c - 1];
+                        const int hup = c == 3 ? hu_d : oldH[c + 1], fup = c == 3 ? fu_d : oldF[c + 1];
+                        const int hd = oldH[c];
+                        const int e_open = hleft - (KP_GAP_OPEN + KP_GAP_EXT), e_ext = eleft - KP_GAP_EXT;
+                        const int f_open = hup - (KP_GAP_OPEN + KP_GAP_EXT), f_ext = fup - KP_GAP_EXT;
+                        int e = e_open >= e_ext ? e_open : e_ext, f = f_open >= f_ext ? f_open : f_ext;
+                        const uint32_t e_extd = e_open >= e_ext ? 0u : 1u, f_extd = f_open >= f_ext ? 0u : 1u;
+                        if (dead(e)) e = JNEG;
+                        if (dead(f)) f = JNEG;
+                        const int sc = (qc > 3 || code > 3) ? KP_SC_N : (qc == code ? KP_SC_MATCH : KP_SC_MISMATCH);
+                        int bv = hd + sc;
+                        uint32_t tb = XT_DIAG;
+                        if (e > bv) { bv = e; tb = XT_E; }
+                        if (f > bv) { bv = f; tb = XT_F; }
+                        if (inside && cont && imp) {
+                            const unsigned long long k1 = imp_horizontal ? kx1[sidx] : kx1[sidx + c], k2 = imp_horizontal ? kx2[sidx] : kx2[sidx + c];
+                            const int pos = imp_horizontal ? t - imp_lo : r;  // (the exporter's frame: columns count from its band's origin)
+                            if (k1) {  // (a row / column with one key has both)
+                                const int c1 = (int)(k1 >> 32) - XBIAS - KP_GAP_OPEN - KP_GAP_EXT * pos;
+                                const int c2 = (int)(k2 >> 32) - XBIAS - KP_GAP_OPEN2 - KP_GAP_EXT2 * pos;
+                                if (c1 > bv) { bv = c1; tb = XT_X1; }
+                                if (c2 > bv) { bv = c2; tb = XT_X2; }
+                            }
+                        }
+                        const bool live = inside && (cont ? !dead(bv) : bv > 0);
+                        if (inside) { E[c] = e; F[c] = f; } else { E[c] = F[c] = JNEG; }
+                        H[c] = live ? bv : none;
+                        word |= ((live ? tb : (uint32_t)XT_RESTART) | (e_extd << 3) | (f_extd << 4)) << (8 * c);
+                        if (live) {
+                            if (cont && r >= rmin && bv > best) { best = bv; best_r = r; best_b = 4 * l + c; }
+                            if (exports && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
+                                const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
+                                const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
+                                atomicMax(&exp[2 * xi], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low);
+                                atomicMax(&exp[2 * xi + 1], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low);
+                            }
+                        }
+                    }
+                    if (fits && m < steps8) tr[(size_t)m * P + l] = word;
+                }
             }
             // END of the piece: the largest score, then the first row, then the first column
 #pragma unroll

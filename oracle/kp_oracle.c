@@ -688,6 +688,7 @@ static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks,
                 for (int j = i - 1; j >= 0; j--) {
                     const kpo_pcl *cj = &pcl[node[j]];
                     if (cj->contig != ci->contig) continue;
+                    if (ci->d0 - cj->dmax <= KP_DIAG_GAP && cj->d0 - ci->dmax <= KP_DIAG_GAP) continue; /* one run of diagonals cut in two by another contig's anchors: the band tasks cover it */
                     const int dq = ci->hq - cj->tq, dr = ci->ht - cj->tt;
                     if (dq <= 0 || dr <= 0 || dq > KP_CHAIN_MAX_DIST || dr > KP_CHAIN_MAX_DIST) continue;
                     const int dd = dr > dq ? dr - dq : dq - dr;
@@ -1069,7 +1070,7 @@ KPO_API int64_t kpo_joins(const kpo_db *db, const uint32_t *words, int64_t padde
 KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padded_len, const int32_t *ctg_start,
                           const int32_t *ctg_len, int n_ctg, const int32_t *n_runs, int n_nruns, kp_hit *out,
                           int64_t cap, int64_t *stats /* optional [3]: anchors, tasks, dp cells */,
-                          int32_t *chain_out /* optional [cap]: the chain score behind every hit */) {
+                          int32_t *chain_out /* optional [cap]: the chain score behind every hit (| order-score bonus << 16) */) {
     kpo_asm a; asm_init(&a, words, padded_len, ctg_start, ctg_len, n_ctg, n_runs, n_nruns);
     uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
     kpo_task *tasks; kpo_pcl *pcl; int64_t np = 0;
@@ -1131,7 +1132,8 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         if (m > 0 && same_span(&hits[m - 1], &hits[i])) continue;
         hits[m++] = hits[i];
     }
-    if (chain_out) for (int64_t i = 0; i < m && i < cap; i++) chain_out[i] = hit_chain_score(&hits[i]);
+    if (chain_out) /* (with the order-score bonus of a joined hit above bit 16: the other input of its mapq that the record does not keep) */
+        for (int64_t i = 0; i < m && i < cap; i++) chain_out[i] = hit_chain_score(&hits[i]) | (int32_t)(((uint32_t)hits[i].score >> KP_HIT_BONUS_SHIFT) << 16);
     for (int64_t i = 0; i < m;) { /* mapping qualities, gene by gene */
         int64_t j = i;
         while (j < m && hits[j].gene == hits[i].gene) j++;

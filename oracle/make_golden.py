@@ -274,6 +274,9 @@ def gen_typing() -> None:
         ("k_second", "k", dict(seed=18, second_locus=3, locus=5, p_is=0, **small)),
         ("k_nrun", "k", dict(seed=19, n_run=40, p_break=0, p_is=0, p_stop=0, **small)),
         ("k_shredded", "k", dict(seed=20, length=90_000, median_contigs=60, min_contig=200, force_split=True)),
+        # (round 5, kp-align v4) insertions and deletions of 33-450 bases inside genes: joined hits
+        ("k_midindel_del", "k", dict(seed=21, p_break=0, p_is=0, p_stop=0, mid_indels=((60, "del"), (151, "del"), (300, "ins")), **small)),
+        ("k_midindel_ins", "k", dict(seed=22, p_is=0, p_stop=0, mid_indels=((45, "ins"), (98, "ins"), (450, "del"), (36, "del")), **small)),
         ("o_plain", "o", dict(seed=31, p_extra=0.0, **small)),
         ("o_extra1", "o", dict(seed=32, p_extra=3.0, **small)),
         ("o_extra2", "o", dict(seed=33, p_extra=3.0, locus=0, **small)),
@@ -355,6 +358,10 @@ FULL_SIZE_CASES = [
     ("k_full_tandem", "kfull", ("kpsc_k", 100), dict(seed=20_005, tandem_gene=1)),
     ("o_fullsize", "ofull", ("kpsc_o", 101), dict(seed=20_006)),                                                   # config 3's O half
     ("ab_full_div6", "abfull", ("ab_k", 102), dict(seed=40_002, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True, sub_rate=0.06)),
+    # (round 5, kp-align v4) mid-size insertions and deletions inside genes at full size
+    ("k_full_midindel", "kfull", ("kpsc_k", 100), dict(seed=20_007, mid_indels=((48, "del"), (100, "ins"), (301, "del"), (450, "ins")))),
+    ("ab_full_midindel", "abfull", ("ab_k", 102), dict(seed=40_003, length=4.0e6, median_contigs=1500, min_contig=200, force_split=True,
+                                                      mid_indels=((33, "ins"), (64, "del"), (150, "ins"), (300, "del")))),
 ]
 
 

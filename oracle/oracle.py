@@ -226,8 +226,8 @@ class OracleDB:
         return out
 
     def align(self, pa, with_stats: bool = False, with_chain: bool = False):
-        """Hits in emission order; ``with_chain`` adds the chain score behind every hit (an input of its mapq that the
-        hit record does not keep)."""
+        """Hits in emission order; ``with_chain`` adds the chain score behind every hit, with the order-score bonus of a
+        joined hit (kp_spec.h) above bit 16 -- the inputs of its mapq and rank that the hit record does not keep."""
         keep, args = self._asm_args(pa)
         stats = np.zeros(3, np.int64)
         cap = 1 << 14

@@ -27,8 +27,10 @@ def test_core_reduction_matches_reference(name, oracle):
         shuffled = np.concatenate([hits, hits[: len(hits) // 7]])[perm]
         # (between the aligner and the mapq computation a record carries its chain score in the mapq / pad bytes)
         chain = np.load(GOLDEN / f"typing_{name}.npz")["hit_chain_scores"]
-        chain = np.minimum(np.concatenate([chain, chain[: len(hits) // 7]])[perm], 65535)
+        chain = np.concatenate([chain, chain[: len(hits) // 7]])[perm]
+        bonus, chain = chain >> 16, np.minimum(chain & 0xFFFF, 65535)  # (a joined hit's order-score bonus rides above bit 16)
         shuffled["mapq"], shuffled["pad"] = chain & 255, chain >> 8
+        shuffled["score"] |= bonus << 20
         again = H.finalise_hits(shuffled)
         assert again.tobytes() == np.ascontiguousarray(hits).tobytes()
 
