@@ -196,6 +196,13 @@ KP_API int kp_batch_wait(kp_ctx *ctx, kp_batch *batch);
  * These are the columns the reference reads off rammappy hit objects (src/kaptive/core/alignment.py:415-446). */
 KP_API int kp_batch_hit_offsets(kp_ctx *ctx, kp_batch *batch, int64_t *hit_off);
 KP_API int kp_batch_hits(kp_ctx *ctx, kp_batch *batch, kp_hit *out, int64_t cap);
+/* Replaces the batch's finished hit table (valid after kp_batch_wait) with the caller's: rows hit_off[a] .. hit_off[a+1] of
+ * `hits` become assembly a's hits, taken as they are -- emission order, mapq and all.  What follows (kp_batch_score,
+ * kp_batch_reduce, kp_batch_typing) then reduces THAT table.  The reference's reduction takes any rammappy hit table
+ * (src/kaptive/core/alignment.py:392-474, src/kaptive/serotyping/core.py:157-396); this is how hit tables no aligner would
+ * produce (equal scores, mapq 0 / 255 / 1 ties: src/kaptive/core/alignment.py:669-675) reach the device reduction in the
+ * parity tests. */
+KP_API int kp_batch_set_hits(kp_ctx *ctx, kp_batch *batch, const kp_hit *hits, const int64_t *hit_off);
 /* counters of the last kp_batch_align: [0] anchors, [1] band tasks, [2] DP cells, [3] hits, [4] overflow retries */
 KP_API int kp_batch_stats(kp_ctx *ctx, kp_batch *batch, int64_t *stats5);
 

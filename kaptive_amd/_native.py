@@ -36,7 +36,7 @@ EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
     "kp_host_free", "kp_host_pinned_bytes", "kp_device_allocations", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
-    "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
+    "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_set_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
@@ -631,6 +631,14 @@ class Batch:
         out = np.zeros(int(off[-1]), HIT_DTYPE)
         self.ctx._check(lib().kp_batch_hits(self.ctx._h, self._h, _p(out), C.c_int64(len(out))), "kp_batch_hits")
         return out, off
+
+    def set_hits(self, hits: np.ndarray, off: np.ndarray) -> None:
+        """Replace the finished hit table by the caller's (kp_batch_set_hits): rows ``off[a]:off[a + 1]`` are assembly a's."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        if len(off) != self.n_asm + 1 or int(off[-1]) != len(hits):
+            raise ValueError("offsets do not describe the hit table")
+        self.ctx._check(lib().kp_batch_set_hits(self.ctx._h, self._h, _p(hits), _p(off)), "kp_batch_set_hits")
 
     def stats(self) -> dict[str, int]:
         s = np.zeros(5, np.int64)

@@ -1189,6 +1189,46 @@ int kp_batch_hits(kp_ctx *ctx, kp_batch *b, kp_hit *out, int64_t cap) {
     return KP_OK;
 }
 
+int kp_batch_set_hits(kp_ctx *ctx, kp_batch *b, const kp_hit *hits, const int64_t *hit_off) {
+    if (!ctx || !b || b->ctx != ctx || !hit_off) return kp_fail(ctx, KP_EINVAL, "bad arguments");
+    KpWork *w = finalised_work(ctx, b);
+    if (!w) return KP_ESTATE;
+    const size_t n_asm = (size_t)b->n_asm;
+    int64_t max_n = 0;
+    for (size_t a = 0; a < n_asm; ++a) {
+        const int64_t n = hit_off[a + 1] - hit_off[a];
+        if (n < 0 || (n > 0 && !hits)) return kp_fail(ctx, KP_EINVAL, "hit offsets must ascend");
+        max_n = std::max(max_n, n);
+    }
+    if (max_n > (1 << 24)) return kp_fail(ctx, KP_EOVERFLOW, "too many hits for one assembly");
+    KP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // nothing may still be reading the table that is about to be replaced
+    KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->post));
+    for (auto &r : w->runs)
+        if (r && r->stream) { KP_HIP_CHECK(ctx, hipStreamSynchronize(r->stream)); if (r->aux) KP_HIP_CHECK(ctx, hipStreamSynchronize(r->aux)); }
+    if ((uint64_t)max_n > w->hit_cap) {
+        w->hit_cap = ((uint32_t)max_n + 255u) & ~255u;
+        ctx->hit_cap = std::max(ctx->hit_cap, w->hit_cap);
+    }
+    KP_HIP_CHECK(ctx, w->d_hits.reserve(n_asm * w->hit_cap));
+    KP_HIP_CHECK(ctx, w->d_hit_counts.reserve(2 * n_asm));
+    w->h_hit_counts.resize(2 * n_asm);
+    w->hit_off.assign(n_asm + 1, 0);
+    for (size_t a = 0; a < n_asm; ++a) {
+        const int64_t n = hit_off[a + 1] - hit_off[a];
+        if (n > 0)
+            KP_HIP_CHECK(ctx, hipMemcpy(w->d_hits.p + a * (size_t)w->hit_cap, hits + hit_off[a], (size_t)n * sizeof(kp_hit), hipMemcpyHostToDevice));
+        w->h_hit_counts[n_asm + a] = (uint32_t)n;
+        w->hit_off[a + 1] = w->hit_off[a] + n;
+    }
+    if (n_asm)
+        KP_HIP_CHECK(ctx, hipMemcpy(w->d_hit_counts.p + n_asm, w->h_hit_counts.data() + n_asm, n_asm * sizeof(uint32_t), hipMemcpyHostToDevice));
+    w->stats[3] = w->hit_off[n_asm];
+    for (auto &r : w->runs)
+        if (r) { r->split = false; r->scored = false; r->reduced = false; r->sums_valid = false; }
+    return KP_OK;
+}
+
 int kp_batch_stats(kp_ctx *ctx, kp_batch *b, int64_t *stats5) {
     if (!ctx || !b || b->ctx != ctx || !stats5) return kp_fail(ctx, KP_EINVAL, "bad arguments");
     KpWork *w = finalised_work(ctx, b);

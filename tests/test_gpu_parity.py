@@ -687,6 +687,70 @@ def _results_equal(a, b, what):
         assert da[grp]["seqs"] == db_[grp]["seqs"] and tuple(da[grp]["ids"]) == tuple(db_[grp]["ids"]), (what, grp)
 
 
+def _adversarial_hits(rng, db, genome, n):
+    """Hit tables no aligner would emit (the recipe of the reference goldens' random_hits cases, oracle/make_golden.py):
+    heavy overlaps around a few hot spots, scores / matches drawn from a handful of values, mapq 0 / 1 / 60 / 255."""
+    hits = np.zeros(n, _native.HIT_DTYPE)
+    genes = np.sort(rng.integers(0, len(db.genes), size=n))
+    glen = db.genes.lengths[genes]
+    ctg = rng.integers(0, len(genome.contigs), size=n)
+    clen = genome.contigs.lengths[ctg]
+    span = np.minimum((glen * rng.uniform(0.05, 1.0, size=n)).astype(np.int64) + 1, np.minimum(glen, clen))
+    hits["gene"], hits["contig"] = genes, ctg
+    hits["q_start"] = (rng.random(n) * (glen - span + 1)).astype(np.int64)
+    hits["q_end"] = hits["q_start"] + span
+    hot = (rng.integers(0, 6, size=n) * 0.15 * clen).astype(np.int64)
+    hits["t_start"] = np.clip(hot + rng.integers(-300, 300, size=n), 0, clen - span)
+    hits["t_end"] = hits["t_start"] + span
+    hits["strand"] = rng.choice(np.array([1, -1], np.int8), size=n)
+    hits["score"] = rng.choice(np.array([80, 120, 120, 500, 500, 900, 2000]), size=n)
+    hits["matches"] = rng.choice(np.array([40, 60, 60, 250, 450]), size=n)
+    hits["block_len"] = span
+    hits["mapq"] = rng.choice(np.array([0, 1, 60, 60, 255], np.uint8), size=n)
+    return hits[np.lexsort((-hits["score"], hits["gene"]))]
+
+
+def test_adversarial_hit_tables_through_the_device_reduction():
+    """The reference's reduction orders the cull by (score + 1e9 * priority, matches, uint8-wrapped -mapq)
+    (src/kaptive/core/alignment.py:669-675) and takes any hit table.  The golden cases random_hits0-4 -- tables with
+    equal scores, equal matches and mapq 0 / 255 / 1 ties, run through the reference's own Serotyper -- and a fuzz of the
+    same recipe go through kp_reduce_kernel (bitonic cull order, 64-wide greedy cull, clustering, translation) by way of
+    kp_batch_set_hits; results equal the goldens field for field and the host reduction on the fuzz."""
+    from kaptive_amd.engine import Engine
+    from tests.golden_util import hits_to_alignments
+
+    names = [n for n in case_names() if n.startswith("random_hits")]
+    assert len(names) == 5
+    for key in ("k", "o"):
+        cases = [load_case(n) for n in names if load_case(n)[0] == key]
+        db = load_db(key)
+        eng = Engine(db)
+        typer = Serotyper(db)
+        typer._engine = eng
+        genomes = [c[1] for c in cases]
+        rng = np.random.default_rng(20260930 + len(cases))
+        tables = [np.asarray(c[2]) for c in cases]
+        for i in range(40):  # the fuzz: the same genomes, fresh tables of 2 to 900 hits
+            g = genomes[i % len(genomes)]
+            genomes.append(g)
+            tables.append(_adversarial_hits(rng, db, g, int(rng.integers(2, 900 if i % 8 else 3000))))
+        batch = eng.ctx.batch([g.packed() for g in genomes])
+        batch.align_async()
+        batch.wait()
+        off = np.concatenate([[0], np.cumsum([len(t) for t in tables])]).astype(np.int64)
+        flat = np.concatenate(tables) if len(tables) else np.zeros(0, _native.HIT_DTYPE)
+        batch.set_hits(flat.astype(_native.HIT_DTYPE), off)
+        got_hits, got_off = batch.hits()
+        assert np.array_equal(got_off, off) and got_hits.tobytes() == flat.astype(_native.HIT_DTYPE).tobytes()
+        res = eng.type_batch(typer, batch, [g.id for g in genomes], genomes, aligned=True).results()
+        for c, r in zip(cases, res):
+            check_result_against_golden(r, c[3], c[4])
+        for g, t, r in zip(genomes[len(cases):], tables[len(cases):], res[len(cases):]):
+            _results_equal(r, typer.reduce(g, hits_to_alignments(db, g, t)), f"fuzz table of {len(t)} hits on {g.id}")
+        batch.close()
+        eng.close()
+
+
 @pytest.mark.parametrize("key", ["k", "o"])
 def test_batched_device_reduction_matches_golden_cases(key):
     """type_many = alignment + reduction on the device for all cases of one database in one batch; every result must
@@ -1013,9 +1077,9 @@ def test_config4_acinetobacter_at_full_size(oracle):
 
 
 def test_parity_sweep_at_full_size(oracle):
-    """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 6: BASELINE configs 2/3 -- 5 Mbp, K
+    """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 48: BASELINE configs 2/3 -- 5 Mbp, K
     and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
-    second loci and tandem copies: the device's hit tables equal the oracle's record for record and its report rows equal the
+    second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v4): the device's hit tables equal the oracle's record for record and its report rows equal the
     host reduction's byte for byte, for every assembly and database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
     import json
     import multiprocessing as mp
@@ -1024,7 +1088,7 @@ def test_parity_sweep_at_full_size(oracle):
     from kaptive_amd.engine import Engine
     from tests import sweep_util as S
 
-    n = int(os.environ.get("KAPTIVE_AMD_SWEEP", "6"))
+    n = int(os.environ.get("KAPTIVE_AMD_SWEEP", "48"))
     per_batch = int(os.environ.get("KAPTIVE_AMD_SWEEP_BATCH", "64"))  # (1024 x 5 Mbp: batch-wide base positions beyond 2^32)
     summary = {}
     with mp.get_context("spawn").Pool(min(16, max(2, (os.cpu_count() or 2) // 2))) as pool:

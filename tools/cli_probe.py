@@ -2,7 +2,7 @@
 """`kaptive assembly` over FASTA files on tmpfs (plain or gzip-compressed), for several reader-thread counts and chunk sizes:
 assemblies per second, steady state (GPU box).
 
-    python tools/cli_probe.py [--gz] [--files 64] [--repeats 32] [--threads 16,32] [--batch 512]
+    python tools/cli_probe.py [--gz] [--files 64] [--repeats 32] [--threads 16,32] [--batch 512] [--devices all]
 """
 import argparse
 import gzip
@@ -37,6 +37,7 @@ def main() -> int:
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--threads", default="0", help="comma-separated -t values (0 = the CLI's default)")
     ap.add_argument("--batch", default="512", help="comma-separated --batch-size values")
+    ap.add_argument("--devices", default="", help="passed on to `kaptive assembly --devices` (e.g. all, or 0,1,2,3)")
     args = ap.parse_args()
     from kaptive_amd.synth import make_db
 
@@ -52,7 +53,8 @@ def main() -> int:
             for batch in [int(x) for x in args.batch.split(",")]:
                 t = time.perf_counter()
                 r = subprocess.run([sys.executable, "-m", "kaptive_amd", "assembly", str(db), *(paths * args.repeats), "-o", str(root / "out.tsv"),
-                                    "--batch-size", str(batch), *(["-t", str(threads)] if threads else [])], env=env, capture_output=True, text=True)
+                                    "--batch-size", str(batch), *(["-t", str(threads)] if threads else []),
+                                    *(["--devices", args.devices] if args.devices else [])], env=env, capture_output=True, text=True)
                 wall = time.perf_counter() - t
                 if r.returncode != 0:
                     print(r.stderr[-600:])
@@ -60,7 +62,7 @@ def main() -> int:
                 tm = json.loads(timing.read_text())
                 marks = tm["rows_written_at"]
                 (n0, t0), (n1, t1) = marks[min(4, len(marks) - 2)], marks[-1]
-                print(json.dumps({"files": len(paths) * args.repeats, "gz": args.gz, "threads": threads, "batch": batch,
+                print(json.dumps({"files": len(paths) * args.repeats, "devices": args.devices or "0", "gz": args.gz, "threads": threads, "batch": batch,
                                   "text_MB_per_file": round(sum(sizes) / len(sizes) / 1e6, 2),
                                   "MB_per_file_on_disk": round(sum(os.path.getsize(p) for p in paths) / len(paths) / 1e6, 2), "wall_s": round(wall, 2),
                                   "first_rows_after_s": round(marks[0][1], 2), "phases_s": tm.get("phases_s"), "assemblies_per_s_steady": round((n1 - n0) / (t1 - t0), 1)}), flush=True)
