@@ -56,8 +56,15 @@
  *
  * A gene seed (start qs on the gene's forward strand, strand bit zq) and a contig seed (start ts, strand bit zt) with the
  * same x make one ANCHOR: same strand if zq == zt, query position qs; otherwise the gene's reverse complement, query
- * position gene_len - KP_K - qs.  (v3.0 applies no occurrence cut: minimap2's -f 2e-4 / min_mid_occ = 10 would drop a gene
- * seed that occurs more than 10 times among the assembly's minimizers.) */
+ * position gene_len - KP_K - qs.
+ *
+ * OCCURRENCE CUT (v4).  minimap2 drops a query seed that occurs more than mid_occ times in the index -- here: among the
+ * assembly's minimizers, both strands -- with mid_occ = max(min_mid_occ = 10, the (1 - 2e-4) quantile of the occurrence
+ * counts of the index's distinct minimizers).  v4 applies the floor: a gene seed with more than KP_MID_OCC anchors in an
+ * assembly (one anchor per occurrence, whichever strand) loses all of them.  Exact whenever the quantile is <= 10, i.e.
+ * unless more than 2 in 10 000 of an assembly's distinct minimizers occur more than ten times (tools/mid_occ_hist.py counts
+ * how often that is); minimap2's rescue of high-occurrence seeds in seed-poor stretches (mm_seed_select) is not restated. */
+#define KP_MID_OCC 10
 #define KP_K 15
 #define KP_W 10
 #define KP_KMER_MASK 0x3FFFFFFFu

@@ -961,6 +961,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         if (rc) return rc;
     }
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
+    kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, stream);
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
     kp_launch_task_order(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, d_task_count, w->task_cap,

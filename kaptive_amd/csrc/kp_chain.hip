@@ -344,6 +344,112 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
     }
 }
 
+// ---- occurrence cut (kp_spec.h, KP_MID_OCC): a gene seed with more than ten anchors in an assembly loses them all ----------------
+// The anchors of gene g -- both strands: gs = 2g and 2g + 1 -- are one stretch of the assembly's sorted list, and the anchors of
+// one of its seeds are those with the same position on the gene's forward strand.  One block per assembly, a wave per slice
+// of the list (slices begin and end where the gene changes); stretches of at most KP_MID_OCC anchors -- nearly all -- are only
+// measured; longer ones are counted in LDS (a counter per position, positions folded into OCC_BINS: exact for genes shorter
+// than that, checked anchor by anchor for longer ones) and the counters they touched are cleared again.  Anchors to drop
+// become tombstones and the list is compacted at the end, which almost never happens.
+constexpr int OCC_WAVES = 4, OCC_BINS = 4096;
+constexpr uint64_t OCC_TOMB = ~0ull;
+
+__global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_t *__restrict__ gene_len, uint64_t *__restrict__ keys,
+                                                                  uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb) {
+    __shared__ uint32_t s_cnt[OCC_WAVES][OCC_BINS];
+    __shared__ uint32_t s_dropped, s_base, s_wave_n[OCC_WAVES];
+    const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t n = count[a];
+    if (n > cap) n = cap;
+    uint64_t *k = keys + (size_t)a * cap;
+    uint32_t *cnt = s_cnt[wave];
+    for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
+    if (threadIdx.x == 0) { s_dropped = 0; s_base = 0; }
+    __syncthreads();
+    const uint32_t per = (((n + OCC_WAVES - 1) / OCC_WAVES) + 63u) & ~63u;
+    const uint32_t lo = (uint32_t)wave * per, hi = min(n, lo + per);
+    uint32_t cur = lo;
+    if (lo > 0 && lo < n) {  // a slice that starts inside a gene's stretch leaves it to the wave before
+        const uint32_t g_prev = kp_ckey_gs(k[lo - 1], kb) >> 1;
+        for (;;) {
+            const uint32_t i = cur + lane;
+            const unsigned long long other = __ballot(i < n && (kp_ckey_gs(k[i], kb) >> 1) != g_prev);
+            if (other) { cur += (uint32_t)__builtin_ctzll(other); break; }
+            cur += 64;
+            if (cur >= n) break;
+        }
+    }
+    while (cur < hi && cur < n) {  // one gene's stretch [cur, end)
+        const uint32_t gene = kp_ckey_gs(k[cur], kb) >> 1;
+        uint32_t end = cur;
+        for (;;) {
+            const uint32_t i = end + lane;
+            const unsigned long long other = __ballot(!(i < n && (kp_ckey_gs(k[i], kb) >> 1) == gene));
+            if (other) { end += (uint32_t)__builtin_ctzll(other); break; }
+            end += 64;
+        }
+        if (end - cur > (uint32_t)KP_MID_OCC) {
+            const int glen = gene_len[gene];
+            auto qf_of = [&](uint64_t key) { const int q = (int)kp_ckey_qpos(key, kb); return (kp_ckey_gs(key, kb) & 1u) ? glen - KP_K - q : q; };
+            auto wave_sync = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+            // positions are counted a window of OCC_BINS at a time: one window for nearly every gene, exact for all
+            for (int w0 = 0; w0 < glen; w0 += OCC_BINS) {
+                for (uint32_t i = cur + lane; i < end; i += 64) {
+                    const uint64_t key = k[i];
+                    if (key == OCC_TOMB) continue;
+                    const int qf = qf_of(key) - w0;
+                    if (qf >= 0 && qf < OCC_BINS) atomicAdd(&cnt[qf], 1u);
+                }
+                wave_sync();
+                bool any_drop = false;
+                for (uint32_t i0 = cur; i0 < end; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const uint64_t key = i < end ? k[i] : OCC_TOMB;
+                    const int qf = key != OCC_TOMB ? qf_of(key) - w0 : -1;
+                    const bool drop = qf >= 0 && qf < OCC_BINS && cnt[qf] > (uint32_t)KP_MID_OCC;
+                    if (drop) k[i] = OCC_TOMB;  // (the counters are read, not changed: every anchor of the seed sees the same count)
+                    any_drop = any_drop || __any(drop);
+                }
+                wave_sync();
+                if (any_drop) {  // rare: the dropped anchors no longer tell which counters they touched
+                    if (lane == 0) s_dropped = 1;
+                    for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
+                } else {
+                    for (uint32_t i = cur + lane; i < end; i += 64) {
+                        const uint64_t key = k[i];
+                        if (key == OCC_TOMB) continue;
+                        const int qf = qf_of(key) - w0;
+                        if (qf >= 0 && qf < OCC_BINS) cnt[qf] = 0;
+                    }
+                }
+                wave_sync();
+            }
+        }
+        cur = end;
+    }
+    __syncthreads();
+    if (!s_dropped) return;
+    // compaction of the whole list, in order, a block-wide chunk at a time (reads of a chunk finish before its writes: the
+    // write position never passes the read position)
+    for (uint32_t c0 = 0; c0 < n; c0 += 64 * OCC_WAVES) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint64_t key = i < n ? k[i] : OCC_TOMB;
+        const bool keep = key != OCC_TOMB;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wave_n[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave_n[w];
+        if (keep) k[off + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < OCC_WAVES; ++w) t += s_wave_n[w]; s_base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[a] = s_base;
+}
+
 __global__ void kp_segments_kernel(const uint32_t *__restrict__ count, uint32_t cap, int n_asm,
                                    uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,6 +629,12 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
     if (n_asm == 0) return;
     hipLaunchKernelGGL(kp_segments_kernel, dim3((n_asm + 255) / 256), dim3(256), 0, stream, count, cap, n_asm, seg_begin,
                        seg_end);
+}
+
+void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
+                       KpKeyBits key_bits, hipStream_t stream) {
+    if (b.n_asm == 0) return;
+    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, gene_len, sorted_anchors, anchor_count, cap, key_bits);
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,

@@ -162,12 +162,17 @@ def make_assembly(
     tandem_gene: int = 0,
     indel_rate: float = 2e-5,
     mid_indels: tuple = (),
+    repeat_segment: tuple = (),
+    is_copies: tuple = (),
 ) -> GenomeAssembly:
     """One synthetic assembly holding a mutated copy of one database locus.
     ``locus`` < 0 plants no locus at all.  ``mid_indels``: (size, "del" | "ins") pairs, each planted inside a gene of
     the locus copy of its own (a deletion of ``size`` bases or an insertion of ``size`` random ones somewhere in the
     gene's middle half) -- the 30-500 base events minimap2 chains across (bw = 500); drawn from a generator of their
-    own, so that the other draws of a seed do not move."""
+    own, so that the other draws of a seed do not move.  ``repeat_segment`` = (length, copies): a stretch of one gene of
+    the locus copy planted ``copies`` more times around the genome, each copy mutated a little (seeds that occur more
+    than ten times: minimap2's occurrence cut); ``is_copies`` = (copies, length): one random IS-like element planted that
+    many times (not in any database: it only moves the quantile minimap2 derives its cut from)."""
     rng = np.random.default_rng(seed)
     gc = DB_SHAPES.get(db.metadata.keyword, {}).get("gc", 0.5) if gc is None else gc
     total = int(length * rng.uniform(0.95, 1.05))
@@ -222,6 +227,30 @@ def make_assembly(
             copy = revcomp(copy)
         where = int(rng.integers(total // 10, total - total // 10 - len(copy)))
         genome[where : where + len(copy)] = copy
+        if repeat_segment or is_copies:
+            rng3 = np.random.default_rng([seed, 0x0CC])
+            free_lo, free_hi = total // 10, total - total // 8  # (the last twelfth belongs to `also`; the locus is avoided below)
+
+            def plant(unit):
+                for _ in range(50):
+                    at = int(rng3.integers(free_lo, free_hi - len(unit)))
+                    if at + len(unit) < where - 3000 or at > where + len(copy) + 3000:
+                        genome[at : at + len(unit)] = unit if rng3.random() < 0.5 else revcomp(unit)
+                        return
+
+            if repeat_segment:
+                seg_len, copies = repeat_segment
+                gi = int(rng3.integers(g0, g1))
+                s0, e0 = int(db.gene_intervals.starts[gi]), int(db.gene_intervals.ends[gi])
+                a0 = o + s0 + int(rng3.integers(0, max(1, e0 - s0 - seg_len)))
+                unit = db.loci.seqs[a0 : a0 + seg_len]
+                for _ in range(copies):
+                    plant(mutate(rng3, unit, 0.005))
+            if is_copies:
+                copies, is_len = is_copies
+                element = random_dna(rng3, is_len, 0.5)
+                for _ in range(copies):
+                    plant(mutate(rng3, element, 0.002))
         if second_locus is not None:  # part of another locus elsewhere in the genome
             o2, n2 = int(db.loci.offsets[second_locus]), int(db.loci.lengths[second_locus])
             other = mutate(rng, db.loci.seqs[o2 : o2 + n2 // 2], 0.01)

@@ -435,6 +435,33 @@ static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **ou
         kpo_sketch(a->codes + a->ctg_start[c], a->ctg_len[c], asm_seed, &k);
     }
     qsort(k.keys, (size_t)k.n, sizeof(uint64_t), cmp_u64);
+    /* occurrence cut (kp_spec.h, KP_MID_OCC): the anchors of one gene seed -- (gene, position on the gene's forward strand) --
+     * are the occurrences of its value among the assembly's minimizers, whichever strand they lie on; a seed with more than
+     * KP_MID_OCC of them is dropped with all its anchors.  Anchors are sorted by gene/strand first, so a gene's anchors are one
+     * stretch of the list. */
+    int64_t kept = 0;
+    for (int64_t i = 0; i < k.n;) {
+        const uint32_t gene = KP_KEY_GS(k.keys[i]) >> 1;
+        int64_t j = i;
+        while (j < k.n && (KP_KEY_GS(k.keys[j]) >> 1) == gene) j++;
+        const int glen = db->off[gene + 1] - db->off[gene];
+        if (j - i > KP_MID_OCC) {
+            int32_t *occ = calloc((size_t)glen + 1, sizeof(int32_t));
+            for (int64_t u = i; u < j; u++) {
+                const int q = (int)KP_KEY_QPOS(k.keys[u]);
+                occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q]++;
+            }
+            for (int64_t u = i; u < j; u++) {
+                const int q = (int)KP_KEY_QPOS(k.keys[u]);
+                if (occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] <= KP_MID_OCC) k.keys[kept++] = k.keys[u];
+            }
+            free(occ);
+        } else {
+            for (int64_t u = i; u < j; u++) k.keys[kept++] = k.keys[u];
+        }
+        i = j;
+    }
+    k.n = kept;
     *out = k.keys;
     return k.n;
 }

@@ -304,6 +304,66 @@ def test_joins_across_mid_size_indels_match_oracle(ctx, small_setup, small_db):
     batch.close()
 
 
+def test_occurrence_cut_matches_oracle(oracle):
+    """minimap2 drops a query seed that occurs more than mid_occ (>= 10) times among the target's minimizers
+    (src/kaptive/core/genome.py:177-191 builds that index per assembly); kp_spec.h's KP_MID_OCC restates the floor: a gene
+    seed with more than ten anchors in an assembly loses them all (kp_occ_cut_kernel).  A stretch of a gene repeated 9, 10,
+    11, 12, 30 and 150 times on both strands, a whole gene in 14 copies, a repeat that lies beyond position 4096 of a 9 kb
+    gene and one that straddles it (the second / both counting windows), next to assemblies without any repeat: anchors
+    (after the cut), band tasks and hits equal the oracle's, and the cut removed what it should."""
+    from kaptive_amd.synth import revcomp
+
+    rng = np.random.default_rng(4242)
+    db = make_db("kpsc_k", seed=7, n_loci=4)
+    long_gene = random_dna(rng, 9_000, 0.5)
+    genes = Sequences.from_records([*[SeqRecord(f"g{i}", db.genes[i].seq) for i in range(len(db.genes))], SeqRecord("long", long_gene.tobytes())])
+    codes, off = pack_sequences_flat(genes)
+    odb = oracle.OracleDB(codes, off)
+    c = _native.Context(0)
+    c.load_genes(codes, off)
+    pad = lambda n: random_dna(rng, n, 0.5)  # noqa: E731
+    g3, g7 = np.frombuffer(db.genes[3].seq, np.uint8), np.frombuffer(db.genes[7].seq, np.uint8)
+
+    def repeats(unit, copies):
+        parts = []
+        for i in range(copies):
+            u = unit.copy()
+            u[rng.integers(0, len(u), size=max(1, len(u) // 300))] = ord("A")  # a little divergence: not every seed survives
+            parts += [pad(int(rng.integers(40, 400))), u if i % 2 else revcomp(u)]
+        return np.concatenate(parts + [pad(100)])
+
+    asms = []
+    for copies in (9, 10, 11, 12, 30, 150):
+        recs = [SeqRecord("gene", np.concatenate([pad(500), g3, pad(300)]).tobytes()),
+                SeqRecord("copies", repeats(g3[200:420], copies - 1).tobytes()),
+                SeqRecord("other", np.concatenate([pad(200), g7, pad(100)]).tobytes())]
+        asms.append(GenomeAssembly(f"repeat_x{copies}", Sequences.from_records(recs)))
+    asms.append(GenomeAssembly("whole_gene_x14", Sequences.from_records([SeqRecord("c", repeats(g7, 14).tobytes())])))
+    asms.append(GenomeAssembly("long_gene_windows", Sequences.from_records([
+        SeqRecord("gene", np.concatenate([pad(100), long_gene, pad(100)]).tobytes()),
+        SeqRecord("second_window", repeats(long_gene[5000:5300], 15).tobytes()),
+        SeqRecord("straddles", repeats(long_gene[3950:4250], 13).tobytes())])))  # fmt: skip
+    asms += [make_assembly(db, seed=s, length=60_000, median_contigs=4, min_contig=200) for s in (3, 4)]
+    packed = [a.packed() for a in asms]
+    batch = c.batch(packed)
+    hits, hoff = batch.align()
+    n_anchors = []
+    for i, pa in enumerate(packed):
+        want = odb.anchors(pa)
+        assert np.array_equal(batch.anchors(i), want), asms[i].id
+        n_anchors.append(len(want))
+        _same_records(np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names)),
+                      np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names)), f"tasks of {asms[i].id}")
+        _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    # up to ten occurrences every copy is a hit; from eleven on the seeds that all copies share are gone (a copy that lost a
+    # seed to its own divergence keeps the others' count at ten or below for that seed), and at thirty nothing is left
+    per_asm = [int(((hits[hoff[i] : hoff[i + 1]]["gene"] == 3) & (hits[hoff[i] : hoff[i + 1]]["contig"] == 1)).sum()) for i in range(6)]
+    assert per_asm[0] == 8 and per_asm[1] == 9 and per_asm[4:] == [0, 0], per_asm
+    assert n_anchors[1] > n_anchors[2] > n_anchors[3] > n_anchors[4] and hoff[7] - hoff[6] == 0  # (fourteen whole copies: every seed of the gene is cut)
+    batch.close()
+    c.close()
+
+
 def test_twelve_thousand_genes_stay_on_the_bucket_sort(oracle):
     """A 540-locus database (about 12 400 genes: 24 800 values of the anchor key's gene/strand field, 97 KB of LDS counters)
     goes through kp_bsort.hip, not the library's radix sort: sorted anchors, tasks and hits equal the oracle's, and the
