@@ -186,6 +186,28 @@ def test_mid_size_indels_give_the_models_rows(dbs, kind):
     assert joined >= 14
 
 
+def test_occurrence_cut_follows_the_model_at_its_floor(dbs):
+    """minimap2's occurrence cut (-f 2e-4, min_mid_occ 10) on a 5 Mbp assembly sits at its floor of 10 unless the assembly is
+    full of repeats; kp_spec.h's KP_MID_OCC restates the floor.  A 220-base stretch of a gene planted 12 more times: the
+    copies' seeds are dropped by both aligners -- same raw hits, same row -- while 9 more copies (10 occurrences) are all
+    reported by both."""
+    db, odb, typer = _db(dbs, "kpsc_k", 100)
+    for copies, cut in ((12, True), (9, False)):
+        genome = make_assembly(db, seed=4100, p_is=0, p_stop=0, repeat_segment=(220, copies))
+        packed = genome.packed()
+        index = mm2.Mm2Index.from_contigs(genome.contigs)
+        assert index.mid_occ == 10
+        hk, hm = odb.align(packed), index.map(db.genes)
+        sk, sm = {_span(h) for h in hk}, {_span(h) for h in hm}
+        assert len(sk ^ sm) <= 4, (copies, len(sk - sm), len(sm - sk))
+        plain = len(odb.align(make_assembly(db, seed=4100, p_is=0, p_stop=0).packed()))
+        assert (len(hk) < plain + 20) if cut else (len(hk) > plain + 500), (copies, len(hk), plain)  # (every family relative hits every copy)
+        if cut:
+            fk = bytes(KaptiveRow.from_result(typer.reduce(genome, hits_to_alignments(db, genome, hk))))
+            fm = bytes(KaptiveRow.from_result(typer.reduce(genome, hits_to_alignments(db, genome, hm))))
+            assert fk == fm
+
+
 # ---- seeds: the oracle's state machine against the model's mm_sketch -----------------------------------------------------------
 _CODE = np.full(256, 4, np.uint8)
 for _i, _c in enumerate(b"ACGT"):

@@ -103,6 +103,15 @@ def cases(scale: float, full_size: int):
                     kw = dict(seed=70_000 + 10_000 * di + 500 * zi + 100 * ki + i, p_is=0, p_stop=0,
                               mid_indels=((size, kind), (size + 1, kind), (size + 2, other)), **small_kw)
                     out.append((f"midindel_{size}_{kind}", [key], key, kw, ()))
+    # the occurrence cut (minimap2 -f 2e-4 with min_mid_occ 10; kp_spec.h KP_MID_OCC): a 150-300 base stretch of a gene of the
+    # locus planted 12 / 20 / 40 more times -- at FULL size, where the 2e-4 quantile of the index stays at its floor of 10 -- and
+    # what the floor cannot follow: 40 copies of an IS-like element lift the model's cut to ~40 (reported, not hidden)
+    for ri, (seg, copies) in enumerate(((220, 12), (150, 20), (300, 40), (220, 9))):
+        for i in range(max(1, per // 4)):
+            out.append((f"repeat_{seg}x{copies}", ["k"], "k", dict(seed=90_000 + 100 * ri + i, p_is=0, p_stop=0, repeat_segment=(seg, copies)), ()))
+    for i in range(max(1, per // 4)):
+        out.append(("is_x40", ["k"], "k", dict(seed=91_000 + i, p_is=0, p_stop=0, is_copies=(40, 1200)), ()))
+        out.append(("is_x40_repeat_220x12", ["k"], "k", dict(seed=91_100 + i, p_is=0, p_stop=0, is_copies=(40, 1200), repeat_segment=(220, 12)), ()))
     return out
 
 
