@@ -164,6 +164,7 @@ def make_assembly(
     mid_indels: tuple = (),
     repeat_segment: tuple = (),
     is_copies: tuple = (),
+    background: str = "iid",
 ) -> GenomeAssembly:
     """One synthetic assembly holding a mutated copy of one database locus.
     ``locus`` < 0 plants no locus at all.  ``mid_indels``: (size, "del" | "ins") pairs, each planted inside a gene of
@@ -172,7 +173,10 @@ def make_assembly(
     own, so that the other draws of a seed do not move.  ``repeat_segment`` = (length, copies): a stretch of one gene of
     the locus copy planted ``copies`` more times around the genome, each copy mutated a little (seeds that occur more
     than ten times: minimap2's occurrence cut); ``is_copies`` = (copies, length): one random IS-like element planted that
-    many times (not in any database: it only moves the quantile minimap2 derives its cut from)."""
+    many times (not in any database: it only moves the quantile minimap2 derives its cut from).  ``background`` = "paralog":
+    the iid background also carries what real genomes hold beside the locus -- 40 diverged relatives (70-92 % identity,
+    small indels) of database genes, half of them of the conserved families, 5-30 copies of two IS-like elements and seven
+    copies of an rRNA-like 5 kb operon -- so that chance seeds, weak chains and repeats exist outside the planted locus."""
     rng = np.random.default_rng(seed)
     gc = DB_SHAPES.get(db.metadata.keyword, {}).get("gc", 0.5) if gc is None else gc
     total = int(length * rng.uniform(0.95, 1.05))
@@ -227,7 +231,7 @@ def make_assembly(
             copy = revcomp(copy)
         where = int(rng.integers(total // 10, total - total // 10 - len(copy)))
         genome[where : where + len(copy)] = copy
-        if repeat_segment or is_copies:
+        if repeat_segment or is_copies or background == "paralog":
             rng3 = np.random.default_rng([seed, 0x0CC])
             free_lo, free_hi = total // 10, total - total // 8  # (the last twelfth belongs to `also`; the locus is avoided below)
 
@@ -251,6 +255,22 @@ def make_assembly(
                 element = random_dna(rng3, is_len, 0.5)
                 for _ in range(copies):
                     plant(mutate(rng3, element, 0.002))
+            if background == "paralog":
+                rng4 = np.random.default_rng([seed, 0xBA6])
+                shared = set(DB_SHAPES.get(db.metadata.keyword, {}).get("shared", ()))
+                ids = [str(i) for i in db.genes.ids]
+                fam = np.array([i for i, name in enumerate(ids) if name.rsplit("_", 1)[-1] in shared], np.int64)
+                picks = np.r_[rng4.choice(fam, size=20) if len(fam) else [], rng4.integers(0, len(ids), size=20)].astype(np.int64)
+                for gi in picks:  # diverged relatives of database genes
+                    go, gn = int(db.genes.offsets[gi]), int(db.genes.lengths[gi])
+                    plant(mutate(rng4, db.genes.seqs[go : go + gn], float(rng4.uniform(0.08, 0.30)), indel_rate=0.004))
+                for _ in range(2):  # IS-like elements
+                    element = random_dna(rng4, int(rng4.integers(800, 1600)), 0.5)
+                    for _ in range(int(rng4.integers(5, 31))):
+                        plant(mutate(rng4, element, 0.002))
+                operon = random_dna(rng4, 5000, 0.5)
+                for _ in range(7):
+                    plant(mutate(rng4, operon, 0.001))
         if second_locus is not None:  # part of another locus elsewhere in the genome
             o2, n2 = int(db.loci.offsets[second_locus]), int(db.loci.lengths[second_locus])
             other = mutate(rng, db.loci.seqs[o2 : o2 + n2 // 2], 0.01)

@@ -364,6 +364,33 @@ def test_occurrence_cut_matches_oracle(oracle):
     c.close()
 
 
+def test_paralog_background_matches_oracle(oracle):
+    """A background that is not iid (kaptive_amd.synth, background="paralog"): diverged relatives of database genes with
+    small indels (weak chains, wide bands), two IS-like families in 5-30 copies and a 7-copy rRNA-like operon next to the
+    planted K and O loci, at full size: anchors, band tasks, joins and hits of both databases equal the oracle's."""
+    db, dbo = make_db("kpsc_k", seed=100), make_db("kpsc_o", seed=101)
+    asms = [make_assembly(db, seed=8800 + i, also=(dbo,), background="paralog") for i in range(3)]
+    packed = [a.packed() for a in asms]
+    n_wide = 0
+    for d in (db, dbo):
+        codes, off = pack_sequences_flat(d.genes)
+        odb = oracle.OracleDB(codes, off)
+        c = _native.Context(0)
+        c.load_genes(codes, off)
+        batch = c.batch(packed)
+        hits, hoff = batch.align()
+        for i, pa in enumerate(packed):
+            assert np.array_equal(batch.anchors(i), odb.anchors(pa)), asms[i].id
+            want_t = np.sort(odb.tasks(pa), order=list(_native.TASK_DTYPE.names))
+            _same_records(np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names)), want_t, f"tasks of {asms[i].id}")
+            n_wide += int((want_t["width"] > 16).sum())
+            assert len(batch.joins(i)) == len(odb.joins(pa))
+            _same_records(hits[hoff[i] : hoff[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+        batch.close()
+        c.close()
+    assert n_wide > 300  # the relatives' indels put many tasks into the wider band classes
+
+
 def test_twelve_thousand_genes_stay_on_the_bucket_sort(oracle):
     """A 540-locus database (about 12 400 genes: 24 800 values of the anchor key's gene/strand field, 97 KB of LDS counters)
     goes through kp_bsort.hip, not the library's radix sort: sorted anchors, tasks and hits equal the oracle's, and the
