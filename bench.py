@@ -304,6 +304,11 @@ def cli_from_fasta(prep: dict, repeats: int = 96, batch: int = 0) -> dict:
                 "fasta_MB_per_assembly": round(prep["nbytes"] / n_files / 1e6, 2), "batch_size": batch or "the CLI's default: 64, 128, 256, then 512", "wall_s": round(wall, 2),
                 "assemblies_per_s_whole_command": round(n_files * repeats / wall, 1),
                 "assemblies_per_s_steady": None if steady is None else round(steady, 1), "first_rows_after_s": round(marks[0][1], 2),
+                # where the whole command's time goes: phases_s and seconds count from the start of the typing; process_s from
+                # the creation of the process (start-up + imports + argument parsing come before run_type, interpreter and HIP
+                # runtime teardown after end_of_run_type: wall_s minus that)
+                "seconds_typing": round(tm["seconds"], 2), "phases_s": tm.get("phases_s"), "process_s": tm.get("process_s"),
+                "exit_s": None if not tm.get("process_s") else round(wall - tm["process_s"]["end_of_run_type"], 2),
                 "database": "K-locus only (the CLI types one database per run, as the reference's does)",
                 "note": "files on tmpfs; steady = assemblies per second between the fifth chunk's rows and the last chunk's"}
     finally:

@@ -21,6 +21,7 @@ from pathlib import Path
 import numpy as np
 
 FILE_SUFFIX = "kaptive_results"
+FAST_EXIT = False  # set by __main__: the process ends right after main() returns, so nothing needs to be torn down in order
 
 
 def result_to_json(result) -> bytes:
@@ -150,15 +151,33 @@ class _TypingPipeline:
 
     PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
 
-    def __init__(self, args: argparse.Namespace, device: int, typer=None) -> None:
+    def __init__(self, args: argparse.Namespace, device: int, typer=None, chunks=None) -> None:
         """``typer``: a ``Serotyper`` the caller already holds (``Serotyper.tsv_from_files``); otherwise one is made from the
-        command line's database and thresholds."""
-        import os
+        command line's database and thresholds.  ``chunks``: what ``run`` will be given -- the first of them are handed to
+        the reader threads before the database is loaded and the device context created (0.3 s in which nothing else
+        would read a file)."""
+        import threading
 
+        from kaptive_amd import usable_cpus
         from kaptive_amd.serotyping.core import Serotyper
 
         self.args = args
         self.marks = {"pipeline_start": time.perf_counter()}  # (KAPTIVE_AMD_CLI_TIMING: where the time before the first rows goes)
+        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins"))
+        self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
+        # PREFETCH + 1 chunks are being parsed at any time, each by one native call: the thread budget is shared out among them
+        # (measured on the 16-CPU box, threads per call 4 / 6 / 8 / 12 / 16 / 24 / 32: 12.5 / 15.2 / 12.1 / 11.0 / 11.0 / 7.4 / 6.5 k
+        # assemblies/s -- a cgroup throttles what oversubscribes its quota)
+        self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
+        self.readers = ThreadPoolExecutor(max_workers=self.threads)
+        self.copiers = ThreadPoolExecutor(max_workers=min(4, self.threads))  # object mode: copies into pinned memory (not queued behind reads)
+        self._pins: list = []  # recycled page-locked buffers
+        self._pin_lock = threading.Lock()
+        self._early: list = []
+        self._order: list = []
+        if chunks is not None:
+            for k, paths in list(chunks)[: self.PREFETCH + 1]:
+                self._early.append((k, self.submit_read(paths)))
         self._own_typer = typer is None
         if typer is None:
             self.db = load_database(args.database)
@@ -169,23 +188,21 @@ class _TypingPipeline:
         self.typer = typer
         self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
         self.marks["context_ready"] = time.perf_counter()
-        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins"))
         self.want_tsv = bool(getattr(args, "out", None))
-        from kaptive_amd import usable_cpus
 
-        self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
-        # PREFETCH + 1 chunks are being parsed at any time, each by one native call: the thread budget is shared out among them
-        # (measured on the 16-CPU box, threads per call 4 / 6 / 8 / 12 / 16 / 24 / 32: 12.5 / 15.2 / 12.1 / 11.0 / 11.0 / 7.4 / 6.5 k
-        # assemblies/s -- a cgroup throttles what oversubscribes its quota)
-        self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
-        self.readers = ThreadPoolExecutor(max_workers=self.threads)
-        import threading
+    def submit_read(self, paths):
+        """One chunk to the reader threads: a future of ``_load_shard`` (TSV / PHA4GE only) or a list of ``_load`` futures."""
+        if self.objects:
+            return [self.readers.submit(self._load, p) for p in paths]
+        return self.readers.submit(self._load_shard, paths)
 
-        self._pins: list = []  # recycled page-locked buffers
-        self._pin_lock = threading.Lock()
-
-    def close(self) -> None:
-        self.readers.shutdown(wait=True, cancel_futures=True)
+    def close(self, fast: bool = False) -> None:
+        """``fast``: the process is about to exit (the command line): reads are cancelled, nothing is waited for or freed --
+        the operating system takes the page-locked memory and the device context back faster than the runtime unwinds them."""
+        self.readers.shutdown(wait=not fast, cancel_futures=True)
+        self.copiers.shutdown(wait=not fast, cancel_futures=True)
+        if fast:
+            return
         if self._own_typer and self.typer._engine is not None:
             self.typer._engine.close()
         for pb in self._pins:
@@ -232,10 +249,15 @@ class _TypingPipeline:
     def _pinned(self, n_words: int):
         from kaptive_amd import _native
 
+        small = None
         with self._pin_lock:  # (reader threads take buffers, the driving thread gives them back)
             for i, pb in enumerate(self._pins):
                 if len(pb.array) >= n_words:
                     return self._pins.pop(i)
+            if len(self._pins) > 2 * (self.PREFETCH + 2):  # the small buffers of the first chunks do not stay page-locked for the whole run
+                small = self._pins.pop(0)
+        if small is not None:
+            small.close()
         return _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
 
     def _make_batch(self, genomes):
@@ -252,52 +274,23 @@ class _TypingPipeline:
         def copy(i):
             pb.array[offs[i] : offs[i + 1]] = packed[i].words
 
-        list(self.readers.map(copy, range(len(packed))))  # (numpy copies of this size run without the interpreter lock)
+        list(self.copiers.map(copy, range(len(packed))))  # (numpy copies of this size run without the interpreter lock; an executor of their own: the readers' queue holds the next chunks' files)
         batch = self.engine.ctx.batch(packed, pinned_words=pb.array[: int(offs[-1])])
         batch._pin = pb
         return batch
 
     def _source(self, chunks):
-        """(batch, ids, genomes) per chunk; files of the next PREFETCH chunks are already being read and their batches
-        created (uploads enqueued) when a chunk is handed on."""
-        from collections import deque
-
-        reading: deque = deque()
-        ready: deque = deque()
-        it = iter(chunks)
-
-        def start_read():
-            try:
-                k, paths = next(it)
-            except StopIteration:
-                return False
-            if self.objects:
-                reading.append((k, [self.readers.submit(self._load, p) for p in paths]))
-            else:
-                reading.append((k, self.readers.submit(self._load_shard, paths)))
-            return True
-
-        for _ in range(self.PREFETCH + 1):
-            start_read()
-        while reading or ready:
-            while reading and len(ready) < self.PREFETCH:
-                k, futures = reading.popleft()
-                genomes = [f.result() for f in futures] if isinstance(futures, list) else futures.result()
-                start_read()
-                ids = genomes[1] if isinstance(genomes, tuple) else [g.id for g in genomes]
-                self.marks.setdefault("first_chunk_parsed", time.perf_counter())
-                ready.append((self._make_batch(genomes), k, ids, genomes if self.objects else None))
-                self.marks.setdefault("first_batch_created", time.perf_counter())
-            batch, k, ids, genomes = ready.popleft()
-            self._order.append(k)
-            yield batch, ids, genomes
+        """(batch, ids, genomes) per chunk, as an iterator with ``ready()`` (``Engine.type_stream`` asks before it would
+        wait): the files of the next PREFETCH chunks are being read while a chunk is handed on; their batches are created
+        (uploads enqueued) as soon as the reads are through."""
+        return _ChunkSource(self, chunks)
 
     # -- stage 3: records -> bytes ------------------------------------------------------------------------------------------------
     def run(self, chunks):
         """Yields ``(k, outputs)`` for every ``(k, paths)`` of ``chunks``, in order; ``outputs`` maps "tsv" / "pha4ge" /
         "json" to the bytes this chunk adds to that stream (per-assembly fasta files are written here)."""
         args = self.args
-        self._order: list = []
+        self._order = []
         done = 0
         for bt, batch in self.engine.type_stream(self.typer, self._source(chunks)):
             out = {}
@@ -323,6 +316,55 @@ class _TypingPipeline:
             done += 1
 
 
+class _ChunkSource:
+    """Reads ahead of the device: PREFETCH + 1 chunks are with the reader threads at any time (started by
+    ``_TypingPipeline.start_reading`` before the device context even exists)."""
+
+    def __init__(self, pipe: "_TypingPipeline", chunks) -> None:
+        from collections import deque
+
+        self.pipe = pipe
+        self.it = iter(chunks)
+        self.reading: deque = deque(pipe._early)  # (k, future or list of futures)
+        pipe._early = []
+        for _ in self.reading:
+            next(self.it)  # (those chunks are already being read)
+        while len(self.reading) < pipe.PREFETCH + 1 and self._start_read():
+            pass
+
+    def _start_read(self) -> bool:
+        try:
+            k, paths = next(self.it)
+        except StopIteration:
+            return False
+        self.reading.append((k, self.pipe.submit_read(paths)))
+        return True
+
+    def ready(self) -> bool:
+        """Whether ``next()`` would return without waiting for a read."""
+        if not self.reading:
+            return True  # (nothing left: StopIteration comes at once)
+        futures = self.reading[0][1]
+        return all(f.done() for f in futures) if isinstance(futures, list) else futures.done()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self.reading:
+            raise StopIteration
+        k, futures = self.reading.popleft()
+        genomes = [f.result() for f in futures] if isinstance(futures, list) else futures.result()
+        self._start_read()
+        pipe = self.pipe
+        ids = genomes[1] if isinstance(genomes, tuple) else [g.id for g in genomes]
+        pipe.marks.setdefault("first_chunk_parsed", time.perf_counter())
+        batch = pipe._make_batch(genomes)
+        pipe.marks.setdefault("first_batch_created", time.perf_counter())
+        pipe._order.append(k)
+        return batch, ids, genomes if pipe.objects else None
+
+
 def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) -> None:
     """One process per device (``--devices a,b,...``): types its chunks and sends ``(k, outputs)`` up the pipe; an
     exception travels the same way and ends the worker."""
@@ -331,19 +373,34 @@ def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) ->
     kaptive_amd.tune_runtime()
     pipe = None
     try:
-        pipe = _TypingPipeline(args, device)
+        pipe = _TypingPipeline(args, device, chunks=chunks)
         for k, out in pipe.run(chunks):
             conn.send((k, out))
         conn.send(None)
     except BaseException as e:  # noqa: BLE001 - handed to the parent, which re-raises it
-        conn.send(e)
+        try:
+            conn.send(e)
+        except Exception:  # noqa: BLE001 - an exception that does not pickle travels as its text
+            conn.send(RuntimeError(f"{type(e).__name__}: {e}"))
     finally:
         if pipe is not None:
-            pipe.close()
+            pipe.close(fast=True)  # (a worker process: it ends here)
         conn.close()
 
 
+def _since_process_start() -> float:
+    """Seconds since the kernel created this process (Linux: /proc; elsewhere 0): interpreter start-up and imports included."""
+    try:
+        with open("/proc/self/stat") as f:
+            start_ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            return float(f.read().split()[0]) - start_ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return 0.0
+
+
 def run_type(args: argparse.Namespace) -> int:
+    entered = _since_process_start()
     if str(args.devices).strip().lower() == "all":
         from kaptive_amd import _native
 
@@ -359,9 +416,19 @@ def run_type(args: argparse.Namespace) -> int:
         n = next(sizes, args.batch_size or 512)
         chunks.append((len(chunks), args.genomes[i : i + n]))
         i += n
+    t_check = time.perf_counter()
+    seen: set = set()
     for p in args.genomes:  # the reference fails before it types anything (src/kaptive/cli.py:287-289)
-        if not Path(p).is_file():
-            raise FileNotFoundError(f"{p} does not exist")
+        if p not in seen:  # (a path listed twice is looked at once; os.stat directly: Path objects cost more than the call)
+            seen.add(p)
+            try:
+                import stat as _stat
+
+                if not _stat.S_ISREG(os.stat(p).st_mode):
+                    raise FileNotFoundError(f"{p} does not exist")
+            except OSError:
+                raise FileNotFoundError(f"{p} does not exist") from None
+    t_check = time.perf_counter() - t_check
     from kaptive_amd.serotyping.io import KaptiveRow, Pha4geRow
 
     handles = {}
@@ -392,13 +459,13 @@ def run_type(args: argparse.Namespace) -> int:
 
     try:
         if len(devices) == 1:
-            pipe = _TypingPipeline(args, devices[0])
+            pipe = _TypingPipeline(args, devices[0], chunks=chunks)
             try:
                 for k, out in pipe.run(chunks):
                     write(out, len(chunks[k][1]))
             finally:
                 phases = {name: round(t - t_start, 3) for name, t in pipe.marks.items()}
-                pipe.close()
+                pipe.close(fast=FAST_EXIT)
         else:
             # chunk k goes to device k mod n; rows come back through pipes and are written in input order
             import multiprocessing as mp
@@ -416,17 +483,29 @@ def run_type(args: argparse.Namespace) -> int:
                 child.close()
                 conns.append(parent)
                 procs.append(proc)
+            ok = False
             try:
                 for k in range(len(chunks)):
-                    msg = conns[k % len(devices)].recv()
+                    dev = devices[k % len(devices)]
+                    try:
+                        msg = conns[k % len(devices)].recv()
+                    except (EOFError, OSError) as e:  # the worker died without a word (killed, crashed in native code)
+                        raise RuntimeError(f"the worker of device {dev} ended unexpectedly (exit code {procs[k % len(devices)].exitcode})") from e
                     if isinstance(msg, BaseException):
                         raise msg
                     if msg is None or msg[0] != k:
-                        raise RuntimeError(f"device worker {devices[k % len(devices)]} ended early or out of order")
+                        raise RuntimeError(f"device worker {dev} ended early or out of order")
                     write(msg[1], len(chunks[k][1]))
+                ok = True
             finally:
+                if not ok:  # the others are blocked on full pipes: nothing to wait for
+                    for proc in procs:
+                        if proc.is_alive():
+                            proc.terminate()
+                for c in conns:
+                    c.close()
                 for proc in procs:
-                    proc.join(timeout=30)
+                    proc.join(timeout=30 if ok else 5)
                     if proc.is_alive():
                         proc.terminate()
     finally:
@@ -438,9 +517,13 @@ def run_type(args: argparse.Namespace) -> int:
     if args.verbose:
         print(file=sys.stderr)
     if timing_path:
+        # process_s: seconds since the process was created at three points -- run_type entered (interpreter start, imports,
+        # argument parsing), typing started (t_start: the origin of rows_written_at / phases_s / seconds), and now
         Path(timing_path).write_text(json.dumps({"assemblies": len(args.genomes), "seconds": time.perf_counter() - t_start,
                                                  "batch_size": args.batch_size, "devices": devices,
-                                                 "rows_written_at": chunk_times, "phases_s": phases}) + "\n")  # fmt: skip
+                                                 "rows_written_at": chunk_times, "phases_s": phases,
+                                                 "process_s": {"run_type_entered": round(entered, 3), "file_check": round(t_check, 3),
+                                                               "end_of_run_type": round(_since_process_start(), 3)}}) + "\n")  # fmt: skip
     return 0
 
 

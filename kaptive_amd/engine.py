@@ -174,7 +174,7 @@ class Engine:
         ``(BatchTyping, batch)`` -- the caller closes the batch.  Same sliding window: at most ``_native.WORK_SLOTS``
         batches are between "alignment enqueued" and "records collected", the next batch is only pulled from ``source``
         (created and uploaded) when a work set is free for it, and batch i's records are collected after batch i + 1's
-        reduction has been enqueued."""
+        reduction has been enqueued -- or at once, when the source has no further batch ready yet."""
         from collections import deque
 
         from kaptive_amd.serotyping import batch as B
@@ -185,9 +185,21 @@ class Engine:
         pending = None  # reduction enqueued, records not yet collected
         exhausted = False
 
-        def fill() -> None:
+        def collect(item):
+            batch, ids, genomes, scores, best = item
+            sums, kept, pieces = batch.typing(self.group)
+            return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes), batch
+
+        # A source may say whether its next item can be had without waiting (``ready()``: the CLI's reader pipeline): the
+        # window is then only topped up with what is there, and the driver waits for the source only when it has nothing
+        # else to do -- the first chunk's rows leave as soon as its reduction is through, not after two more chunks were read.
+        can_pull = getattr(source, "ready", None)
+
+        def fill_ready() -> None:
             nonlocal exhausted
             while not exhausted and len(live) + (1 if pending is not None else 0) < depth:
+                if can_pull is not None and (live or pending is not None) and not can_pull():
+                    return
                 try:
                     item = next(it)
                 except StopIteration:
@@ -196,24 +208,29 @@ class Engine:
                 item[0].align_async()
                 live.append(item)
 
-        def collect(item):
-            batch, ids, genomes, scores, best = item
-            sums, kept, pieces = batch.typing(self.group)
-            return B.BatchTyping(typer, ids, sums, kept, pieces, scores, best, genomes), batch
-
-        fill()
-        while live:
-            batch, ids, genomes = live.popleft()
-            scores, counts = batch.score(typer.min_gene_coverage, self.group)
-            best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
-            batch.reduce_async(best, self.typing_params(typer), self.group)
-            if pending is not None:
-                done, pending = pending, None
-                yield collect(done)
-            pending = (batch, ids, genomes, scores, best)
-            fill()
-        if pending is not None:
-            yield collect(pending)
+        try:
+            while True:
+                fill_ready()
+                if live:
+                    batch, ids, genomes = live.popleft()
+                    scores, counts = batch.score(typer.min_gene_coverage, self.group)
+                    best, _, _ = B.choose_best_loci(scores, counts, typer._expected_genes_per_locus)
+                    batch.reduce_async(best, self.typing_params(typer), self.group)
+                    if pending is not None:
+                        done, pending = pending, None
+                        yield collect(done)
+                    pending = (batch, ids, genomes, scores, best)
+                elif pending is not None:
+                    done, pending = pending, None
+                    yield collect(done)
+                elif exhausted:
+                    break
+        finally:  # (an error, or a consumer that stopped early: whatever is still in the window is closed before the context goes)
+            for item in list(live) + ([pending] if pending is not None else []):
+                try:
+                    item[0].close()
+                except Exception:  # noqa: BLE001
+                    pass
 
     def reduce_batches(self, typer, batches: Sequence, aligned: bool = False) -> list:
         """Scores back, best loci chosen (numpy), reductions enqueued, for up to WORK_SLOTS batches at once.  Returns what

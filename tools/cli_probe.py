@@ -36,7 +36,8 @@ def main() -> int:
     ap.add_argument("--repeats", type=int, default=32)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--threads", default="0", help="comma-separated -t values (0 = the CLI's default)")
-    ap.add_argument("--batch", default="512", help="comma-separated --batch-size values")
+    ap.add_argument("--batch", default="512", help="comma-separated --batch-size values (0 = the CLI's default ramp)")
+    ap.add_argument("--marks", action="store_true", help="also print when each chunk's rows were written")
     ap.add_argument("--devices", default="", help="passed on to `kaptive assembly --devices` (e.g. all, or 0,1,2,3)")
     args = ap.parse_args()
     from kaptive_amd.synth import make_db
@@ -53,7 +54,7 @@ def main() -> int:
             for batch in [int(x) for x in args.batch.split(",")]:
                 t = time.perf_counter()
                 r = subprocess.run([sys.executable, "-m", "kaptive_amd", "assembly", str(db), *(paths * args.repeats), "-o", str(root / "out.tsv"),
-                                    "--batch-size", str(batch), *(["-t", str(threads)] if threads else []),
+                                    *(["--batch-size", str(batch)] if batch else []), *(["-t", str(threads)] if threads else []),
                                     *(["--devices", args.devices] if args.devices else [])], env=env, capture_output=True, text=True)
                 wall = time.perf_counter() - t
                 if r.returncode != 0:
@@ -65,7 +66,9 @@ def main() -> int:
                 print(json.dumps({"files": len(paths) * args.repeats, "devices": args.devices or "0", "gz": args.gz, "threads": threads, "batch": batch,
                                   "text_MB_per_file": round(sum(sizes) / len(sizes) / 1e6, 2),
                                   "MB_per_file_on_disk": round(sum(os.path.getsize(p) for p in paths) / len(paths) / 1e6, 2), "wall_s": round(wall, 2),
-                                  "first_rows_after_s": round(marks[0][1], 2), "phases_s": tm.get("phases_s"), "assemblies_per_s_steady": round((n1 - n0) / (t1 - t0), 1)}), flush=True)
+                                  "first_rows_after_s": round(marks[0][1], 2), "phases_s": tm.get("phases_s"), "seconds_typing": round(tm["seconds"], 2),
+                                  **({"rows_written_at": [(n, round(t, 3)) for n, t in marks[:12]] + ["..."] + [(n, round(t, 3)) for n, t in marks[-3:]]} if args.marks else {}),
+                                  "process_s": tm.get("process_s"), "exit_s": None if not tm.get("process_s") else round(wall - tm["process_s"]["end_of_run_type"], 2), "assemblies_per_s_steady": round((n1 - n0) / (t1 - t0), 1)}), flush=True)
         return 0
     finally:
         shutil.rmtree(root, ignore_errors=True)
