@@ -884,6 +884,11 @@ def main() -> None:
                 "kernel": "kp_sw_kernel", "cells_per_step": [s["dp_cells"] for s in per_step],
                 "ms_per_step": sw_ms, "gcups": cells / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else None,
                 "tasks_per_step": [s["tasks"] for s in per_step], "anchors_per_step": [s["anchors"] for s in per_step],
+                # band tasks that end below the -s 80 cut (their direction bits were written for nothing): tasks without a hit.
+                # (hits are counted after same-span duplicates were dropped, so this is an upper bound.)  Were it large, a
+                # score-only first fill would pay; at a few per cent it does not.
+                "hits_per_step": [s["hits"] for s in per_step],
+                "tasks_without_hit_frac": [round(1.0 - s["hits"] / max(s["tasks"], 1), 4) for s in per_step],
                 # fill kernel against its own roof, VALU issue: cycles the instruction mix of its 8-step body needs (tools/
                 # isa_cost.py with the per-opcode costs measured by tools/microbench/valu_rate*.hip) over the SIMD cycles
                 # the launch had, at the shader clock the PMC run saw (GRBM_GUI_ACTIVE / duration, profiles/)

@@ -107,11 +107,11 @@ __device__ __forceinline__ int chain_small(const uint64_t *__restrict__ keys, in
 // cluster shows whether the two belong to a group: a lone cluster then goes to the block's stage as before, a member of a
 // group is appended to the global list at once -- its slot is what the group record refers to -- and the finished group
 // record (tasks, anchor ranges) goes to the group list.  Groups are rare; the stage keeps serving nearly every task.
-struct JoinWave {
-    KpTask pend;
+struct JoinWave {  // the pending cluster: registers of lane 0 (a chain of LDS round trips per cluster cost 0.2 ms per pass); the open
+    KpTask pend;   // group record, touched once in a blue moon, lives in LDS
     uint32_t pend_first, pend_cnt, pend_dmax;
     int pend_valid, pend_in_group;
-    KpGroup grp;
+    KpGroup *grp;
 };
 struct GroupOut {
     KpGroup *groups;
@@ -136,9 +136,9 @@ __device__ __forceinline__ void pending_to_group(JoinWave &J, KpTask *tasks, uin
     const int cls = class_of_width(J.pend.width);
     const uint32_t slot = atomicAdd(&task_count[cls], 1u);
     if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = J.pend;
-    const int n = J.grp.n;
-    J.grp.task[n] = KP_TASK_REF(cls, slot); J.grp.first[n] = J.pend_first; J.grp.cnt[n] = J.pend_cnt;
-    J.grp.n = n + 1;
+    const int n = J.grp->n;
+    J.grp->task[n] = KP_TASK_REF(cls, slot); J.grp->first[n] = J.pend_first; J.grp->cnt[n] = J.pend_cnt;
+    J.grp->n = n + 1;
 }
 
 __device__ __forceinline__ void pending_flush(JoinWave &J, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, TaskStage &st,
@@ -147,7 +147,7 @@ __device__ __forceinline__ void pending_flush(JoinWave &J, KpTask *tasks, uint32
     if (J.pend_in_group) {
         pending_to_group(J, tasks, task_count, task_cap);
         const uint32_t g = atomicAdd(go.count, 1u);
-        if (g < go.cap) go.groups[g] = J.grp;  // beyond cap: counted, not stored (host retries)
+        if (g < go.cap) go.groups[g] = *J.grp;  // beyond cap: counted, not stored (host retries)
     } else {
         emit_staged(J.pend, tasks, task_count, task_cap, st);
     }
@@ -174,9 +174,9 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     t.qspan = qmin | (qmax << 16);
     // does it follow the pending cluster within the join bandwidth (kp_spec.h, GROUPS)?
     const bool joins = J.pend_valid && J.pend.gs == t.gs && d0 - J.pend_dmax <= (uint32_t)KP_JOIN_BW &&
-                       (J.pend_in_group ? J.grp.n + 1 : 1) < KP_JOIN_GROUP_MAX;
+                       (J.pend_in_group ? J.grp->n + 1 : 1) < KP_JOIN_GROUP_MAX;
     if (joins) {
-        if (!J.pend_in_group) { J.grp.n = 0; J.grp.asm_id = a; }
+        if (!J.pend_in_group) { J.grp->n = 0; J.grp->asm_id = a; }
         pending_to_group(J, tasks, task_count, task_cap);
     } else {
         pending_flush(J, tasks, task_count, task_cap, st, go);
@@ -197,8 +197,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
                                                       uint32_t task_cap, GroupOut go) {
     __shared__ TaskStage st;
-    __shared__ JoinWave s_jw[CHAIN_WAVES];
-    JoinWave &jw = s_jw[threadIdx.x >> 6];
+    __shared__ KpGroup s_grp[CHAIN_WAVES];
+    JoinWave jw;
+    jw.grp = &s_grp[threadIdx.x >> 6];
     const int a = blockIdx.y, lane = threadIdx.x & 63;
     uint32_t n = count[a];
     if (n > cap) n = cap;
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         return l - 1;
     };
     if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
-    if (lane == 0) { jw.pend_valid = 0; jw.pend_in_group = 0; jw.grp.n = 0; }
+    jw.pend_valid = 0; jw.pend_in_group = 0; jw.pend_first = jw.pend_cnt = jw.pend_dmax = 0;
+    jw.pend.asm_id = 0; jw.pend.gs = 0; jw.pend.contig = 0; jw.pend.lo = 0; jw.pend.width = 16; jw.pend.n_anchors = 0; jw.pend.qspan = 0; jw.pend.chain_score = 0;
+    if (lane == 0) jw.grp->n = 0;
     __syncthreads();
     // A wave owns the gene/strand GROUPS OF ANCHORS that start in its slice (kp-align v4: the clusters of one gene/strand must
     // pass through one lane in order, see JoinWave): a slice that starts inside such a group leaves it to the wave before it
