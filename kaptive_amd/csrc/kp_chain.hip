@@ -382,55 +382,115 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
             if (cur >= n) break;
         }
     }
-    while (cur < hi && cur < n) {  // one gene's stretch [cur, end)
+    // The exact count of one gene's stretch [cur, end): rare (see the certificate below), so it may reload what it needs.
+    auto exact_cut = [&](uint32_t cur, uint32_t end) {
         const uint32_t gene = kp_ckey_gs(k[cur], kb) >> 1;
-        uint32_t end = cur;
+        const int glen = gene_len[gene];
+        auto qf_of = [&](uint64_t key) { const int q = (int)kp_ckey_qpos(key, kb); return (kp_ckey_gs(key, kb) & 1u) ? glen - KP_K - q : q; };
+        auto wave_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        // positions are counted a window of OCC_BINS at a time: one window for nearly every gene, exact for all
+        for (int w0 = 0; w0 < glen; w0 += OCC_BINS) {
+            for (uint32_t i = cur + lane; i < end; i += 64) {
+                const uint64_t key = k[i];
+                if (key == OCC_TOMB) continue;
+                const int qf = qf_of(key) - w0;
+                if (qf >= 0 && qf < OCC_BINS) atomicAdd(&cnt[qf], 1u);
+            }
+            wave_sync();
+            bool any_drop = false;
+            for (uint32_t i0 = cur; i0 < end; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const uint64_t key = i < end ? k[i] : OCC_TOMB;
+                const int qf = key != OCC_TOMB ? qf_of(key) - w0 : -1;
+                const bool drop = qf >= 0 && qf < OCC_BINS && cnt[qf] > (uint32_t)KP_MID_OCC;
+                if (drop) k[i] = OCC_TOMB;  // (the counters are read, not changed: every anchor of the seed sees the same count)
+                any_drop = any_drop || __any(drop);
+            }
+            wave_sync();
+            if (any_drop) {  // rare: the dropped anchors no longer tell which counters they touched
+                if (lane == 0) s_dropped = 1;
+                for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
+            } else {
+                for (uint32_t i = cur + lane; i < end; i += 64) {
+                    const uint64_t key = k[i];
+                    if (key == OCC_TOMB) continue;
+                    const int qf = qf_of(key) - w0;
+                    if (qf >= 0 && qf < OCC_BINS) cnt[qf] = 0;
+                }
+            }
+            wave_sync();
+        }
+    };
+    // CERTIFICATE.  The anchors of one seed lie on different (gene/strand, diagonal) pairs, so a stretch with anchors on ten or
+    // fewer of them cannot hold a seed with more than ten anchors -- and a gene's anchors in an assembly sit on one or two
+    // diagonals unless the assembly really repeats it.  Rounds of 64 anchors: gene changes and diagonal changes are two
+    // ballots, every stretch that begins in the round counts its own diagonals from them (the one that reaches into the next
+    // round is carried); only a stretch that fails the certificate is counted exactly.  No memory is touched beyond the keys.
+    uint32_t open_start = cur, open_diags = 0;  // the stretch that reaches the current round from before it
+    bool open = false;
+    uint64_t next_key = cur + lane < n ? k[cur + lane] : 0ull;
+    uint64_t prev_key = cur > 0 ? k[cur - 1] : 0ull;
+    const uint32_t g_hi = hi > 0 && hi <= n ? kp_ckey_gs(k[hi - 1], kb) >> 1 : 0xFFFFFFFFu;
+    for (uint32_t w = cur; w < n; w += 64) {
+        const uint32_t i = w + lane;
+        const uint64_t key = next_key;
+        next_key = i + 64 < n ? k[i + 64] : 0ull;
+        const uint32_t gsd_hi = (uint32_t)(key >> 32), gene = kp_ckey_gs(key, kb) >> 1;
+        // the round's anchors that are this wave's: up to the slice's end, and beyond it while the gene stays the same
+        const unsigned long long foreign = __ballot(!(i < n && (i < hi || gene == g_hi)));
+        const int n_valid = foreign ? (int)__builtin_ctzll(foreign) : 64;
+        if (n_valid == 0) break;
+        const bool valid = lane < n_valid;
+        uint64_t pk = ((uint64_t)__shfl_up(gsd_hi, 1) << 32) | __shfl_up((uint32_t)key, 1);
+        if (lane == 0) pk = prev_key;
+        const bool first_ever = w == 0 && lane == 0;
+        const bool head = valid && (first_ever || (kp_ckey_gs(pk, kb) >> 1) != gene || (w == cur && lane == 0 && !open));
+        const bool newdiag = valid && (first_ever || (pk >> kb.qb) != (key >> kb.qb));  // another gene/strand or diagonal than the anchor before
+        const unsigned long long heads = __ballot(head), diags = __ballot(newdiag);
+        prev_key = __shfl(key, n_valid - 1);
+        const int first_head = heads ? (int)__builtin_ctzll(heads) : n_valid;
+        const unsigned long long valid_mask = n_valid == 64 ? ~0ull : ((1ull << n_valid) - 1ull);
+        if (open) {  // the carried stretch goes on for `first_head` anchors of this round
+            open_diags += (uint32_t)__builtin_popcountll(diags & (first_head == 64 ? ~0ull : ((1ull << first_head) - 1ull)));
+            if (first_head < n_valid || n_valid < 64) {  // ... and ends here
+                if (open_diags > (uint32_t)KP_MID_OCC) exact_cut(open_start, w + (uint32_t)first_head);
+                open = false;
+            }
+        }
+        if (heads) {
+            // every head lane measures its own stretch: [lane, my_end) and its diagonals (its own anchor opens the first)
+            const unsigned long long later = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
+            const int my_end = later ? (int)__builtin_ctzll(later) : n_valid;
+            const unsigned long long range = (my_end == 64 ? ~0ull : ((1ull << my_end) - 1ull)) & ~((1ull << lane) - 1ull) & valid_mask;
+            const uint32_t my_diags = (uint32_t)__builtin_popcountll((diags | (1ull << lane)) & range);
+            const bool closed = head && (later != 0ull || n_valid < 64);  // ends inside the round (or with the wave's anchors)
+            unsigned long long todo = __ballot(closed && my_diags > (uint32_t)KP_MID_OCC);
+            while (todo) {  // (almost never)
+                const int pos = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                exact_cut(w + (uint32_t)pos, w + (uint32_t)__shfl(my_end, pos));
+            }
+            const int last_head = 63 - (int)__builtin_clzll(heads);
+            if (n_valid == 64) {  // the last stretch of the round reaches the next one
+                open = true;
+                open_start = w + (uint32_t)last_head;
+                open_diags = (uint32_t)__shfl((int)my_diags, last_head);
+            }
+        }
+        if (n_valid < 64) break;
+    }
+    if (open && open_diags > (uint32_t)KP_MID_OCC) {  // (the list ended with the carried stretch)
+        uint32_t end = open_start;
+        const uint32_t gene = kp_ckey_gs(k[open_start], kb) >> 1;
         for (;;) {
             const uint32_t i = end + lane;
             const unsigned long long other = __ballot(!(i < n && (kp_ckey_gs(k[i], kb) >> 1) == gene));
             if (other) { end += (uint32_t)__builtin_ctzll(other); break; }
             end += 64;
         }
-        if (end - cur > (uint32_t)KP_MID_OCC) {
-            const int glen = gene_len[gene];
-            auto qf_of = [&](uint64_t key) { const int q = (int)kp_ckey_qpos(key, kb); return (kp_ckey_gs(key, kb) & 1u) ? glen - KP_K - q : q; };
-            auto wave_sync = [&]() {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-            // positions are counted a window of OCC_BINS at a time: one window for nearly every gene, exact for all
-            for (int w0 = 0; w0 < glen; w0 += OCC_BINS) {
-                for (uint32_t i = cur + lane; i < end; i += 64) {
-                    const uint64_t key = k[i];
-                    if (key == OCC_TOMB) continue;
-                    const int qf = qf_of(key) - w0;
-                    if (qf >= 0 && qf < OCC_BINS) atomicAdd(&cnt[qf], 1u);
-                }
-                wave_sync();
-                bool any_drop = false;
-                for (uint32_t i0 = cur; i0 < end; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    const uint64_t key = i < end ? k[i] : OCC_TOMB;
-                    const int qf = key != OCC_TOMB ? qf_of(key) - w0 : -1;
-                    const bool drop = qf >= 0 && qf < OCC_BINS && cnt[qf] > (uint32_t)KP_MID_OCC;
-                    if (drop) k[i] = OCC_TOMB;  // (the counters are read, not changed: every anchor of the seed sees the same count)
-                    any_drop = any_drop || __any(drop);
-                }
-                wave_sync();
-                if (any_drop) {  // rare: the dropped anchors no longer tell which counters they touched
-                    if (lane == 0) s_dropped = 1;
-                    for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
-                } else {
-                    for (uint32_t i = cur + lane; i < end; i += 64) {
-                        const uint64_t key = k[i];
-                        if (key == OCC_TOMB) continue;
-                        const int qf = qf_of(key) - w0;
-                        if (qf >= 0 && qf < OCC_BINS) cnt[qf] = 0;
-                    }
-                }
-                wave_sync();
-            }
-        }
-        cur = end;
+        exact_cut(open_start, end);
     }
     __syncthreads();
     if (!s_dropped) return;
