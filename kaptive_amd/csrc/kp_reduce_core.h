@@ -145,8 +145,8 @@ KP_HD bool kp_same_span(const kp_hit &x, const kp_hit &y) {
 }
 
 // ---- scoring (core.py:164-201) ----------------------------------------------------------------------------------------
-// hits are in emission order (gene ascending, score descending).  Best hit of gene g = highest query coverage among hits
-// with coverage >= min_cov, ties by higher score then earlier emission, i.e. the first maximum when walking the run.
+// hits are in emission order (gene ascending).  Best hit of gene g = highest query coverage among hits with coverage >=
+// min_cov (core.py:174-182 breaks ties by score, but only the coverage enters the locus score).
 KP_HD int kp_lower_bound_gene(const kp_hit *hits, int n, int gene) {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -256,14 +256,22 @@ KP_HD void kp_cluster_and_pieces(KpKept *kept, int nk, const KpTypingDb &db, int
         k.cluster = cur;
     }
     const int n_clusters = nk ? cur + 1 : 0;
-    // flags; the first kept hit of an expected gene is its top-scoring one (emission order = gene asc, score desc)
+    // flags; the primary hit of an expected gene is its top-scoring kept hit, the earliest in emission order on ties
+    // (core.py:236-245: first of lexsort((-score, gene))).  Emission order is gene ascending but NOT score descending: a joined
+    // hit is ranked by its order score (kp_spec.h), which can put it before a hit with a higher alignment score.
     for (int i = 0; i < nk; ++i) {
         KpKept &k = kept[i];
         uint8_t f = 0;
         if (info ? info[i].extra : db.gene_extra[k.gene]) f |= KP_F_EXTRA;
         else if ((int)(info ? info[i].locus : db.gene_locus[k.gene]) == best_locus) f |= KP_F_EXPECTED;
-        if ((f & KP_F_EXPECTED) && (i == 0 || kept[i - 1].gene != k.gene)) f |= KP_F_PRIMARY;
         k.flags = f;
+    }
+    for (int i = 0; i < nk;) {
+        int j = i, top = i;
+        for (; j < nk && kept[j].gene == kept[i].gene; ++j)
+            if (kept[j].score > kept[top].score) top = j;
+        if (kept[top].flags & KP_F_EXPECTED) kept[top].flags |= KP_F_PRIMARY;
+        i = j;
     }
     // one piece per cluster (ascending id) that holds a primary hit
     int np = 0;
