@@ -774,9 +774,10 @@ def _results_equal(a, b, what):
         assert da[grp]["seqs"] == db_[grp]["seqs"] and tuple(da[grp]["ids"]) == tuple(db_[grp]["ids"]), (what, grp)
 
 
-def _adversarial_hits(rng, db, genome, n):
+def _adversarial_hits(rng, db, genome, n, by_score=True):
     """Hit tables no aligner would emit (the recipe of the reference goldens' random_hits cases, oracle/make_golden.py):
-    heavy overlaps around a few hot spots, scores / matches drawn from a handful of values, mapq 0 / 1 / 60 / 255."""
+    heavy overlaps around a few hot spots, scores / matches drawn from a handful of values, mapq 0 / 1 / 60 / 255.
+    ``by_score=False``: a gene's hits in any order (minimap2 ranks by dp_max, not by the alignment score: joined hits)."""
     hits = np.zeros(n, _native.HIT_DTYPE)
     genes = np.sort(rng.integers(0, len(db.genes), size=n))
     glen = db.genes.lengths[genes]
@@ -794,7 +795,7 @@ def _adversarial_hits(rng, db, genome, n):
     hits["matches"] = rng.choice(np.array([40, 60, 60, 250, 450]), size=n)
     hits["block_len"] = span
     hits["mapq"] = rng.choice(np.array([0, 1, 60, 60, 255], np.uint8), size=n)
-    return hits[np.lexsort((-hits["score"], hits["gene"]))]
+    return hits[np.lexsort((-hits["score"] if by_score else rng.random(n), hits["gene"]))]
 
 
 def test_adversarial_hit_tables_through_the_device_reduction():
@@ -820,7 +821,7 @@ def test_adversarial_hit_tables_through_the_device_reduction():
         for i in range(40):  # the fuzz: the same genomes, fresh tables of 2 to 900 hits
             g = genomes[i % len(genomes)]
             genomes.append(g)
-            tables.append(_adversarial_hits(rng, db, g, int(rng.integers(2, 900 if i % 8 else 3000))))
+            tables.append(_adversarial_hits(rng, db, g, int(rng.integers(2, 900 if i % 8 else 3000)), by_score=i % 2 == 0))
         batch = eng.ctx.batch([g.packed() for g in genomes])
         batch.align_async()
         batch.wait()

@@ -131,3 +131,29 @@ def test_float32_sum_has_numpys_association():
         assert got.tobytes() == np.float32(np.add.reduce(vals) if n else 0).tobytes(), n
         if n:
             assert np.float32(np.float64(got) / n).tobytes() == np.float32(np.mean(vals)).tobytes(), n
+
+
+def test_primary_hit_is_the_top_scoring_one_whatever_the_emission_order(oracle):
+    """Emission order ranks a joined hit by its order score (kp_spec.h), so a gene's hits are not in descending order of
+    their alignment score; the primary hit of an expected gene is still its top-scoring kept hit (core.py:236-245).  The
+    k_plain1 table with every gene's hits in random order: the device core's records equal the host reduction's."""
+    from tests.golden_util import hits_to_alignments
+    from tests.test_gpu_parity import _adversarial_hits, _results_equal
+
+    key, genome, hits, exp, scalars, kwargs = load_case("k_split")
+    db = load_db(key)
+    typer = Serotyper(db, aligner=lambda g: None, protein_aligner=lambda q, t: __import__("kaptive_amd.core.pairwise", fromlist=["x"]).PairwiseAlignments.from_table(
+        oracle.protein_align(q.seqs, q.offsets, q.lengths, t.seqs, t.offsets, t.lengths)), **kwargs)
+    hdb, prm = H.HarnessDb(db), H.params(db, typer)
+    rng = np.random.default_rng(5)
+    pa = genome.packed()
+    for it in range(6):
+        table = hits[np.lexsort((rng.random(len(hits)), hits["gene"]))] if it < 3 else _adversarial_hits(rng, db, genome, 300, by_score=False)
+        scores, counts = H.locus_scores(table, hdb, typer.min_gene_coverage)
+        best, _, _ = B.choose_best_loci(scores[None, :], counts[None, :], typer._expected_genes_per_locus)
+        kept, pieces, summary, prot = H.reduce(table, hdb, prm, best[0], pa)
+        t_off, t_len = db.translations.offsets[kept["gene"]], db.translations.lengths[kept["gene"]]
+        dp = oracle.protein_align(prot, kept["prot_off"], kept["prot_len"], db.translations.seqs, t_off, t_len)
+        kept = H.states(kept, hdb, prm, genome.contigs.lengths, dp)
+        res = B.assemble(typer, genome.id, summary, kept, pieces, scores[best[0]], genome=genome)
+        _results_equal(res, typer.reduce(genome, hits_to_alignments(db, genome, table)), f"table {it}")
