@@ -36,14 +36,17 @@ struct JNode {
     uint32_t ref;
 };
 
-__global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
+__global__ __launch_bounds__(256) void kp_join_chain_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
                                                            const KpTask *__restrict__ tasks, uint32_t task_cap,
                                                            const KpGroup *__restrict__ groups, const uint32_t *__restrict__ group_count,
                                                            uint32_t group_cap, KpJoin *__restrict__ joins, uint32_t *__restrict__ join_count,
                                                            uint32_t join_cap) {
     uint32_t n_groups = *group_count;
     if (n_groups > group_cap) n_groups = group_cap;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+    // one wave per group: the lanes share out the scan of a cluster's anchors (a thread on its own took 0.2 ms for two clusters
+    // of 240 anchors: a chain of memory round trips), lane 0 chains the nodes
+    const int lane = threadIdx.x & 63;
+    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (blockDim.x >> 6)) {
         const KpGroup &G = groups[g];
         JNode node[KP_JOIN_GROUP_MAX];
         int m = 0;
@@ -55,11 +58,18 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
             // head: the anchor with the smallest (query position, diagonal); tail: the one with the largest
             const uint64_t *k = keys + (size_t)G.asm_id * cap + G.first[c];
             uint64_t head = ~0ull, tail = 0ull;
-            for (uint32_t i = 0; i < G.cnt[c]; ++i) {
+            for (uint32_t i = (uint32_t)lane; i < G.cnt[c]; i += 64) {
                 const uint64_t key = k[i];
                 const uint64_t qd = ((uint64_t)kp_ckey_qpos(key, kb) << 32) | kp_ckey_diag(key, kb);
                 if (qd < head) head = qd;
-                if (qd >= tail) tail = qd;
+                if (qd > tail) tail = qd;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint64_t h2 = ((uint64_t)__shfl_xor((uint32_t)(head >> 32), o) << 32) | __shfl_xor((uint32_t)head, o);
+                const uint64_t t2 = ((uint64_t)__shfl_xor((uint32_t)(tail >> 32), o) << 32) | __shfl_xor((uint32_t)tail, o);
+                if (h2 < head) head = h2;
+                if (t2 > tail) tail = t2;
             }
             JNode &N = node[m++];
             N.hq = (int)(head >> 32); N.ht = (int)(uint32_t)head - KP_DIAG_BIAS + N.hq;
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
             N.lo = t.lo; N.width = t.width; N.ref = ref;
             N.d0 = (int)kp_ckey_diag(k[0], kb); N.dmax = (int)kp_ckey_diag(k[G.cnt[c] - 1], kb);  // (sorted by diagonal first)
         }
+        if (lane != 0) continue;
         if (m < 2) continue;
         int ord[KP_JOIN_GROUP_MAX];
         for (int i = 0; i < m; ++i) {  // by (head t, head q, list order): stable insertion sort
@@ -441,7 +452,7 @@ void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
                           KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream) {
     (void)b; (void)genes;
-    hipLaunchKernelGGL(kp_join_chain_kernel, dim3(64), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
+    hipLaunchKernelGGL(kp_join_chain_kernel, dim3(64), dim3(256), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
                        group_count, group_cap, joins, join_count, join_cap);
 }
 
