@@ -179,11 +179,13 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
  * the pieces it runs through.
  *
  * GROUPS.  A cluster is PROVISIONAL when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases (it may
- * still be rejected by its chain score).  Walking an assembly's provisional clusters in the order of the sorted anchors,
- * a cluster joins the group of the provisional cluster before it iff both have the same gene/strand, its lowest diagonal is
- * at most KP_JOIN_BW above the highest diagonal of that cluster, and the group holds fewer than KP_JOIN_GROUP_MAX clusters;
- * otherwise it starts a new group.  (Diagonals are in the assembly's padded coordinates: near a contig boundary clusters of
- * two contigs interleave, so a group may hold clusters of several contigs.)  Groups of one are nothing.
+ * still be rejected by its chain score).  Per gene/strand AND contig, take the provisional clusters in the order of the sorted
+ * anchors (diagonals are in the assembly's padded coordinates: near a contig boundary the clusters of two contigs interleave
+ * in that order, which is why the contig is part of the key): a cluster continues the open sequence of its contig iff its
+ * lowest diagonal is at most KP_JOIN_BW above the highest diagonal of the sequence's last cluster and the sequence holds
+ * fewer than KP_JOIN_GROUP_MAX clusters; otherwise it closes that sequence and opens a new one.  At most KP_JOIN_OPEN
+ * sequences of a gene/strand are open at a time: the cluster of a further contig closes the one whose last cluster ends on
+ * the lowest diagonal (the lowest contig on ties).  A closed sequence of two or more clusters is a GROUP.
  *
  * CHAINS OF CLUSTERS.  Nodes are the group's ACCEPTED clusters (chain score >= KP_MIN_CHAIN_SCORE; cs = that score, n = its
  * anchor count).  HEAD of a cluster = its anchor with the smallest (query position, diagonal), TAIL = the one with the
@@ -247,6 +249,7 @@ KP_SPEC_FN int kp_log2x2(uint32_t n) { /* 2 log2(1 + n) to the nearest integer o
     return 2 * e + (mant >= 3u) + (mant >= 11u);
 }
 #define KP_JOIN_GROUP_MAX 16
+#define KP_JOIN_OPEN 4
 #define KP_JOIN_MAX_PIECES 8
 #define KP_JOIN_DROP (400 - KP_GAP_OPEN2)
 

@@ -103,15 +103,26 @@ __device__ __forceinline__ int chain_small(const uint64_t *__restrict__ keys, in
 
 // ---- kp-align v4: groups of provisional clusters (kp_spec.h) --------------------------------------------------------------------
 // Lane 0 of a wave meets its clusters in the order of the sorted anchors, so it can tell which provisional clusters of one
-// gene/strand follow each other within KP_JOIN_BW diagonals.  One cluster is held back (PENDING) until the next provisional
-// cluster shows whether the two belong to a group: a lone cluster then goes to the block's stage as before, a member of a
-// group is appended to the global list at once -- its slot is what the group record refers to -- and the finished group
-// record (tasks, anchor ranges) goes to the group list.  Groups are rare; the stage keeps serving nearly every task.
-struct JoinWave {  // the pending cluster: registers of lane 0 (a chain of LDS round trips per cluster cost 0.2 ms per pass); the open
-    KpTask pend;   // group record, touched once in a blue moon, lives in LDS
-    uint32_t pend_first, pend_cnt, pend_dmax;
-    int pend_valid, pend_in_group;
-    KpGroup *grp;
+// gene/strand and contig follow each other within KP_JOIN_BW diagonals.  The last cluster of every OPEN sequence (one per
+// contig, at most KP_JOIN_OPEN per gene/strand) is held back until a later cluster shows whether the sequence goes on: a lone
+// cluster then goes to the block's stage as before, a member of a group is appended to the global list at once -- its slot is
+// what the group record refers to -- and the finished group record (tasks, anchor ranges) goes to the group list.  Nearly
+// always one sequence is open: its entry lives in lane 0's registers (a chain of LDS round trips per cluster cost 0.2 ms per
+// pass); further ones -- the clusters of a gene that a contig boundary cuts interleave by diagonal -- wait in LDS.
+struct PendEntry {
+    KpTask t;
+    uint32_t first, cnt, dmax;
+    int in_group;
+};
+struct JoinLds {
+    PendEntry e[KP_JOIN_OPEN];
+    KpGroup g[KP_JOIN_OPEN];
+};
+struct JoinWave {
+    PendEntry A;  // the open sequence touched last; its group record is L->g[a_slot]
+    int a_valid, a_slot;
+    uint32_t others;  // slots of L->e that hold further open sequences
+    JoinLds *L;
 };
 struct GroupOut {
     KpGroup *groups;
@@ -132,26 +143,36 @@ __device__ __forceinline__ void emit_staged(const KpTask &t, KpTask *tasks, uint
     if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = t;  // beyond cap: counted, not stored (host retries)
 }
 
-__device__ __forceinline__ void pending_to_group(JoinWave &J, KpTask *tasks, uint32_t *task_count, uint32_t task_cap) {
-    const int cls = class_of_width(J.pend.width);
+__device__ __forceinline__ void entry_to_group(const PendEntry &E, KpGroup &G, KpTask *tasks, uint32_t *task_count, uint32_t task_cap) {
+    const int cls = class_of_width(E.t.width);
     const uint32_t slot = atomicAdd(&task_count[cls], 1u);
-    if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = J.pend;
-    const int n = J.grp->n;
-    J.grp->task[n] = KP_TASK_REF(cls, slot); J.grp->first[n] = J.pend_first; J.grp->cnt[n] = J.pend_cnt;
-    J.grp->n = n + 1;
+    if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = E.t;
+    const int n = G.n;
+    G.task[n] = KP_TASK_REF(cls, slot); G.first[n] = E.first; G.cnt[n] = E.cnt;
+    G.n = n + 1;
+}
+
+// the sequence ends with E
+__device__ __forceinline__ void close_entry(const PendEntry &E, KpGroup &G, KpTask *tasks, uint32_t *task_count, uint32_t task_cap,
+                                            TaskStage &st, const GroupOut &go) {
+    if (E.in_group) {
+        entry_to_group(E, G, tasks, task_count, task_cap);
+        const uint32_t g = atomicAdd(go.count, 1u);
+        if (g < go.cap) go.groups[g] = G;  // beyond cap: counted, not stored (host retries)
+    } else {
+        emit_staged(E.t, tasks, task_count, task_cap, st);
+    }
 }
 
 __device__ __forceinline__ void pending_flush(JoinWave &J, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, TaskStage &st,
                                               const GroupOut &go) {
-    if (!J.pend_valid) return;
-    if (J.pend_in_group) {
-        pending_to_group(J, tasks, task_count, task_cap);
-        const uint32_t g = atomicAdd(go.count, 1u);
-        if (g < go.cap) go.groups[g] = *J.grp;  // beyond cap: counted, not stored (host retries)
-    } else {
-        emit_staged(J.pend, tasks, task_count, task_cap, st);
+    if (J.a_valid) close_entry(J.A, J.L->g[J.a_slot], tasks, task_count, task_cap, st, go);
+    J.a_valid = 0;
+    while (J.others) {
+        const int s = __builtin_ctz(J.others);
+        J.others &= J.others - 1;
+        close_entry(J.L->e[s], J.L->g[s], tasks, task_count, task_cap, st, go);
     }
-    J.pend_valid = 0;
 }
 
 // called by one lane.  A cluster whose anchors cover fewer than KP_MIN_SEED_SPAN query bases cannot chain to
@@ -168,21 +189,51 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
         need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN;
         w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
     }
-    KpTask t;
-    t.asm_id = a; t.gs = (int32_t)gs; t.contig = ctg; t.width = w; t.n_anchors = cnt; t.chain_score = (int32_t)first;
-    t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
-    t.qspan = qmin | (qmax << 16);
-    // does it follow the pending cluster within the join bandwidth (kp_spec.h, GROUPS)?
-    const bool joins = J.pend_valid && J.pend.gs == t.gs && d0 - J.pend_dmax <= (uint32_t)KP_JOIN_BW &&
-                       (J.pend_in_group ? J.grp->n + 1 : 1) < KP_JOIN_GROUP_MAX;
-    if (joins) {
-        if (!J.pend_in_group) { J.grp->n = 0; J.grp->asm_id = a; }
-        pending_to_group(J, tasks, task_count, task_cap);
-    } else {
-        pending_flush(J, tasks, task_count, task_cap, st, go);
+    PendEntry c;
+    c.t.asm_id = a; c.t.gs = (int32_t)gs; c.t.contig = ctg; c.t.width = w; c.t.n_anchors = cnt; c.t.chain_score = (int32_t)first;
+    c.t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
+    c.t.qspan = qmin | (qmax << 16);
+    c.first = first; c.cnt = (uint32_t)cnt; c.dmax = dmax; c.in_group = 0;
+    // (kp_spec.h, GROUPS) all open sequences belong to one gene/strand
+    if (J.a_valid && J.A.t.gs != c.t.gs) pending_flush(J, tasks, task_count, task_cap, st, go);
+    bool found = J.a_valid && J.A.t.contig == ctg;
+    if (!found && J.others) {  // (rare: the gene has open sequences on other contigs)
+        for (uint32_t m = J.others; m; m &= m - 1) {
+            const int s = __builtin_ctz(m);
+            if (J.L->e[s].t.contig != ctg) continue;
+            J.L->e[J.a_slot] = J.A;  // A waits in its own slot, the contig's sequence comes to the registers
+            J.others = (J.others | (1u << J.a_slot)) & ~(1u << s);
+            J.A = J.L->e[s];
+            J.a_slot = s;
+            found = true;
+            break;
+        }
     }
-    J.pend = t; J.pend_first = first; J.pend_cnt = (uint32_t)cnt; J.pend_dmax = dmax;
-    J.pend_valid = 1; J.pend_in_group = joins ? 1 : 0;
+    if (found) {
+        KpGroup &G = J.L->g[J.a_slot];
+        if (d0 - J.A.dmax <= (uint32_t)KP_JOIN_BW && (J.A.in_group ? G.n + 1 : 1) < KP_JOIN_GROUP_MAX) {
+            if (!J.A.in_group) { G.n = 0; G.asm_id = a; }
+            entry_to_group(J.A, G, tasks, task_count, task_cap);
+            c.in_group = 1;
+        } else {
+            close_entry(J.A, G, tasks, task_count, task_cap, st, go);
+        }
+    } else if (J.a_valid) {  // a further contig: A waits in LDS; when all slots are taken, the sequence that ends lowest closes
+        J.L->e[J.a_slot] = J.A;
+        J.others |= 1u << J.a_slot;
+        if (J.others == (1u << KP_JOIN_OPEN) - 1u) {
+            int ev = -1;
+            for (uint32_t m = J.others; m; m &= m - 1) {
+                const int s = __builtin_ctz(m);
+                if (ev < 0 || J.L->e[s].dmax < J.L->e[ev].dmax || (J.L->e[s].dmax == J.L->e[ev].dmax && J.L->e[s].t.contig < J.L->e[ev].t.contig)) ev = s;
+            }
+            close_entry(J.L->e[ev], J.L->g[ev], tasks, task_count, task_cap, st, go);
+            J.others &= ~(1u << ev);
+        }
+        J.a_slot = __builtin_ctz(~J.others);
+    }
+    J.A = c;
+    J.a_valid = 1;
 }
 
 struct Cluster {  // wave-uniform
@@ -197,9 +248,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
                                                       KpTask *__restrict__ tasks, uint32_t *__restrict__ task_count,
                                                       uint32_t task_cap, GroupOut go) {
     __shared__ TaskStage st;
-    __shared__ KpGroup s_grp[CHAIN_WAVES];
+    __shared__ JoinLds s_join[CHAIN_WAVES];
     JoinWave jw;
-    jw.grp = &s_grp[threadIdx.x >> 6];
+    jw.L = &s_join[threadIdx.x >> 6];
     const int a = blockIdx.y, lane = threadIdx.x & 63;
     uint32_t n = count[a];
     if (n > cap) n = cap;
@@ -219,9 +270,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         return l - 1;
     };
     if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
-    jw.pend_valid = 0; jw.pend_in_group = 0; jw.pend_first = jw.pend_cnt = jw.pend_dmax = 0;
-    jw.pend.asm_id = 0; jw.pend.gs = 0; jw.pend.contig = 0; jw.pend.lo = 0; jw.pend.width = 16; jw.pend.n_anchors = 0; jw.pend.qspan = 0; jw.pend.chain_score = 0;
-    if (lane == 0) jw.grp->n = 0;
+    jw.a_valid = 0; jw.a_slot = 0; jw.others = 0;
+    jw.A.first = jw.A.cnt = jw.A.dmax = 0; jw.A.in_group = 0;
+    jw.A.t.asm_id = 0; jw.A.t.gs = 0; jw.A.t.contig = 0; jw.A.t.lo = 0; jw.A.t.width = 16; jw.A.t.n_anchors = 0; jw.A.t.qspan = 0; jw.A.t.chain_score = 0;
     __syncthreads();
     // A wave owns the gene/strand GROUPS OF ANCHORS that start in its slice (kp-align v4: the clusters of one gene/strand must
     // pass through one lane in order, see JoinWave): a slice that starts inside such a group leaves it to the wave before it

@@ -693,14 +693,43 @@ static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks,
     static const uint8_t pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
     int64_t cap = 64, nj = 0;
     kpo_join *joins = malloc((size_t)cap * sizeof(kpo_join));
-    int64_t g0 = 0;
-    while (g0 < np) {
-        int64_t g1 = g0 + 1;
-        while (g1 < np && g1 - g0 < KP_JOIN_GROUP_MAX && pcl[g1].gs == pcl[g1 - 1].gs && pcl[g1].d0 - pcl[g1 - 1].dmax <= KP_JOIN_BW)
-            g1++;
+    /* GROUPS (kp_spec.h): per gene/strand and contig, the provisional clusters in list order; a cluster continues the open
+     * sequence of its contig iff its lowest diagonal is within KP_JOIN_BW of that sequence's last cluster's highest one and
+     * the sequence holds fewer than KP_JOIN_GROUP_MAX clusters.  At most KP_JOIN_OPEN sequences of a gene/strand are open
+     * at a time: a new contig's cluster closes the open sequence whose last cluster ends lowest (lowest contig on ties). */
+    typedef struct { int n; int member[KP_JOIN_GROUP_MAX]; } kpo_seq;
+    kpo_seq open[KP_JOIN_OPEN];
+    int n_open = 0;
+    int64_t gcap = 64, ng = 0;
+    kpo_seq *groups = malloc((size_t)gcap * sizeof(kpo_seq));
+#define KPO_CLOSE(slot) do { if (open[slot].n >= 2) { if (ng == gcap) { gcap *= 2; groups = realloc(groups, (size_t)gcap * sizeof(kpo_seq)); } groups[ng++] = open[slot]; } \
+                             open[slot] = open[--n_open]; } while (0)
+    for (int64_t c = 0; c <= np; c++) {
+        if (c == np || (n_open > 0 && pcl[open[0].member[0]].gs != pcl[c].gs))
+            while (n_open > 0) KPO_CLOSE(0);
+        if (c == np) break;
+        int found = -1;
+        for (int s2 = 0; s2 < n_open; s2++)
+            if (pcl[open[s2].member[0]].contig == pcl[c].contig) found = s2;
+        if (found >= 0) {
+            const kpo_pcl *last = &pcl[open[found].member[open[found].n - 1]];
+            if (pcl[c].d0 - last->dmax <= KP_JOIN_BW && open[found].n < KP_JOIN_GROUP_MAX) { open[found].member[open[found].n++] = (int)c; continue; }
+            KPO_CLOSE(found);
+        } else if (n_open == KP_JOIN_OPEN) {
+            int ev = 0;
+            for (int s2 = 1; s2 < n_open; s2++) {
+                const kpo_pcl *x = &pcl[open[s2].member[open[s2].n - 1]], *y = &pcl[open[ev].member[open[ev].n - 1]];
+                if (x->dmax < y->dmax || (x->dmax == y->dmax && x->contig < y->contig)) ev = s2;
+            }
+            KPO_CLOSE(ev);
+        }
+        open[n_open].n = 1; open[n_open].member[0] = (int)c; n_open++;
+    }
+#undef KPO_CLOSE
+    for (int64_t gi = 0; gi < ng; gi++) {
         int node[KP_JOIN_GROUP_MAX], m = 0;
-        for (int64_t c = g0; c < g1; c++)
-            if (pcl[c].task >= 0) node[m++] = (int)c;
+        for (int c = 0; c < groups[gi].n; c++)
+            if (pcl[groups[gi].member[c]].task >= 0) node[m++] = groups[gi].member[c];
         if (m >= 2) {
             for (int i = 1; i < m; i++) { /* order by (head t, head q, list order): insertion sort, stable */
                 const int x = node[i];
@@ -752,8 +781,8 @@ static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks,
                 }
             }
         }
-        g0 = g1;
     }
+    free(groups);
     *out = joins;
     return nj;
 }
