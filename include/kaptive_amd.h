@@ -311,6 +311,49 @@ KP_API int64_t kp_format_rows(const kp_row_tables *tables, int32_t n_asm, const 
                               const kp_kept *kept, int32_t kept_stride, const kp_row_columns *columns, char *out,
                               int64_t cap);
 
+/* ---- JSON lines of a whole batch (host only) ----------------------------------------------------------------------------------
+ * Replaces orjson.dumps(SerotypingResult.to_dict(), OPT_SERIALIZE_NUMPY | OPT_APPEND_NEWLINE) per genome
+ * (src/kaptive/serotyping/cli.py:67-76, src/kaptive/serotyping/models.py:629-654) together with the construction of the
+ * result object it serialises (GeneHits columns: src/kaptive/serotyping/core.py:303-329; locus / gene / protein sequences:
+ * src/kaptive/core/seq.py:327-408): one line per assembly from the records of kp_batch_typing, the columns the host
+ * finished and the contigs' text.  Strings that come from the database or the batch arrive as ready JSON literals (quotes
+ * and escapes included; blobs with n + 1 offsets); contig names of the locus pieces arrive escaped but unquoted.  Returns the
+ * number of bytes the lines need (written to `out` while they fit `cap`), or a negative error code. */
+typedef struct kp_json_tables {  /* per database */
+    const char *head;            /* {"kaptive_version":"..","database_name":"..",...,"database_taxon":N,"genome": */
+    int32_t head_len;
+    const char *gene_names;      /* Database.genes.ids (missing genes, ids of gene and protein sequences) */
+    const int64_t *gene_name_off;
+    const char *gene_ids, *cluster_names, *products;  /* GeneHits text columns: S32 / S10 / S64 truncations, per gene */
+    const int64_t *gene_id_off, *cluster_name_off, *product_off;
+    const char *locus_names;
+    const int64_t *locus_name_off;
+    const int32_t *locus_gene_off, *locus_gene_len;
+    const int32_t *gene_position; /* Database.gene_positions */
+    const int8_t *gene_strand;    /* Database.gene_intervals.strands */
+    const uint8_t *comp_map;      /* [256] complement of a sequence byte (core/seq.py) */
+    const uint8_t *char_map;      /* [256] byte -> 0..4 */
+    const uint8_t *codon_map;     /* [125] codon -> amino acid, 42 = stop */
+} kp_json_tables;
+typedef struct kp_json_columns { /* per assembly of the batch */
+    const char *asm_ids;
+    const int64_t *asm_id_off;
+    const char *phenotypes;
+    const int64_t *phenotype_off;
+    const int32_t *best_locus;
+    const uint8_t *typeable;
+    const int32_t *problems;
+    const double *best_score, *completeness, *identity, *coverage, *length_discrepancy;
+    const int32_t *piece_order;  /* [n_asm * piece_stride] numpy's argsort of the pieces' mean positions */
+    const char *piece_ctg_names; /* escaped name of the contig of piece [a * piece_stride + p] */
+    const int64_t *piece_ctg_name_off;
+    const uint8_t *const *ctg_seqs;  /* per assembly: the contigs' text back to back ... */
+    const int32_t *const *ctg_off;   /* ... and where each contig starts in it */
+} kp_json_columns;
+KP_API int64_t kp_format_json(const kp_json_tables *tables, int32_t n_asm, const kp_asm_summary *summaries, const kp_kept *kept,
+                              int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *columns,
+                              char *out, int64_t cap);
+
 /* ---- protein alignment ------------------------------------------------------------------------------------------
  * Replaces PairwiseAligner.__call__ / _batched_banded_gotoh (src/kaptive/core/pairwise.py:255-325, 395-584) in its
  * unseeded mode with the defaults gap_open 11, gap_extend 1, k 20.  Sequences are raw bytes (amino-acid letters).

@@ -39,7 +39,7 @@ EXPORTS = (
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_set_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
-    "kp_fasta_free", "kp_format_rows", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
+    "kp_fasta_free", "kp_format_rows", "kp_format_json", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
 
@@ -377,6 +377,116 @@ class RowFormatter:
                 return out[:need].tobytes()
             out = np.empty(int(need), np.uint8)
         raise NativeError("kp_format_rows: size kept changing")
+
+
+class JsonTables(C.Structure):  # kp_json_tables
+    _fields_ = [("head", C.c_char_p), ("head_len", C.c_int32), ("gene_names", C.c_void_p), ("gene_name_off", C.c_void_p),
+                ("gene_ids", C.c_void_p), ("cluster_names", C.c_void_p), ("products", C.c_void_p), ("gene_id_off", C.c_void_p),
+                ("cluster_name_off", C.c_void_p), ("product_off", C.c_void_p), ("locus_names", C.c_void_p),
+                ("locus_name_off", C.c_void_p), ("locus_gene_off", C.c_void_p), ("locus_gene_len", C.c_void_p),
+                ("gene_position", C.c_void_p), ("gene_strand", C.c_void_p), ("comp_map", C.c_void_p), ("char_map", C.c_void_p),
+                ("codon_map", C.c_void_p)]  # fmt: skip
+
+
+class JsonColumns(C.Structure):  # kp_json_columns
+    _fields_ = [("asm_ids", C.c_void_p), ("asm_id_off", C.c_void_p), ("phenotypes", C.c_void_p), ("phenotype_off", C.c_void_p),
+                ("best_locus", C.c_void_p), ("typeable", C.c_void_p), ("problems", C.c_void_p), ("best_score", C.c_void_p),
+                ("completeness", C.c_void_p), ("identity", C.c_void_p), ("coverage", C.c_void_p), ("length_discrepancy", C.c_void_p),
+                ("piece_order", C.c_void_p), ("piece_ctg_names", C.c_void_p), ("piece_ctg_name_off", C.c_void_p),
+                ("ctg_seqs", C.c_void_p), ("ctg_off", C.c_void_p)]  # fmt: skip
+
+
+def _blob64(strings) -> tuple[np.ndarray, np.ndarray]:
+    """utf-8 strings -> (bytes back to back, n + 1 int64 offsets)."""
+    enc = [s if isinstance(s, bytes) else str(s).encode("utf-8") for s in strings]
+    off = np.zeros(len(enc) + 1, np.int64)
+    if enc:
+        np.cumsum([len(e) for e in enc], out=off[1:])
+    return np.frombuffer(b"".join(enc) or b"\0", np.uint8), off
+
+
+class JsonFormatter:
+    """The JSON lines of whole batches (kp_format_json): what ``dumps_line(result.to_dict())`` writes per assembly
+    (kaptive_amd/serotyping/jsonl.py), without an object per assembly.  The database's strings are escaped once."""
+
+    def __init__(self, typer, kaptive_version: str) -> None:
+        from kaptive_amd.core.seq import CHAR_MAP, CODON_MAP, COMP_MAP
+        from kaptive_amd.serotyping.jsonl import _str
+
+        db = typer._db
+        meta = db.metadata
+        head = ("{" + f'"kaptive_version":{_str(kaptive_version)},"database_name":{_str(meta.name)},"database_version":{_str(meta.version)},'
+                f'"database_organism":{_str(meta.organism)},"database_taxon":{int(meta.taxon)},"genome":').encode("utf-8")
+        text = lambda col: [_str(v.decode("utf-8", "replace")) for v in col.tolist()]  # noqa: E731  (GeneHits.to_dict decodes the truncated bytes)
+        self._keep = dict(
+            head=head, gene_names=_blob64([_str(x) for x in db.genes.ids]), gene_ids=_blob64(text(typer._gene_ids_s32)),
+            cluster=_blob64(text(typer._cluster_s10)), product=_blob64(text(typer._product_s64)),
+            locus=_blob64([_str(x) for x in db.loci.ids]),
+            locus_gene_off=_c(db.locus_gene_offsets, np.int32), locus_gene_len=_c(db.locus_gene_lengths, np.int32),
+            gene_position=_c(db.gene_positions, np.int32), gene_strand=_c(db.gene_intervals.strands, np.int8),
+            comp=_c(COMP_MAP, np.uint8), char=_c(CHAR_MAP, np.uint8), codon=_c(CODON_MAP, np.uint8),
+        )  # fmt: skip
+        k = self._keep
+        self._tables = JsonTables(
+            head=head, head_len=len(head), gene_names=_p(k["gene_names"][0]).value, gene_name_off=_p(k["gene_names"][1]).value,
+            gene_ids=_p(k["gene_ids"][0]).value, cluster_names=_p(k["cluster"][0]).value, products=_p(k["product"][0]).value,
+            gene_id_off=_p(k["gene_ids"][1]).value, cluster_name_off=_p(k["cluster"][1]).value, product_off=_p(k["product"][1]).value,
+            locus_names=_p(k["locus"][0]).value, locus_name_off=_p(k["locus"][1]).value,
+            locus_gene_off=_p(k["locus_gene_off"]).value, locus_gene_len=_p(k["locus_gene_len"]).value,
+            gene_position=_p(k["gene_position"]).value, gene_strand=_p(k["gene_strand"]).value, comp_map=_p(k["comp"]).value,
+            char_map=_p(k["char"]).value, codon_map=_p(k["codon"]).value,
+        )  # fmt: skip
+
+    def format(self, ids, phenotypes, sums, kept, pieces, best_locus, best_score, completeness, typeable, problems, identity,
+               coverage, discrepancy, genomes) -> bytes:
+        from kaptive_amd.serotyping.jsonl import _str
+
+        n = len(sums)
+        if n == 0:
+            return b""
+        sums, kept, pieces = np.ascontiguousarray(sums), np.ascontiguousarray(kept), np.ascontiguousarray(pieces)
+        kstride = kept.shape[1] if kept.ndim == 2 else 0
+        pstride = pieces.shape[1] if pieces.ndim == 2 else 0
+        # order of the locus pieces: numpy's argsort of their mean positions (core.py:281), per assembly; names of their contigs
+        order = np.zeros((n, max(pstride, 1)), np.int32)
+        order[:] = np.arange(max(pstride, 1), dtype=np.int32)[None, :]
+        names = [b""] * (n * pstride)
+        n_pieces = sums["n_pieces"]
+        for a in np.flatnonzero(n_pieces > 0):
+            m = int(n_pieces[a])
+            if m > 1:
+                order[a, :m] = np.argsort(np.ascontiguousarray(pieces["mean_pos"][a, :m]))
+            cids = genomes[a].contigs.ids
+            for p_ in range(m):
+                names[a * pstride + p_] = _str(cids[int(pieces["contig"][a, p_])])[1:-1].encode("utf-8")
+        ids_b, ids_o = _blob64([_str(x) for x in ids])
+        ph_b, ph_o = _blob64([_str(x) for x in phenotypes])
+        nm_b, nm_o = _blob64(names)
+        seq_arrays = [np.ascontiguousarray(g.contigs.seqs, dtype=np.uint8) for g in genomes]
+        off_arrays = [np.ascontiguousarray(g.contigs.offsets, dtype=np.int32) for g in genomes]
+        seq_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in seq_arrays])
+        off_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in off_arrays])
+        cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
+                    score=_c(best_score, np.float64), compl=_c(completeness, np.float64), identity=_c(identity, np.float64),
+                    coverage=_c(coverage, np.float64), discrepancy=_c(discrepancy, np.float64), order=order)  # fmt: skip
+        c = JsonColumns(asm_ids=_p(ids_b).value, asm_id_off=_p(ids_o).value, phenotypes=_p(ph_b).value, phenotype_off=_p(ph_o).value,
+                        best_locus=_p(cols["best"]).value, typeable=_p(cols["typeable"]).value, problems=_p(cols["problems"]).value,
+                        best_score=_p(cols["score"]).value, completeness=_p(cols["compl"]).value, identity=_p(cols["identity"]).value,
+                        coverage=_p(cols["coverage"]).value, length_discrepancy=_p(cols["discrepancy"]).value,
+                        piece_order=_p(order).value, piece_ctg_names=_p(nm_b).value, piece_ctg_name_off=_p(nm_o).value,
+                        ctg_seqs=C.cast(seq_ptrs, C.c_void_p).value, ctg_off=C.cast(off_ptrs, C.c_void_p).value)  # fmt: skip
+        h = lib()
+        h.kp_format_json.restype = C.c_int64
+        out = np.empty(max(1 << 16, 80_000 * n), np.uint8)
+        for _ in range(2):
+            need = h.kp_format_json(C.byref(self._tables), C.c_int32(n), _p(sums), _p(kept), C.c_int32(kstride), _p(pieces),
+                                    C.c_int32(pstride), C.byref(c), _p(out), C.c_int64(len(out)))
+            if need < 0:
+                raise ValueError(f"kp_format_json failed ({need})")
+            if need <= len(out):
+                return out[:need].tobytes()
+            out = np.empty(int(need), np.uint8)
+        raise NativeError("kp_format_json: size kept changing")
 
 
 class TypingParams(C.Structure):  # kp_typing_params

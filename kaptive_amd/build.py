@@ -19,7 +19,7 @@ CSRC = PKG / "csrc"
 INCLUDE = PKG.parent / "include"
 LIB = PKG / "libkaptive_amd.so"
 SOURCES = ("kp_capi.hip", "kp_scan.hip", "kp_sort.hip", "kp_bsort.hip", "kp_chain.hip", "kp_join.hip", "kp_sw.hip", "kp_prot.hip", "kp_reduce.hip",
-           "kp_fasta.cpp", "kp_rows.cpp", "kp_kmers.cpp")
+           "kp_fasta.cpp", "kp_rows.cpp", "kp_json.cpp", "kp_kmers.cpp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          *os.environ.get("KAPTIVE_AMD_EXTRA_FLAGS", "").split()]  # (experiments: -DKP_SW_WAVES=6 and the like)

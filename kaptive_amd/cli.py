@@ -146,8 +146,9 @@ class _TypingPipeline:
     uploaded on the copy stream, and chunk k - 1's rows are formatted.  When only the TSV and / or PHA4GE reports are asked for,
     no per-assembly object is ever built: the rows come from ``BatchTyping.tsv()`` (``kp_format_rows``, byte for byte what
     ``KaptiveRow.from_result`` gives) and ``BatchTyping.pha4ge()``, and the files' sequence text is not even kept.  The
-    other outputs (``-j``, ``-l``, ``-g``, ``-p``) go through ``SerotypingResult`` objects, as the reference's writers do
-    (src/kaptive/serotyping/cli.py:20-114)."""
+    JSON lines (``-j``) come from ``BatchTyping.jsonl()`` (``kp_format_json``) and need the files' text but no objects either;
+    only the per-assembly fasta outputs (``-l``, ``-g``, ``-p``) go through ``SerotypingResult`` objects, as the reference's
+    writers do (src/kaptive/serotyping/cli.py:20-114)."""
 
     PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
 
@@ -163,7 +164,8 @@ class _TypingPipeline:
 
         self.args = args
         self.marks = {"pipeline_start": time.perf_counter()}  # (KAPTIVE_AMD_CLI_TIMING: where the time before the first rows goes)
-        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins"))
+        self.objects = any(getattr(args, f, None) for f in ("json", "loci", "genes", "proteins"))  # the files' text is kept
+        self.fasta_outputs = any(getattr(args, f, None) for f in ("loci", "genes", "proteins"))  # ... and result objects are built
         self.threads = max(1, args.threads or usable_cpus())  # (the cgroup's quota, not the 256 CPUs a container may see)
         # PREFETCH + 1 chunks are being parsed at any time, each by one native call: the thread budget is shared out among them
         # (measured on the 16-CPU box, threads per call 4 / 6 / 8 / 12 / 16 / 24 / 32: 12.5 / 15.2 / 12.1 / 11.0 / 11.0 / 7.4 / 6.5 k
@@ -329,10 +331,10 @@ class _TypingPipeline:
                 out["tsv"] = bt.tsv()
             if getattr(args, "pha4ge", None):
                 out["pha4ge"] = bt.pha4ge()
-            if self.objects:
+            if getattr(args, "json", None):  # one native call per batch (kp_format_json): byte for byte result_to_json of every result
+                out["json"] = bt.jsonl()
+            if self.fasta_outputs:
                 results = bt.results()
-                if getattr(args, "json", None):
-                    out["json"] = b"".join(result_to_json(r) for r in results)
                 for flag, attr, ext in (("loci", "locus_seqs", "fna"), ("genes", "gene_seqs", "ffn"), ("proteins", "translations", "faa")):
                     if d := getattr(args, flag, None):
                         d = Path(d)

@@ -217,6 +217,21 @@ class BatchTyping:
                           self.percent_identity, self.percent_coverage, self.length_discrepancy)  # fmt: skip
 
 
+    def jsonl(self) -> bytes:
+        """The JSON lines of the whole batch (``-j``), from the batch's columns and the genomes' text (``genomes`` must have
+        been given): byte for byte ``dumps_line(result(i).to_dict())`` for every assembly (reference:
+        src/kaptive/serotyping/cli.py:67-76) without an object per assembly (kp_format_json)."""
+        if self.genomes is None:
+            raise ValueError("JSON lines carry the extracted sequences: the batch needs its genomes")
+        fmt = getattr(self.typer, "_json_formatter", None)
+        if fmt is None:
+            from kaptive_amd import KAPTIVE_COMPAT_VERSION, _native
+
+            fmt = self.typer._json_formatter = _native.JsonFormatter(self.typer, KAPTIVE_COMPAT_VERSION)
+        return fmt.format(self.ids, self.phenotype, self.sums, self.kept, self.pieces, self.best_locus, self.best_score,
+                          self.completeness, self.typeable, self.problems, self.percent_identity, self.percent_coverage,
+                          self.length_discrepancy, self.genomes)  # fmt: skip
+
     def pha4ge(self) -> bytes:
         """The PHA4GE lines of the whole batch (``--pha4ge``), from the batch's columns: byte for byte what
         ``Pha4geRow.from_result(result(i))`` gives (reference: src/kaptive/serotyping/io.py, ``Pha4geRow``) without an object

@@ -157,3 +157,59 @@ def test_primary_hit_is_the_top_scoring_one_whatever_the_emission_order(oracle):
         kept = H.states(kept, hdb, prm, genome.contigs.lengths, dp)
         res = B.assemble(typer, genome.id, summary, kept, pieces, scores[best[0]], genome=genome)
         _results_equal(res, typer.reduce(genome, hits_to_alignments(db, genome, table)), f"table {it}")
+
+
+@pytest.mark.parametrize("key", ["k", "o", "kfull", "abfull"])
+def test_native_json_lines_equal_the_python_serialiser(key, oracle):
+    """``BatchTyping.jsonl()`` (kp_format_json: one native call per batch) writes, for every golden case, the bytes that
+    ``dumps_line(result(i).to_dict())`` writes -- the restatement of orjson's conventions the reference's ``-j`` output is held
+    to (kaptive_amd/serotyping/jsonl.py; src/kaptive/serotyping/cli.py:67-76) --, and the lines read back through
+    ``SerotypingResult.from_dict`` into the same rows."""
+    import json
+
+    from kaptive_amd.serotyping.io import KaptiveRow
+    from kaptive_amd.serotyping.jsonl import dumps_line
+    from kaptive_amd.serotyping.models import SerotypingResult
+
+    names = [n for n in case_names() if not n.startswith("k_divergent_") and load_case(n)[0] == key]
+    typer, genomes, exps, bt = _batch_from_cases(names, oracle)
+    lines = bt.jsonl().splitlines(keepends=True)
+    assert len(lines) == len(names)
+    for i, name in enumerate(names):
+        res = bt.result(i)
+        want = dumps_line(res.to_dict())
+        assert lines[i] == want, (name, next((j, lines[i][max(0, j - 60): j + 60], want[max(0, j - 60): j + 60]) for j in range(min(len(want), len(lines[i]))) if lines[i][j] != want[j]))
+        back = SerotypingResult.from_dict(json.loads(lines[i]))
+        assert bytes(KaptiveRow.from_result(back)) == bytes(KaptiveRow.from_result(res))
+
+
+def test_native_json_number_layout():
+    """The number layouts of kp_format_json against jsonl.py's: float64 and float32 values across the switch points of Ryu's
+    format (16 / 13 digits to the right, 5 / 6 zeros to the left), NaN, infinities, zeros, through a one-hit batch."""
+    from kaptive_amd.serotyping.jsonl import format_f32, format_f64
+
+    key, genome, hits, exp, scalars, kwargs = load_case("k_plain1")
+    db = load_db(key)
+    typer = Serotyper(db, aligner=lambda g: None)
+    rng = np.random.default_rng(3)
+    vals = [0.0, -0.0, 1.0, 100.0, 0.1, 1e15, 1e16, 1e17, 123456789012345680.0, 1e-5, 1e-6, 1e-7, 9.999999e-5, float("nan"), float("inf"),
+            5e-324, 1.7976931348623157e308, 99.32123565673828, 28.33096164055609, 1e21, 1e22, 12345.678]
+    vals += list(np.exp(rng.uniform(-40, 40, 200))) + [float(np.float32(v)) for v in np.exp(rng.uniform(-30, 30, 100))]
+    sums = np.zeros(len(vals), B.SUMMARY_DTYPE)
+    sums["n_kept"] = 1
+    kept = np.zeros((len(vals), 1), B.KEPT_DTYPE)
+    with np.errstate(over="ignore"):
+        f32 = np.array(vals, np.float64).astype(np.float32)
+    kept["coverage"][:, 0] = f32
+    kept["pident"][:, 0] = f32[::-1]
+    kept["t_end"] = 9
+    kept["strand"] = 1
+    pieces = np.zeros((len(vals), 1), B.PIECE_DTYPE)
+    scores = np.zeros((len(vals), len(db.loci)))
+    scores[:, 0] = vals
+    bt = B.BatchTyping(typer, [f"g{i}" for i in range(len(vals))], sums, kept, pieces, scores, np.zeros(len(vals), np.int32), [genome] * len(vals))
+    for i, line in enumerate(bt.jsonl().splitlines()):
+        text = line.decode()
+        assert f'"best_locus_score":{format_f64(vals[i])},' in text, (vals[i], text[:400])
+        assert f'"coverages":[{format_f32(f32[i])}]' in text, (vals[i], text)
+        assert f'"protein_identities":[{format_f32(f32[::-1][i])}]' in text, (vals[::-1][i], text)
