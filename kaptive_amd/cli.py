@@ -172,6 +172,7 @@ class _TypingPipeline:
         # assemblies/s -- a cgroup throttles what oversubscribes its quota)
         self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
+        self.formatters = ThreadPoolExecutor(max_workers=2)  # a chunk's rows and JSON lines, beside the driving thread
         self.copiers = ThreadPoolExecutor(max_workers=min(4, self.threads))  # object mode: copies into pinned memory (not queued behind reads)
         self._pins: list = []  # recycled page-locked buffers
         self._pin_lock = threading.Lock()
@@ -227,6 +228,7 @@ class _TypingPipeline:
         the operating system takes the page-locked memory and the device context back faster than the runtime unwinds them."""
         self.readers.shutdown(wait=not fast, cancel_futures=True)
         self.copiers.shutdown(wait=not fast, cancel_futures=True)
+        self.formatters.shutdown(wait=not fast, cancel_futures=True)
         if fast:
             return
         if self._own_typer and self.typer._engine is not None:
@@ -322,10 +324,12 @@ class _TypingPipeline:
     def run(self, chunks):
         """Yields ``(k, outputs)`` for every ``(k, paths)`` of ``chunks``, in order; ``outputs`` maps "tsv" / "pha4ge" /
         "json" to the bytes this chunk adds to that stream (per-assembly fasta files are written here)."""
+        from collections import deque
+
         args = self.args
         self._order = []
-        done = 0
-        for bt, batch in self.engine.type_stream(self.typer, self._source(chunks)):
+
+        def render(bt) -> dict:
             out = {}
             if self.want_tsv:
                 out["tsv"] = bt.tsv()
@@ -341,12 +345,24 @@ class _TypingPipeline:
                         d.mkdir(parents=True, exist_ok=True)
                         for r in results:
                             (d / f"{r.genome}_{FILE_SUFFIX}.{ext}").write_bytes(getattr(r, attr).to_fasta())
+            return out
+
+        # The rows of a chunk are rendered beside the driving thread (the native formatters release the interpreter lock: 35 MB
+        # of JSON per 512 assemblies would otherwise stand between two submissions to the device); they leave in input order.
+        rendering: deque = deque()
+        done = 0
+        for bt, batch in self.engine.type_stream(self.typer, self._source(chunks)):
             pb, batch._pin = getattr(batch, "_pin", None), None
             batch.close()  # (waits for whatever of the batch is still in flight: the pinned words are free after it)
             if pb is not None:
                 with self._pin_lock:
                     self._pins.append(pb)
-            yield self._order[done], out
+            rendering.append(self.formatters.submit(render, bt))
+            while rendering and (rendering[0].done() or len(rendering) > 2):
+                yield self._order[done], rendering.popleft().result()
+                done += 1
+        while rendering:
+            yield self._order[done], rendering.popleft().result()
             done += 1
 
 
