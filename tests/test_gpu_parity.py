@@ -1067,6 +1067,15 @@ def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_p
     assert len(chunks) == 3 and KaptiveRow.header() + b"".join(chunks) == fast.read_bytes()
     again = typer.type_many(paths[:2])
     assert [bytes(KaptiveRow.from_result(r)) for r in again] == rows[1:3]
+    # -j: the native JSON lines of the batch (kp_format_json) are the lines the Python serialiser writes for the result objects,
+    # and `-j` with `-g` beside it (result objects for the fasta files) writes the same lines
+    from kaptive_amd.cli import result_to_json
+
+    everyone = typer.type_many(paths)
+    assert (tmp_path / "r.jsonl").read_bytes() == b"".join(result_to_json(r) for r in everyone)
+    assert main(["assembly", str(db_path), *paths, "-o", str(tmp_path / "s3.tsv"), "-j", str(tmp_path / "r3.jsonl"), "-g", str(tmp_path / "genes3"),
+                 "--batch-size", "4"]) == 0  # fmt: skip
+    assert (tmp_path / "r3.jsonl").read_bytes() == (tmp_path / "r.jsonl").read_bytes()
 
 
 # ---- BASELINE.json configs at their real shape --------------------------------------------------------------------------
