@@ -56,8 +56,7 @@ KP_API void *kp_ctx_stream(kp_ctx *ctx);
 /* Tuning knobs.  Defaults are read from the environment once, in kp_ctx_create (KAPTIVE_AMD_<NAME in upper case>);
  * names: anchor_cap, tasks_per_asm, hit_cap, trace_kb_per_asm, kept_cap, piece_cap, prot_cap (initial sizes of the work
  * buffers; trace_kb_per_asm: direction bits of the banded Smith-Waterman, KiB per assembly of a batch -- setting
- * one also forgets what the context has learnt for it), no_lds_filter (seed scan probes the L2 tier of the presence
- * filter even for small databases), library_sort (anchors are sorted by the library's segmented radix sort instead of
+ * one also forgets what the context has learnt for it), library_sort (anchors are sorted by the library's segmented radix sort instead of
  * the bucket sort of kp_bsort.hip; same result), scan_mode (ablation modes of the scan kernel, tools/scan_ablate.py). */
 KP_API int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value);
 #define KP_WORK_SLOTS 3

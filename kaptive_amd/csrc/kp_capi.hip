@@ -131,7 +131,6 @@ struct KpOptions {
     uint32_t trace_kb_per_asm = 2048;  // first guess for the DP trace buffer (a 5 Mbp K-locus assembly needs ~12 MB)
     uint32_t kept_cap = 256, piece_cap = 32, prot_cap = 32768;
     int scan_mode = 0;           // KAPTIVE_AMD_SCAN_ABLATE (tools/scan_ablate.py)
-    int no_lds_filter = 0;       // tests compare the two filter tiers
     int library_sort = 0;        // anchors through kp_anchor_compact + rocPRIM's segmented radix sort instead of kp_bsort.hip
     uint32_t upload_piece_mb = 4096;  // H2D copies of a batch's words are enqueued in pieces of this size (batch_make)
     int readback_copy_engine = 0;   // results read back with hipMemcpyAsync instead of the read-back kernel (see Fetch)
@@ -277,7 +276,7 @@ struct kp_ctx {
     int64_t n_postings = 0;
     std::vector<int32_t> gene_len;  // host copy (finalisation flips reverse-strand coordinates)
     DevBuf<uint2> d_slots;
-    DevBuf<uint64_t> d_filter, d_filter2, d_lds_filter;
+    DevBuf<uint64_t> d_filter, d_filter2;
     DevBuf<uint64_t> d_postings;
     DevBuf<uint32_t> d_nib;
     DevBuf<int32_t> d_nib_off, d_gene_len;
@@ -355,7 +354,6 @@ void options_from_env(KpOptions &o) {
     o.piece_cap = env_u32("KAPTIVE_AMD_PIECE_CAP", o.piece_cap);
     o.prot_cap = env_u32("KAPTIVE_AMD_PROT_CAP", o.prot_cap);
     o.scan_mode = (int)env_u32("KAPTIVE_AMD_SCAN_ABLATE", 0);
-    o.no_lds_filter = (int)env_u32("KAPTIVE_AMD_NO_LDS_FILTER", 0);
     o.library_sort = (int)env_u32("KAPTIVE_AMD_LIBRARY_SORT", 0);
     o.upload_piece_mb = std::max<uint32_t>(1, env_u32("KAPTIVE_AMD_UPLOAD_PIECE_MB", 4096));
     { const char *rb = getenv("KAPTIVE_AMD_READBACK"); o.readback_copy_engine = rb && std::string(rb) == "copy"; }
@@ -414,11 +412,16 @@ struct Fetch {
     size_t used = 0;
     bool by_copy_engine;
     Fetch(kp_ctx *c, hipStream_t s) : ctx(c), stream(s), by_copy_engine(c->opt.readback_copy_engine != 0) {}
+    // A Fetch that is dropped half-way (an error between add() and finish()) leaves kernels writing into the landing
+    // area: wait for them, so that the next begin() never frees or reuses memory that is still being written.
+    ~Fetch() { if (!items.empty()) (void)hipStreamSynchronize(stream); }
     // total bytes of everything that will be added before finish()
     int begin(size_t total) {
         if (by_copy_engine) return KP_OK;
         total += 64 * 8;
         if (total > ctx->bounce_bytes) {
+            // (calls on a context are serialised and every Fetch waits for its stream before it goes away, so nothing
+            // is in flight towards the old area here)
             if (ctx->bounce) pinned_free(ctx->bounce);
             ctx->bounce = nullptr; ctx->bounce_bytes = 0;
             const size_t want = total + total / 4 + (1u << 20);
@@ -437,7 +440,9 @@ struct Fetch {
         return KP_OK;
     }
     int finish() {
-        KP_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { items.clear(); used = 0; }
+        KP_HIP_CHECK(ctx, e);
         for (const Item &it : items) std::memcpy(it.dst, ctx->bounce + it.off, it.bytes);
         items.clear(); used = 0;
         return KP_OK;
@@ -654,7 +659,7 @@ void kp_ctx_destroy(kp_ctx *ctx) {
     ctx->free_inputs.clear();
     for (auto &w : ctx->work) w.release();
     if (ctx->bounce) { pinned_free(ctx->bounce); ctx->bounce = nullptr; ctx->bounce_bytes = 0; }
-    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_lds_filter.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release(); ctx->d_gene_prof.release(); ctx->d_gene_has_n.release();
+    ctx->d_slots.release(); ctx->d_filter.release(); ctx->d_filter2.release(); ctx->d_postings.release(); ctx->d_nib.release(); ctx->d_nib_off.release(); ctx->d_gene_prof.release(); ctx->d_gene_has_n.release();
     ctx->d_gene_len.release(); ctx->d_blosum.release(); ctx->d_pq.release(); ctx->d_pt.release();
     ctx->d_pmeta.release(); ctx->d_pout.release(); ctx->d_pscratch.release(); ctx->d_ln.release();
     for (auto &g : ctx->groups)
@@ -697,7 +702,6 @@ int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value) {
     else if (n == "piece_cap") { o.piece_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.piece_cap = 0; }
     else if (n == "prot_cap") { o.prot_cap = (uint32_t)std::max<int64_t>(value, 1); for (auto &c : ctx->run_caps) c.prot_cap = 0; }
     else if (n == "scan_mode") o.scan_mode = (int)value;
-    else if (n == "no_lds_filter") o.no_lds_filter = value != 0;
     else if (n == "library_sort") o.library_sort = value != 0;
     else if (n == "upload_piece_mb") o.upload_piece_mb = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     else return kp_fail(ctx, KP_EINVAL, "unknown option: " + n);
@@ -788,11 +792,6 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     const uint32_t n_slots = 1u << log_slots, mask = n_slots - 1, shift = 32 - log_slots;
     std::vector<uint2> slots(n_slots, make_uint2(0xFFFFFFFFu, 0u));
     std::vector<uint64_t> filter((size_t)1 << (KP_FILTER_LOG2 - 6), 0ull), filter2((size_t)1 << (KP_FILTER2_LOG2 - 6), 0ull);
-    // LDS tier of the filter for databases with few k-mers: >= 10 bits per k-mer must fit KP_LDS_FILTER_BLOCKS blocks
-    uint32_t lds_blocks = 0;
-    if (n_unique > 0 && n_unique * 10 <= (size_t)KP_LDS_FILTER_BLOCKS * 64)
-        lds_blocks = (uint32_t)std::min<size_t>(KP_LDS_FILTER_BLOCKS, std::max<size_t>(256, (n_unique * 16 + 63) / 64));
-    std::vector<uint64_t> lds_filter(std::max<uint32_t>(lds_blocks, 1), 0ull);
     std::vector<uint64_t> flat;
     flat.reserve(2 * post.size() + n_unique + 1);
     for (size_t i = 0; i < post.size();) {
@@ -806,7 +805,6 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
             const uint2 m2 = kp_filter2_mask2(post[i].key);
             filter2[kp_filter2_block(post[i].key)] |= ((uint64_t)m2.y << 32) | m2.x;
         }
-        if (lds_blocks) lds_filter[kp_lds_filter_block(post[i].key, lds_blocks)] |= kp_filter_mask(post[i].key);
         flat.push_back((uint64_t)(j - i));
         for (uint32_t zt = 0; zt < 2; ++zt)  // the anchors a contig seed with strand bit zt makes with these gene seeds
             for (size_t x = i; x < j; ++x) {
@@ -822,7 +820,6 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_filter, filter.data(), filter.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_filter2, filter2.data(), filter2.size()))) return rcode;
-    if ((rcode = upload(ctx, ctx->d_lds_filter, lds_filter.data(), lds_filter.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_postings, flat.data(), flat.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib, nib.data(), nib.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_nib_off, nib_off.data(), nib_off.size()))) return rcode;
@@ -830,7 +827,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if ((rcode = upload(ctx, ctx->d_gene_has_n, has_n.data(), has_n.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_filter2.p, lds_blocks ? ctx->d_lds_filter.p : nullptr, lds_blocks, ctx->d_slots.p,
+    ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_filter2.p, ctx->d_slots.p,
                              ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes, ctx->d_gene_prof.p, ctx->d_gene_has_n.p};
     ctx->n_genes = n_genes;

@@ -11,8 +11,10 @@
 // search, hard-break flag against its predecessor), the breaks are a ballot, and the pieces between breaks are merged
 // into the cluster the wave carries in uniform registers (first / last diagonal by readlane -- diagonals ascend within
 // a run --, query extent by a wave reduction).  Only a piece that would stretch the cluster past KP_MAX_SPREAD is walked
-// anchor by anchor.  A slice that starts inside a run leaves that run to the wave before it, which keeps going past its
-// own end until the run is over.
+// anchor by anchor.  A wave owns the gene/strand groups that START inside its slice: it skips the rest of the group its
+// slice starts in and keeps going past its own end until its last group is over, because the clusters of a gene/strand
+// have to meet in one place for the joins of kp-align v4 (open sequences of clusters within KP_JOIN_BW diagonals,
+// JoinWave below; kp_join.hip chains and aligns them).
 #include "kp_internal.h"
 
 namespace {

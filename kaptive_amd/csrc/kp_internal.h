@@ -58,17 +58,9 @@ __host__ __device__ inline uint64_t kp_cand_pack(uint64_t pos, uint32_t z, uint3
 // (no ambiguous base) a 15-mer that starts at t is the streaming kernel's iff t >= S + KP_W and t + KP_K + KP_W <= E.
 __host__ __device__ inline bool kp_seed_is_interior(int64_t t, int64_t S, int64_t E) { return t >= S + KP_W && t + KP_K + KP_W <= E; }
 
-// Small databases also get an LDS-sized copy of the filter: lds_filter_blocks 64-bit blocks (0 = none), block of a
-// k-mer = high word of hash * lds_filter_blocks, same KP_FILTER_K bits within the block.
-#define KP_LDS_FILTER_BLOCKS 12288  // 96 KB
-__host__ __device__ inline uint32_t kp_lds_filter_block(uint32_t kmer, uint32_t n_blocks) {
-    return (uint32_t)(((uint64_t)(kmer * 2654435769u) * n_blocks) >> 32);
-}
 struct KpSeedIndex {
     const uint64_t *filter;    // [2^KP_FILTER_LOG2 / 64] presence filter over the indexed k-mers
     const uint64_t *filter2;   // [2^KP_FILTER2_LOG2 / 64] recheck filter (see above)
-    const uint64_t *lds_filter;  // [lds_filter_blocks] or null
-    uint32_t lds_filter_blocks;
     const uint2 *slots;        // [n_slots], key == 0xFFFFFFFF marks an empty slot
     const uint64_t *postings;  // count word + postings, per distinct k-mer
     uint32_t slot_mask;        // n_slots - 1 (power of two)

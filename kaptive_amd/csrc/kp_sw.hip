@@ -350,7 +350,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
             have[h] = slot < n_tasks;
             ti[h] = have[h] ? order[slot] : 0u;
             tk[h].asm_id = 0; tk[h].gs = 0; tk[h].contig = 0; tk[h].lo = 0;
-            if (have[h]) {  // the first four fields are all the fill needs (one 16-byte load; the whole record is nine words)
+            if (have[h]) {  // the first four fields are all the fill needs (one 16-byte load; the whole record is eight words)
                 const int4 head = *reinterpret_cast<const int4 *>(&tasks[ti[h]]);
                 tk[h].asm_id = head.x; tk[h].gs = head.y; tk[h].contig = head.z; tk[h].lo = head.w;
             }

@@ -420,27 +420,6 @@ def test_twelve_thousand_genes_stay_on_the_bucket_sort(oracle):
     c.close()
 
 
-def test_lds_and_l2_filter_tiers_agree(ctx, small_db, monkeypatch):
-    """A small database is scanned with its presence filter in LDS; KAPTIVE_AMD_NO_LDS_FILTER=1 sends the same batch
-    through the L2 tier.  The filter only prunes, so anchors and hits must be identical."""
-    asms = _assemblies(small_db)
-    packed = [a.packed() for a in asms]
-    lds = ctx.batch(packed)
-    hits_lds, off_lds = lds.align()
-    ctx.set_option("no_lds_filter", 1)
-    try:
-        l2 = ctx.batch(packed)
-        hits_l2, off_l2 = l2.align()
-    finally:
-        ctx.set_option("no_lds_filter", 0)
-    assert np.array_equal(off_lds, off_l2)
-    _same_records(hits_lds, hits_l2, "LDS vs L2 filter tier")
-    for i in range(len(packed)):
-        assert np.array_equal(lds.anchors(i), l2.anchors(i))
-    lds.close()
-    l2.close()
-
-
 def test_genes_with_ambiguous_bases_match_oracle(oracle, small_db):
     """N inside the GENES (code 4 on the query side): the fill kernel reads the genes as ready-made row profiles
     (KpGenes::prof) and takes "this gene holds an N" from the database's per-gene flag, and the traceback then counts
