@@ -162,6 +162,7 @@ def make_assembly(
     tandem_gene: int = 0,
     indel_rate: float = 2e-5,
     mid_indels: tuple = (),
+    indel_storm: tuple = (),
     repeat_segment: tuple = (),
     is_copies: tuple = (),
     background: str = "iid",
@@ -170,7 +171,9 @@ def make_assembly(
     ``locus`` < 0 plants no locus at all.  ``mid_indels``: (size, "del" | "ins") pairs, each planted inside a gene of
     the locus copy of its own (a deletion of ``size`` bases or an insertion of ``size`` random ones somewhere in the
     gene's middle half) -- the 30-500 base events minimap2 chains across (bw = 500); drawn from a generator of their
-    own, so that the other draws of a seed do not move.  ``repeat_segment`` = (length, copies): a stretch of one gene of
+    own, so that the other draws of a seed do not move.  ``indel_storm`` = (events, smallest, largest): that many insertions /
+    deletions of smallest..largest bases ANYWHERE in the locus copy (several per gene, gene ends, spacers: chains of
+    three and more pieces, weak end pieces, events closer together than a band is wide).  ``repeat_segment`` = (length, copies): a stretch of one gene of
     the locus copy planted ``copies`` more times around the genome, each copy mutated a little (seeds that occur more
     than ten times: minimap2's occurrence cut); ``is_copies`` = (copies, length): one random IS-like element planted that
     many times (not in any database: it only moves the quantile minimap2 derives its cut from).  ``background`` = "paralog":
@@ -215,6 +218,15 @@ def make_assembly(
                 edits.append((at, int(size), kind, random_dna(rng2, int(size), gc)))
             for at, size, kind, ins in sorted(edits, key=lambda t: -t[0]):  # from the far end: earlier coordinates stay put
                 copy = np.delete(copy, slice(at, at + size)) if kind == "del" else np.concatenate([copy[:at], ins, copy[at:]])
+        if indel_storm:
+            rng4 = np.random.default_rng([seed, 0x5702])
+            n_ev, lo_size, hi_size = indel_storm
+            for at in sorted((int(x) for x in rng4.integers(200, len(copy) - 200 - hi_size, size=n_ev)), reverse=True):
+                size = int(rng4.integers(lo_size, hi_size + 1))
+                if rng4.random() < 0.5:
+                    copy = np.delete(copy, slice(at, at + size))
+                else:
+                    copy = np.concatenate([copy[:at], random_dna(rng4, size, gc), copy[at:]])
         if tandem_gene:  # `tandem_gene` extra copies of one gene, head to tail, each mutated on its own (multi-copy stress)
             gi = int(rng.integers(g0, g1))
             s, e = int(db.gene_intervals.starts[gi]), min(int(db.gene_intervals.ends[gi]), len(copy))

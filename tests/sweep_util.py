@@ -12,12 +12,24 @@ _STATE: dict = {}
 CONFIGS = {
     "kpsc": dict(main=("kpsc_k", 100), also=("kpsc_o", 101), asm={}),
     "ab_k": dict(main=("ab_k", 102), also=None, asm=dict(length=4.0e6, median_contigs=1500, min_contig=200, force_split=True)),
+    # small assemblies whose locus copy is riddled with insertions / deletions anywhere (several per gene, gene ends,
+    # spacers): chains of three and more pieces, weak end pieces, events closer together than a band is wide
+    "storm": dict(main=("kpsc_k", 100), also=("kpsc_o", 101), asm=dict(length=3.0e5, median_contigs=6, min_contig=200, p_is=0.0)),
 }
+STORM_SIZES = ((33, 500), (20, 60), (100, 300), (400, 520), (1, 40), (30, 36), (490, 510))
 
 
 def assembly_kwargs(config: str, i: int) -> dict:
     """Deterministic variety: divergence from 0 to 12 %, indels, N runs, a second locus, a tandem gene copy, mid-size indels."""
     kw = dict(CONFIGS[config]["asm"])
+    if config == "storm":
+        kw["sub_rate"] = [0.0, 0.01, 0.03, 0.06, 0.1][i % 5]
+        kw["indel_storm"] = (2 + (7 * i) % 23, *STORM_SIZES[i % len(STORM_SIZES)])
+        if i % 6 == 5:
+            kw["tandem_gene"] = 1
+        if i % 9 == 7:
+            kw["median_contigs"], kw["force_split"] = 150, True
+        return kw
     kw["sub_rate"] = [None, 0.0, 0.01, 0.03, 0.06, 0.09, 0.12, None][i % 8]
     if i % 5 == 1:
         kw["indel_rate"] = 2e-3

@@ -1155,7 +1155,8 @@ def test_config4_acinetobacter_at_full_size(oracle):
 def test_parity_sweep_at_full_size(oracle):
     """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 128: BASELINE configs 2/3 -- 5 Mbp, K
     and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
-    second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v4): the device's hit tables equal the oracle's record for record and its report rows equal the
+    second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v4), and as
+    many small assemblies whose locus copy carries 2-24 insertions / deletions of 1-520 bases anywhere ("storm"): the device's hit tables equal the oracle's record for record and its report rows equal the
     host reduction's byte for byte, for every assembly and database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
     import json
     import multiprocessing as mp
@@ -1168,7 +1169,7 @@ def test_parity_sweep_at_full_size(oracle):
     per_batch = int(os.environ.get("KAPTIVE_AMD_SWEEP_BATCH", "64"))  # (1024 x 5 Mbp: batch-wide base positions beyond 2^32)
     summary = {}
     with mp.get_context("spawn").Pool(min(16, max(2, (os.cpu_count() or 2) // 2))) as pool:
-        for config in S.CONFIGS:
+        for config in os.environ.get("KAPTIVE_AMD_SWEEP_CONFIGS", ",".join(S.CONFIGS)).split(","):
             jobs = [(config, i) for i in range(n)]
             pending = pool.map_async(S.oracle_hits, jobs, chunksize=1)
             made = [S.make(config, i) for i in range(n)]
