@@ -65,6 +65,12 @@ KP_API int kp_ctx_set_option(kp_ctx *ctx, const char *name, int64_t value);
  * For callers that stream shards: kp_batch_create_async only overlaps with device work when `words` is page-locked. */
 KP_API int kp_host_alloc(size_t bytes, void **out);
 KP_API void kp_host_free(void *p);
+/* The same in two steps, for a caller whose own threads fill the block: kp_host_reserve hands out plain anonymous
+ * memory (2 MB-aligned, advised to use huge pages; no call into the device runtime, so it works -- and costs nothing --
+ * before a context exists), kp_host_lock page-locks it once it has been written (2 ms per GB of touched huge pages;
+ * untouched pages are faulted in by the lock itself, on the calling thread).  kp_host_free takes either state. */
+KP_API int kp_host_reserve(size_t bytes, void **out);
+KP_API int kp_host_lock(void *p);
 /* Page-locked bytes this process currently holds through the library: kp_host_alloc blocks plus the table staging of
  * the contexts' input buffers.  (What a rank pins matters when eight of them share one host.) */
 KP_API int64_t kp_host_pinned_bytes(void);

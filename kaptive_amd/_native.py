@@ -34,7 +34,7 @@ JOIN_DTYPE = np.dtype(
 
 EXPORTS = (
     "kp_ctx_create", "kp_ctx_destroy", "kp_last_error", "kp_ctx_stream", "kp_ctx_set_option", "kp_host_alloc",
-    "kp_host_free", "kp_host_pinned_bytes", "kp_device_allocations", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
+    "kp_host_free", "kp_host_reserve", "kp_host_lock", "kp_host_pinned_bytes", "kp_device_allocations", "kp_db_load", "kp_db_n_postings", "kp_batch_create", "kp_batch_create_async",
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_set_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
@@ -544,6 +544,8 @@ def lib() -> C.CDLL:
                 h.kp_host_free.restype = None
                 h.kp_host_free.argtypes = [C.c_void_p]
                 h.kp_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+                h.kp_host_reserve.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+                h.kp_host_lock.argtypes = [C.c_void_p]
                 _lib = h
     return _lib
 
@@ -892,17 +894,28 @@ def device_allocations() -> int:
 
 
 class PinnedBuffer:
-    """Page-locked host memory (kp_host_alloc) exposed as a numpy array; freed by ``close`` / garbage collection."""
+    """Page-locked host memory (kp_host_alloc) exposed as a numpy array; freed by ``close`` / garbage collection.
+    ``lazy``: plain huge-page memory for now (kp_host_reserve: no call into the device runtime), page-locked by ``lock()``
+    once the caller's threads have filled it -- the first touch is then theirs, spread over as many threads as they are,
+    and the lock itself takes 2 ms per GB."""
 
-    def __init__(self, n_items: int, dtype=np.uint32) -> None:
+    def __init__(self, n_items: int, dtype=np.uint32, lazy: bool = False) -> None:
         self._p = C.c_void_p()
         dt = np.dtype(dtype)
         nbytes = max(1, int(n_items) * dt.itemsize)
-        rc = lib().kp_host_alloc(C.c_size_t(nbytes), C.byref(self._p))
+        self.locked = not lazy
+        rc = (lib().kp_host_reserve if lazy else lib().kp_host_alloc)(C.c_size_t(nbytes), C.byref(self._p))
         if rc != 0:
             raise NativeError(f"kp_host_alloc failed ({rc}): {lib().kp_last_error(None).decode()}")
         buf = (C.c_uint8 * nbytes).from_address(self._p.value)
         self.array = np.frombuffer(buf, dtype=dt, count=int(n_items))
+
+    def lock(self) -> None:
+        if not self.locked:
+            rc = lib().kp_host_lock(self._p)
+            if rc != 0:
+                raise NativeError(f"kp_host_lock failed ({rc}): {lib().kp_last_error(None).decode()}")
+            self.locked = True
 
     def close(self) -> None:
         if getattr(self, "_p", None) and self._p.value:

@@ -21,6 +21,7 @@ from pathlib import Path
 import numpy as np
 
 FILE_SUFFIX = "kaptive_results"
+_KEEP: list = []  # FAST_EXIT: what must not be finalised one object at a time on the way out
 FAST_EXIT = False  # set by __main__: the process ends right after main() returns, so nothing needs to be torn down in order
 
 
@@ -172,27 +173,39 @@ class _TypingPipeline:
         # assemblies/s -- a cgroup throttles what oversubscribes its quota)
         self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
+        # whole chunks (TSV-only runs) are parsed PREFETCH + 1 at a time, each by shard_threads native threads, in input order
+        self.shard_readers = ThreadPoolExecutor(max_workers=self.PREFETCH + 1)
         self.formatters = ThreadPoolExecutor(max_workers=2)  # a chunk's rows and JSON lines, beside the driving thread
         self.copiers = ThreadPoolExecutor(max_workers=min(4, self.threads))  # object mode: copies into pinned memory (not queued behind reads)
+        self.janitor = ThreadPoolExecutor(max_workers=1)  # gives page-locked buffers back to the system while the run goes on
         self._pins: list = []  # recycled page-locked buffers
         self._pin_lock = threading.Lock()
+        self._pin_need = 0  # the largest buffer asked for so far: smaller ones are not worth keeping
+        self._unread = 0  # chunks that have not been handed to the readers yet
         self._early: list = []
         self._order: list = []
         if chunks is not None:
             chunks = list(chunks)
-            for k, paths in chunks[: self.PREFETCH + 1]:
+            # The readers start before the database is loaded and the device context exists (0.4-1 s), and they keep going for
+            # as long as the read-ahead budget lasts: the words land in plain huge-page memory (kp_host_reserve: no device
+            # runtime involved) that is page-locked when its batch is created.  A run is then as long as reading its files
+            # takes, plus what the last chunk needs on the device.
+            budget, ahead, sizes = _read_ahead_bytes() // max(1, getattr(args, "read_ahead_share", 1)), 0, {}
+            for n, (k, paths) in enumerate(chunks):
+                if n >= self.PREFETCH + 1:
+                    if self.objects or any(str(p).endswith((".gz", ".bz2", ".xz")) for p in paths):
+                        break  # (texts are kept / sizes unknown: no deeper than the steady state reads ahead)
+                    try:
+                        for p in paths:
+                            if p not in sizes:
+                                sizes[p] = os.stat(p).st_size
+                    except OSError:
+                        break
+                    ahead += int(sum(sizes[p] for p in paths) * 0.3)  # 2 bits per base and the tables, with head-room
+                    if ahead > budget:
+                        break
                 self._early.append((k, self.submit_read(paths)))
-            # page-locking a chunk's buffer takes as long as parsing the chunk; the buffers of the full-size chunks are locked
-            # now, beside the database load and the context creation, instead of in the way of the first large chunks
-            if not self.objects and len(chunks) > self.PREFETCH + 1:
-                biggest = max(chunks[self.PREFETCH + 1 :], key=lambda c: len(c[1]))[1]
-                try:
-                    if not any(str(p).endswith((".gz", ".bz2", ".xz")) for p in biggest):
-                        n_words = int(sum(os.stat(p).st_size for p in biggest) / 16 * 1.02) + 64 * len(biggest)
-                        for _ in range(min(self.PREFETCH + 2, len(chunks) - (self.PREFETCH + 1))):
-                            self.readers.submit(self._prepin, n_words)
-                except OSError:
-                    pass
+            self._unread = len(chunks) - len(self._early)
         self._own_typer = typer is None
         if typer is None:
             self.db = load_database(args.database)
@@ -214,21 +227,32 @@ class _TypingPipeline:
         try:
             batch.upload_wait()
         finally:
-            with self._pin_lock:
+            self._give_back(pb)
+
+    def _give_back(self, pb) -> None:
+        """A buffer whose upload is through: kept for one of the chunks still to be read (if it is large enough for
+        them), otherwise unlocked and unmapped now, beside the run, rather than by the exiting process (30 ms per 0.8 GB
+        either way, but the exit is on the command's clock)."""
+        with self._pin_lock:
+            if len(pb.array) >= self._pin_need and len(self._pins) < min(self.PREFETCH + 2, self._unread + self.PREFETCH + 1):
                 self._pins.append(pb)
+                return
+        try:
+            self.janitor.submit(pb.close)
+        except RuntimeError:  # (shut down already: the process is ending)
+            pass
 
     def submit_read(self, paths):
         """One chunk to the reader threads: a future of ``_load_shard`` (TSV / PHA4GE only) or a list of ``_load`` futures."""
         if self.objects:
             return [self.readers.submit(self._load, p) for p in paths]
-        return self.readers.submit(self._load_shard, paths)
+        return self.shard_readers.submit(self._load_shard, paths)
 
     def close(self, fast: bool = False) -> None:
         """``fast``: the process is about to exit (the command line): reads are cancelled, nothing is waited for or freed --
         the operating system takes the page-locked memory and the device context back faster than the runtime unwinds them."""
-        self.readers.shutdown(wait=not fast, cancel_futures=True)
-        self.copiers.shutdown(wait=not fast, cancel_futures=True)
-        self.formatters.shutdown(wait=not fast, cancel_futures=True)
+        for pool in (self.readers, self.shard_readers, self.copiers, self.formatters, self.janitor):
+            pool.shutdown(wait=not fast, cancel_futures=True)
         if fast:
             return
         if self._own_typer and self.typer._engine is not None:
@@ -277,27 +301,17 @@ class _TypingPipeline:
     def _pinned(self, n_words: int):
         from kaptive_amd import _native
 
-        small = None
         with self._pin_lock:  # (reader threads take buffers, the driving thread gives them back)
+            self._pin_need = max(self._pin_need, n_words)
             for i, pb in enumerate(self._pins):
                 if len(pb.array) >= n_words:
                     return self._pins.pop(i)
-            if len(self._pins) > 2 * (self.PREFETCH + 2):  # the small buffers of the first chunks do not stay page-locked for the whole run
-                small = self._pins.pop(0)
-        if small is not None:
-            small.close()
-        return _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
-
-    def _prepin(self, n_words: int) -> None:
-        from kaptive_amd import _native
-
-        pb = _native.PinnedBuffer(n_words + n_words // 8, np.uint32)
-        with self._pin_lock:
-            self._pins.append(pb)
+        return _native.PinnedBuffer(n_words + n_words // 8, np.uint32, lazy=True)  # page-locked in _make_batch, once it is full
 
     def _make_batch(self, genomes):
         if isinstance(genomes, tuple):  # ((tables, words, pinned buffer), ids) of _load_shard
             tables, total, pb = genomes[0]
+            pb.lock()
             batch = self.engine.ctx.batch(None, pinned_words=pb.array[:total], tables=tables)
             batch._pin = pb
             return batch
@@ -310,6 +324,7 @@ class _TypingPipeline:
             pb.array[offs[i] : offs[i + 1]] = packed[i].words
 
         list(self.copiers.map(copy, range(len(packed))))  # (numpy copies of this size run without the interpreter lock; an executor of their own: the readers' queue holds the next chunks' files)
+        pb.lock()
         batch = self.engine.ctx.batch(packed, pinned_words=pb.array[: int(offs[-1])])
         batch._pin = pb
         return batch
@@ -355,8 +370,7 @@ class _TypingPipeline:
             pb, batch._pin = getattr(batch, "_pin", None), None
             batch.close()  # (waits for whatever of the batch is still in flight: the pinned words are free after it)
             if pb is not None:
-                with self._pin_lock:
-                    self._pins.append(pb)
+                self._give_back(pb)
             rendering.append(self.formatters.submit(render, bt))
             while rendering and (rendering[0].done() or len(rendering) > 2):
                 yield self._order[done], rendering.popleft().result()
@@ -388,6 +402,7 @@ class _ChunkSource:
             k, paths = next(self.it)
         except StopIteration:
             return False
+        self.pipe._unread -= 1
         self.reading.append((k, self.pipe.submit_read(paths)))
         return True
 
@@ -420,6 +435,30 @@ class _ChunkSource:
         if prev is not None:
             pipe.release_pin(prev)
         return batch, ids, genomes if pipe.objects else None
+
+
+def _read_ahead_bytes() -> int:
+    """How much packed input the readers may hold before the device has taken any (KAPTIVE_AMD_READ_AHEAD_GB; default: a
+    quarter of what the machine / the cgroup has available, at most 12 GB)."""
+    if v := os.environ.get("KAPTIVE_AMD_READ_AHEAD_GB"):
+        return int(float(v) * 2**30)
+    avail = 64 * 2**30
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+                    break
+        for name in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            if os.path.exists(name):
+                with open(name) as f:
+                    text = f.read().strip()
+                if text.isdigit():
+                    avail = min(avail, int(text))
+                break
+    except (OSError, ValueError):
+        pass
+    return min(12 * 2**30, avail // 4)
 
 
 def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) -> None:
@@ -523,6 +562,8 @@ def run_type(args: argparse.Namespace) -> int:
             finally:
                 phases = {name: round(t - t_start, 3) for name, t in pipe.marks.items()}
                 pipe.close(fast=FAST_EXIT)
+                if FAST_EXIT:
+                    _KEEP.append(pipe)  # (its buffers and its context leave with the process, not through their destructors)
         else:
             # chunk k goes to device k mod n; rows come back through pipes and are written in input order
             import multiprocessing as mp
@@ -533,6 +574,7 @@ def run_type(args: argparse.Namespace) -> int:
 
             # the device processes share the host: each gets its part of the reader-thread budget
             args.threads = max(1, (args.threads or usable_cpus()) // len(devices))
+            args.read_ahead_share = len(devices)  # ... and of the read-ahead memory
             for i, d in enumerate(devices):
                 parent, child = ctx.Pipe(duplex=False)
                 proc = ctx.Process(target=_device_worker, args=(args, d, chunks[i :: len(devices)], child), daemon=True)

@@ -1297,6 +1297,28 @@ def test_async_upload_from_pinned_memory_and_shared_device_words(ctx, oracle, sm
     _same_records(hits, hits2, "second context on the same device words")
     for i, pa in enumerate(packed):
         _same_records(hits[off[i] : off[i + 1]], odb.align(pa), asms[i].id)
+    # the same words from a block that was reserved as plain huge-page memory, filled, and only then page-locked
+    # (kp_host_reserve / kp_host_lock: what the command line's readers do before a context exists); large enough for the
+    # mapped kind of kp_host_alloc as well
+    lazy = _native.PinnedBuffer(3 << 20, np.uint32, lazy=True)
+    assert not lazy.locked and lazy.array.ctypes.data % (2 << 20) == 0
+    n = len(pin.array)
+    lazy.array[:n] = pin.array
+    before = _native.pinned_bytes()
+    lazy.lock()
+    lazy.lock()  # (idempotent)
+    assert _native.pinned_bytes() - before >= 12 << 20
+    big = _native.PinnedBuffer(3 << 20, np.uint32)  # eager: reserve + lock in one call
+    big.array[:n] = pin.array
+    for buf in (lazy, big):
+        again = ctx.batch(packed, pinned_words=buf.array[:n])
+        hits3, off3 = again.align()
+        assert np.array_equal(off, off3)
+        _same_records(hits, hits3, "words from a mapped block")
+        again.close()
+        held = _native.pinned_bytes()
+        buf.close()
+        assert held - _native.pinned_bytes() >= 12 << 20
     twin.close()
     other.close()
     up.close()

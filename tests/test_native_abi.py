@@ -52,3 +52,19 @@ def test_no_gpu_means_loud_failure():
     key, genome, *_ = load_case("k_plain1")
     with pytest.raises(_native.NativeError):
         Serotyper(load_db(key))(genome)
+
+
+def test_host_reserve_needs_no_device():
+    """kp_host_reserve hands out 2 MB-aligned anonymous memory without touching the device runtime (the command line's
+    readers fill such blocks before a context exists); kp_host_free takes a block that was never locked."""
+    import numpy as np
+
+    from kaptive_amd import _native
+
+    pb = _native.PinnedBuffer(1 << 20, np.uint32, lazy=True)
+    assert not pb.locked and pb.array.ctypes.data % (2 << 20) == 0 and len(pb.array) == 1 << 20
+    pb.array[:] = np.arange(1 << 20, dtype=np.uint32)
+    assert int(pb.array[-1]) == (1 << 20) - 1
+    assert _native.pinned_bytes() == 0  # nothing is page-locked yet
+    pb.close()
+    pb.close()
