@@ -1391,7 +1391,11 @@ def test_genes_beyond_the_packed_score_range(oracle):
             SeqRecord("indel", np.concatenate([pad(64), indel, pad(64)]).tobytes()),
             SeqRecord("n_run", np.concatenate([pad(10), with_n, pad(10), revcomp(small[1])]).tobytes()),
             SeqRecord("tail_only", huge[25_000:].tobytes()),
-            SeqRecord("head_only", np.concatenate([pad(5), revcomp(huge[:17_000])]).tobytes())]  # fmt: skip
+            SeqRecord("head_only", np.concatenate([pad(5), revcomp(huge[:17_000])]).tobytes()),
+            # ... and with insertions / deletions beyond a band's reach: joined alignments (kp-align v4) whose pieces are tasks
+            # of the 32-bit fill, three pieces over 20 000 rows and two over 41 000
+            SeqRecord("big_joined", np.concatenate([pad(40), big[:8000], big[8200:15_000], pad(90), big[15_000:], pad(40)]).tobytes()),
+            SeqRecord("huge_joined_rc", revcomp(np.concatenate([pad(40), huge[:22_000], huge[22_450:], pad(40)])).tobytes())]  # fmt: skip
     asm = GenomeAssembly("longer_genes", Sequences.from_records(recs))
     pa = asm.packed()
     batch = ctx.batch([pa, pa])
@@ -1399,6 +1403,10 @@ def test_genes_beyond_the_packed_score_range(oracle):
     want = odb.align(pa)
     for i in range(2):
         _same_records(hits[hoff[i] : hoff[i + 1]], want, "hits of genes beyond the packed range")
+    joins = odb.joins(pa)
+    assert sorted(joins["n_pieces"][(joins["piece"][:, :, 0] == 1).any(axis=1)].tolist()) == [2, 3], joins["n_pieces"]
+    for f in joins.dtype.names:
+        assert np.array_equal(np.sort(joins, order=["gs", "contig"])[f], np.sort(batch.joins(0), order=["gs", "contig"])[f]), f
     assert (want["score"] == 2 * 20_000).any() and want["score"].max() > 80_000 and (want["gene"] == 2).sum() >= 3 and (want["gene"] == 4).any()
     batch.close()
     too_long = Sequences.from_records([SeqRecord("g", random_dna(rng, _native.MAX_GENE_LEN + 1, 0.5).tobytes())])
