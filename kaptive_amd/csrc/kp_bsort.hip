@@ -372,13 +372,22 @@ __global__ __launch_bounds__(BS_THREADS) void kp_anchor_bsort_kernel(const uint6
 size_t kp_bsort_lds_bytes(uint32_t n_bins) { return (size_t)n_bins * sizeof(uint32_t); }
 
 // The bucket counters are dynamic LDS on top of ~19 KB of static LDS (s_tile, s_big, s_part, s_huge, s_off); gfx950 has
-// 160 KB per CU.  BS_DYN_MAX = 128 KB of counters = 32768 values of the top key field = 16384 genes: the Kaptive-shaped
-// databases (a few thousand genes: 15-30 KB, three or more blocks per CU) are unaffected, a context that holds several
-// large databases at once runs one block per CU instead of falling back to the library's radix sort.
+// 160 KB per CU.  BS_DYN_MAX = 128 KB of counters = 32768 buckets.  The Kaptive-shaped databases (a few thousand genes:
+// 15-30 KB, three or more blocks per CU) have one bucket per value of the top key field (gene * 2 + strand); a context
+// with more than 16384 genes (several large databases at once) gets buckets of 2, 4 or 8 neighbouring values -- a bucket
+// is sorted on the whole key, so what it spans does not matter to the result -- and one block per CU.
 constexpr size_t BS_DYN_MAX = 128u * 1024u;
 
-// true when the bucket path can take a database with n_bins = 2 * genes values of the top key field
-bool kp_bsort_fits(uint32_t n_bins) { return n_bins > 0 && kp_bsort_lds_bytes(n_bins) <= BS_DYN_MAX; }
+// how many low bits of the top key field a bucket spans for a database with n_bins = 2 * genes values of it
+static uint32_t bucket_span_bits(uint32_t n_bins) {
+    uint32_t s = 0;
+    while (kp_bsort_lds_bytes((n_bins + (1u << s) - 1) >> s) > BS_DYN_MAX) ++s;
+    return s;
+}
+
+// true when the bucket path can take a database with n_bins = 2 * genes values of the top key field (always, up to
+// KP_MAX_GENES; the library's radix sort stays behind the `library_sort` option)
+bool kp_bsort_fits(uint32_t n_bins) { return n_bins > 0; }
 
 void kp_launch_anchor_bsort(const KpBatchView &b, const uint64_t *sliced, const uint32_t *sub_count, uint32_t sub_cap,
                             uint64_t *grouped, uint64_t *out, uint32_t *count, uint32_t *need, uint32_t n_bins,
@@ -395,6 +404,7 @@ void kp_launch_anchor_bsort(const KpBatchView &b, const uint64_t *sliced, const 
                                   (int)BS_DYN_MAX);
         raised.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kp_anchor_bsort_kernel, dim3(b.n_asm), dim3(BS_THREADS), kp_bsort_lds_bytes(n_bins), stream, sliced,
-                       sub_count, sub_cap, grouped, out, count, need, n_bins, kb.qb + kb.db);
+    const uint32_t span = bucket_span_bits(n_bins), n_buckets = (n_bins + (1u << span) - 1) >> span;
+    hipLaunchKernelGGL(kp_anchor_bsort_kernel, dim3(b.n_asm), dim3(BS_THREADS), kp_bsort_lds_bytes(n_buckets), stream, sliced,
+                       sub_count, sub_cap, grouped, out, count, need, n_buckets, kb.qb + kb.db + span);
 }

@@ -538,6 +538,35 @@ def test_seeds_at_contig_ends_n_runs_and_repeats_match_oracle(oracle):
     c.close()
 
 
+@pytest.mark.parametrize("n_loci", [800, 1500])
+def test_more_than_16384_genes_sort_in_wider_buckets(oracle, n_loci):
+    """More values of the gene/strand field than LDS holds counters for (32 768): a bucket then spans 2 (18 k genes) or 4
+    (34 k genes) neighbouring values and is sorted on the whole key as before -- the hand-written sort takes every
+    database up to KP_MAX_GENES; sorted anchors, tasks and hits equal the oracle's and the library path's."""
+    db = make_db("ab_k", seed=105, n_loci=n_loci)
+    assert len(db.genes) > (16_384 if n_loci == 800 else 32_768)
+    codes, goff = pack_sequences_flat(db.genes)
+    odb = oracle.OracleDB(codes, goff)
+    asms = [make_assembly(db, seed=3300 + i, locus=(n_loci - 1) * i, length=200_000, median_contigs=30, min_contig=200, force_split=True) for i in range(2)]
+    packed = [a.packed() for a in asms]
+    c = _native.Context(0)
+    c.load_genes(codes, goff)
+    batch = c.batch(packed)
+    hits, off = batch.align()
+    for i, pa in enumerate(packed):
+        assert np.array_equal(batch.anchors(i), odb.anchors(pa)), asms[i].id
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert len(hits) > 300 and hits["gene"].max() > len(db.genes) - 40  # (genes of the last locus: the top buckets)
+    c.set_option("library_sort", 1)
+    lib = c.batch(packed)
+    hits_lib, off_lib = lib.align()
+    assert np.array_equal(off, off_lib)
+    _same_records(hits, hits_lib, "wide buckets vs library sort")
+    for b in (batch, lib):
+        b.close()
+    c.close()
+
+
 def test_bucket_sort_and_library_sort_give_the_same_anchors(oracle):
     """kp_bsort.hip against rocPRIM's segmented radix sort (`library_sort`) and the oracle, on an assembly built to hit
     every bucket size class of the bucket sort: single anchors, a few (sorting network in one lane), tens (wave ranking),
