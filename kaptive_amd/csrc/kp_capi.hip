@@ -1014,7 +1014,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         // buckets of the gene/strand field, each sorted on its own (kp_bsort.hip); sorted keys end up where the chaining reads them
         kp_launch_anchor_bsort(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_anchors_a.p,
                                w->d_counts.p, w->d_counts.p + n_asm + KP_N_CLASSES, 2u * (uint32_t)ctx->n_genes, w->key_bits, stream);
-    } else {  // databases with more genes than the bucket counters hold in LDS (or `library_sort`): compaction + library sort
+    } else {  // `library_sort`: compaction + the library's segmented radix sort (tests compare the two)
         kp_launch_anchor_compact(b->view, w->d_anchors_a.p, w->d_sub_counts.p, sub_cap, w->d_anchors_b.p, w->d_counts.p,
                                  w->d_counts.p + n_asm + KP_N_CLASSES, stream);
         int rc = kp_sort_anchors(ctx, w->d_anchors_b.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, b->n_asm,

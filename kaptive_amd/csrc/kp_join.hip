@@ -6,8 +6,9 @@
 // this file puts the join on top of them (include/kp_spec.h, "kp-align v4", is the specification; oracle/kp_oracle.c
 // make_joins / join_run the CPU statement):
 //
-//   kp_join_chain_kernel   one lane per GROUP of provisional clusters (kp_chain.hip finds them): minimap2's chaining DP on
-//                          the accepted clusters, backtracking, one KpJoin per chain of two or more
+//   kp_join_chain_kernel   one wave per GROUP of provisional clusters (kp_chain.hip finds them): the lanes share the scan of
+//                          each cluster's anchors for its first and last one, lane 0 runs minimap2's chaining DP on the
+//                          accepted clusters and the backtracking: one KpJoin per chain of two or more
 //   kp_join_fill_kernel    P lanes per join (band of 4P diagonals, the mapping of kp_sw.hip's 32-bit kernel): the pieces one
 //                          after the other -- piece 0 as a local alignment, the later ones as CONTINUATIONS that only the
 //                          cross gaps from the piece before can enter; what a piece offers the next one (per row or per
