@@ -988,7 +988,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(2));  // [0] the streaming kernel's candidates (front), [1] the edge kernel's (back)
     KP_HIP_CHECK(ctx, w->d_ends.reserve(KP_N_CLASSES * (size_t)w->task_cap));
-    KP_HIP_CHECK(ctx, w->d_trace_top.reserve(2));  // [0] trace units handed out, [1] the fill kernel's quad counter
+    KP_HIP_CHECK(ctx, w->d_trace_top.reserve(4));  // [0] trace units handed out, [1..2] the fill kernel's quad counters (four 32-bit words)
     KP_HIP_CHECK(ctx, w->d_trace.reserve(w->trace_cap));
     KP_HIP_CHECK(ctx, w->d_groups.reserve(w->group_cap));
     KP_HIP_CHECK(ctx, w->d_joins.reserve(KP_N_CLASSES * (size_t)w->join_cap));
@@ -999,7 +999,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_sub_counts.p, 0, n_asm * KP_ANCHOR_SUBS * sizeof(uint32_t), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cand_count.p, 0, 2 * sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_order.p, 0, ORDER_HEAD * sizeof(uint32_t), stream));
-    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 2 * sizeof(unsigned long long), stream));
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_trace_top.p, 0, 4 * sizeof(unsigned long long), stream));
     KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_join_counts.p, 0, (1 + KP_N_CLASSES) * sizeof(uint32_t), stream));
     uint32_t *d_task_count = w->d_counts.p + n_asm;
     const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;

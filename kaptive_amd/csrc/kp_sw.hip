@@ -328,7 +328,7 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     // keep taking until it is exhausted: 32 per CU, twice what is resident, so the dispatcher always has a block to put
     // into a slot another kernel gives back, and the tail is as even as the last quads are short.  (One block per quad --
     // short-lived blocks, slots turning over every millisecond for other streams' kernels -- was measured too: 10.7 ms
-    // against 10.3 ms for this launch and 36.1 k against 37.5 k assemblies/s.)  Blocks of the wide classes stride.
+    // against 10.3 ms for this launch and 36.1 k against 37.5 k assemblies/s.)  The wide classes have counters of their own (kp_sw_kernel).
     auto take = [&]() -> uint32_t {
         uint32_t q = 0;
         if (lane == 0) q = atomicAdd(next_quad, 1u);
@@ -578,10 +578,11 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
     }
 }
 
-// One launch for all four band classes.  The wide classes hold few tasks but each of their waves runs a long step chain
-// (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of the grid and
-// run underneath the 16-diagonal class that fills the chip.
-constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class (they stride over their quads)
+// One launch for all four band classes.  On the headline workload the wide classes hold few tasks but each of their waves
+// runs a long step chain (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of
+// the grid and run underneath the 16-diagonal class that fills the chip.
+constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class at the front of the grid
+constexpr uint32_t HELP_BLOCKS = 3072;  // ... and behind the narrow class's blocks (as many as the chip holds waves of this kernel)
 #ifndef KP_SW_NARROW_BLOCKS_PER_CU
 #define KP_SW_NARROW_BLOCKS_PER_CU 32
 #endif
@@ -604,17 +605,24 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     for (uint32_t v = threadIdx.x; v < SPREAD_WORDS; v += 64)
         s_spread[v] = 3u * ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18));
     // (every use comes after the first chunk's barriers)
-    // class c (0..3 = 16/32/64/128 diagonals): tasks, order and results at c * task_cap, count at task_count[c]
-    const uint32_t blk = blockIdx.x;
-    const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : 0;
+    // class c (0..3 = 16/32/64/128 diagonals): tasks, order and results at c * task_cap, count at task_count[c].  Every class
+    // hands its quads out by a counter of its own (trace_top[1..2]: four 32-bit words, zeroed with trace_top before the
+    // launch).  The grid: WIDE_BLOCKS blocks per wide class first (they run underneath the narrow class), the narrow class's
+    // blocks, then HELP_BLOCKS more per wide class, widest first.  Those are dispatched as the narrow blocks retire and
+    // leave at once when their class has nothing left; on a workload rich in wide bands (diverged relatives with indels:
+    // `bench.py --background paralog`) they are what finishes the wide classes on the whole chip instead of on the 3 x 512
+    // wave slots of the first blocks -- that launch ran at 0.44 of its issue roof.  (A block that goes on to the next class
+    // itself, a loop around the four instantiations, costs 23 more VGPRs and 124 bytes of scratch per lane.)
+    const uint32_t blk = blockIdx.x, narrow_end = 3 * WIDE_BLOCKS + 256u * NARROW_BLOCKS_PER_CU;
+    const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : blk < narrow_end ? 0 : 3 - (int)((blk - narrow_end) / HELP_BLOCKS);
     const size_t off = (size_t)c * task_cap;
     uint32_t n = task_count[c];
     if (n > task_cap) n = task_cap;
-    unsigned int *next_quad = reinterpret_cast<unsigned int *>(trace_top + 1);  // zeroed with trace_top before the launch
-    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
-    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
-    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 2 * WIDE_BLOCKS, WIDE_BLOCKS, nullptr, s_prof, s_t, s_tw, s_spread);
-    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, blk - 3 * WIDE_BLOCKS, gridDim.x - 3 * WIDE_BLOCKS, next_quad, s_prof, s_t, s_tw, s_spread);
+    unsigned int *next_quad = reinterpret_cast<unsigned int *>(trace_top + 1) + c;
+    if (c == 3) sw_class<32>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, 0, 1, next_quad, s_prof, s_t, s_tw, s_spread);
+    else if (c == 2) sw_class<16>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, 0, 1, next_quad, s_prof, s_t, s_tw, s_spread);
+    else if (c == 1) sw_class<8>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, 0, 1, next_quad, s_prof, s_t, s_tw, s_spread);
+    else sw_class<4>(b, genes, tasks + off, n, order + off, ends + off, trace, trace_top, trace_cap, 0, 1, next_quad, s_prof, s_t, s_tw, s_spread);
 }
 
 
@@ -927,7 +935,7 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
                   uint32_t task_cap, const uint32_t *order, KpSwEnd *ends, void *trace, unsigned long long *trace_top,
                   uint64_t trace_cap_units, KpSwResult *results, bool has_long_genes, hipStream_t stream,
                   hipEvent_t after_fill) {
-    const dim3 grid(3 * WIDE_BLOCKS + 256u * NARROW_BLOCKS_PER_CU), block(64);
+    const dim3 grid(3 * WIDE_BLOCKS + 256u * NARROW_BLOCKS_PER_CU + 3 * HELP_BLOCKS), block(64);
     hipLaunchKernelGGL(kp_sw_kernel, grid, block, 0, stream, b, genes, tasks, task_count, task_cap, order, ends,
                        reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
     if (has_long_genes)  // (a database property: the Kaptive-shaped ones have none and never launch it)
