@@ -26,22 +26,25 @@ namespace {
 #define KP_CHAIN_WAVES 4
 #endif
 constexpr int CHAIN_SLICES = KP_CHAIN_SLICES;  // waves per assembly
-constexpr int CHAIN_WAVES = KP_CHAIN_WAVES;  // ... of which a block holds this many: they share one task stage, so that its 9.5 KB of LDS
-                                  // do not keep the CUs at half of the waves they could hold (the kernel is a chain of memory trips)
+constexpr int CHAIN_WAVES = KP_CHAIN_WAVES;  // ... of which a block holds this many: they share one task stage, so that its 22 KB of LDS
+                                  // do not keep the CUs at a fraction of the waves they could hold (the kernel is a chain of memory trips)
 static_assert(CHAIN_SLICES % CHAIN_WAVES == 0, "whole blocks");
 
 // Tasks are staged per block in LDS and appended to the global lists with one atomic per block and class: a batch
-// produces ~10^6 tasks for three counters, which would otherwise serialise on those three words.
-#ifndef KP_CHAIN_STAGE0
-#define KP_CHAIN_STAGE0 512
+// produces ~10^6 tasks for four counters, which would otherwise serialise on those words.  One stage for all classes
+// (an entry remembers its rank within its class): with a stage per class the wide classes had room for 32 tasks a block,
+// which a workload rich in wide bands -- diverged relatives with indels, `bench.py --background paralog` -- overflowed
+// into 0.8 M single appends per batch (kp_chain_kernel 4.2 ms instead of 0.7).
+#ifndef KP_CHAIN_STAGE
+#define KP_CHAIN_STAGE 640
 #endif
-constexpr int STAGE0 = KP_CHAIN_STAGE0, STAGE_REST = 32;  // staged tasks per block for the narrowest class / each wider class
+constexpr int STAGE = KP_CHAIN_STAGE;  // staged tasks per block (an assembly's ~1200-2100 tasks come from four blocks)
 
 struct TaskStage {
-    KpTask t0[STAGE0], rest[KP_N_CLASSES - 1][STAGE_REST];
+    KpTask t[STAGE];
+    uint16_t rank[STAGE];  // ... of the entry among the staged tasks of its class
+    uint32_t total;        // entries asked for (may exceed STAGE: the excess was appended directly)
     uint32_t n[KP_N_CLASSES], base[KP_N_CLASSES];
-    __device__ KpTask *list(int cls) { return cls == 0 ? t0 : rest[cls - 1]; }
-    __device__ static uint32_t room(int cls) { return cls == 0 ? STAGE0 : STAGE_REST; }
 };
 
 __constant__ uint8_t c_chain_pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
@@ -136,9 +139,10 @@ __device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w =
 
 __device__ __forceinline__ void emit_staged(const KpTask &t, KpTask *tasks, uint32_t *task_count, uint32_t task_cap, TaskStage &st) {
     const int cls = class_of_width(t.width);
-    const uint32_t s = atomicAdd(&st.n[cls], 1u);  // (the block's waves share the stage)
-    if (s < TaskStage::room(cls)) {
-        st.list(cls)[s] = t;
+    const uint32_t s = atomicAdd(&st.total, 1u);  // (the block's waves share the stage)
+    if (s < (uint32_t)STAGE) {
+        st.t[s] = t;
+        st.rank[s] = (uint16_t)atomicAdd(&st.n[cls], 1u);
         return;
     }
     const uint32_t slot = atomicAdd(&task_count[cls], 1u);  // stage full: append directly
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
         return l - 1;
     };
     if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) st.total = 0;
     jw.a_valid = 0; jw.a_slot = 0; jw.others = 0;
     jw.A.first = jw.A.cnt = jw.A.dmax = 0; jw.A.in_group = 0;
     jw.A.t.asm_id = 0; jw.A.t.gs = 0; jw.A.t.contig = 0; jw.A.t.lo = 0; jw.A.t.width = 16; jw.A.t.n_anchors = 0; jw.A.t.qspan = 0; jw.A.t.chain_score = 0;
@@ -384,19 +389,13 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
     if (lane == 0) pending_flush(jw, tasks, task_count, task_cap, st, go);
     }
     __syncthreads();
-    if (threadIdx.x < KP_N_CLASSES) {
-        const uint32_t room = TaskStage::room(threadIdx.x);
-        const uint32_t m = st.n[threadIdx.x] < room ? st.n[threadIdx.x] : room;
-        st.n[threadIdx.x] = m;
-        st.base[threadIdx.x] = m ? atomicAdd(&task_count[threadIdx.x], m) : 0u;
-    }
+    if (threadIdx.x < KP_N_CLASSES) st.base[threadIdx.x] = st.n[threadIdx.x] ? atomicAdd(&task_count[threadIdx.x], st.n[threadIdx.x]) : 0u;
     __syncthreads();
-    for (int cls = 0; cls < KP_N_CLASSES; ++cls) {
-        const KpTask *src = st.list(cls);
-        for (uint32_t i = threadIdx.x; i < st.n[cls]; i += 64 * CHAIN_WAVES) {
-            const uint32_t slot = st.base[cls] + i;
-            if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = src[i];
-        }
+    const uint32_t staged = min(st.total, (uint32_t)STAGE);
+    for (uint32_t i = threadIdx.x; i < staged; i += 64 * CHAIN_WAVES) {
+        const int cls = class_of_width(st.t[i].width);
+        const uint32_t slot = st.base[cls] + st.rank[i];
+        if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = st.t[i];
     }
 }
 
