@@ -8,7 +8,7 @@ import csv, glob, os, sys
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + f"/gpurun_out/ct_{sys.argv[1]}/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-    if n.startswith(("kp_chain", "kp_sw_kernel", "kp_occ", "kp_task", "kp_sw_trace", "kp_scan_dense")):
+    if n.startswith(("kp_chain", "kp_sw_kernel", "kp_occ", "kp_task", "kp_sw_trace", "kp_scan_dense", "kp_protein", "kp_hit_sort", "kp_reduce")):
         print(f"{sys.argv[1]:8s} {n:28s} avg {float(r['AverageNs'])/1e3:9.1f} us  max {float(r['MaxNs'])/1e3:9.1f}")
 PY
 done
