@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * DENSE_WAVES, KP_SCAN_WAVES_PER_SIMD) void kp_s
 }
 
 // ---- pass 1b: the seeds next to contig ends and N runs ---------------------------------------------------------------------
-// One thread per contig walks its clean stretches [S, E) (no ambiguous base) and runs kp_spec.h's state machine
+// Two threads per contig walk its clean stretches [S, E) (no ambiguous base) and run kp_spec.h's state machine
 // (kp_sketch.h) where kp_seed_is_interior says the streaming kernel must not decide: over the first bases of a stretch
 // from a fresh state (at a contig start that is mm_sketch's own start; after an N run every older entry has left the
 // window and the tracked minimum has been dropped by the time the stretch's first 15-mer is complete), and over its last
@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void kp_edge_kernel(KpBatchView b, KpSeedIndex
                                                        int32_t n_ctg_total) {
     const uint2 *g_filter = reinterpret_cast<const uint2 *>(idx.filter);
     const uint2 *g_filter2 = reinterpret_cast<const uint2 *>(idx.filter2);
-    const int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    // two threads per contig: the left flanks of its stretches (and stretches too short to have two) and the right flanks --
+    // the kernel is a chain of dependent steps per thread (2.0 ms per 1000 assemblies of 1500 contigs with one thread per contig)
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t c = (int32_t)(tid >> 1);
+    const int side = (int)(tid & 1);
     if (c >= n_ctg_total) return;
     const int a = upper_bound_i32(b.asm_first_ctg, b.n_asm + 1, c) - 1;  // the contig's assembly
     const int64_t asm_base = (int64_t)b.asm_word_off[a] << 4;
@@ -306,11 +310,12 @@ __global__ __launch_bounds__(256) void kp_edge_kernel(KpBatchView b, KpSeedIndex
             const int64_t stop = min(E + KP_W, ce);  // by then the tracked minimum has left the window
             const int64_t warm = E - (KP_K + KP_W) - 48;
             if (warm <= S) {
-                run(S, stop);
-            } else {
+                if (side == 0) run(S, stop);
+            } else if (side == 0) {
                 keep_right = false;
                 run(S, S + 2 * KP_W + KP_K);  // settles every position before S + KP_W (retired by step S + KP_W - 1 + KP_K - 1 + KP_W)
-                keep_right = true, keep_left = false;
+            } else {
+                keep_left = false;
                 run(warm, stop);
             }
         }
@@ -484,7 +489,7 @@ void kp_launch_scan(const KpBatchView &b, const KpSeedIndex &idx, uint64_t *cand
     else if (mode == 2) hipLaunchKernelGGL((kp_scan_dense_kernel<2>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
     else hipLaunchKernelGGL((kp_scan_dense_kernel<0>), grid, block, 0, stream, b, idx, cand, n_cand, cand_cap);
     if (mode == 0 && n_ctg_total > 0)
-        hipLaunchKernelGGL(kp_edge_kernel, dim3((unsigned)((n_ctg_total + 255) / 256)), dim3(256), 0, stream, b, idx, cand, n_cand,
+        hipLaunchKernelGGL(kp_edge_kernel, dim3((unsigned)((2 * (int64_t)n_ctg_total + 255) / 256)), dim3(256), 0, stream, b, idx, cand, n_cand,
                            cand_cap, n_ctg_total);
     if (after_scan) (void)hipEventRecord(after_scan, stream);
     hipLaunchKernelGGL(kp_expand_kernel, dim3(256 * 8), dim3(256), 0, stream, b, idx, cand, n_cand, cand_cap,
