@@ -97,7 +97,10 @@ __global__ __launch_bounds__(64) void kp_join_hits_kernel(KpBatchView b, const i
 // duplicate / mapq pass on neighbours of the sorted list (kp_same_span is an equivalence, so "equal to the last kept
 // hit" is "equal to the predecessor") with a block prefix sum for the compaction, then the mapping qualities per gene.  `raw` is scratch once the ranks are
 // known: the compacted list is built there and copied back.
-constexpr int SORT_THREADS = 256;
+#ifndef KP_SORT_THREADS
+#define KP_SORT_THREADS 1024
+#endif
+constexpr int SORT_THREADS = KP_SORT_THREADS;
 
 __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__restrict__ raw, const uint32_t *__restrict__ n_raw,
                                                                    uint32_t hit_cap, uint64_t *__restrict__ keys,
