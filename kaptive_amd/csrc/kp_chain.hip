@@ -409,7 +409,13 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
 // the exact counts of a block took turns, and an assembly with diverged relatives of database genes -- their anchors lie on
 // more than ten diagonals per gene, the certificate fails for thousands of genes -- ran this kernel in 0.75 ms instead of 0.13.
 // Anchors to drop become tombstones and the list is compacted at the end, which almost never happens.
-constexpr int OCC_WAVES = 16, OCC_BINS = 1024;
+#ifndef KP_OCC_WAVES
+#define KP_OCC_WAVES 16
+#endif
+#ifndef KP_OCC_BINS
+#define KP_OCC_BINS 1024
+#endif
+constexpr int OCC_WAVES = KP_OCC_WAVES, OCC_BINS = KP_OCC_BINS;
 constexpr uint64_t OCC_TOMB = ~0ull;
 
 __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_t *__restrict__ gene_len, uint64_t *__restrict__ keys,

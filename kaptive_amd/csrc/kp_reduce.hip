@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void kp_join_hits_kernel(KpBatchView b, const i
 // hit" is "equal to the predecessor") with a block prefix sum for the compaction, then the mapping qualities per gene.  `raw` is scratch once the ranks are
 // known: the compacted list is built there and copied back.
 #ifndef KP_SORT_THREADS
-#define KP_SORT_THREADS 1024
+#define KP_SORT_THREADS 256
 #endif
 constexpr int SORT_THREADS = KP_SORT_THREADS;
 

@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void kp_edge_kernel(KpBatchView b, KpSeedIndex
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t c = (int32_t)(tid >> 1);
     const int side = (int)(tid & 1);
+#ifdef KP_EDGE_ONE_THREAD
+    if (side == 1) return;
+#endif
     if (c >= n_ctg_total) return;
     const int a = upper_bound_i32(b.asm_first_ctg, b.n_asm + 1, c) - 1;  // the contig's assembly
     const int64_t asm_base = (int64_t)b.asm_word_off[a] << 4;
@@ -314,6 +317,10 @@ __global__ __launch_bounds__(256) void kp_edge_kernel(KpBatchView b, KpSeedIndex
             } else if (side == 0) {
                 keep_right = false;
                 run(S, S + 2 * KP_W + KP_K);  // settles every position before S + KP_W (retired by step S + KP_W - 1 + KP_K - 1 + KP_W)
+#ifdef KP_EDGE_ONE_THREAD
+                keep_right = true, keep_left = false;
+                run(warm, stop);
+#endif
             } else {
                 keep_left = false;
                 run(warm, stop);

@@ -582,7 +582,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 // runs a long step chain (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of
 // the grid and run underneath the 16-diagonal class that fills the chip.
 constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class at the front of the grid
-constexpr uint32_t HELP_BLOCKS = 3072;  // ... and behind the narrow class's blocks (as many as the chip holds waves of this kernel)
+#ifndef KP_SW_HELP_BLOCKS
+#define KP_SW_HELP_BLOCKS 3072
+#endif
+constexpr uint32_t HELP_BLOCKS = KP_SW_HELP_BLOCKS;  // ... and behind the narrow class's blocks (as many as the chip holds waves of this kernel)
 #ifndef KP_SW_NARROW_BLOCKS_PER_CU
 #define KP_SW_NARROW_BLOCKS_PER_CU 32
 #endif
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     // wave slots of the first blocks -- that launch ran at 0.44 of its issue roof.  (A block that goes on to the next class
     // itself, a loop around the four instantiations, costs 23 more VGPRs and 124 bytes of scratch per lane.)
     const uint32_t blk = blockIdx.x, narrow_end = 3 * WIDE_BLOCKS + 256u * NARROW_BLOCKS_PER_CU;
-    const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : blk < narrow_end ? 0 : 3 - (int)((blk - narrow_end) / HELP_BLOCKS);
+    const int c = blk < 3 * WIDE_BLOCKS ? 3 - (int)(blk / WIDE_BLOCKS) : blk < narrow_end ? 0 : 3 - (int)((blk - narrow_end) / (HELP_BLOCKS ? HELP_BLOCKS : 1u));
     const size_t off = (size_t)c * task_cap;
     uint32_t n = task_count[c];
     if (n > task_cap) n = task_cap;
