@@ -114,32 +114,69 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
     kp_hit *dst = hits + (size_t)a * hit_cap;
     uint64_t *k = keys + (size_t)a * hit_cap * 3;
     __shared__ uint64_t s_k0[SORT_LDS];  // leading key of every hit: almost every comparison is decided by it
+    __shared__ uint16_t s_ix[SORT_LDS];
     __shared__ uint32_t s_scan[SORT_THREADS];
     for (uint32_t i = tid; i < n; i += SORT_THREADS) {
         kp_hit_keys(src[i], k + 3 * (size_t)i);
         if (i < SORT_LDS) s_k0[i] = k[3 * (size_t)i];
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += SORT_THREADS) {  // rank sort: all lanes read the same key j -> LDS broadcast
-        // The leading key (gene, score, contig) decides almost every comparison, so the loop over the other hits only counts
-        // the smaller and the equal leading keys -- no branch, two compares and two adds per hit (with the tie test inside
-        // it the loop was 30 instructions per hit, most of them the scalar bookkeeping of a divergent branch, and the
-        // kernel's longest phase) -- and the rare hit that shares its leading key with another one settles its ties in a
-        // second loop by the full order.
+    if (n <= SORT_LDS) {
+        // Up to SORT_LDS hits (every assembly but constructed ones): a bitonic network in LDS on (leading key, index) pairs --
+        // the index makes the pairs distinct and the result the stable order by the leading key -- then every run of equal
+        // leading keys (rare and short: hits of one gene with the same score on the same contig) is ranked by the full
+        // order.  n log^2 n compare-exchanges; the rank sort this replaces (every hit against every other: n^2 pairs at eight
+        // instructions each) was 0.2 ms of the whole chip's vector issue per 1000 assemblies of 1000 hits and 0.7 ms at 1800.
+        uint32_t n2 = 64;
+        while (n2 < n) n2 <<= 1;
+        for (uint32_t i = tid; i < n2; i += SORT_THREADS) {
+            if (i >= n) s_k0[i] = ~0ull;
+            s_ix[i] = (uint16_t)i;
+        }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= n2; kk <<= 1) {
+            for (uint32_t j = kk >> 1; j >= 1; j >>= 1) {
+                for (uint32_t t = tid; t < n2 / 2; t += SORT_THREADS) {
+                    const uint32_t lo_i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo_i | j;  // the pair (i, i ^ j), i < i ^ j
+                    const bool asc = (lo_i & kk) == 0;
+                    const uint64_t a = s_k0[lo_i], c = s_k0[hi_i];
+                    const uint16_t ia = s_ix[lo_i], ic = s_ix[hi_i];
+                    const bool a_first = a < c || (a == c && ia < ic);
+                    if (a_first != asc) { s_k0[lo_i] = c; s_k0[hi_i] = a; s_ix[lo_i] = ic; s_ix[hi_i] = ia; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t p = tid; p < n; p += SORT_THREADS) {
+            const uint64_t m0 = s_k0[p];
+            const uint32_t i = s_ix[p];
+            uint32_t a = p, e = p + 1;  // the run of equal leading keys around p
+            while (a > 0 && s_k0[a - 1] == m0) --a;
+            while (e < n && s_k0[e] == m0) ++e;
+            uint32_t rank = 0;
+            if (e - a > 1) {
+                const uint64_t mine[3] = {m0, k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
+                const uint32_t seeds_mine = kp_hit_seeds_key(src[i]);
+                for (uint32_t q = a; q < e; ++q) {
+                    const uint32_t j = s_ix[q];
+                    if (j != i) rank += kp_keys_less(k + 3 * (size_t)j, kp_hit_seeds_key(src[j]), j, mine, seeds_mine, i) ? 1u : 0u;
+                }
+            }
+            dst[a + rank] = src[i];
+        }
+    } else
+    for (uint32_t i = tid; i < n; i += SORT_THREADS) {  // more hits than LDS holds keys for: rank sort, every hit against every other
         const uint64_t m0 = k[3 * (size_t)i];
         uint32_t rank = 0, equal = 0;
-        const uint32_t n_lds = n < SORT_LDS ? n : SORT_LDS;
         uint32_t j = 0;
-        for (; j + 8 <= n_lds; j += 8) {  // eight broadcast reads in flight, then the compares
+        for (; j + 8 <= (uint32_t)SORT_LDS; j += 8) {  // eight broadcast reads in flight, then the compares
             uint64_t o[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) o[u] = s_k0[j + u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { rank += o[u] < m0 ? 1u : 0u; equal += o[u] == m0 ? 1u : 0u; }
         }
-        for (; j < n_lds; ++j) { rank += s_k0[j] < m0 ? 1u : 0u; equal += s_k0[j] == m0 ? 1u : 0u; }
         for (; j < n; ++j) { const uint64_t other = k[3 * (size_t)j]; rank += other < m0 ? 1u : 0u; equal += other == m0 ? 1u : 0u; }
-        if (equal > 1) {  // (one is the hit itself)
+        if (equal > 1) {  // (one is the hit itself) ties on the leading key: settled by the full order
             const uint64_t mine[3] = {m0, k[3 * (size_t)i + 1], k[3 * (size_t)i + 2]};
             for (j = 0; j < n; ++j) {
                 const uint64_t other = j < SORT_LDS ? s_k0[j] : k[3 * (size_t)j];
