@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64) void kp_join_hits_kernel(KpBatchView b, const i
 }
 
 // ---- 2. emission order, duplicates, mapq (kp_spec.h) -------------------------------------------------------------------
-// One block per assembly: rank sort (leading keys in LDS, every thread counts the hits that precede its own), then the
+// One block per assembly: the hits sorted by their leading keys with a bitonic network in LDS, ties settled by the full
+// order (a rank sort -- every thread counts the hits that precede its own -- for more than SORT_LDS hits), then the
 // duplicate / mapq pass on neighbours of the sorted list (kp_same_span is an equivalence, so "equal to the last kept
 // hit" is "equal to the predecessor") with a block prefix sum for the compaction, then the mapping qualities per gene.  `raw` is scratch once the ranks are
 // known: the compacted list is built there and copied back.
