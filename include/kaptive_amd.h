@@ -358,6 +358,13 @@ typedef struct kp_json_columns { /* per assembly of the batch */
 KP_API int64_t kp_format_json(const kp_json_tables *tables, int32_t n_asm, const kp_asm_summary *summaries, const kp_kept *kept,
                               int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *columns,
                               char *out, int64_t cap);
+/* The per-assembly FASTA outputs (-l / -g / -p; src/kaptive/serotyping/cli.py:78-114: locus_seqs / gene_seqs /
+ * translations .to_fasta() per result) from the same tables: kind 0 = locus pieces, 1 = gene sequences, 2 = translations;
+ * `names` are RAW bytes -- for kind 0 the contig name of piece slot [a * piece_stride + p], for 1 and 2 the gene names by
+ * gene index --; the records of all assemblies back to back, asm_end[a] = end of assembly a's.  Returns the size needed. */
+KP_API int64_t kp_format_fasta(const kp_json_tables *tables, int32_t n_asm, const kp_asm_summary *summaries, const kp_kept *kept,
+                               int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *columns,
+                               int32_t kind, const char *names, const int64_t *name_off, char *out, int64_t cap, int64_t *asm_end);
 
 /* ---- protein alignment ------------------------------------------------------------------------------------------
  * Replaces PairwiseAligner.__call__ / _batched_banded_gotoh (src/kaptive/core/pairwise.py:255-325, 395-584) in its

@@ -39,7 +39,7 @@ EXPORTS = (
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_set_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
     "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
-    "kp_fasta_free", "kp_format_rows", "kp_format_json", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
+    "kp_fasta_free", "kp_format_rows", "kp_format_json", "kp_format_fasta", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
 
@@ -414,6 +414,7 @@ class JsonFormatter:
         from kaptive_amd.serotyping.jsonl import _str
 
         db = typer._db
+        self._typer_gene_ids = tuple(db.genes.ids)
         meta = db.metadata
         head = ("{" + f'"kaptive_version":{_str(kaptive_version)},"database_name":{_str(meta.name)},"database_version":{_str(meta.version)},'
                 f'"database_organism":{_str(meta.organism)},"database_taxon":{int(meta.taxon)},"genome":').encode("utf-8")
@@ -437,13 +438,12 @@ class JsonFormatter:
             char_map=_p(k["char"]).value, codon_map=_p(k["codon"]).value,
         )  # fmt: skip
 
-    def format(self, ids, phenotypes, sums, kept, pieces, best_locus, best_score, completeness, typeable, problems, identity,
-               coverage, discrepancy, genomes) -> bytes:
+    def _prepare(self, ids, phenotypes, sums, kept, pieces, best_locus, best_score, completeness, typeable, problems, identity,
+                 coverage, discrepancy, genomes) -> dict:
+        """The batch's columns as kp_json_columns (and everything that must stay alive while the library reads them)."""
         from kaptive_amd.serotyping.jsonl import _str
 
         n = len(sums)
-        if n == 0:
-            return b""
         sums, kept, pieces = np.ascontiguousarray(sums), np.ascontiguousarray(kept), np.ascontiguousarray(pieces)
         kstride = kept.shape[1] if kept.ndim == 2 else 0
         pstride = pieces.shape[1] if pieces.ndim == 2 else 0
@@ -451,6 +451,7 @@ class JsonFormatter:
         order = np.zeros((n, max(pstride, 1)), np.int32)
         order[:] = np.arange(max(pstride, 1), dtype=np.int32)[None, :]
         names = [b""] * (n * pstride)
+        raw_names = [b""] * (n * pstride)
         n_pieces = sums["n_pieces"]
         for a in np.flatnonzero(n_pieces > 0):
             m = int(n_pieces[a])
@@ -458,14 +459,16 @@ class JsonFormatter:
                 order[a, :m] = np.argsort(np.ascontiguousarray(pieces["mean_pos"][a, :m]))
             cids = genomes[a].contigs.ids
             for p_ in range(m):
-                names[a * pstride + p_] = _str(cids[int(pieces["contig"][a, p_])])[1:-1].encode("utf-8")
+                cid = cids[int(pieces["contig"][a, p_])]
+                names[a * pstride + p_] = _str(cid)[1:-1].encode("utf-8")
+                raw_names[a * pstride + p_] = cid.encode()
         ids_b, ids_o = _blob64([_str(x) for x in ids])
         ph_b, ph_o = _blob64([_str(x) for x in phenotypes])
         nm_b, nm_o = _blob64(names)
         seq_arrays = [np.ascontiguousarray(g.contigs.seqs, dtype=np.uint8) for g in genomes]
         off_arrays = [np.ascontiguousarray(g.contigs.offsets, dtype=np.int32) for g in genomes]
-        seq_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in seq_arrays])
-        off_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in off_arrays])
+        seq_ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in seq_arrays])
+        off_ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in off_arrays])
         cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
                     score=_c(best_score, np.float64), compl=_c(completeness, np.float64), identity=_c(identity, np.float64),
                     coverage=_c(coverage, np.float64), discrepancy=_c(discrepancy, np.float64), order=order)  # fmt: skip
@@ -475,18 +478,61 @@ class JsonFormatter:
                         coverage=_p(cols["coverage"]).value, length_discrepancy=_p(cols["discrepancy"]).value,
                         piece_order=_p(order).value, piece_ctg_names=_p(nm_b).value, piece_ctg_name_off=_p(nm_o).value,
                         ctg_seqs=C.cast(seq_ptrs, C.c_void_p).value, ctg_off=C.cast(off_ptrs, C.c_void_p).value)  # fmt: skip
+        return dict(n=n, sums=sums, kept=kept, pieces=pieces, kstride=kstride, pstride=pstride, c=c, raw_piece_names=raw_names,
+                    keep=(ids_b, ids_o, ph_b, ph_o, nm_b, nm_o, seq_arrays, off_arrays, seq_ptrs, off_ptrs, cols))
+
+    def format(self, *columns) -> bytes:
+        """``columns``: ids, phenotypes, sums, kept, pieces, best_locus, best_score, completeness, typeable, problems, identity,
+        coverage, length discrepancy, genomes (the attributes of a ``BatchTyping``)."""
+        if len(columns[2]) == 0:
+            return b""
+        q = self._prepare(*columns)
         h = lib()
         h.kp_format_json.restype = C.c_int64
-        out = np.empty(max(1 << 16, 80_000 * n), np.uint8)
+        out = np.empty(max(1 << 16, 80_000 * q["n"]), np.uint8)
         for _ in range(2):
-            need = h.kp_format_json(C.byref(self._tables), C.c_int32(n), _p(sums), _p(kept), C.c_int32(kstride), _p(pieces),
-                                    C.c_int32(pstride), C.byref(c), _p(out), C.c_int64(len(out)))
+            need = h.kp_format_json(C.byref(self._tables), C.c_int32(q["n"]), _p(q["sums"]), _p(q["kept"]), C.c_int32(q["kstride"]),
+                                    _p(q["pieces"]), C.c_int32(q["pstride"]), C.byref(q["c"]), _p(out), C.c_int64(len(out)))
             if need < 0:
                 raise ValueError(f"kp_format_json failed ({need})")
             if need <= len(out):
                 return out[:need].tobytes()
             out = np.empty(int(need), np.uint8)
         raise NativeError("kp_format_json: size kept changing")
+
+    def fasta(self, kinds, *columns) -> dict:
+        """Per-assembly FASTA bytes (kp_format_fasta) for every kind asked for -- "loci", "genes", "proteins": what
+        ``result.locus_seqs / gene_seqs / translations .to_fasta()`` give per result -- as ``{kind: [bytes per assembly]}``."""
+        n = len(columns[2])
+        if n == 0:
+            return {kind: [] for kind in kinds}
+        q = self._prepare(*columns)
+        if "gene_names_raw" not in self._keep:
+            self._keep["gene_names_raw"] = _blob64([x.encode() for x in self._typer_gene_ids])
+        piece_b, piece_o = _blob64(q["raw_piece_names"])
+        h = lib()
+        h.kp_format_fasta.restype = C.c_int64
+        out = {}
+        for kind in kinds:
+            code = {"loci": 0, "genes": 1, "proteins": 2}[kind]
+            nb, no = (piece_b, piece_o) if code == 0 else self._keep["gene_names_raw"]
+            ends = np.zeros(n, np.int64)
+            buf = np.empty(max(1 << 16, (40_000 if code < 2 else 12_000) * n), np.uint8)
+            for _ in range(2):
+                need = h.kp_format_fasta(C.byref(self._tables), C.c_int32(n), _p(q["sums"]), _p(q["kept"]), C.c_int32(q["kstride"]),
+                                         _p(q["pieces"]), C.c_int32(q["pstride"]), C.byref(q["c"]), C.c_int32(code), _p(nb), _p(no),
+                                         _p(buf), C.c_int64(len(buf)), _p(ends))
+                if need < 0:
+                    raise ValueError(f"kp_format_fasta failed ({need})")
+                if need <= len(buf):
+                    break
+                buf = np.empty(int(need), np.uint8)
+            else:
+                raise NativeError("kp_format_fasta: size kept changing")
+            blob = buf[:need].tobytes()
+            starts = np.concatenate([[0], ends[:-1]])
+            out[kind] = [blob[int(a):int(b)] for a, b in zip(starts, ends)]
+        return out
 
 
 class TypingParams(C.Structure):  # kp_typing_params

@@ -352,14 +352,13 @@ class _TypingPipeline:
                 out["pha4ge"] = bt.pha4ge()
             if getattr(args, "json", None):  # one native call per batch (kp_format_json): byte for byte result_to_json of every result
                 out["json"] = bt.jsonl()
-            if self.fasta_outputs:
-                results = bt.results()
-                for flag, attr, ext in (("loci", "locus_seqs", "fna"), ("genes", "gene_seqs", "ffn"), ("proteins", "translations", "faa")):
-                    if d := getattr(args, flag, None):
-                        d = Path(d)
-                        d.mkdir(parents=True, exist_ok=True)
-                        for r in results:
-                            (d / f"{r.genome}_{FILE_SUFFIX}.{ext}").write_bytes(getattr(r, attr).to_fasta())
+            if self.fasta_outputs:  # a file per assembly and kind, as the reference writes them; the records come per batch (kp_format_fasta)
+                wanted = {flag: (Path(d), ext) for flag, ext in (("loci", "fna"), ("genes", "ffn"), ("proteins", "faa")) if (d := getattr(args, flag, None))}
+                for flag, per_asm in bt.fasta(tuple(wanted)).items():
+                    d, ext = wanted[flag]
+                    d.mkdir(parents=True, exist_ok=True)
+                    for genome, blob in zip(bt.ids, per_asm):
+                        (d / f"{genome}_{FILE_SUFFIX}.{ext}").write_bytes(blob)
             return out
 
         # The rows of a chunk are rendered beside the driving thread (the native formatters release the interpreter lock: 35 MB

@@ -301,3 +301,64 @@ extern "C" int64_t kp_format_json(const kp_json_tables *t, int32_t n_asm, const 
     }
     return o.n;
 }
+
+// The per-assembly FASTA outputs of `kaptive assembly` (-l / -g / -p; reference: src/kaptive/serotyping/cli.py:78-114 writes
+// result.locus_seqs / gene_seqs / translations .to_fasta() to a file per assembly): the records of every assembly of the batch,
+// ">id\nsequence\n" each (Sequences.to_fasta, core/seq.py), back to back; asm_end[a] = where assembly a's records end.
+// kind 0: the locus pieces in the order of their mean positions, ids "<contig>_<start>_<end>_<strand>" (names[a * piece_stride
+// + p] = the piece's contig); 1: the kept genes' sequences; 2: their translations (frame (-q_start) mod 3, up to the first stop)
+// -- ids = names[gene] for both.  Names are raw bytes here (not JSON strings).
+extern "C" int64_t kp_format_fasta(const kp_json_tables *t, int32_t n_asm, const kp_asm_summary *sums, const kp_kept *kept,
+                                   int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *c,
+                                   int32_t kind, const char *names, const int64_t *name_off, char *out, int64_t cap, int64_t *asm_end) {
+    if (!t || !c || !names || !name_off || !asm_end || kind < 0 || kind > 2 || n_asm < 0 ||
+        (n_asm > 0 && (!sums || !kept || !pieces)) || cap < 0 || (cap > 0 && !out))
+        return KP_EINVAL;
+    Out o{out, cap};
+    for (int a = 0; a < n_asm; ++a) {
+        const kp_asm_summary &s = sums[a];
+        const kp_kept *k = kept + (size_t)a * (size_t)kept_stride;
+        const kp_piece *pc = pieces + (size_t)a * (size_t)piece_stride;
+        const int32_t *order = c->piece_order + (size_t)a * (size_t)piece_stride;
+        const uint8_t *seqs = c->ctg_seqs[a];
+        const int32_t *ctg_off = c->ctg_off[a];
+        if (kind == 0) {
+            for (int i = 0; i < s.n_pieces; ++i) {
+                const kp_piece &q = pc[order[i]];
+                const int64_t id = (int64_t)a * piece_stride + order[i];
+                o.put('>');
+                o.put(names + name_off[id], name_off[id + 1] - name_off[id]);
+                o.put('_'); o.num(q.start); o.put('_'); o.num(q.end); o.put('_'); o.num(q.strand);
+                o.put('\n');
+                put_extract(o, seqs, ctg_off[q.contig], q.start, q.end, q.strand, t->comp_map);
+                o.put('\n');
+            }
+        } else {
+            for (int i = 0; i < s.n_kept; ++i) {
+                if (!alive(k[i])) continue;
+                const kp_kept &h = k[i];
+                o.put('>');
+                o.put(names + name_off[h.gene], name_off[h.gene + 1] - name_off[h.gene]);
+                o.put('\n');
+                if (kind == 1) {
+                    put_extract(o, seqs, ctg_off[h.contig], h.t_start, h.t_end, h.strand, t->comp_map);
+                } else {
+                    const int len = h.t_end - h.t_start, frame = ((-h.q_start) % 3 + 3) % 3;
+                    const int64_t base = ctg_off[h.contig];
+                    for (int p = frame; p + 3 <= len; p += 3) {
+                        uint8_t b[3];
+                        for (int z = 0; z < 3; ++z)
+                            b[z] = h.strand >= 0 ? seqs[base + h.t_start + p + z] : t->comp_map[seqs[base + h.t_end - 1 - (p + z)]];
+                        const uint8_t aa = t->codon_map[t->char_map[b[0]] * 25 + t->char_map[b[1]] * 5 + t->char_map[b[2]]];
+                        if (aa == 42) break;
+                        o.put((char)aa);
+                    }
+                }
+                o.put('\n');
+            }
+        }
+        asm_end[a] = o.n;
+    }
+    return o.n;
+}
+

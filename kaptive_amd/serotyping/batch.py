@@ -223,14 +223,27 @@ class BatchTyping:
         src/kaptive/serotyping/cli.py:67-76) without an object per assembly (kp_format_json)."""
         if self.genomes is None:
             raise ValueError("JSON lines carry the extracted sequences: the batch needs its genomes")
+        return self._formatter().format(self.ids, self.phenotype, self.sums, self.kept, self.pieces, self.best_locus, self.best_score,
+                          self.completeness, self.typeable, self.problems, self.percent_identity, self.percent_coverage,
+                                        self.length_discrepancy, self.genomes)  # fmt: skip
+
+    def _formatter(self):
         fmt = getattr(self.typer, "_json_formatter", None)
         if fmt is None:
             from kaptive_amd import KAPTIVE_COMPAT_VERSION, _native
 
             fmt = self.typer._json_formatter = _native.JsonFormatter(self.typer, KAPTIVE_COMPAT_VERSION)
-        return fmt.format(self.ids, self.phenotype, self.sums, self.kept, self.pieces, self.best_locus, self.best_score,
-                          self.completeness, self.typeable, self.problems, self.percent_identity, self.percent_coverage,
-                          self.length_discrepancy, self.genomes)  # fmt: skip
+        return fmt
+
+    def fasta(self, kinds=("loci", "genes", "proteins")) -> dict:
+        """``{kind: [bytes per assembly]}``: what ``result(i).locus_seqs / gene_seqs / translations .to_fasta()`` give -- the
+        per-assembly files of ``-l / -g / -p`` (reference: src/kaptive/serotyping/cli.py:78-114) -- without an object per
+        assembly (kp_format_fasta; ``genomes`` must have been given)."""
+        if self.genomes is None:
+            raise ValueError("the extracted sequences need the genomes' text: the batch was made without its genomes")
+        return self._formatter().fasta(tuple(kinds), self.ids, self.phenotype, self.sums, self.kept, self.pieces, self.best_locus,
+                                       self.best_score, self.completeness, self.typeable, self.problems, self.percent_identity,
+                                       self.percent_coverage, self.length_discrepancy, self.genomes)  # fmt: skip
 
     def pha4ge(self) -> bytes:
         """The PHA4GE lines of the whole batch (``--pha4ge``), from the batch's columns: byte for byte what

@@ -1084,6 +1084,17 @@ def test_cli_tsv_fast_path_equals_the_per_result_path_and_device_processes(tmp_p
     assert main(["assembly", str(db_path), *paths, "-o", str(tmp_path / "s3.tsv"), "-j", str(tmp_path / "r3.jsonl"), "-g", str(tmp_path / "genes3"),
                  "--batch-size", "4"]) == 0  # fmt: skip
     assert (tmp_path / "r3.jsonl").read_bytes() == (tmp_path / "r.jsonl").read_bytes()
+    # -l / -g / -p: a file per assembly and kind, their records made per batch (kp_format_fasta): the bytes of the result
+    # objects' locus_seqs / gene_seqs / translations .to_fasta()
+    from kaptive_amd.cli import FILE_SUFFIX
+
+    assert main(["assembly", str(db_path), *paths, "-o", str(tmp_path / "s4.tsv"), "-l", str(tmp_path / "loci4"), "-g", str(tmp_path / "genes4"),
+                 "-p", str(tmp_path / "prot4"), "--batch-size", "3"]) == 0  # fmt: skip
+    assert (tmp_path / "s4.tsv").read_bytes() == (tmp_path / "s3.tsv").read_bytes()
+    for r in everyone:
+        for d, ext, seqs in (("loci4", "fna", r.locus_seqs), ("genes4", "ffn", r.gene_seqs), ("prot4", "faa", r.translations)):
+            assert (tmp_path / d / f"{r.genome}_{FILE_SUFFIX}.{ext}").read_bytes() == seqs.to_fasta(), (r.genome, ext)
+    assert (tmp_path / "genes3" / f"{everyone[0].genome}_{FILE_SUFFIX}.ffn").read_bytes() == everyone[0].gene_seqs.to_fasta()
 
 
 # ---- BASELINE.json configs at their real shape --------------------------------------------------------------------------

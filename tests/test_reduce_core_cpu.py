@@ -183,6 +183,26 @@ def test_native_json_lines_equal_the_python_serialiser(key, oracle):
         assert bytes(KaptiveRow.from_result(back)) == bytes(KaptiveRow.from_result(res))
 
 
+@pytest.mark.parametrize("key", ["k", "o", "kfull", "abfull"])
+def test_native_fasta_records_equal_the_result_objects(key, oracle):
+    """``BatchTyping.fasta()`` (kp_format_fasta: one native call per batch and kind) gives, per assembly, the bytes of
+    ``result(i).locus_seqs / gene_seqs / translations .to_fasta()`` -- what ``-l / -g / -p`` write per assembly (reference:
+    src/kaptive/serotyping/cli.py:78-114) -- for every golden case."""
+    names = [n for n in case_names() if not n.startswith("k_divergent_") and load_case(n)[0] == key]
+    typer, genomes, exps, bt = _batch_from_cases(names, oracle)
+    got = bt.fasta()
+    assert set(got) == {"loci", "genes", "proteins"} and all(len(v) == len(names) for v in got.values())
+    n_records = 0
+    for i, name in enumerate(names):
+        res = bt.result(i)
+        for kind, attr in (("loci", "locus_seqs"), ("genes", "gene_seqs"), ("proteins", "translations")):
+            want = getattr(res, attr).to_fasta()
+            assert got[kind][i] == want, (name, kind, got[kind][i][:120], want[:120])
+            n_records += want.count(b">")
+    assert n_records > 20 * len(names)
+    assert bt.fasta(("genes",)).keys() == {"genes"}
+
+
 def test_native_json_number_layout():
     """The number layouts of kp_format_json against jsonl.py's: float64 and float32 values across the switch points of Ryu's
     format (16 / 13 digits to the right, 5 / 6 zeros to the left), NaN, infinities, zeros, through a one-hit batch."""

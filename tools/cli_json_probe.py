@@ -18,7 +18,7 @@ def main():
         with Pool(16) as pool: pool.map(one, [(i, str(root)) for i in range(96)])
         paths = sorted(str(p) for p in root.glob("asm*.fasta")) * 48
         env = dict(os.environ, PYTHONPATH=str(ROOT), KAPTIVE_AMD_CLI_TIMING=str(root / "t.json"))
-        for extra in (["-j", str(root / "o.jsonl")], ["--pha4ge", str(root / "o.pha4ge")]):
+        for extra in (["-j", str(root / "o.jsonl")], ["--pha4ge", str(root / "o.pha4ge")], ["-g", str(root / "genes"), "-p", str(root / "prot"), "-l", str(root / "loci")]):
             t = time.perf_counter()
             r = subprocess.run([sys.executable, "-m", "kaptive_amd", "assembly", str(db), *paths, "-o", str(root / "o.tsv"), *extra], env=env, capture_output=True, text=True)
             wall = time.perf_counter() - t
