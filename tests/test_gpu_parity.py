@@ -538,6 +538,33 @@ def test_seeds_at_contig_ends_n_runs_and_repeats_match_oracle(oracle):
     c.close()
 
 
+def test_batches_whose_tasks_are_mostly_wide_match_oracle(oracle):
+    """Locus copies with an insertion or deletion every ~60 bases: nearly every cluster spans more than 16 diagonals, so the
+    32- to 128-diagonal classes hold most of the batch's tasks and outlast the narrow class in the fill launch -- the blocks
+    behind the narrow class's (kp_sw_kernel's helper blocks) and the one task stage per block of kp_chain_kernel do real
+    work here, which they do not on the other tests' inputs.  Tasks and hits equal the oracle's."""
+    db = make_db("kpsc_k", seed=100)
+    odb = oracle.OracleDB(*pack_sequences_flat(db.genes))
+    asms = [make_assembly(db, seed=8100 + i, length=120_000, median_contigs=4, min_contig=200, indel_rate=0.016, sub_rate=0.01 * (i % 4), p_is=0.0)
+            for i in range(16)]
+    packed = [a.packed() for a in asms]
+    c = _native.Context(0)
+    c.load_genes(*pack_sequences_flat(db.genes))
+    batch = c.batch(packed)
+    hits, off = batch.align()
+    wide = narrow = 0
+    for i in range(0, len(packed), 4):
+        want_t = np.sort(odb.tasks(packed[i]), order=list(_native.TASK_DTYPE.names))
+        _same_records(np.sort(batch.tasks(i), order=list(_native.TASK_DTYPE.names)), want_t, f"tasks of {asms[i].id}")
+        wide += int((want_t["width"] > 16).sum())
+        narrow += int((want_t["width"] == 16).sum())
+    for i, pa in enumerate(packed):
+        _same_records(hits[off[i] : off[i + 1]], odb.align(pa), f"hits of {asms[i].id}")
+    assert wide > 2 * narrow, (wide, narrow)
+    batch.close()
+    c.close()
+
+
 @pytest.mark.parametrize("n_loci", [800, 1500])
 def test_more_than_16384_genes_sort_in_wider_buckets(oracle, n_loci):
     """More values of the gene/strand field than LDS holds counters for (32 768): a bucket then spans 2 (18 k genes) or 4
