@@ -308,10 +308,23 @@ class _TypingPipeline:
                     return self._pins.pop(i)
         return _native.PinnedBuffer(n_words + n_words // 8, np.uint32, lazy=True)  # page-locked in _make_batch, once it is full
 
+    def _locked(self, pb, n_words: int):
+        """``pb`` page-locked -- or, on a host that refuses to register it, a block of the runtime's own with the same words."""
+        from kaptive_amd import _native
+
+        try:
+            pb.lock()
+            return pb
+        except _native.NativeError:
+            eager = _native.PinnedBuffer(len(pb.array), np.uint32)
+            eager.array[:n_words] = pb.array[:n_words]
+            pb.close()
+            return eager
+
     def _make_batch(self, genomes):
         if isinstance(genomes, tuple):  # ((tables, words, pinned buffer), ids) of _load_shard
             tables, total, pb = genomes[0]
-            pb.lock()
+            pb = self._locked(pb, total)
             batch = self.engine.ctx.batch(None, pinned_words=pb.array[:total], tables=tables)
             batch._pin = pb
             return batch
@@ -324,7 +337,7 @@ class _TypingPipeline:
             pb.array[offs[i] : offs[i + 1]] = packed[i].words
 
         list(self.copiers.map(copy, range(len(packed))))  # (numpy copies of this size run without the interpreter lock; an executor of their own: the readers' queue holds the next chunks' files)
-        pb.lock()
+        pb = self._locked(pb, int(offs[-1]))
         batch = self.engine.ctx.batch(packed, pinned_words=pb.array[: int(offs[-1])])
         batch._pin = pb
         return batch

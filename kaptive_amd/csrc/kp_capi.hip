@@ -760,8 +760,8 @@ int kp_host_alloc(size_t bytes, void **out) {
     *out = nullptr;
     if (bytes >= 4 * HUGE_PAGE) {
         int rc = kp_host_reserve(bytes, out);
-        if (rc == KP_OK && (rc = kp_host_lock(*out)) != KP_OK) { pinned_free(*out); *out = nullptr; }
-        return rc;
+        if (rc == KP_OK && (rc = kp_host_lock(*out)) == KP_OK) return KP_OK;
+        if (*out) { pinned_free(*out); *out = nullptr; }  // (a host that will not register mapped memory: the runtime's own allocation)
     }
     const hipError_t e = pinned_alloc(out, std::max<size_t>(bytes, 1));
     if (e != hipSuccess) return kp_fail(nullptr, KP_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
