@@ -581,7 +581,10 @@ __device__ __forceinline__ void sw_class(const KpBatchView &b, const KpGenes &ge
 // One launch for all four band classes.  On the headline workload the wide classes hold few tasks but each of their waves
 // runs a long step chain (a launch of its own costs ~1 ms of latency at the end of the pass), so they get the first blocks of
 // the grid and run underneath the 16-diagonal class that fills the chip.
-constexpr uint32_t WIDE_BLOCKS = 512;  // blocks per wide class at the front of the grid
+#ifndef KP_SW_WIDE_BLOCKS
+#define KP_SW_WIDE_BLOCKS 512
+#endif
+constexpr uint32_t WIDE_BLOCKS = KP_SW_WIDE_BLOCKS;  // blocks per wide class at the front of the grid
 #ifndef KP_SW_HELP_BLOCKS
 #define KP_SW_HELP_BLOCKS 3072
 #endif
