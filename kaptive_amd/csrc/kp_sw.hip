@@ -882,7 +882,13 @@ __global__ __launch_bounds__(TB_THREADS) void kp_sw_traceback_kernel(KpBatchView
             }
             const uint32_t word = piece_word(cur, k);
             if (state == 0 && !has_n && (step & 7) == 7 && (word & 0xAAAAAAAAu) == 0u) {  // eight plain diagonal steps (D and L are stored inverted)
-                cols += 8; diag += 8; r -= 8;
+                // ... and the eight before them when they are the same cell's other piece of the group in hand (a diagonal step
+                // stays on its lane and cell): a wave goes round this loop as often as its slowest lane, and most paths are plain
+                int n = 8;
+#ifndef KP_TB_NO16
+                if (TG == 2 && (pc & 1) && (piece_word(curq[0], k) & 0xAAAAAAAAu) == 0u) n = 16;
+#endif
+                cols += n; diag += n; r -= n;
                 continue;
             }
             // a cell's word: steps 0-3 in the low half, 4-7 in the high half; per half a byte of [L, F opened] pairs below
