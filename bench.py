@@ -283,6 +283,11 @@ def cli_from_fasta(prep: dict, repeats: int = 96, batch: int = 0) -> dict:
     root, paths, n_files = prep["root"], prep["paths"], len(prep["paths"])
 
     def one(reps: int) -> dict:
+        # The process before this one -- the other run of this leg, or this process's own page-locked shards given back a moment
+        # ago -- left the kernel gigabytes of locked pages and a device context to take apart, which it does after the process
+        # is gone as far as its parent can see; a command started into that waits for it at its first device work (first rows
+        # after 1.5 s instead of 0.6 s, every time, for the 960-file run that follows the 18 432-file one).  Not the command's.
+        time.sleep(float(os.environ.get("KAPTIVE_AMD_BENCH_CLI_SETTLE_S", "2.0")))
         out, timing = root / "out.tsv", root / "timing.json"
         env = dict(os.environ, KAPTIVE_AMD_CLI_TIMING=str(timing), PYTHONPATH=str(Path(__file__).resolve().parent))
         argv = [sys.executable, "-m", "kaptive_amd", "assembly", str(prep["db_path"]), *(paths * reps), "-o", str(out), *(["--batch-size", str(batch)] if batch else [])]
@@ -783,7 +788,11 @@ def main() -> None:
         for pb in pins:
             pb.close()
         if cli_prep is not None:
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
             e2e["cli_from_fasta"] = cli_from_fasta(cli_prep)
+            # (the command runs beside this process, which keeps its resident batches and work sets: what it left of the device)
+            e2e["cli_from_fasta"]["device_memory_free_GB_when_started"] = round(free_b / 2**30, 1)
+            e2e["cli_from_fasta"]["device_memory_total_GB"] = round(total_b / 2**30, 1)
 
     if rank == 0:
         n_total = args.assemblies * world * args.steps

@@ -171,7 +171,7 @@ class _TypingPipeline:
         # PREFETCH + 1 chunks are being parsed at any time, each by one native call: the thread budget is shared out among them
         # (measured on the 16-CPU box, threads per call 4 / 6 / 8 / 12 / 16 / 24 / 32: 12.5 / 15.2 / 12.1 / 11.0 / 11.0 / 7.4 / 6.5 k
         # assemblies/s -- a cgroup throttles what oversubscribes its quota)
-        self.shard_threads = max(1, -(-self.threads // (self.PREFETCH + 1)))
+        self.shard_threads = int(os.environ.get("KAPTIVE_AMD_SHARD_THREADS", 0)) or max(1, -(-self.threads // (self.PREFETCH + 1)))
         self.readers = ThreadPoolExecutor(max_workers=self.threads)
         # whole chunks (TSV-only runs) are parsed PREFETCH + 1 at a time, each by shard_threads native threads, in input order
         self.shard_readers = ThreadPoolExecutor(max_workers=self.PREFETCH + 1)
