@@ -2,6 +2,7 @@
 // orchestration of the alignment kernels on the context's stream, and host-side finalisation of the hit table.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
 
 #include "kp_internal.h"
@@ -815,41 +817,80 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
         nib_off[(size_t)n_genes + g] = (int32_t)n_words;
         n_words += (size_t)(ctx->gene_len[(size_t)g] + 7) / 8;
     }
+    const bool load_timing = std::getenv("KAPTIVE_AMD_LOAD_TIMING") != nullptr;
+    const auto t_load0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (load_timing) std::fprintf(stderr, "[kp_db_load] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load0).count()); };
     std::vector<uint32_t> nib(std::max<size_t>(n_words, 1), 0x44444444u);
     std::vector<uint16_t> prof(8 * nib.size(), 0);  // eight rows per word of `nib`
     std::vector<uint8_t> has_n(std::max<size_t>((size_t)n_genes, 1), 0);
-    std::vector<uint8_t> rc;
+    // Packing, profiles and sketches gene by gene on a few threads (45 ms of a 120 ms load on one: a command that types one
+    // genome spends a fifth of its 0.6 s here); every thread keeps the postings of its own genes, joined in gene order
     std::vector<HostPosting> post;
-    for (int g = 0; g < n_genes; ++g) {
-        const int len = ctx->gene_len[(size_t)g];
-        const uint8_t *fwd = gene_codes + gene_off[g];
-        rc.resize((size_t)len);
-        for (int i = 0; i < len; ++i) {
-            const uint8_t c = fwd[len - 1 - i];
-            rc[(size_t)i] = c > 3 ? 4 : (uint8_t)(3 - c);
-        }
-        for (int s = 0; s < 2; ++s) {
-            const uint8_t *c = s ? rc.data() : fwd;
-            uint32_t *dst = nib.data() + nib_off[(size_t)(s ? n_genes + g : g)];
+    {
+        const int n_thr = std::max(1, std::min({4, (int)std::thread::hardware_concurrency(), n_genes / 256}));
+        std::vector<std::vector<HostPosting>> part((size_t)n_thr);
+        auto work = [&](int t) {
+            const int g_lo = (int)((int64_t)n_genes * t / n_thr), g_hi = (int)((int64_t)n_genes * (t + 1) / n_thr);
+            std::vector<uint8_t> rc;
+            std::vector<HostPosting> &post = part[(size_t)t];
+            for (int g = g_lo; g < g_hi; ++g) {
+            const int len = ctx->gene_len[(size_t)g];
+            const uint8_t *fwd = gene_codes + gene_off[g];
+            rc.resize((size_t)len);
             for (int i = 0; i < len; ++i) {
-                const uint32_t code = c[i] > 3 ? 4u : c[i];
-                dst[i >> 3] = (dst[i >> 3] & ~(15u << (4 * (i & 7)))) | (code << (4 * (i & 7)));
-                prof[8 * (size_t)(dst - nib.data()) + (size_t)i] = (uint16_t)kp_row_profile(code);
-                if (code > 3u) has_n[(size_t)g] = 1;
+                const uint8_t c = fwd[len - 1 - i];
+                rc[(size_t)i] = c > 3 ? 4 : (uint8_t)(3 - c);
             }
-        }
-        // the gene's seeds: minimap2 sketches a query on its forward strand (kp_spec.h; kp_sketch.h is the state machine)
-        KpSketchState st;
-        kp_sketch_reset(st);
-        auto emit = [&](int64_t start, uint32_t z, uint32_t x) { post.push_back(HostPosting{x, (uint32_t)g, (uint32_t)start, z}); };
-        for (int i = 0; i < len; ++i) kp_sketch_step(st, i, fwd[i], emit);
-        if (len > 0) kp_sketch_final(st, len - 1, emit);
+            for (int s = 0; s < 2; ++s) {
+                const uint8_t *c = s ? rc.data() : fwd;
+                uint32_t *dst = nib.data() + nib_off[(size_t)(s ? n_genes + g : g)];
+                for (int i = 0; i < len; ++i) {
+                    const uint32_t code = c[i] > 3 ? 4u : c[i];
+                    dst[i >> 3] = (dst[i >> 3] & ~(15u << (4 * (i & 7)))) | (code << (4 * (i & 7)));
+                    prof[8 * (size_t)(dst - nib.data()) + (size_t)i] = (uint16_t)kp_row_profile(code);
+                    if (code > 3u) has_n[(size_t)g] = 1;
+                }
+            }
+            // the gene's seeds: minimap2 sketches a query on its forward strand (kp_spec.h; kp_sketch.h is the state machine)
+            KpSketchState st;
+            kp_sketch_reset(st);
+            auto emit = [&](int64_t start, uint32_t z, uint32_t x) { post.push_back(HostPosting{x, (uint32_t)g, (uint32_t)start, z}); };
+            for (int i = 0; i < len; ++i) kp_sketch_step(st, i, fwd[i], emit);
+            if (len > 0) kp_sketch_final(st, len - 1, emit);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+        size_t total = 0;
+        for (const auto &v : part) total += v.size();
+        post.reserve(total);
+        for (const auto &v : part) post.insert(post.end(), v.begin(), v.end());
     }
-    std::sort(post.begin(), post.end(), [](const HostPosting &a, const HostPosting &b) {
-        if (a.key != b.key) return a.key < b.key;
-        if (a.gene != b.gene) return a.gene < b.gene;
-        return a.pos < b.pos;
-    });
+    lap("genes packed and sketched");
+    {   // by (key, gene, pos): three stable counting passes over the 30-bit key, then the few postings that share a key --
+        // they arrive in gene order, positions nearly so -- put right by insertion (a comparison sort took 45 ms of the load)
+        static_assert(KP_KMER_MASK < (1u << 30), "three passes of ten bits cover the key");
+        std::vector<HostPosting> tmp(post.size());
+        for (int pass = 0; pass < 3; ++pass) {
+            const int sh = 10 * pass;
+            size_t cnt[1025] = {0};
+            for (const HostPosting &q : post) ++cnt[((q.key >> sh) & 1023u) + 1];
+            for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
+            for (const HostPosting &q : post) tmp[cnt[(q.key >> sh) & 1023u]++] = q;
+            post.swap(tmp);
+        }
+        auto less = [](const HostPosting &a, const HostPosting &b) { return a.gene != b.gene ? a.gene < b.gene : a.pos < b.pos; };
+        for (size_t i = 1; i < post.size(); ++i) {
+            if (post[i].key != post[i - 1].key || !less(post[i], post[i - 1])) continue;
+            const HostPosting q = post[i];
+            size_t j = i;
+            for (; j > 0 && post[j - 1].key == q.key && less(q, post[j - 1]); --j) post[j] = post[j - 1];
+            post[j] = q;
+        }
+    }
+    lap("postings sorted");
     size_t n_unique = 0;
     for (size_t i = 0; i < post.size(); ++i) n_unique += (i == 0 || post[i].key != post[i - 1].key);
     uint32_t log_slots = 10;
@@ -882,6 +923,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     }
     if (flat.size() > 0xFFFFFFFFull) return kp_fail(ctx, KP_EINVAL, "seed index too large");
     if (flat.empty()) flat.push_back(0);
+    lap("table, filters and anchor lists built");
     int rcode;
     if ((rcode = upload(ctx, ctx->d_slots, slots.data(), slots.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_filter, filter.data(), filter.size()))) return rcode;
@@ -893,6 +935,7 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     if ((rcode = upload(ctx, ctx->d_gene_has_n, has_n.data(), has_n.size()))) return rcode;
     if ((rcode = upload(ctx, ctx->d_gene_len, ctx->gene_len.data(), ctx->gene_len.size()))) return rcode;
     KP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("uploaded");
     ctx->index = KpSeedIndex{ctx->d_filter.p, ctx->d_filter2.p, ctx->d_slots.p,
                              ctx->d_postings.p, mask, shift};
     ctx->genes = KpGenes{ctx->d_nib.p, ctx->d_nib_off.p, ctx->d_gene_len.p, n_genes, ctx->d_gene_prof.p, ctx->d_gene_has_n.p};
