@@ -829,7 +829,9 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
     {
         const int n_thr = std::max(1, std::min({4, (int)std::thread::hardware_concurrency(), n_genes / 256}));
         std::vector<std::vector<HostPosting>> part((size_t)n_thr);
+        std::atomic<bool> failed{false};
         auto work = [&](int t) {
+            try {
             const int g_lo = (int)((int64_t)n_genes * t / n_thr), g_hi = (int)((int64_t)n_genes * (t + 1) / n_thr);
             std::vector<uint8_t> rc;
             std::vector<HostPosting> &post = part[(size_t)t];
@@ -858,11 +860,13 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
             for (int i = 0; i < len; ++i) kp_sketch_step(st, i, fwd[i], emit);
             if (len > 0) kp_sketch_final(st, len - 1, emit);
             }
+            } catch (...) { failed.store(true); }  // (out of memory in a worker must not end the process)
         };
         std::vector<std::thread> pool;
         for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
         work(0);
         for (auto &th : pool) th.join();
+        if (failed.load()) return kp_fail(ctx, KP_ENOMEM, "out of host memory while sketching the genes");
         size_t total = 0;
         for (const auto &v : part) total += v.size();
         post.reserve(total);
