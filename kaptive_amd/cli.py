@@ -147,9 +147,10 @@ class _TypingPipeline:
     uploaded on the copy stream, and chunk k - 1's rows are formatted.  When only the TSV and / or PHA4GE reports are asked for,
     no per-assembly object is ever built: the rows come from ``BatchTyping.tsv()`` (``kp_format_rows``, byte for byte what
     ``KaptiveRow.from_result`` gives) and ``BatchTyping.pha4ge()``, and the files' sequence text is not even kept.  The
-    JSON lines (``-j``) come from ``BatchTyping.jsonl()`` (``kp_format_json``) and need the files' text but no objects either;
-    only the per-assembly fasta outputs (``-l``, ``-g``, ``-p``) go through ``SerotypingResult`` objects, as the reference's
-    writers do (src/kaptive/serotyping/cli.py:20-114)."""
+    JSON lines (``-j``) come from ``BatchTyping.jsonl()`` (``kp_format_json``) and the records of the per-assembly fasta files
+    (``-l``, ``-g``, ``-p``) from ``BatchTyping.fasta()`` (``kp_format_fasta``): they need the files' text but no objects either
+    (the reference's writers work on one ``SerotypingResult`` at a time, src/kaptive/serotyping/cli.py:20-114).  The readers
+    start with the process: their buffers are plain huge-page memory (``kp_host_reserve``) until a batch is made of them."""
 
     PREFETCH = 2  # chunks being read / uploaded ahead of the one whose alignment pass is enqueued next
 
@@ -394,7 +395,7 @@ class _TypingPipeline:
 
 class _ChunkSource:
     """Reads ahead of the device: PREFETCH + 1 chunks are with the reader threads at any time (started by
-    ``_TypingPipeline.start_reading`` before the device context even exists)."""
+    ``_TypingPipeline.__init__`` -- as many as its read-ahead budget allows -- before the device context even exists)."""
 
     def __init__(self, pipe: "_TypingPipeline", chunks) -> None:
         from collections import deque
