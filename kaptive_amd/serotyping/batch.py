@@ -224,7 +224,7 @@ class BatchTyping:
         if self.genomes is None:
             raise ValueError("JSON lines carry the extracted sequences: the batch needs its genomes")
         return self._formatter().format(self.ids, self.phenotype, self.sums, self.kept, self.pieces, self.best_locus, self.best_score,
-                          self.completeness, self.typeable, self.problems, self.percent_identity, self.percent_coverage,
+                                        self.completeness, self.typeable, self.problems, self.percent_identity, self.percent_coverage,
                                         self.length_discrepancy, self.genomes)  # fmt: skip
 
     def _formatter(self):
