@@ -16,6 +16,9 @@ CONFIGS = {
     # spacers): chains of three and more pieces, weak end pieces, events closer together than a band is wide
     "storm": dict(main=("kpsc_k", 100), also=("kpsc_o", 101), asm=dict(length=3.0e5, median_contigs=6, min_contig=200, p_is=0.0)),
 }
+# ... and full-size assemblies whose background is not iid (diverged relatives of database genes, IS-like repeats, an operon
+# in seven copies: wide bands, occurrence cuts, many weak tasks -- bench.py --background paralog)
+CONFIGS["paralog"] = dict(main=("kpsc_k", 100), also=("kpsc_o", 101), asm=dict(background="paralog"))
 STORM_SIZES = ((33, 500), (20, 60), (100, 300), (400, 520), (1, 40), (30, 36), (490, 510))
 
 

@@ -1223,7 +1223,8 @@ def test_parity_sweep_at_full_size(oracle):
     """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 128: BASELINE configs 2/3 -- 5 Mbp, K
     and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
     second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v4), and as
-    many small assemblies whose locus copy carries 2-24 insertions / deletions of 1-520 bases anywhere ("storm"): the device's hit tables equal the oracle's record for record and its report rows equal the
+    many small assemblies whose locus copy carries 2-24 insertions / deletions of 1-520 bases anywhere ("storm"), and as many full-size ones on the
+    background that is not iid ("paralog"): the device's hit tables equal the oracle's record for record and its report rows equal the
     host reduction's byte for byte, for every assembly and database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
     import json
     import multiprocessing as mp
