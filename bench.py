@@ -323,6 +323,10 @@ def cli_from_fasta(prep: dict, repeats: int = 96, batch: int = 0) -> dict:
         small = one(max(1, round(1000 / n_files)))  # the reference's everyday use: about a thousand genomes
         return {**big, "distinct_files": n_files, "fasta_MB_per_assembly": round(prep["nbytes"] / n_files / 1e6, 2),
                 "batch_size": batch or "the CLI's default: 64, 128, 256, then 512", "about_1000_files": small,
+                "settle_s_before_each_run": float(os.environ.get("KAPTIVE_AMD_BENCH_CLI_SETTLE_S", "2.0")),
+                "deferred_teardown": "untimed: the command ends with os._exit once its outputs are closed; the kernel unpins its page-locked shards and frees "
+                                     "the device context after the parent has seen it exit (exit_s is what the parent waited), and a command started right "
+                                     "behind it would wait for that at its first device call -- hence the settle time before each run, which no number here includes",
                 "database": "K-locus only (the CLI types one database per run, as the reference's does)",
                 "note": "files on tmpfs; steady = assemblies per second between the fifth chunk's rows and the last chunk's"}
     finally:

@@ -339,6 +339,7 @@ typedef struct kp_json_tables {  /* per database */
     const uint8_t *comp_map;      /* [256] complement of a sequence byte (core/seq.py) */
     const uint8_t *char_map;      /* [256] byte -> 0..4 */
     const uint8_t *codon_map;     /* [125] codon -> amino acid, 42 = stop */
+    int32_t n_loci, n_genes;      /* sizes of the tables above: every locus / gene index of the records is checked against them */
 } kp_json_tables;
 typedef struct kp_json_columns { /* per assembly of the batch */
     const char *asm_ids;
@@ -354,6 +355,8 @@ typedef struct kp_json_columns { /* per assembly of the batch */
     const int64_t *piece_ctg_name_off;
     const uint8_t *const *ctg_seqs;  /* per assembly: the contigs' text back to back ... */
     const int32_t *const *ctg_off;   /* ... and where each contig starts in it */
+    const int32_t *n_ctg;            /* per assembly: how many contigs ctg_off[a] lists ... */
+    const int64_t *ctg_text_len;     /* ... and how many bytes ctg_seqs[a] holds: records that point outside are KP_EINVAL */
 } kp_json_columns;
 KP_API int64_t kp_format_json(const kp_json_tables *tables, int32_t n_asm, const kp_asm_summary *summaries, const kp_kept *kept,
                               int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *columns,

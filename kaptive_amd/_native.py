@@ -356,7 +356,9 @@ class RowFormatter:
             return b""
         ids_b, ids_o = _blob(ids)
         ph_b, ph_o = _blob(phenotypes)
-        cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
+        n_ctg = np.array([len(o) for o in off_arrays], np.int32)
+        text_len = np.array([len(a) for a in seq_arrays], np.int64)
+        cols = dict(n_ctg=n_ctg, text_len=text_len, best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
                     identity=_c(identity, np.float64), coverage=_c(coverage, np.float64),
                     discrepancy=_c(discrepancy, np.float64))  # fmt: skip
         c = RowColumns(asm_ids=_p(ids_b).value, asm_id_off=_p(ids_o).value, phenotypes=_p(ph_b).value,
@@ -385,7 +387,7 @@ class JsonTables(C.Structure):  # kp_json_tables
                 ("cluster_name_off", C.c_void_p), ("product_off", C.c_void_p), ("locus_names", C.c_void_p),
                 ("locus_name_off", C.c_void_p), ("locus_gene_off", C.c_void_p), ("locus_gene_len", C.c_void_p),
                 ("gene_position", C.c_void_p), ("gene_strand", C.c_void_p), ("comp_map", C.c_void_p), ("char_map", C.c_void_p),
-                ("codon_map", C.c_void_p)]  # fmt: skip
+                ("codon_map", C.c_void_p), ("n_loci", C.c_int32), ("n_genes", C.c_int32)]  # fmt: skip
 
 
 class JsonColumns(C.Structure):  # kp_json_columns
@@ -393,7 +395,7 @@ class JsonColumns(C.Structure):  # kp_json_columns
                 ("best_locus", C.c_void_p), ("typeable", C.c_void_p), ("problems", C.c_void_p), ("best_score", C.c_void_p),
                 ("completeness", C.c_void_p), ("identity", C.c_void_p), ("coverage", C.c_void_p), ("length_discrepancy", C.c_void_p),
                 ("piece_order", C.c_void_p), ("piece_ctg_names", C.c_void_p), ("piece_ctg_name_off", C.c_void_p),
-                ("ctg_seqs", C.c_void_p), ("ctg_off", C.c_void_p)]  # fmt: skip
+                ("ctg_seqs", C.c_void_p), ("ctg_off", C.c_void_p), ("n_ctg", C.c_void_p), ("ctg_text_len", C.c_void_p)]  # fmt: skip
 
 
 def _blob64(strings) -> tuple[np.ndarray, np.ndarray]:
@@ -435,7 +437,7 @@ class JsonFormatter:
             locus_names=_p(k["locus"][0]).value, locus_name_off=_p(k["locus"][1]).value,
             locus_gene_off=_p(k["locus_gene_off"]).value, locus_gene_len=_p(k["locus_gene_len"]).value,
             gene_position=_p(k["gene_position"]).value, gene_strand=_p(k["gene_strand"]).value, comp_map=_p(k["comp"]).value,
-            char_map=_p(k["char"]).value, codon_map=_p(k["codon"]).value,
+            char_map=_p(k["char"]).value, codon_map=_p(k["codon"]).value, n_loci=len(db.loci.ids), n_genes=len(db.genes.ids),
         )  # fmt: skip
 
     def _prepare(self, ids, phenotypes, sums, kept, pieces, best_locus, best_score, completeness, typeable, problems, identity,
@@ -453,13 +455,18 @@ class JsonFormatter:
         names = [b""] * (n * pstride)
         raw_names = [b""] * (n * pstride)
         n_pieces = sums["n_pieces"]
+        if n and (int(n_pieces.min()) < 0 or int(n_pieces.max()) > pstride):
+            raise ValueError("kp_format_json: a summary counts more locus pieces than the piece table holds")
         for a in np.flatnonzero(n_pieces > 0):
             m = int(n_pieces[a])
             if m > 1:
                 order[a, :m] = np.argsort(np.ascontiguousarray(pieces["mean_pos"][a, :m]))
             cids = genomes[a].contigs.ids
             for p_ in range(m):
-                cid = cids[int(pieces["contig"][a, p_])]
+                ci = int(pieces["contig"][a, p_])
+                if not 0 <= ci < len(cids):
+                    raise ValueError("kp_format_json: a locus piece names a contig the assembly does not have")
+                cid = cids[ci]
                 names[a * pstride + p_] = _str(cid)[1:-1].encode("utf-8")
                 raw_names[a * pstride + p_] = cid.encode()
         ids_b, ids_o = _blob64([_str(x) for x in ids])
@@ -469,7 +476,9 @@ class JsonFormatter:
         off_arrays = [np.ascontiguousarray(g.contigs.offsets, dtype=np.int32) for g in genomes]
         seq_ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in seq_arrays])
         off_ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in off_arrays])
-        cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
+        n_ctg = np.array([len(o) for o in off_arrays], np.int32)
+        text_len = np.array([len(a) for a in seq_arrays], np.int64)
+        cols = dict(n_ctg=n_ctg, text_len=text_len, best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
                     score=_c(best_score, np.float64), compl=_c(completeness, np.float64), identity=_c(identity, np.float64),
                     coverage=_c(coverage, np.float64), discrepancy=_c(discrepancy, np.float64), order=order)  # fmt: skip
         c = JsonColumns(asm_ids=_p(ids_b).value, asm_id_off=_p(ids_o).value, phenotypes=_p(ph_b).value, phenotype_off=_p(ph_o).value,
@@ -477,7 +486,8 @@ class JsonFormatter:
                         best_score=_p(cols["score"]).value, completeness=_p(cols["compl"]).value, identity=_p(cols["identity"]).value,
                         coverage=_p(cols["coverage"]).value, length_discrepancy=_p(cols["discrepancy"]).value,
                         piece_order=_p(order).value, piece_ctg_names=_p(nm_b).value, piece_ctg_name_off=_p(nm_o).value,
-                        ctg_seqs=C.cast(seq_ptrs, C.c_void_p).value, ctg_off=C.cast(off_ptrs, C.c_void_p).value)  # fmt: skip
+                        ctg_seqs=C.cast(seq_ptrs, C.c_void_p).value, ctg_off=C.cast(off_ptrs, C.c_void_p).value,
+                        n_ctg=_p(n_ctg).value, ctg_text_len=_p(text_len).value)  # fmt: skip
         return dict(n=n, sums=sums, kept=kept, pieces=pieces, kstride=kstride, pstride=pstride, c=c, raw_piece_names=raw_names,
                     keep=(ids_b, ids_o, ph_b, ph_o, nm_b, nm_o, seq_arrays, off_arrays, seq_ptrs, off_ptrs, cols))
 

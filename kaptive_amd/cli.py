@@ -23,6 +23,7 @@ import numpy as np
 FILE_SUFFIX = "kaptive_results"
 _KEEP: list = []  # FAST_EXIT: what must not be finalised one object at a time on the way out
 FAST_EXIT = False  # set by __main__: the process ends right after main() returns, so nothing needs to be torn down in order
+FAST_EXIT_ARMED = False  # set by run_type once its output handles are closed: only then may __main__ skip the interpreter's teardown
 
 
 def result_to_json(result) -> bytes:
@@ -208,16 +209,43 @@ class _TypingPipeline:
                 self._early.append((k, self.submit_read(paths)))
             self._unread = len(chunks) - len(self._early)
         self._own_typer = typer is None
-        if typer is None:
-            self.db = load_database(args.database)
-            self.marks["database_loaded"] = time.perf_counter()
-            typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
-                              allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
-                              device=device)  # fmt: skip
-        self.typer = typer
-        self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
+        try:
+            if typer is None:
+                self.db = load_database(args.database)
+                self.marks["database_loaded"] = time.perf_counter()
+                typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
+                                  allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
+                                  device=device)  # fmt: skip
+            self.typer = typer
+            self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
+        except BaseException:
+            # a bad database path, no device, no memory: the reads queued above must not be drained (gigabytes of FASTA) by
+            # the interpreter's exit hook before the error is reported
+            self._abandon_reads()
+            raise
         self.marks["context_ready"] = time.perf_counter()
         self.want_tsv = bool(getattr(args, "out", None))
+
+    def _abandon_reads(self) -> None:
+        """Cancel every queued read, drop what finished reads hold (shards' page-locked blocks), keep no worker waiting."""
+        for pool in (self.readers, self.shard_readers, self.copiers, self.formatters, self.janitor):
+            pool.shutdown(wait=False, cancel_futures=True)
+        for _, futures in self._early:
+            for f in futures if isinstance(futures, list) else [futures]:
+                if f.done() and not f.cancelled() and f.exception() is None:
+                    got = f.result()
+                    if isinstance(got, tuple) and isinstance(got[0], tuple):  # ((tables, words, pinned buffer), ids)
+                        try:
+                            got[0][2].close()
+                        except Exception:
+                            pass
+        self._early = []
+        for pb in self._pins:
+            try:
+                pb.close()
+            except Exception:
+                pass
+        self._pins = []
 
     def release_pin(self, batch) -> None:
         """The batch's page-locked words back to the pool, once its upload has completed (waits for it if need be)."""
@@ -626,6 +654,11 @@ def run_type(args: argparse.Namespace) -> int:
                 h.close()
             else:
                 h.flush()
+    if FAST_EXIT:
+        # every stream this command writes is closed or flushed: what is left (reader threads, page-locked shards, the device
+        # context) may leave with the process.  Other subcommands, and a run that raised, end through the interpreter.
+        global FAST_EXIT_ARMED
+        FAST_EXIT_ARMED = True
     if args.verbose:
         print(file=sys.stderr)
     if timing_path:

@@ -862,9 +862,18 @@ int kp_db_load(kp_ctx *ctx, const uint8_t *gene_codes, const int32_t *gene_off, 
             }
             } catch (...) { failed.store(true); }  // (out of memory in a worker must not end the process)
         };
+        // A thread that cannot be started (std::system_error under a thread limit, bad_alloc) must not let the exception
+        // leave this extern "C" function past joinable threads (std::terminate): the calling thread takes the ranges that
+        // got no thread of their own
         std::vector<std::thread> pool;
-        for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+        int n_started = 1;
+        try {
+            pool.reserve((size_t)n_thr);
+            for (; n_started < n_thr; ++n_started) pool.emplace_back(work, n_started);
+        } catch (...) {
+        }
         work(0);
+        for (int t = n_started; t < n_thr; ++t) work(t);
         for (auto &th : pool) th.join();
         if (failed.load()) return kp_fail(ctx, KP_ENOMEM, "out of host memory while sketching the genes");
         size_t total = 0;

@@ -144,12 +144,44 @@ void put_extract(Out &o, const uint8_t *seqs, int64_t base, int start, int end, 
     o.n += len;
 }
 
+// Everything the formatters index with values that come out of the records (a corrupt or untyped record must be an error
+// code, not a read past a table): the best locus, its gene range, every live hit's gene / contig / interval, every piece.
+bool records_in_range(const kp_json_tables *t, const kp_json_columns *c, int a, const kp_asm_summary &s, const kp_kept *k,
+                      int kept_stride, const kp_piece *pc, int piece_stride, const int32_t *order, bool need_locus) {
+    const int best = c->best_locus[a];
+    if (need_locus) {
+        if (best < 0 || best >= t->n_loci) return false;
+        const int64_t g0 = t->locus_gene_off[best], ng = t->locus_gene_len[best];
+        if (g0 < 0 || ng < 0 || g0 + ng > t->n_genes) return false;
+    }
+    if (s.n_kept < 0 || s.n_kept > kept_stride || s.n_pieces < 0 || s.n_pieces > piece_stride) return false;
+    const int n_ctg = c->n_ctg[a];
+    const int64_t text = c->ctg_text_len[a];
+    const int32_t *off = c->ctg_off[a];
+    auto span_ok = [&](int ctg, int64_t start, int64_t end) {
+        return ctg >= 0 && ctg < n_ctg && start >= 0 && start <= end && off[ctg] >= 0 && (int64_t)off[ctg] + end <= text;
+    };
+    int n_alive = 0;
+    for (int i = 0; i < s.n_kept; ++i) {
+        if (!alive(k[i])) continue;
+        ++n_alive;
+        if (k[i].gene < 0 || k[i].gene >= t->n_genes || !span_ok(k[i].contig, k[i].t_start, k[i].t_end)) return false;
+    }
+    if (n_alive > 4096) return false;  // (the translation lengths of a line are kept on the stack)
+    for (int i = 0; i < s.n_pieces; ++i) {
+        if (order[i] < 0 || order[i] >= piece_stride) return false;
+        const kp_piece &q = pc[order[i]];
+        if (!span_ok(q.contig, q.start, q.end)) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int64_t kp_format_json(const kp_json_tables *t, int32_t n_asm, const kp_asm_summary *sums, const kp_kept *kept,
                                   int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *c,
                                   char *out, int64_t cap) {
-    if (!t || !c || n_asm < 0 || (n_asm > 0 && (!sums || !kept || !pieces)) || cap < 0 || (cap > 0 && !out)) return KP_EINVAL;
+    if (!t || !c || n_asm < 0 || (n_asm > 0 && (!sums || !kept || !pieces || !c->n_ctg || !c->ctg_text_len)) || cap < 0 || (cap > 0 && !out)) return KP_EINVAL;
     Out o{out, cap};
     for (int a = 0; a < n_asm; ++a) {
         const kp_asm_summary &s = sums[a];
@@ -159,6 +191,7 @@ extern "C" int64_t kp_format_json(const kp_json_tables *t, int32_t n_asm, const 
         const int n = s.n_kept, np = s.n_pieces, best = c->best_locus[a];
         const uint8_t *seqs = c->ctg_seqs[a];
         const int32_t *ctg_off = c->ctg_off[a];
+        if (!records_in_range(t, c, a, s, k, kept_stride, pc, piece_stride, order, true)) return KP_EINVAL;
         o.put(t->head, t->head_len);  // {"kaptive_version":...,"database_taxon":N,"genome":
         o.put(c->asm_ids + c->asm_id_off[a], c->asm_id_off[a + 1] - c->asm_id_off[a]);
         o.lit(",\"best_locus_idx\":"); o.num(best);
@@ -292,7 +325,6 @@ extern "C" int64_t kp_format_json(const kp_json_tables *t, int32_t n_asm, const 
             if (n_alive < 4096) plen[n_alive] = count;
             ++n_alive;
         }
-        if (n_alive > 4096) return KP_EOVERFLOW;
         o.lit("\",\"offsets\":[");
         { long long at = 0; for (int i = 0; i < n_alive; ++i) { if (i) o.put(','); o.num(at); at += plen[i]; } }
         o.lit("],\"lengths\":[");
@@ -312,7 +344,7 @@ extern "C" int64_t kp_format_fasta(const kp_json_tables *t, int32_t n_asm, const
                                    int32_t kept_stride, const kp_piece *pieces, int32_t piece_stride, const kp_json_columns *c,
                                    int32_t kind, const char *names, const int64_t *name_off, char *out, int64_t cap, int64_t *asm_end) {
     if (!t || !c || !names || !name_off || !asm_end || kind < 0 || kind > 2 || n_asm < 0 ||
-        (n_asm > 0 && (!sums || !kept || !pieces)) || cap < 0 || (cap > 0 && !out))
+        (n_asm > 0 && (!sums || !kept || !pieces || !c->n_ctg || !c->ctg_text_len)) || cap < 0 || (cap > 0 && !out))
         return KP_EINVAL;
     Out o{out, cap};
     for (int a = 0; a < n_asm; ++a) {
@@ -322,6 +354,7 @@ extern "C" int64_t kp_format_fasta(const kp_json_tables *t, int32_t n_asm, const
         const int32_t *order = c->piece_order + (size_t)a * (size_t)piece_stride;
         const uint8_t *seqs = c->ctg_seqs[a];
         const int32_t *ctg_off = c->ctg_off[a];
+        if (!records_in_range(t, c, a, s, k, kept_stride, pc, piece_stride, order, false)) return KP_EINVAL;
         if (kind == 0) {
             for (int i = 0; i < s.n_pieces; ++i) {
                 const kp_piece &q = pc[order[i]];

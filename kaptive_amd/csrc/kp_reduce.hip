@@ -121,6 +121,7 @@ __global__ __launch_bounds__(SORT_THREADS) void kp_hit_sort_kernel(kp_hit *__res
         kp_hit_keys(src[i], k + 3 * (size_t)i);
         if (i < SORT_LDS) s_k0[i] = k[3 * (size_t)i];
     }
+    __syncthreads();  // both branches read keys (LDS and global) that other waves of the block wrote
     if (n <= SORT_LDS) {
         // Up to SORT_LDS hits (every assembly but constructed ones): a bitonic network in LDS on (leading key, index) pairs --
         // the index makes the pairs distinct and the result the stable order by the leading key -- then every run of equal

@@ -358,3 +358,38 @@ def test_from_files_equals_from_file(tmp_path):
     bad.write_bytes(gzip.compress(b">x\nACGT\n")[:12])
     with pytest.raises(ValueError):
         GenomeAssembly.from_files([paths[0], bad])
+
+
+def test_failing_pipeline_start_cancels_its_queued_reads(tmp_path, monkeypatch):
+    """A bad database (or no device) after the early reads were queued: the constructor shuts its reader pools down and
+    cancels what is queued, so that the error is reported at once instead of after every queued FASTA was read by the
+    interpreter's exit hook (advisor finding, round 5)."""
+    import threading
+
+    from kaptive_amd import cli as C
+
+    gate, started = threading.Event(), []
+
+    def slow_shard(self, paths):
+        started.append(paths)
+        gate.wait(5)
+        raise RuntimeError("reader let go")
+
+    monkeypatch.setattr(C._TypingPipeline, "_load_shard", slow_shard)
+    monkeypatch.setattr(C._TypingPipeline, "PREFETCH", 0)  # one shard reader: every chunk but the first stays queued
+    files = []
+    for i in range(6):
+        f = tmp_path / f"g{i}.fasta"
+        f.write_text(">c\nACGT\n")
+        files.append(str(f))
+    args = C.build_parser().parse_args(["assembly", str(tmp_path / "missing_db.npz"), *files, "-o", str(tmp_path / "o.tsv")])
+    monkeypatch.setenv("KAPTIVE_AMD_READ_AHEAD_GB", "1")
+    pipe = C._TypingPipeline.__new__(C._TypingPipeline)
+    chunks = [(k, [p]) for k, p in enumerate(files)]
+    with pytest.raises((FileNotFoundError, OSError)):
+        pipe.__init__(args, 0, chunks=chunks)
+    gate.set()
+    for pool in (pipe.readers, pipe.shard_readers, pipe.copiers, pipe.formatters, pipe.janitor):
+        assert pool._shutdown
+        pool.shutdown(wait=True)  # returns at once: nothing is left to drain
+    assert len(started) <= 1 and pipe._early == []  # the five queued chunks were cancelled, not read

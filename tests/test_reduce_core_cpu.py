@@ -233,3 +233,44 @@ def test_native_json_number_layout():
         assert f'"best_locus_score":{format_f64(vals[i])},' in text, (vals[i], text[:400])
         assert f'"coverages":[{format_f32(f32[i])}]' in text, (vals[i], text)
         assert f'"protein_identities":[{format_f32(f32[::-1][i])}]' in text, (vals[::-1][i], text)
+
+
+def test_native_formatters_refuse_records_that_point_outside_their_tables():
+    """kp_format_json / kp_format_fasta index the database's and the assembly's tables with values taken from the records:
+    an untyped assembly (best locus -1), a gene or contig index past its table, an interval past the contig text or more
+    kept hits than the stride are KP_EINVAL -- a ValueError here --, not a read past a buffer."""
+    key, genome, hits, exp, scalars, kwargs = load_case("k_plain1")
+    db = load_db(key)
+    typer = Serotyper(db, aligner=lambda g: None)
+
+    def batch(**edit):
+        sums = np.zeros(1, B.SUMMARY_DTYPE)
+        sums["n_kept"] = 1
+        kept = np.zeros((1, 1), B.KEPT_DTYPE)
+        kept["t_end"] = 9
+        kept["strand"] = 1
+        pieces = np.zeros((1, 1), B.PIECE_DTYPE)
+        bt = B.BatchTyping(typer, ["g"], sums, kept, pieces, np.zeros((1, len(db.loci))), np.zeros(1, np.int32), [genome])
+        bt.phenotype  # noqa: B018  (the host columns are computed from the valid records; the damage comes afterwards)
+        for name, v in edit.items():
+            if name == "best":
+                bt.best_locus[:] = v
+            elif name in sums.dtype.names:
+                bt.sums[name] = v
+            elif name.startswith("piece_"):
+                bt.pieces[name[6:]] = v
+            else:
+                bt.kept[name] = v
+        return bt
+
+    assert batch().jsonl().startswith(b'{"kaptive_version"')
+    n_text = len(genome.contigs.seqs)
+    bad = [dict(best=-1), dict(best=len(db.loci)), dict(gene=len(db.genes.ids)), dict(gene=-1), dict(contig=len(genome.contigs.offsets)),
+           dict(contig=-1), dict(t_end=n_text + 1), dict(t_start=-1), dict(t_start=12), dict(n_kept=2), dict(n_pieces=2),
+           dict(n_pieces=1, piece_contig=-1), dict(n_pieces=1, piece_end=n_text + 5)]  # fmt: skip
+    for edit in bad:
+        with pytest.raises(ValueError):
+            batch(**edit).jsonl()
+        if "best" not in edit:
+            with pytest.raises(ValueError):
+                batch(**edit).fasta()
