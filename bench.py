@@ -75,7 +75,15 @@ def _make_one(job):
     from kaptive_amd.synth import make_assembly
 
     also = (_DBS["also"],) if _DBS["also"] is not None else ()
-    g = make_assembly(_DBS["main"], seed=seed, length=length, also=also, **_WL["asm_kw"])
+    kw = dict(_WL["asm_kw"])
+    if _WL.get("mix") == "joins":
+        # a workload that JOINS (kp_spec.h, kp-align v5): every fourth assembly carries three insertions / deletions of 64-300
+        # bases inside genes of its locus, every fourth a storm of six 33-300 base events anywhere in the locus copy
+        if seed % 4 == 0:
+            kw.update(mid_indels=((64, "del"), (150, "ins"), (300, "del")), p_is=0)
+        elif seed % 4 == 1:
+            kw.update(indel_storm=(6, 33, 300), p_is=0)
+    g = make_assembly(_DBS["main"], seed=seed, length=length, also=also, **kw)
     return g.id, g.packed()
 
 
@@ -426,6 +434,43 @@ def cpu_baseline(seed0: int, length: float, per_worker: int = 3) -> dict:
     }  # fmt: skip
 
 
+SECONDARY = (  # (key, what, arguments): short legs of the default run, each the resident-batch number of a run of its own
+    ("config4_ab_k", "BASELINE.json config 4: 5 000 fragmented 4 Mbp assemblies (~1 500 contigs), A. baumannii-shaped K database",
+     ["--db", "ab_k", "--assemblies", "5000"]),
+    ("paralog_background", "2 000 KpSC assemblies on the non-iid background (diverged relatives, IS-like repeats, a 7-copy operon), K+O",
+     ["--background", "paralog", "--assemblies", "2000"]),
+    ("join_heavy", "2 000 KpSC assemblies, K+O: every fourth with three 64-300 base insertions / deletions inside genes, every fourth with "
+     "a storm of six 33-300 base events in its locus (kp_join.hip's kernels have work)", ["--mix", "joins", "--assemblies", "2000"]),
+)
+
+
+def secondary_legs() -> dict:
+    """The short secondary legs of the default run: the same script, two timed steps over resident batches, for
+    config 4, the non-iid background and a workload that joins; each in a process of its own beside this one (which keeps
+    its context).  What comes back per leg: value, the digest of its rows, kernel milliseconds per step."""
+    import subprocess
+
+    out = {}
+    for key, what, extra in SECONDARY:
+        argv = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                "--no-e2e", "--no-secondary", *extra]
+        t = time.perf_counter()
+        try:
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not rows:
+                out[key] = {"workload": what, "error": (r.stderr or r.stdout)[-300:]}
+                continue
+            sub = json.loads(rows[-1])
+            out[key] = {"workload": what, "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"],
+                        "tsv_rows_sha1": sub["config"]["tsv_rows_sha1"], "typeable_in_last_step": sub["config"]["typeable_in_last_step"],
+                        "kernel_ms_per_step": sub["kernel_ms_per_step"], "dp_cells_per_step": sub["dp"]["cells_per_step"],
+                        "roofline_alone_frac": sub["roofline"]["alone"]["frac"], "wall_s": round(time.perf_counter() - t, 1)}
+        except Exception as e:  # noqa: BLE001  (a secondary leg never costs the headline its line)
+            out[key] = {"workload": what, "error": repr(e)[:300]}
+    return out
+
+
 def rank_seed0(rank: int, assemblies_per_rank: int) -> int:
     """First assembly seed of a rank: ranks hold disjoint, consecutive runs of the one seeded assembly series (weak
     scaling: every rank types `assemblies_per_rank` of its own; rank r of any world size holds the same assemblies)."""
@@ -472,6 +517,11 @@ def main() -> None:
                     help="what surrounds the planted loci: uniform random sequence (the headline workload, SURVEY.md 8d) or a "
                          "background that also holds diverged relatives of database genes, IS-like repeats and an rRNA-like "
                          "operon in seven copies (kaptive_amd.synth.make_assembly): what the throughput means on real genomes")
+    ap.add_argument("--mix", choices=("plain", "joins"), default="plain",
+                    help="joins: every fourth assembly with three 64-300 base insertions / deletions inside genes, every fourth with a "
+                         "storm of six 33-300 base events in its locus (the kernels of kp_join.hip get work)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short secondary legs (config 4, the non-iid background, the join-heavy mix), each a run of this script of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two end-to-end legs (host shards -> rows)")
     ap.add_argument("--upload-ahead", type=int, default=2,
@@ -509,7 +559,13 @@ def main() -> None:
         if hi_r - lo_r != args.assemblies_total // world:
             raise SystemExit(f"--assemblies-total {args.assemblies_total} does not divide over {world} ranks")
         args.assemblies = hi_r - lo_r
-    workers = args.workers or max(1, min(64, (os.cpu_count() or 1) // max(world, 1)))
+    # every rank moves to its device's share of the granted CPUs on the device's NUMA node before it allocates anything large
+    # (kaptive_amd/affinity.py; a one-node box keeps its whole mask; the devices' nodes are asked in a process of its own, so no
+    # HIP state exists here when the workload workers are forked).
+    from kaptive_amd import affinity
+
+    placement = affinity.place(local_rank, list(range(world))) if world > 1 and not args.share_gpu else affinity.place(local_rank)
+    workers = args.workers or max(1, min(64, len(os.sched_getaffinity(0)) if world > 1 else (os.cpu_count() or 1) // max(world, 1)))
     # torch (and with it the HIP runtime it bundles) has to be loaded before libkaptive_amd.so, which the packer below
     # already needs: in the other order the process ends up with two HIP runtimes and sees no device
     import torch  # noqa: F401
@@ -518,6 +574,7 @@ def main() -> None:
         _WL["asm_kw"] = dict(_WL["asm_kw"], sub_rate=args.sub_rate)
     if args.background != "iid":
         _WL["asm_kw"] = dict(_WL["asm_kw"], background=args.background)
+    _WL["mix"] = args.mix
     length = args.length or _WL["length"]
     if args.as_rank >= 0 and world > 1:
         raise SystemExit("--as-rank is for single-process runs")
@@ -696,7 +753,8 @@ def main() -> None:
     host_busy = (time.thread_time() - cpu0) / max(elapsed, 1e-9)
     import resource
 
-    host_rank = {"rank": rank, "driving_thread_cpu_s": round(time.thread_time() - cpu0, 3),
+    host_rank = {"rank": rank, "numa_node": placement["numa_node"], "cpus_pinned": len(placement["cpus"] or []) if placement["applied"] else None,
+                 "driving_thread_cpu_s": round(time.thread_time() - cpu0, 3),
                  "process_cpu_s": round(time.process_time() - proc0, 3), "elapsed_s": round(elapsed, 3),
                  "max_rss_MB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, 1),
                  "pinned_host_MB": round(_native.pinned_bytes() / 2**20, 1),
@@ -909,9 +967,12 @@ def main() -> None:
             },
             "kernel_ms_per_step": {k: [round(m[k], 3) for m in mean_ms] for k in ("scan", "sort", "chain", "sw16", "sw32")},
         }  # fmt: skip
+        line["kernel_ms_per_step"]["join_fill_and_walk"] = [round(m["sw64"], 3) for m in mean_ms]  # (kp_join.hip; its chaining kernel is part of "chain")
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["ingest"] = ingest
+        if world == 1 and not args.no_secondary and not args.no_e2e:
+            line["extra"] = secondary_legs()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

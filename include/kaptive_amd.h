@@ -46,6 +46,9 @@ typedef struct kp_batch kp_batch; /* a set of packed assemblies resident in HBM,
 /* GPUs the process sees (>= 0), or a negative KP_E* code: `kaptive assembly --devices all` shards over all of them, one
  * process each (the reference has no device notion; its unit of parallelism is the worker thread, cli.py:183-210). */
 KP_API int kp_device_count(void);
+/* NUMA node of a GPU (its PCI function's /sys/bus/pci/devices/<bus id>/numa_node), -1 when the host does not say: the
+ * per-device processes pin themselves and their page-locked shards to it (kaptive_amd/affinity.py).  No context needed. */
+KP_API int kp_device_numa_node(int device_id);
 KP_API int kp_ctx_create(int device_id, kp_ctx **out);
 KP_API void kp_ctx_destroy(kp_ctx *ctx);
 /* Message of the last failed call on ctx (ctx may be NULL for a failed kp_ctx_create). Never NULL. */

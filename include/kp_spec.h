@@ -1,11 +1,11 @@
-/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v4") and of the packed data layout.
+/* kp_spec.h -- constants of the kaptive_amd nucleotide aligner ("kp-align v5") and of the packed data layout.
  *
  * The reference delegates gene-vs-contig alignment to the third-party rammappy 0.1.3 wheel
  * (src/kaptive/serotyping/core.py:147-155), whose source is not in the reference tree; parity at that stage is
  * UNPINNED. This header is therefore the specification of the replacement: the HIP kernels
  * (kaptive_amd/csrc) and the CPU restatement (oracle/kp_oracle.c) both include it and must agree bit for bit.
  * Parameters follow minimap2's documented defaults where the design has an equivalent (k, scoring, -s 80 peak score,
- * >=3 seeds and >=40 seeded bases per chain); DESIGN.md lists every deviation.
+ * >=3 seeds and >=40 seeded bases per chain, chaining of anchors across diagonal jumps of up to 500); DESIGN.md lists every deviation.
  */
 #ifndef KP_SPEC_H
 #define KP_SPEC_H
@@ -171,65 +171,99 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
 #define KP_MASK_LEVEL_DEN 2   /* KP_MASK_LEVEL_NUM / KP_MASK_LEVEL_DEN of the shorter one's query span (minimap2 -M 0.5) */
 #define KP_NEG_INF (-(1 << 29))
 
-/* ---- kp-align v4: chains across diagonal jumps of up to KP_JOIN_BW (minimap2's bw = 500) -----------------------------------
- * minimap2 chains anchors whose diagonals differ by up to bw = 500 and aligns through the gap (global fill between the
- * flanking anchors under min(4 + 2n, 24 + n)); a gene with an insertion or deletion of 33-500 bases is ONE hit there.  The
- * clusters above stop at KP_DIAG_GAP; v4 puts the JOIN on top of them and leaves everything else as it was: every accepted
- * cluster is still a band task with a hit of its own, and a joined alignment that passes the tests below REPLACES the hits of
- * the pieces it runs through.
+/* ---- kp-align v5: chains of ANCHORS across diagonal jumps of up to KP_JOIN_BW (minimap2's bw = 500) --------------------------
+ * minimap2 chains anchors whose diagonals differ by up to bw = 500 and aligns through the gap; a gene with an insertion or
+ * deletion of 33-500 bases is ONE hit there -- also when the stretch beyond the event is too short to be a chain of its own
+ * (an event next to a gene's end), and when two events nearly cancel so that the stretches before and after them share a
+ * diagonal.  The clusters above stop at KP_DIAG_GAP; the JOIN sits on top of them and leaves everything else as it was: every
+ * accepted cluster is still a band task with a hit of its own unless a chain CONSUMES it (below).
  *
- * GROUPS.  A cluster is PROVISIONAL when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases (it may
- * still be rejected by its chain score).  Per gene/strand AND contig, take the provisional clusters in the order of the sorted
+ * GROUPS.  Every cluster counts, weak ones (fewer than KP_MIN_ANCHORS anchors or than KP_MIN_SEED_SPAN query bases: no band
+ * task) included; a cluster is PROVISIONAL when it has >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases (it
+ * may still be rejected by its chain score).  Per gene/strand AND contig, take the clusters in the order of the sorted
  * anchors (diagonals are in the assembly's padded coordinates: near a contig boundary the clusters of two contigs interleave
  * in that order, which is why the contig is part of the key): a cluster continues the open sequence of its contig iff its
  * lowest diagonal is at most KP_JOIN_BW above the highest diagonal of the sequence's last cluster and the sequence holds
  * fewer than KP_JOIN_GROUP_MAX clusters; otherwise it closes that sequence and opens a new one.  At most KP_JOIN_OPEN
  * sequences of a gene/strand are open at a time: the cluster of a further contig closes the one whose last cluster ends on
- * the lowest diagonal (the lowest contig on ties).  A closed sequence of two or more clusters is a GROUP.
+ * the lowest diagonal (the lowest contig on ties).  A closed sequence of two or more clusters, at least one of them
+ * provisional, whose clusters hold KP_MIN_ANCHORS..KP_JOIN_ANCHOR_MAX anchors in all, is a GROUP.
  *
- * CHAINS OF CLUSTERS.  Nodes are the group's ACCEPTED clusters (chain score >= KP_MIN_CHAIN_SCORE; cs = that score, n = its
- * anchor count).  HEAD of a cluster = its anchor with the smallest (query position, diagonal), TAIL = the one with the
- * largest; t = q + diagonal.  Nodes are ordered by (head t, head q, order of the sorted anchors).  minimap2's chaining DP on
- * that order:  f[i] = cs[i] + max(0, max over earlier j of f[j] + link(j, i)), the FIRST maximum met going backwards from
- * i - 1 (a predecessor is taken only if it beats "none"), with, for dq = head_q[i] - tail_q[j], dr = head_t[i] - tail_t[j],
- * dd = |dr - dq|:  link = invalid unless i and j lie on the same contig, their diagonal ranges are more than KP_DIAG_GAP apart
- * (closer ones are one run that another contig's anchors cut in two: each band task covers both), 0 < dq <= KP_CHAIN_MAX_DIST, 0 < dr <= KP_CHAIN_MAX_DIST and dd <= KP_JOIN_BW;
- * link = min(KP_K, dq, dr) - KP_K - kp_chain_pen[dd]  (what mm_chain_dp gives the first anchor of i after the last of j,
- * relative to starting afresh).  Backtracking as mg_chain_backtrack: repeatedly take the unused node with the largest f
- * (the later one on ties) and walk the predecessors until a used node, the start, or KP_JOIN_MAX_PIECES nodes; the walked
- * nodes are a chain with score f[end] - f[node the walk stopped at] (f[end] at the start) and the sum of their anchor
- * counts.  Chains of >= 2 nodes that score >= KP_MIN_CHAIN_SCORE are JOINS; their pieces are numbered in query order (0 = first).
+ * CHAINS OF ANCHORS.  All anchors of the group's clusters, (t, q) = (target, query) position, t = q + diagonal, in (t, q)
+ * order, are chained as mm_chain_dp chains them -- exactly, i.e. without its max_skip / max_iter shortcuts:
+ *     f[i] = max(KP_K, max over earlier j of f[j] + sc(i, j)),  the FIRST maximum met going backwards from i - 1,
+ * sc as for a cluster's chain (above: dq = q_i - q_j, dr = t_i - t_j; invalid if dq <= 0, dr == 0, dq or dr > KP_CHAIN_MAX_DIST;
+ * dd = |dr - dq|, dg = min(dr, dq); sc = min(KP_K, dg) minus kp_chain_pen[dd] if dd != 0 or dg > KP_K) and also invalid if
+ * dd > KP_JOIN_BW.  Backtracking as mg_chain_backtrack: repeatedly take the unused anchor with the largest f >=
+ * KP_MIN_CHAIN_SCORE (the later one on ties) and walk its predecessors until a used anchor or the start, stopping early once
+ * the score counted from the end has fallen KP_JOIN_BW below its peak; the chain is cut at that peak, its score is the peak
+ * and its anchors become used -- also when it is then discarded for scoring below KP_MIN_CHAIN_SCORE or holding fewer than
+ * KP_MIN_ANCHORS anchors.
  *
- * JOINED FILL.  All pieces get the band width W of the widest piece's task; a narrower task's band is widened evenly
- * (lo - (W - width) / 2).  Piece 0 is filled as a band task (the recurrence above: local, H >= 0, restarts).  Piece k > 0 is
- * a CONTINUATION: no restart -- a cell that no path from piece k - 1 reaches is DEAD (H = E = F = KP_NEG_INF; also the cells
- * outside the contig), its scores may be negative (minimap2 fills globally between the anchors that flank a gap: a short
- * piece before a long gap must not be lost because the gap costs more than the piece scored) -- and H has two more
- * candidates, the CROSS gaps from piece k - 1.  When piece k lies on higher diagonals (lo[k] > lo[k-1]: an insertion in the
- * contig) a gap along row r from a live cell (r, t') of piece k - 1 left of piece k's band in that row (t' < lo[k] + r):
+ * PIECES.  A chain's anchors in query order fall into pieces: a new piece starts where the diagonal differs from the anchor
+ * before by more than KP_DIAG_GAP, or where the piece would come to span more than KP_MAX_SPREAD diagonals.  A chain of one
+ * piece is what its cluster's band task already aligns; a chain of 2..KP_JOIN_MAX_PIECES pieces is a JOIN (more pieces: none).
+ * Every piece gets a band of the same width W -- the smallest of 32, 64, 128 that holds the widest piece's diagonal range
+ * widened by KP_BAND_MARGIN on both sides --, centred on its own range:  lo[k] = dmin[k] - KP_BAND_MARGIN - (W - need[k]) / 2,
+ * need[k] = dmax[k] - dmin[k] + 1 + 2 KP_BAND_MARGIN.  n_anchors and chain score of the join are the chain's.
+ *
+ * JOINED FILL.  Every piece is filled as a band task over the whole gene (the recurrence above: local, H >= 0, restarts); in a
+ * piece k > 0, H has two more candidates, the CROSS gaps from piece k - 1.  When piece k lies on higher diagonals
+ * (lo[k] > lo[k-1]: an insertion in the contig) a gap along row r from a live cell (r, t') of piece k - 1 left of piece k's
+ * band in that row (t' < lo[k] + r):
  *     X1 = max (H(r, t') + 2 t') - 4 - 2 t        X2 = max (H(r, t') + t') - 24 - t      (first / second piece of the gap cost)
  * otherwise (a deletion) a gap down column t from a live cell (r', t) of piece k - 1 on a diagonal above piece k's band
  * (t - r' > lo[k] + W - 1):   X1 = max (H(r', t) + 2 r') - 4 - 2 r,   X2 = max (H(r', t) + r') - 24 - r.
- * (Live: H > 0 in piece 0, not dead in a continuation.)  The source cell of a maximum is the first one in increasing t' (r').
- * H = max(diagonal, E, F, X1, X2) with ties in that order (a candidate must beat everything before it); a value below
- * KP_NEG_INF / 2 is dead and normalised to KP_NEG_INF, as are E and F.  The END of piece k > 0 is its first maximum of H, in
- * (row, column) order, over live cells in rows >= qmax + KP_K - 1 (qmax: the largest query position of the piece's anchors
- * -- a joined path runs through the piece's anchors, as minimap2's does).
+ * (Live: H > 0.)  The source cell of a maximum is the first one in increasing t' (r').  H = max(diagonal, E, F, X1, X2) with
+ * ties in that order (a candidate must beat everything before it); H <= 0 is a restart cell.  A path therefore crosses a gap
+ * only where that pays -- which is what minimap2 comes to: it cuts a chain's end off when it is shorter than twice the gap
+ * behind it (mm_fix_bad_ends) and lets the extension, a free local decision, reach across or not; an end long enough to be
+ * kept always pays for its gap at the identities Kaptive works with.
  *
- * JOINED HITS.  For k = last piece down to 1, unless piece k lies on a joined path reported before: if piece k has an END
- * with H >= KP_MIN_DP_SCORE, walk back from it (through cross gaps into earlier pieces, to the start of the path in piece
- * 0 or wherever a band edge ends it).  On the way: suf = score of the part of the path behind the current cell, sufmax =
- * its largest value at a cell in state H so far; at a cross gap, if sufmax - suf > KP_JOIN_DROP the path is REJECTED
- * (minimap2's z-drop of 400 against the open cost of the second gap piece: behind the gap the path fell that far below where
- * it arrived, so minimap2 would have split there).  An accepted path is a hit: score = H(END) + the long-gap credit of its
- * in-band gaps, coordinates from its first and last cell, columns = cells + gap columns, matches counted base by base,
- * n_seeds and chain score those of the join, plus the BONUS of its order score (below); the hits of the band tasks of every
- * piece it visited are dropped, and those pieces report no joined path of their own.
+ * THE JOINED PATH.  The best cell of a piece is its first maximum of H in (row, column) order.  The pieces are tried in the
+ * order of their best cells' scores (the earlier piece on ties): nothing is reported from a best cell below KP_MIN_DP_SCORE;
+ * otherwise walk back from it (through cross gaps into earlier pieces, to where the path starts).  On the way: suf = score of
+ * the part of the path behind the current cell with the costs of the cross gaps left out, sufmax = its largest value at a cell
+ * in state H so far; at a cell that takes a cross gap, and at every cell in state H once a gap has been crossed, if
+ * sufmax - suf > KP_JOIN_DROP the path is REJECTED (minimap2's z-drop of 400 against the open cost of the second gap piece,
+ * which forgives a gap its length: mm_test_zdrop would have split the chain there), the piece is set aside and the next one
+ * tried.  The first path that is not
+ * rejected settles the chain: if it crosses at least one gap it is the JOINED HIT -- score = H(best cell) + the long-gap
+ * credit of its in-band gaps, coordinates from its first and last cell, columns = cells + gap columns, matches counted base
+ * by base, n_seeds and chain score those of the chain, plus the BONUS of its order score (below) --; if it crosses none, the
+ * band task of that piece's cluster already reports it.
  *
- * Not restated: minimap2 also chains single anchors and clusters below -n / -m into a chain and forces the alignment
- * through them (v4 joins accepted clusters only; minimap2's own mm_fix_bad_ends / mm_filter_bad_seeds trim most such ends
- * again); two clusters whose query ranges interleave (two indels that nearly cancel) are not joined. */
+ * CONSUMED PIECES.  minimap2 reports one alignment per chain (two where it splits one), and it cuts a chain's end off before
+ * aligning when that end is shorter than twice the gap behind it (mm_fix_bad_ends): such an end is reported only if the
+ * extension reaches across the gap.  So: the band tasks of the clusters that hold an anchor of a piece the joined hit runs
+ * through report no hit of their own; and, unless a path of the chain was rejected, neither do those of the pieces of the
+ * chain's WEAK ENDS (kp_weak_ends below) that the settled path does not run through.
+ *
+ * Not restated: minimap2's max_skip heuristic in the chaining DP, its mm_filter_bad_seeds (anchors between gaps that nearly
+ * cancel are skipped as fill boundaries: the joined fill has no fill boundaries inside a piece), an extension that reaches
+ * across a gap to a stretch WITHOUT any anchor (its band of 751 diagonals finds it, a piece needs an anchor to exist), the
+ * re-chaining with bw_long = 20 000. */
 #define KP_JOIN_BW 500
+/* WEAK ENDS of a chain of n pieces (kp_spec.h, CONSUMED PIECES; minimap2's mm_fix_bad_ends restated on pieces).  qlo / qhi:
+ * query position of every piece's first / last anchor; jump_before[k]: the diagonal jump between piece k - 1 and k.  Going in
+ * from the first piece, L = query bases from the chain's first anchor to the end of piece k: pieces 0..k are a weak end if the
+ * jump behind piece k exceeds L / 2; the walk ends once L >= KP_JOIN_BW or 2 L >= the chain's query extent.  Likewise from
+ * the last piece.  Returns the mask of weak-end pieces. */
+KP_SPEC_FN int kp_weak_ends(int n, const int *qlo, const int *qhi, const int *jump_before) {
+    const int extent = qhi[n - 1] + KP_K - qlo[0];
+    int mask = 0;
+    for (int k = 0; k + 1 < n; ++k) {
+        const int L = qhi[k] + KP_K - qlo[0];
+        if (2 * jump_before[k + 1] > L) mask |= (1 << (k + 1)) - 1;
+        if (L >= KP_JOIN_BW || 2 * L >= extent) break;
+    }
+    for (int k = n - 1; k >= 1; --k) {
+        const int L = qhi[n - 1] + KP_K - qlo[k];
+        if (2 * jump_before[k] > L) mask |= ((1 << n) - 1) & ~((1 << k) - 1);
+        if (L >= KP_JOIN_BW || 2 * L >= extent) break;
+    }
+    return mask;
+}
 /* ORDER SCORE.  minimap2 orders a query's hits, filters them (-s) and computes mapping qualities with dp_max -- the best
  * running score of the path when a gap of n columns is charged KP_GAP_OPEN + 2 log2(1 + n) -- not with the alignment score.
  * For band tasks the two are as good as equal; a joined path's cross gaps make them differ by hundreds.  A joined hit
@@ -249,6 +283,7 @@ KP_SPEC_FN int kp_log2x2(uint32_t n) { /* 2 log2(1 + n) to the nearest integer o
     return 2 * e + (mant >= 3u) + (mant >= 11u);
 }
 #define KP_JOIN_GROUP_MAX 16
+#define KP_JOIN_ANCHOR_MAX 4096 /* groups with more anchors than this are not chained (a gene beyond ~22 kb whose group holds them all) */
 #define KP_JOIN_OPEN 4
 #define KP_JOIN_MAX_PIECES 8
 #define KP_JOIN_DROP (400 - KP_GAP_OPEN2)

@@ -38,7 +38,7 @@ EXPORTS = (
     "kp_batch_upload_wait", "kp_batch_depends_on", "kp_batch_create_device", "kp_batch_device_words", "kp_batch_destroy", "kp_batch_align", "kp_batch_wait",
     "kp_batch_hit_offsets", "kp_batch_hits", "kp_batch_set_hits", "kp_batch_stats", "kp_batch_profile", "kp_batch_anchors",
     "kp_batch_tasks", "kp_batch_task_results", "kp_batch_joins", "kp_db_load_typing", "kp_db_load_typing_group", "kp_batch_use_group", "kp_batch_score", "kp_batch_reduce", "kp_batch_typing_caps",
-    "kp_device_count", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
+    "kp_device_count", "kp_device_numa_node", "kp_batch_typing", "kp_batch_proteins", "kp_protein_align", "kp_fasta_pack", "kp_fasta_ingest", "kp_fasta_ingest_many", "kp_fasta_ingest_file", "kp_fasta_ingest_shard", "kp_shard_words_into", "kp_shard_free", "kp_fasta_simd", "kp_pack_contigs",
     "kp_fasta_free", "kp_format_rows", "kp_format_json", "kp_format_fasta", "kp_protein_align_seeded", "kp_randstrobes", "kp_randstrobe_top_hits",
 )  # fmt: skip
 
@@ -356,9 +356,7 @@ class RowFormatter:
             return b""
         ids_b, ids_o = _blob(ids)
         ph_b, ph_o = _blob(phenotypes)
-        n_ctg = np.array([len(o) for o in off_arrays], np.int32)
-        text_len = np.array([len(a) for a in seq_arrays], np.int64)
-        cols = dict(n_ctg=n_ctg, text_len=text_len, best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
+        cols = dict(best=_c(best_locus, np.int32), typeable=_c(typeable, np.uint8), problems=_c(problems, np.int32),
                     identity=_c(identity, np.float64), coverage=_c(coverage, np.float64),
                     discrepancy=_c(discrepancy, np.float64))  # fmt: skip
         c = RowColumns(asm_ids=_p(ids_b).value, asm_id_off=_p(ids_o).value, phenotypes=_p(ph_b).value,

@@ -502,12 +502,17 @@ def _read_ahead_bytes() -> int:
     return min(12 * 2**30, avail // 4)
 
 
-def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn) -> None:
+def _device_worker(args: argparse.Namespace, device: int, chunks: list, conn, devices=None, nodes=None) -> None:
     """One process per device (``--devices a,b,...``): types its chunks and sends ``(k, outputs)`` up the pipe; an
-    exception travels the same way and ends the worker."""
+    exception travels the same way and ends the worker.  Before it reads a file the process moves to its device's share of
+    the granted CPUs on the device's NUMA node (kaptive_amd/affinity.py): reader threads and page-locked shards follow."""
     import kaptive_amd
+    from kaptive_amd import affinity
 
     kaptive_amd.tune_runtime()
+    placed = affinity.place(device, devices, nodes)
+    if os.environ.get("KAPTIVE_AMD_CLI_TIMING"):
+        print(f"[kaptive_amd] device {device}: NUMA node {placed['numa_node']}, {len(placed['cpus'] or [])} CPUs, pinned={placed['applied']}", file=sys.stderr)
     pipe = None
     try:
         pipe = _TypingPipeline(args, device, chunks=chunks)
@@ -616,9 +621,12 @@ def run_type(args: argparse.Namespace) -> int:
             # the device processes share the host: each gets its part of the reader-thread budget
             args.threads = max(1, (args.threads or usable_cpus()) // len(devices))
             args.read_ahead_share = len(devices)  # ... and of the read-ahead memory
+            from kaptive_amd import affinity
+
+            nodes = affinity.device_numa_nodes(list(devices))  # asked once, in a process of its own (0.3 s beside the first reads)
             for i, d in enumerate(devices):
                 parent, child = ctx.Pipe(duplex=False)
-                proc = ctx.Process(target=_device_worker, args=(args, d, chunks[i :: len(devices)], child), daemon=True)
+                proc = ctx.Process(target=_device_worker, args=(args, d, chunks[i :: len(devices)], child, list(devices), nodes), daemon=True)
                 proc.start()
                 child.close()
                 conns.append(parent)

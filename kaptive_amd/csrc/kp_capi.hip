@@ -14,6 +14,7 @@
 #include <unordered_map>
 
 #include "kp_internal.h"
+#include <cctype>
 #include <sys/mman.h>
 #include "kp_sketch.h"
 #include "kp_reduce_core.h"
@@ -656,6 +657,19 @@ int kp_device_count(void) {
     return n_dev;
 }
 
+int kp_device_numa_node(int device_id) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device_id) != hipSuccess) return -1;
+    for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);  // sysfs names are lower case
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    std::FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
 int kp_ctx_create(int device_id, kp_ctx **out) {
     if (!out) return kp_fail(nullptr, KP_EINVAL, "out is null");
     *out = nullptr;
@@ -1095,9 +1109,11 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->max_gene_len > KP_FILL16_MAX_GENE_LEN,
                  stream, ev[4]);
     // ... and their joined alignment; it marks the band tasks a joined path replaces, so it follows their traceback
+    // (ev[5]..ev[6]: the joined fill and walk-back, reported in the "sw64" slot of kp_batch_profile; the last slot reads 0)
+    KP_HIP_CHECK(ctx, hipEventRecord(ev[5], stream));
     kp_launch_join_sw(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_trace_top.p,
                       w->trace_cap, w->d_results.p, stream);
-    for (int c = 1; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
+    for (int c = 2; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
 }

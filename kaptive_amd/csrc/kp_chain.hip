@@ -118,6 +118,7 @@ struct PendEntry {
     KpTask t;
     uint32_t first, cnt, dmax;
     int in_group;
+    int weak;  // (v5) too few anchors / query bases for a band task: a member of its group all the same, never a task
 };
 struct JoinLds {
     PendEntry e[KP_JOIN_OPEN];
@@ -150,11 +151,15 @@ __device__ __forceinline__ void emit_staged(const KpTask &t, KpTask *tasks, uint
 }
 
 __device__ __forceinline__ void entry_to_group(const PendEntry &E, KpGroup &G, KpTask *tasks, uint32_t *task_count, uint32_t task_cap) {
-    const int cls = class_of_width(E.t.width);
-    const uint32_t slot = atomicAdd(&task_count[cls], 1u);
-    if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = E.t;
+    uint32_t ref = KP_REF_NONE;
+    if (!E.weak) {
+        const int cls = class_of_width(E.t.width);
+        const uint32_t slot = atomicAdd(&task_count[cls], 1u);
+        if (slot < task_cap) tasks[(size_t)cls * task_cap + slot] = E.t;
+        ref = KP_TASK_REF(cls, slot);
+    }
     const int n = G.n;
-    G.task[n] = KP_TASK_REF(cls, slot); G.first[n] = E.first; G.cnt[n] = E.cnt;
+    G.task[n] = ref; G.first[n] = E.first; G.cnt[n] = E.cnt;
     G.n = n + 1;
 }
 
@@ -163,9 +168,13 @@ __device__ __forceinline__ void close_entry(const PendEntry &E, KpGroup &G, KpTa
                                             TaskStage &st, const GroupOut &go) {
     if (E.in_group) {
         entry_to_group(E, G, tasks, task_count, task_cap);
-        const uint32_t g = atomicAdd(go.count, 1u);
-        if (g < go.cap) go.groups[g] = G;  // beyond cap: counted, not stored (host retries)
-    } else {
+        bool any = false;  // a group needs a provisional cluster (kp_spec.h): weak clusters alone chain to nothing that is reported
+        for (int i = 0; i < G.n; ++i) any = any || G.task[i] != KP_REF_NONE;
+        if (any) {
+            const uint32_t g = atomicAdd(go.count, 1u);
+            if (g < go.cap) go.groups[g] = G;  // beyond cap: counted, not stored (host retries)
+        }
+    } else if (!E.weak) {
         emit_staged(E.t, tasks, task_count, task_cap, st);
     }
 }
@@ -188,7 +197,7 @@ __device__ __forceinline__ void pending_flush(JoinWave &J, KpTask *tasks, uint32
 __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint32_t d0, uint32_t dmax, uint32_t qmin,
                                               uint32_t qmax, int cnt, uint32_t first, KpTask *tasks, uint32_t *task_count,
                                               uint32_t task_cap, TaskStage &st, JoinWave &J, const GroupOut &go) {
-    if (cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN) return;
+    const int weak = cnt < KP_MIN_ANCHORS || (int)(qmax - qmin) + KP_K < KP_MIN_SEED_SPAN;
     int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
     if (need > 16) {
         margin = KP_BAND_MARGIN;
@@ -199,7 +208,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     c.t.asm_id = a; c.t.gs = (int32_t)gs; c.t.contig = ctg; c.t.width = w; c.t.n_anchors = cnt; c.t.chain_score = (int32_t)first;
     c.t.lo = (int32_t)d0 - KP_DIAG_BIAS - margin - (w - need) / 2;
     c.t.qspan = qmin | (qmax << 16);
-    c.first = first; c.cnt = (uint32_t)cnt; c.dmax = dmax; c.in_group = 0;
+    c.first = first; c.cnt = (uint32_t)cnt; c.dmax = dmax; c.in_group = 0; c.weak = weak;
     // (kp_spec.h, GROUPS) all open sequences belong to one gene/strand
     if (J.a_valid && J.A.t.gs != c.t.gs) pending_flush(J, tasks, task_count, task_cap, st, go);
     bool found = J.a_valid && J.A.t.contig == ctg;
@@ -218,7 +227,7 @@ __device__ __forceinline__ void flush_cluster(int a, uint32_t gs, int ctg, uint3
     if (found) {
         KpGroup &G = J.L->g[J.a_slot];
         if (d0 - J.A.dmax <= (uint32_t)KP_JOIN_BW && (J.A.in_group ? G.n + 1 : 1) < KP_JOIN_GROUP_MAX) {
-            if (!J.A.in_group) { G.n = 0; G.asm_id = a; }
+            if (!J.A.in_group) { G.n = 0; G.asm_id = a; G.gs = (int32_t)gs; G.contig = ctg; }
             entry_to_group(J.A, G, tasks, task_count, task_cap);
             c.in_group = 1;
         } else {
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
     if (threadIdx.x < KP_N_CLASSES) st.n[threadIdx.x] = 0;
     if (threadIdx.x == 0) st.total = 0;
     jw.a_valid = 0; jw.a_slot = 0; jw.others = 0;
-    jw.A.first = jw.A.cnt = jw.A.dmax = 0; jw.A.in_group = 0;
+    jw.A.first = jw.A.cnt = jw.A.dmax = 0; jw.A.in_group = 0; jw.A.weak = 0;
     jw.A.t.asm_id = 0; jw.A.t.gs = 0; jw.A.t.contig = 0; jw.A.t.lo = 0; jw.A.t.width = 16; jw.A.t.n_anchors = 0; jw.A.t.qspan = 0; jw.A.t.chain_score = 0;
     __syncthreads();
     // A wave owns the gene/strand GROUPS OF ANCHORS that start in its slice (kp-align v4: the clusters of one gene/strand must
@@ -369,7 +378,11 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
             // are visited.
             const unsigned long long later = lane < 63 ? heads & (~0ull << (lane + 1)) : 0ull;
             const int my_end = later ? min(n_valid, (int)__builtin_ctzll(later)) : n_valid;
-            unsigned long long todo = __ballot(head && (my_end - lane >= KP_MIN_ANCHORS || my_end == n_valid));
+            // (v5) ... or lie within KP_JOIN_BW diagonals of the run before or after them: weak clusters are members of groups.  A
+            // stray run further than that from both neighbours can neither join a sequence nor keep one open.
+            const unsigned long long linked = __ballot(head && has_pred && kp_ckey_gs(pk, kb) == gs && d - kp_ckey_diag(pk, kb) <= (uint32_t)KP_JOIN_BW);
+            const bool near = ((linked >> lane) & 1ull) || (my_end < n_valid && ((linked >> my_end) & 1ull));
+            unsigned long long todo = __ballot(head && (my_end - lane >= KP_MIN_ANCHORS || my_end == n_valid || near));
             while (todo) {
                 const int pos = (int)__builtin_ctzll(todo);
                 todo &= todo - 1;

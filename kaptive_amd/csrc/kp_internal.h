@@ -159,33 +159,39 @@ struct KpSwEnd {
 };
 #define KP_SWEND_HAS_N 0x100  // the gene or the task's target window holds an N (matches are then counted base by base)
 
-// ---- kp-align v4: joins (kp_spec.h) ------------------------------------------------------------------------------------------------
-// A task reference: band class in the top bits, slot in the class's list below.
+// ---- kp-align v5: joins (kp_spec.h) ------------------------------------------------------------------------------------------------
+// A task reference: band class in the top bits, slot in the class's list below; KP_REF_NONE = a cluster without a band task.
 #define KP_TASK_REF(cls, slot) (((uint32_t)(cls) << 28) | (uint32_t)(slot))
 #define KP_REF_CLS(ref) ((ref) >> 28)
 #define KP_REF_SLOT(ref) ((ref) & 0x0FFFFFFFu)
-// A group of provisional clusters of one gene/strand (kp_chain.hip appends them as it meets them): their tasks and where
-// their anchors lie in the assembly's sorted list.
+#define KP_REF_NONE 0xFFFFFFFFu
+// A group of clusters of one gene/strand and contig (kp_chain.hip appends them as it meets them): their tasks and where
+// their anchors lie in the assembly's sorted list.  Weak clusters (too few anchors / query bases for a band task) are members
+// too: the chaining DP of kp_join.hip runs over all the group's anchors.
 struct KpGroup {
     int32_t asm_id, n;
-    uint32_t task[KP_JOIN_GROUP_MAX];   // KP_TASK_REF
+    int32_t gs, contig;
+    uint32_t task[KP_JOIN_GROUP_MAX];   // KP_TASK_REF or KP_REF_NONE
     uint32_t first[KP_JOIN_GROUP_MAX];  // first anchor
     uint32_t cnt[KP_JOIN_GROUP_MAX];    // anchors of the cluster (all of them, not the chain's)
 };
-// A join: a chain of two or more accepted clusters.  The chaining kernel fills the head, the joined fill the per-piece
-// bookkeeping, the walk-back the results (same meaning as the oracle's kpo_join).
+// A join: a chain of anchors that falls into two or more pieces.  The chaining kernel fills the head, the joined fill the
+// per-piece bookkeeping, the walk-back the results (same meaning as the oracle's kpo_join).
 struct KpJoin {
     int32_t asm_id, gs, contig, n_pieces, n_anchors, chain_score, width;
-    uint32_t task[KP_JOIN_MAX_PIECES];  // KP_TASK_REF of every piece's band task, query order
-    int32_t lo[KP_JOIN_MAX_PIECES];     // lowest diagonal of its (widened) band
-    int32_t qmax[KP_JOIN_MAX_PIECES];
+    int32_t lo[KP_JOIN_MAX_PIECES];     // lowest diagonal of every piece's band, query order
+    int32_t cmask[KP_JOIN_MAX_PIECES];  // bit c: the piece holds an anchor of the group's cluster c
+    int32_t n_members;
+    int32_t weak_mask;                  // bit k: piece k belongs to a weak end of the chain (kp_weak_ends)
+    uint32_t member_task[KP_JOIN_GROUP_MAX];  // the group's clusters: KP_TASK_REF of their band tasks or KP_REF_NONE
     // joined fill: where each piece's direction bytes and its exports towards the next piece are (16-byte units of the
-    // trace buffer; 0xFFFFFFFF = the buffer had no room: the host grows it and reruns the pass), its END cell
+    // trace buffer; 0xFFFFFFFF = the buffer had no room: the host grows it and reruns the pass), its best cell
     uint32_t trace_off[KP_JOIN_MAX_PIECES], export_off[KP_JOIN_MAX_PIECES];
     int32_t end_s[KP_JOIN_MAX_PIECES], end_r[KP_JOIN_MAX_PIECES], end_b[KP_JOIN_MAX_PIECES];
     // walk-back
     int32_t state[KP_JOIN_MAX_PIECES], visited[KP_JOIN_MAX_PIECES];
     int32_t res[KP_JOIN_MAX_PIECES][9];
+    int32_t drop_mask;
 };
 
 #define KP_HIP_CHECK(ctx, expr)                                                                     \

@@ -6,9 +6,9 @@
 // this file puts the join on top of them (include/kp_spec.h, "kp-align v4", is the specification; oracle/kp_oracle.c
 // make_joins / join_run the CPU statement):
 //
-//   kp_join_chain_kernel   one wave per GROUP of provisional clusters (kp_chain.hip finds them): the lanes share the scan of
-//                          each cluster's anchors for its first and last one, lane 0 runs minimap2's chaining DP on the
-//                          accepted clusters and the backtracking: one KpJoin per chain of two or more
+//   kp_join_chain_kernel   one wave per GROUP of clusters (kp_chain.hip finds them; round 6: weak clusters are members): minimap2's
+//                          chaining DP over all the group's ANCHORS, the backtracking, every chain cut into pieces where its
+//                          diagonal jumps: one KpJoin per chain of two or more pieces
 //   kp_join_fill_kernel    P lanes per join (band of 4P diagonals, the mapping of kp_sw.hip's 32-bit kernel): the pieces one
 //                          after the other -- piece 0 as a local alignment, the later ones as CONTINUATIONS that only the
 //                          cross gaps from the piece before can enter; what a piece offers the next one (per row or per
@@ -20,6 +20,7 @@
 // Joins are rare (a few per assembly at most on anything but constructed inputs): these kernels are written for clarity
 // in plain 32-bit arithmetic, not for the vector pipe.
 #include "kp_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -32,111 +33,184 @@ constexpr int XBIAS = 1 << 23;  // export keys: (value + e * position + XBIAS) i
 __device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w == 32 ? 1 : (w == 64 ? 2 : 3)); }
 
 // ---- groups -> joins ---------------------------------------------------------------------------------------------------------------
-struct JNode {
-    int hq, ht, tq, tt, cs, cnt, ctg, qmax, lo, width, d0, dmax;
-    uint32_t ref;
-};
+// One wave per group (kp_spec.h, CHAINS OF ANCHORS; oracle/kp_oracle.c chain_group): the group's anchors are gathered into LDS
+// as (target, query, cluster) words and sorted by a bitonic network; minimap2's chaining DP runs over them -- anchor by anchor,
+// the 64 lanes sharing the earlier anchors of each, the winner by a wave reduction on (score, index) --; lane 0 backtracks
+// (mg_chain_backtrack), cuts every chain into pieces and appends a KpJoin per chain of two or more pieces.
+constexpr int JA_MAX = KP_JOIN_ANCHOR_MAX;
+static_assert((JA_MAX & (JA_MAX - 1)) == 0 && JA_MAX <= 4096 && KP_K * JA_MAX < 65536, "bitonic network; 13-bit indices; 16-bit scores");
 
-__global__ __launch_bounds__(256) void kp_join_chain_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
-                                                           const KpTask *__restrict__ tasks, uint32_t task_cap,
-                                                           const KpGroup *__restrict__ groups, const uint32_t *__restrict__ group_count,
-                                                           uint32_t group_cap, KpJoin *__restrict__ joins, uint32_t *__restrict__ join_count,
-                                                           uint32_t join_cap) {
+__device__ __forceinline__ int ja_t(uint64_t w) { return (int)(w >> 20); }
+__device__ __forceinline__ int ja_q(uint64_t w) { return (int)((w >> 4) & 0xFFFFu); }
+__device__ __forceinline__ int ja_c(uint64_t w) { return (int)(w & 15u); }
+static_assert(KP_JOIN_GROUP_MAX <= 16 && KP_MAX_GENE_LEN <= 0xFFFF, "anchor word layout");
+
+__global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
+                                                          const KpTask *__restrict__ tasks, uint32_t task_cap,
+                                                          const KpGroup *__restrict__ groups, const uint32_t *__restrict__ group_count,
+                                                          uint32_t group_cap, KpJoin *__restrict__ joins, uint32_t *__restrict__ join_count,
+                                                          uint32_t join_cap) {
+    __shared__ uint64_t s_a[JA_MAX];
+    __shared__ uint16_t s_f[JA_MAX];   // a chain of n anchors scores at most KP_K * n
+    __shared__ uint16_t s_pm[JA_MAX];  // prefix maximum of f: the scan for predecessors stops where nothing earlier can win
+    __shared__ int16_t s_p[JA_MAX];
+    __shared__ uint8_t s_used[JA_MAX];  // 0 free, 1 member of a chain, 2 free but already tried as a chain's end
+    int16_t *s_chain = reinterpret_cast<int16_t *>(s_pm);  // (the backtracking no longer needs the prefix maxima)
     uint32_t n_groups = *group_count;
     if (n_groups > group_cap) n_groups = group_cap;
-    // one wave per group: the lanes share out the scan of a cluster's anchors (a thread on its own took 0.2 ms for two clusters
-    // of 240 anchors: a chain of memory round trips), lane 0 chains the nodes
-    const int lane = threadIdx.x & 63;
-    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (blockDim.x >> 6)) {
+    const int lane = threadIdx.x;
+    (void)tasks; (void)task_cap;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const KpGroup &G = groups[g];
-        JNode node[KP_JOIN_GROUP_MAX];
-        int m = 0;
-        for (int c = 0; c < G.n; ++c) {
-            const uint32_t ref = G.task[c];
-            if (KP_REF_SLOT(ref) >= task_cap) continue;  // (the list overflowed: the host reruns the pass)
-            const KpTask t = tasks[(size_t)KP_REF_CLS(ref) * task_cap + KP_REF_SLOT(ref)];
-            if (t.n_anchors == 0) continue;  // rejected by its chain score: not a node
-            // head: the anchor with the smallest (query position, diagonal); tail: the one with the largest
+        const int n_members = G.n;
+        int n = 0;
+        for (int c = 0; c < n_members; ++c) n += (int)G.cnt[c];
+        if (n > JA_MAX || n < KP_MIN_ANCHORS) continue;  // (kp_spec.h: such a group is not chained)
+        __syncthreads();  // the group before is done with the arrays
+        int base = 0;
+        for (int c = 0; c < n_members; ++c) {
             const uint64_t *k = keys + (size_t)G.asm_id * cap + G.first[c];
-            uint64_t head = ~0ull, tail = 0ull;
-            for (uint32_t i = (uint32_t)lane; i < G.cnt[c]; i += 64) {
+            const int cnt = (int)G.cnt[c];
+            for (int i = lane; i < cnt; i += 64) {
                 const uint64_t key = k[i];
-                const uint64_t qd = ((uint64_t)kp_ckey_qpos(key, kb) << 32) | kp_ckey_diag(key, kb);
-                if (qd < head) head = qd;
-                if (qd > tail) tail = qd;
+                const uint32_t q = kp_ckey_qpos(key, kb);
+                const uint32_t t = kp_ckey_diag(key, kb) - (uint32_t)KP_DIAG_BIAS + q;
+                s_a[base + i] = ((uint64_t)t << 20) | ((uint64_t)q << 4) | (uint64_t)c;
             }
+            base += cnt;
+        }
+        int n2 = 64;
+        while (n2 < n) n2 <<= 1;
+        for (int i = n + lane; i < n2; i += 64) s_a[i] = ~0ull;
+        for (int i = lane; i < n; i += 64) s_used[i] = 0;
+        __syncthreads();
+        for (int kk = 2; kk <= n2; kk <<= 1)  // by (target, query): no two anchors of a gene/strand share both
+            for (int j = kk >> 1; j >= 1; j >>= 1) {
+                for (int t = lane; t < n2 / 2; t += 64) {
+                    const int lo_i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo_i | j;
+                    const bool asc = (lo_i & kk) == 0;
+                    const uint64_t a = s_a[lo_i], c = s_a[hi_i];
+                    if ((a < c) != asc) { s_a[lo_i] = c; s_a[hi_i] = a; }
+                }
+                __syncthreads();
+            }
+        // the chaining DP: f[i] = max(K, max over earlier j of f[j] + sc(i, j)), the first maximum met going backwards
+        for (int i = 0; i < n; ++i) {
+            const uint64_t wi = s_a[i];
+            const int ti = ja_t(wi), qi = ja_q(wi);
+            int best = KP_K, bj = 0;  // bj = j + 1, 0 = none
+            for (int jb = i - 1; jb >= 0; jb -= 64) {
+                if (ti - ja_t(s_a[jb]) > KP_CHAIN_MAX_DIST) break;  // (sorted by target: every earlier anchor is further still)
+                // a link adds at most KP_K: once the best f of everything from jb down cannot beat what a lane already holds,
+                // nothing earlier can (exact pruning: on a co-linear chain the scan ends after its first round)
+                int seen = best;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint64_t h2 = ((uint64_t)__shfl_xor((uint32_t)(head >> 32), o) << 32) | __shfl_xor((uint32_t)head, o);
-                const uint64_t t2 = ((uint64_t)__shfl_xor((uint32_t)(tail >> 32), o) << 32) | __shfl_xor((uint32_t)tail, o);
-                if (h2 < head) head = h2;
-                if (t2 > tail) tail = t2;
+                for (int o = 32; o >= 1; o >>= 1) seen = max(seen, __shfl_xor(seen, o));
+                if ((int)s_pm[jb] + KP_K <= seen) break;
+                const int j = jb - lane;
+                if (j >= 0) {
+                    const uint64_t wj = s_a[j];
+                    const int dr = ti - ja_t(wj), dq = qi - ja_q(wj);
+                    if (dr <= KP_CHAIN_MAX_DIST && dq > 0 && dq <= KP_CHAIN_MAX_DIST && dr != 0) {
+                        const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+                        if (dd <= KP_JOIN_BW) {
+                            int sc = dg < KP_K ? dg : KP_K;
+                            if (dd || dg > KP_K) sc -= (int)c_join_pen[dd];
+                            sc += (int)s_f[j];
+                            if (sc > best) { best = sc; bj = j + 1; }
+                        }
+                    }
+                }
             }
-            JNode &N = node[m++];
-            N.hq = (int)(head >> 32); N.ht = (int)(uint32_t)head - KP_DIAG_BIAS + N.hq;
-            N.tq = (int)(tail >> 32); N.tt = (int)(uint32_t)tail - KP_DIAG_BIAS + N.tq;
-            N.cs = t.chain_score; N.cnt = t.n_anchors; N.ctg = t.contig; N.qmax = (int)(t.qspan >> 16);
-            N.lo = t.lo; N.width = t.width; N.ref = ref;
-            N.d0 = (int)kp_ckey_diag(k[0], kb); N.dmax = (int)kp_ckey_diag(k[G.cnt[c] - 1], kb);  // (sorted by diagonal first)
-        }
-        if (lane != 0) continue;
-        if (m < 2) continue;
-        int ord[KP_JOIN_GROUP_MAX];
-        for (int i = 0; i < m; ++i) {  // by (head t, head q, list order): stable insertion sort
-            int j = i;
-            while (j > 0 && (node[ord[j - 1]].ht > node[i].ht || (node[ord[j - 1]].ht == node[i].ht && node[ord[j - 1]].hq > node[i].hq))) { ord[j] = ord[j - 1]; --j; }
-            ord[j] = i;
-        }
-        int f[KP_JOIN_GROUP_MAX], p[KP_JOIN_GROUP_MAX];
-        bool used[KP_JOIN_GROUP_MAX];
-        for (int i = 0; i < m; ++i) {
-            const JNode &ci = node[ord[i]];
-            int best = 0, bj = -1;
-            for (int j = i - 1; j >= 0; --j) {
-                const JNode &cj = node[ord[j]];
-                if (cj.ctg != ci.ctg) continue;
-                if (ci.d0 - cj.dmax <= KP_DIAG_GAP && cj.d0 - ci.dmax <= KP_DIAG_GAP) continue;  // one run of diagonals, cut in two by another contig's anchors
-                const int dq = ci.hq - cj.tq, dr = ci.ht - cj.tt;
-                if (dq <= 0 || dr <= 0 || dq > KP_CHAIN_MAX_DIST || dr > KP_CHAIN_MAX_DIST) continue;
-                const int dd = dr > dq ? dr - dq : dq - dr;
-                if (dd > KP_JOIN_BW) continue;
-                const int dg = dr < dq ? dr : dq;
-                const int link = (dg < KP_K ? dg : KP_K) - KP_K - (int)c_join_pen[dd];
-                if (f[j] + link > best) { best = f[j] + link; bj = j; }
+            uint32_t key = ((uint32_t)best << 13) | (uint32_t)bj;  // the largest score, the largest j among equals
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o));
+            if (lane == 0) {
+                const uint16_t fi = (uint16_t)(key >> 13);
+                s_f[i] = fi; s_p[i] = (int16_t)((int)(key & 0x1FFFu) - 1);
+                s_pm[i] = i > 0 && s_pm[i - 1] > fi ? s_pm[i - 1] : fi;
             }
-            f[i] = ci.cs + best; p[i] = bj; used[i] = false;
+            __syncthreads();
         }
+        // mg_chain_backtrack: ends by (f, index) descending
         for (;;) {
-            int end = -1;
-            for (int i = 0; i < m; ++i)
-                if (!used[i] && (end < 0 || f[i] >= f[end])) end = i;
-            if (end < 0) break;
-            int chain[KP_JOIN_MAX_PIECES], len = 0, i = end;
-            while (i >= 0 && !used[i] && len < KP_JOIN_MAX_PIECES) { chain[len++] = i; used[i] = true; i = p[i]; }
-            const int score = f[end] - (i >= 0 ? f[i] : 0);
-            if (len < 2 || score < KP_MIN_CHAIN_SCORE) continue;
-            KpJoin J;
-            const JNode &E = node[ord[end]];
-            J.asm_id = G.asm_id; J.gs = tasks[(size_t)KP_REF_CLS(E.ref) * task_cap + KP_REF_SLOT(E.ref)].gs; J.contig = E.ctg;
-            J.n_pieces = len; J.chain_score = score; J.n_anchors = 0; J.width = 0;
-            for (int k = 0; k < len; ++k) {  // the walk went backwards: piece 0 is the last node walked
-                const JNode &N = node[ord[chain[len - 1 - k]]];
-                J.task[k] = N.ref; J.qmax[k] = N.qmax; J.n_anchors += N.cnt;
-                if (N.width > J.width) J.width = N.width;
+            uint32_t key = 0;
+            for (int i = lane; i < n; i += 64)
+                if (s_used[i] == 0 && s_f[i] >= KP_MIN_CHAIN_SCORE) key = max(key, ((uint32_t)s_f[i] << 13) | (uint32_t)(i + 1));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o));
+            if (key == 0) break;
+            const int end = (int)(key & 0x1FFFu) - 1;
+            if (lane == 0) {
+                const int f_end = (int)s_f[end];
+                int i = end, max_s = 0, steps = 0, cut = 0;
+                do {  // back until a used anchor or the start; the chain is cut where the score counted from its end peaks
+                    i = s_p[i]; ++steps;
+                    const int sc = i < 0 ? f_end : f_end - (int)s_f[i];
+                    if (sc > max_s) { max_s = sc; cut = steps; }
+                    else if (max_s - sc > KP_JOIN_BW) break;
+                } while (i >= 0 && s_used[i] != 1);
+                int len = 0;
+                for (i = end; len < cut; i = s_p[i]) { s_chain[len++] = (int16_t)i; s_used[i] = 1; }
+                // (the walk ran into a used anchor below its own level: no chain ends here.  The anchor is not tried as an end
+                // again -- the ends are visited once, in order -- but stays free for the walks of later ends: 2)
+                if (cut == 0) s_used[end] = 2;
+                if (max_s >= KP_MIN_CHAIN_SCORE && len >= KP_MIN_ANCHORS) {
+                    // pieces, in query order (the chain was walked backwards)
+                    int np = 0, dmin[KP_JOIN_MAX_PIECES], dmax[KP_JOIN_MAX_PIECES], cm[KP_JOIN_MAX_PIECES];
+                    int qlo[KP_JOIN_MAX_PIECES], qhi[KP_JOIN_MAX_PIECES], jump_before[KP_JOIN_MAX_PIECES];
+                    int prev_d = 0;
+                    bool over = false;
+                    for (int z = len - 1; z >= 0; --z) {
+                        const uint64_t w = s_a[s_chain[z]];
+                        const int d = ja_t(w) - ja_q(w);
+                        bool fresh = np == 0;
+                        if (!fresh) {
+                            const int jump = d > prev_d ? d - prev_d : prev_d - d;
+                            const int lo2 = min(d, dmin[np - 1]), hi2 = max(d, dmax[np - 1]);
+                            fresh = jump > KP_DIAG_GAP || hi2 - lo2 > KP_MAX_SPREAD;
+                        }
+                        if (fresh) {
+                            if (np == KP_JOIN_MAX_PIECES) { over = true; break; }
+                            dmin[np] = dmax[np] = d; cm[np] = 0; qlo[np] = ja_q(w);
+                            jump_before[np] = np ? (d > prev_d ? d - prev_d : prev_d - d) : 0;
+                            ++np;
+                        }
+                        dmin[np - 1] = min(dmin[np - 1], d); dmax[np - 1] = max(dmax[np - 1], d);
+                        cm[np - 1] |= 1 << ja_c(w);
+                        qhi[np - 1] = ja_q(w);
+                        prev_d = d;
+                    }
+                    if (!over && np >= 2) {
+                        int width = 0;
+                        for (int k = 0; k < np; ++k) {
+                            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
+                            width = max(width, need <= 32 ? 32 : (need <= 64 ? 64 : 128));
+                        }
+                        const int cls = class_of_width(width);
+                        const uint32_t slot = atomicAdd(&join_count[cls], 1u);
+                        if (slot < join_cap) {  // beyond cap: counted, not stored (host retries)
+                            KpJoin *J = joins + (size_t)cls * join_cap + slot;
+                            J->asm_id = G.asm_id; J->gs = G.gs; J->contig = G.contig; J->n_pieces = np; J->n_anchors = len;
+                            J->chain_score = max_s; J->width = width; J->n_members = n_members; J->drop_mask = 0;
+                            J->weak_mask = kp_weak_ends(np, qlo, qhi, jump_before);
+                            for (int c = 0; c < KP_JOIN_GROUP_MAX; ++c) J->member_task[c] = c < n_members ? G.task[c] : KP_REF_NONE;
+                            for (int k = 0; k < KP_JOIN_MAX_PIECES; ++k) {
+                                if (k < np) {
+                                    const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
+                                    J->lo[k] = dmin[k] - KP_BAND_MARGIN - (width - need) / 2;
+                                    J->cmask[k] = cm[k];
+                                } else { J->lo[k] = 0; J->cmask[k] = 0; }
+                                J->trace_off[k] = J->export_off[k] = 0xFFFFFFFFu;
+                                J->end_s[k] = 0; J->end_r[k] = J->end_b[k] = -1;
+                                J->state[k] = 0; J->visited[k] = 0;
+                                for (int z = 0; z < 9; ++z) J->res[k][z] = 0;
+                            }
+                        }
+                    }
+                }
             }
-            for (int k = 0; k < KP_JOIN_MAX_PIECES; ++k) {
-                if (k < len) {
-                    const JNode &N = node[ord[chain[len - 1 - k]]];
-                    J.lo[k] = N.lo - (J.width - N.width) / 2;
-                } else { J.task[k] = 0; J.qmax[k] = 0; J.lo[k] = 0; }
-                J.trace_off[k] = J.export_off[k] = 0xFFFFFFFFu;
-                J.end_s[k] = JNEG; J.end_r[k] = J.end_b[k] = -1;
-                J.state[k] = 0; J.visited[k] = 0;
-                for (int z = 0; z < 9; ++z) J.res[k][z] = 0;
-            }
-            const int cls = class_of_width(J.width);
-            const uint32_t slot = atomicAdd(&join_count[cls], 1u);
-            if (slot < join_cap) joins[(size_t)cls * join_cap + slot] = J;  // beyond cap: counted, not stored (host retries)
+            __syncthreads();
         }
     }
 }
@@ -178,8 +252,8 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
         for (int k = 0; k < max_pieces; ++k) {
             const bool act = ok && k < n_pieces;
             const int lo = act ? J->lo[k] : 0;
-            const bool cont = k > 0;
-            const int none = cont ? JNEG : 0;
+            const bool cont = k > 0;  // (pieces after the first take the cross gaps of the piece before; every piece is local: H >= 0, restarts)
+            const int none = 0;
             int q0 = 0, r_hi = 0;
             if (act) kp_task_rows(lo, W, cstart, cend, qlen, &q0, &r_hi);
             const int steps = act ? (r_hi - q0) + P - 1 : 0;
@@ -188,7 +262,6 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             const bool exp_horizontal = exports && J->lo[k + 1] > lo;
             const int exp_len = exports ? (exp_horizontal ? qlen : qlen + W) : 0;
             const int lo_next = exports ? J->lo[k + 1] : 0;
-            const int rmin = act ? J->qmax[k] + KP_K - 1 : 0;
             // room: direction bytes (a word per lane and step) and the export array (two 64-bit keys per index)
             const unsigned long long t_units = (unsigned long long)steps8 * P / 4, x_units = (unsigned long long)exp_len;
             unsigned long long toff = 0;
@@ -207,7 +280,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             int H[4], E[4], F[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { H[c] = none; E[c] = F[c] = JNEG; }
-            int best = JNEG, best_r = -1, best_b = 4 * l;
+            int best = 0, best_r = -1, best_b = 4 * l;
             // Eight steps at a time: what they read -- the query rows, the target bases and the keys of the cross gaps -- does not
             // depend on the cells before them, so it is all requested up front and the eight dependent steps then run from
             // registers (a step that fetched its own operands waited for memory three times: 3.3 ms for a 1300-row piece).
@@ -293,12 +366,12 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                                 if (c2 > bv) { bv = c2; tb = XT_X2; }
                             }
                         }
-                        const bool live = inside && (cont ? !dead(bv) : bv > 0);
+                        const bool live = inside && bv > 0;
                         if (inside) { E[c] = e; F[c] = f; } else { E[c] = F[c] = JNEG; }
                         H[c] = live ? bv : none;
                         word |= ((live ? tb : (uint32_t)XT_RESTART) | (e_extd << 3) | (f_extd << 4)) << (8 * c);
                         if (live) {
-                            if (cont && r >= rmin && bv > best) { best = bv; best_r = r; best_b = 4 * l + c; }
+                            if (bv > best) { best = bv; best_r = r; best_b = 4 * l + c; }
                             if (exports && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
                                 const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
                                 const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
@@ -320,7 +393,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             if (act && l == 0) {
                 J->trace_off[k] = fits ? (uint32_t)toff : 0xFFFFFFFFu;
                 J->export_off[k] = fits && exports ? (uint32_t)(toff + t_units) : 0xFFFFFFFFu;
-                J->end_s[k] = fits && best_r >= 0 ? best : JNEG; J->end_r[k] = best_r; J->end_b[k] = best_b;
+                J->end_s[k] = fits && best_r >= 0 ? best : 0; J->end_r[k] = fits ? best_r : -1; J->end_b[k] = best_b;
             }
             __threadfence();  // this piece's exports are in memory before the next piece reads them
             imp = fits && exports ? exp : nullptr;
@@ -345,6 +418,9 @@ __global__ __launch_bounds__(64) void kp_join_fill_kernel(KpBatchView b, KpGenes
 }
 
 // ---- walk-back: one lane per join -------------------------------------------------------------------------------------------------
+// THE JOINED PATH and the CONSUMED PIECES of kp_spec.h (oracle: join_run): the pieces are tried in the order of their best cells'
+// scores; the first path the drop test does not reject settles the chain -- a hit if it crosses a gap --, and the band tasks of
+// the group's clusters that the chain's pieces hold anchors of lose their own hits (sign of the result's score flipped).
 __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGenes genes, KpJoin *__restrict__ joins,
                                                            const uint32_t *__restrict__ join_count, uint32_t join_cap,
                                                            uint32_t task_cap, const uint4 *__restrict__ trace,
@@ -365,13 +441,19 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
         const int32_t *runs = b.n_runs + 2 * (size_t)r0n;
         bool complete = true;
         for (int k = 0; k < m; ++k) complete = complete && J->trace_off[k] != 0xFFFFFFFFu;
-        int on_path = 0;
-        for (int k = m - 1; k >= 1; --k) {
-            J->state[k] = 0; J->visited[k] = 0;
-            if (!complete || ((on_path >> k) & 1)) continue;
-            if (J->end_r[k] < 0 || J->end_s[k] < KP_MIN_DP_SCORE) continue;
+        for (int k = 0; k < m; ++k) { J->state[k] = 0; J->visited[k] = 0; }
+        J->drop_mask = 0;
+        if (!complete) continue;  // (the trace buffer ran out: the host grows it and reruns the pass)
+        int settled = 0, hit_k = -1, alone_k = -1;
+        bool any_rejected = false;
+        for (;;) {
+            int k = -1;
+            for (int z = 0; z < m; ++z)
+                if (!((settled >> z) & 1) && (k < 0 || J->end_s[z] > J->end_s[k])) k = z;
+            if (k < 0) break;
+            if (J->end_r[k] < 0 || J->end_s[k] < KP_MIN_DP_SCORE) { alone_k = k; break; }
             int pk = k, r = J->end_r[k], bi = J->end_b[k], state = 0, matches = 0, cols = 0, gap = 0, credit = 0;
-            int sr = r, sb = bi, spk = k, suf = 0, sufmax = 0, visited = 1 << k, bonus = 0;
+            int sr = r, sb = bi, spk = k, suf = 0, sufmax = 0, gsum = 0, visited = 1 << k, bonus = 0;
             bool rejected = false;
             int lo = J->lo[pk], q0 = 0, r_hi = 0;
             kp_task_rows(lo, W, cstart, cend, qlen, &q0, &r_hi);
@@ -383,7 +465,9 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                 if (state == 0) {
                     const uint32_t tb = byte & 7u;
                     if (tb == XT_RESTART) break;
-                    if (suf > sufmax) sufmax = suf;
+                    // the drop test: at every cross gap, and at every cell once a gap has been crossed (cross-gap costs left out)
+                    if (suf + gsum > sufmax) sufmax = suf + gsum;
+                    else if ((tb >= XT_X1 || visited != (1 << k)) && sufmax - (suf + gsum) > KP_JOIN_DROP) { rejected = true; break; }
                     if (tb == XT_DIAG) {
                         sr = r; sb = bi; spk = pk; ++cols;
                         const uint32_t qc = nib4(qnib[r >> 3], r & 7);
@@ -402,7 +486,6 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                     } else if (tb == XT_E || tb == XT_F) {
                         state = (int)tb;
                     } else {  // a cross gap: on to the cell of piece pk - 1 it came from
-                        if (sufmax - suf > KP_JOIN_DROP) { rejected = true; break; }
                         const int lo_prev = J->lo[pk - 1];
                         const bool horizontal = lo > lo_prev;
                         const unsigned long long *exp = reinterpret_cast<const unsigned long long *>(trace + J->export_off[pk - 1]);
@@ -412,7 +495,7 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                         const int ngap = horizontal ? (t - lo_prev) - pos : r - pos;
                         cols += ngap;
                         const int cost = tb == XT_X1 ? KP_GAP_OPEN + KP_GAP_EXT * ngap : KP_GAP_OPEN2 + KP_GAP_EXT2 * ngap;
-                        suf -= cost;
+                        suf -= cost; gsum += cost;
                         const int lg = KP_GAP_OPEN + kp_log2x2((uint32_t)ngap);
                         if (cost > lg) bonus += cost - lg;
                         if (horizontal) bi = pos - r;               // same row, column lo_prev + pos
@@ -431,18 +514,30 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                 }
             }
             J->visited[k] = visited;
-            if (rejected) { J->state[k] = 2; continue; }
-            J->state[k] = 1;
-            on_path |= visited;
+            if (rejected) { J->state[k] = 2; any_rejected = true; settled |= 1 << k; continue; }
+            if (visited == (1 << k)) { alone_k = k; break; }  // crosses no gap: the band task of the piece's cluster covers it
+            J->state[k] = 1; hit_k = k;
             J->res[k][0] = J->end_s[k]; J->res[k][1] = sr; J->res[k][2] = J->end_r[k] + 1;
             J->res[k][3] = sr + J->lo[spk] + sb; J->res[k][4] = J->end_r[k] + J->lo[k] + J->end_b[k] + 1;
             J->res[k][5] = matches; J->res[k][6] = cols; J->res[k][7] = J->end_s[k] + credit;
             J->res[k][8] = bonus < KP_HIT_BONUS_MAX ? bonus : KP_HIT_BONUS_MAX;
-            for (int v = 0; v < m; ++v)  // the band tasks of the visited pieces no longer report a hit of their own
-                if ((visited >> v) & 1) {
-                    KpSwResult &R = results[(size_t)KP_REF_CLS(J->task[v]) * task_cap + KP_REF_SLOT(J->task[v])];
-                    if (R.score > 0) R.score = -R.score;
-                }
+            break;
+        }
+        // CONSUMED PIECES: the clusters of the pieces the joined hit runs through, and those of the chain's weak ends that no
+        // reported path reaches
+        const int on = hit_k >= 0 ? J->visited[hit_k] : 0;
+        int drop = 0;
+        for (int k = 0; k < m; ++k) {
+            if ((on >> k) & 1) drop |= J->cmask[k];
+            else if (!any_rejected && ((J->weak_mask >> k) & 1) && k != alone_k) drop |= J->cmask[k];
+        }
+        if (alone_k >= 0) drop &= ~J->cmask[alone_k];
+        J->drop_mask = drop;
+        for (int c = 0; c < J->n_members; ++c) {
+            const uint32_t ref = J->member_task[c];
+            if (!((drop >> c) & 1) || ref == KP_REF_NONE || KP_REF_SLOT(ref) >= task_cap) continue;
+            KpSwResult &R = results[(size_t)KP_REF_CLS(ref) * task_cap + KP_REF_SLOT(ref)];
+            if (R.score > 0) R.score = -R.score;
         }
     }
 }
@@ -453,15 +548,20 @@ void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
                           KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream) {
     (void)b; (void)genes;
-    hipLaunchKernelGGL(kp_join_chain_kernel, dim3(64), dim3(256), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
+    if (const char *e = std::getenv("KAPTIVE_AMD_SKIP_JOINS")) if (std::atoi(e) & 1) return;  // (debugging aid: bit 0 chaining, 1 fill, 2 walk-back)
+    hipLaunchKernelGGL(kp_join_chain_kernel, dim3(512), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
                        group_count, group_cap, joins, join_count, join_cap);
 }
 
 void kp_launch_join_sw(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
                        uint32_t task_cap, void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, KpSwResult *results,
                        hipStream_t stream) {
+    const char *skip_env = std::getenv("KAPTIVE_AMD_SKIP_JOINS");
+    const int skip = skip_env ? std::atoi(skip_env) : 0;
+    if (!(skip & 2))
     hipLaunchKernelGGL(kp_join_fill_kernel, dim3(128, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap,
                        reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
+    if (!(skip & 4))
     hipLaunchKernelGGL(kp_join_trace_kernel, dim3(32, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap, task_cap,
                        reinterpret_cast<const uint4 *>(trace), results);
 }

@@ -163,6 +163,7 @@ def make_assembly(
     indel_rate: float = 2e-5,
     mid_indels: tuple = (),
     indel_storm: tuple = (),
+    placed_indels: tuple = (),
     repeat_segment: tuple = (),
     is_copies: tuple = (),
     background: str = "iid",
@@ -173,7 +174,11 @@ def make_assembly(
     gene's middle half) -- the 30-500 base events minimap2 chains across (bw = 500); drawn from a generator of their
     own, so that the other draws of a seed do not move.  ``indel_storm`` = (events, smallest, largest): that many insertions /
     deletions of smallest..largest bases ANYWHERE in the locus copy (several per gene, gene ends, spacers: chains of
-    three and more pieces, weak end pieces, events closer together than a band is wide).  ``repeat_segment`` = (length, copies): a stretch of one gene of
+    three and more pieces, weak end pieces, events closer together than a band is wide).  ``placed_indels``: one entry per gene
+    to edit, each a tuple of events ``(kind, size, offset)`` at an EXPLICIT place -- ``offset`` >= 0 counts from the gene's first
+    base in locus coordinates, ``offset`` < 0 from its end (a deletion then ends, an insertion sits, ``-offset`` bases before
+    the end) -- so that events next to a gene's ends and pairs of events that nearly cancel can be planted (``mid_indels`` only
+    reaches the middle half of a gene); genes long enough for their entry are drawn from a generator of their own.  ``repeat_segment`` = (length, copies): a stretch of one gene of
     the locus copy planted ``copies`` more times around the genome, each copy mutated a little (seeds that occur more
     than ten times: minimap2's occurrence cut); ``is_copies`` = (copies, length): one random IS-like element planted that
     many times (not in any database: it only moves the quantile minimap2 derives its cut from).  ``background`` = "paralog":
@@ -217,6 +222,25 @@ def make_assembly(
                 at = s + int(rng2.integers((e - s) // 4, max((e - s) // 4 + 1, 3 * (e - s) // 4 - (size if kind == "del" else 0))))
                 edits.append((at, int(size), kind, random_dna(rng2, int(size), gc)))
             for at, size, kind, ins in sorted(edits, key=lambda t: -t[0]):  # from the far end: earlier coordinates stay put
+                copy = np.delete(copy, slice(at, at + size)) if kind == "del" else np.concatenate([copy[:at], ins, copy[at:]])
+        if placed_indels:
+            rng5 = np.random.default_rng([seed, 0xE2D])
+            glen = db.gene_intervals.ends[g0:g1].astype(np.int64) - db.gene_intervals.starts[g0:g1]
+            taken: set = set()
+            edits = []
+            for entry in placed_indels:
+                need = 60 + max(abs(int(off)) + (int(size) if kind == "del" else 0) for kind, size, off in entry)
+                ok = [g0 + i for i in range(g1 - g0) if glen[i] >= need and g0 + i not in taken]
+                if not ok:
+                    continue
+                gi = int(rng5.choice(ok))
+                taken.add(gi)
+                s, e = int(db.gene_intervals.starts[gi]), int(db.gene_intervals.ends[gi])
+                for kind, size, off in entry:
+                    size, off = int(size), int(off)
+                    at = s + off if off >= 0 else (e + off - size if kind == "del" else e + off)
+                    edits.append((at, size, kind, random_dna(rng5, size, gc)))
+            for at, size, kind, ins in sorted(edits, key=lambda t: -t[0]):
                 copy = np.delete(copy, slice(at, at + size)) if kind == "del" else np.concatenate([copy[:at], ins, copy[at:]])
         if indel_storm:
             rng4 = np.random.default_rng([seed, 0x5702])

@@ -24,6 +24,7 @@
  *                       against that model's (tests/test_mm2_concordance.py, profiles/concordance_r4.md).
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -532,13 +533,14 @@ static int contig_of(const kpo_asm *a, int64_t t) { /* largest c with ctg_start[
     return lo;
 }
 
-/* a provisional cluster (kp_spec.h, v4): what the join stage needs of it */
+/* a cluster (kp_spec.h, v5): what the join stage needs of it -- every cluster is listed, weak ones (fewer than KP_MIN_ANCHORS
+ * anchors, or fewer than KP_MIN_SEED_SPAN query bases) included */
 typedef struct kpo_pcl {
     int32_t gs, contig;
     int32_t d0, dmax;       /* lowest / highest anchor diagonal (true values) */
-    int32_t task;           /* index into the task list, -1 when its chain score rejected it */
-    int32_t hq, ht, tq, tt; /* head and tail anchor: query position, target position */
-    int32_t qmax;
+    int32_t task;           /* index into the task list, -1 when it has no band task (weak, or rejected by its chain score) */
+    int32_t provisional;    /* >= KP_MIN_ANCHORS anchors covering >= KP_MIN_SEED_SPAN query bases */
+    int64_t first; int32_t cnt; /* its anchors in the sorted list */
 } kpo_pcl;
 
 static int64_t make_tasks_x(const kpo_asm *a, const uint64_t *keys, int64_t n, kpo_task **out, kpo_pcl **pcl_out, int64_t *n_pcl_out) {
@@ -550,7 +552,6 @@ static int64_t make_tasks_x(const kpo_asm *a, const uint64_t *keys, int64_t n, k
         uint32_t gs = KP_KEY_GS(keys[i]), d0 = KP_KEY_DIAG(keys[i]), q = KP_KEY_QPOS(keys[i]);
         int ctg = contig_of(a, (int64_t)d0 - KP_DIAG_BIAS + q);
         uint32_t dprev = d0, dmax = d0, qmin = q, qmax = q;
-        uint32_t hq = q, hd = d0, tq = q, td = d0; /* head: smallest (q, diagonal); tail: largest */
         int cnt = 1;
         int64_t j = i + 1;
         for (; j < n; j++) {
@@ -560,8 +561,6 @@ static int64_t make_tasks_x(const kpo_asm *a, const uint64_t *keys, int64_t n, k
             dprev = d2; dmax = d2; cnt++;
             if (q2 < qmin) qmin = q2;
             if (q2 > qmax) qmax = q2;
-            if (q2 < hq) { hq = q2; hd = d2; }  /* (diagonals ascend: the first anchor with the smallest q has the smallest diagonal) */
-            if (q2 >= tq) { tq = q2; td = d2; }
         }
         const int provisional = cnt >= KP_MIN_ANCHORS && (int)(qmax - qmin) + KP_K >= KP_MIN_SEED_SPAN;
         int chain_cnt = cnt, chain_sc = 0, ok;
@@ -573,15 +572,15 @@ static int64_t make_tasks_x(const kpo_asm *a, const uint64_t *keys, int64_t n, k
             ok = span >= KP_MIN_SEED_SPAN;
             chain_sc = KP_K * cnt < span ? KP_K * cnt : span;
         }
-        if (provisional) {
+        {
             if (np == pcap) { pcap *= 2; pcl = realloc(pcl, (size_t)pcap * sizeof(kpo_pcl)); }
             kpo_pcl *c = &pcl[np++];
             c->gs = (int32_t)gs; c->contig = ctg;
             c->d0 = (int32_t)((int64_t)d0 - KP_DIAG_BIAS); c->dmax = (int32_t)((int64_t)dmax - KP_DIAG_BIAS);
+            c->provisional = provisional;
+            ok = ok && provisional;
             c->task = ok ? (int32_t)nt : -1;
-            c->hq = (int32_t)hq; c->ht = (int32_t)((int64_t)hd - KP_DIAG_BIAS + hq);
-            c->tq = (int32_t)tq; c->tt = (int32_t)((int64_t)td - KP_DIAG_BIAS + tq);
-            c->qmax = (int32_t)qmax;
+            c->first = i; c->cnt = cnt;
         }
         if (ok) {
             int margin = KP_BAND_MARGIN_NARROW, need = (int)(dmax - d0) + 1 + 2 * KP_BAND_MARGIN_NARROW, w = 16;
@@ -675,34 +674,146 @@ static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstar
     free(H); free(E); free(F); free(tH); free(tE); free(tF);
 }
 
-/* ---- kp-align v4: joins (kp_spec.h) ----------------------------------------------------------------------------------------- */
+/* ---- kp-align v5: chains of anchors across diagonal jumps, their pieces and the joined alignment (kp_spec.h) ---------------- */
 typedef struct kpo_join {
     int32_t gs, contig, n_pieces, n_anchors, chain_score, width;
-    int32_t task[KP_JOIN_MAX_PIECES]; /* task of every piece, query order */
-    int32_t lo[KP_JOIN_MAX_PIECES];   /* lowest diagonal of its (widened) band */
-    int32_t qmax[KP_JOIN_MAX_PIECES];
-    /* results, per piece k > 0: res[k] = cell score, q_start, q_end, t_start, t_end, matches, block_len, reported score;
-     * state[k]: 0 = no END / below the cut-off / on a path reported before, 1 = hit, 2 = rejected by the drop test;
-     * visited[k] = mask of the pieces the path of piece k runs through */
-    int32_t res[KP_JOIN_MAX_PIECES][9]; /* [8]: the bonus of the order score */
+    int32_t lo[KP_JOIN_MAX_PIECES];    /* lowest diagonal of every piece's band, query order */
+    int32_t cmask[KP_JOIN_MAX_PIECES]; /* bit c: the piece holds an anchor of the group's cluster c */
+    int32_t n_members, member_task[KP_JOIN_GROUP_MAX]; /* the group's clusters: their band tasks (-1 = none) */
+    int32_t weak_mask; /* bit k: piece k belongs to a WEAK END of the chain (kp_spec.h) */
+    /* results: end_s[k] = the piece's best cell score (piece 0 included); per piece k > 0: res[k] = cell score, q_start, q_end,
+     * t_start, t_end, matches, block_len, reported score, bonus of the order score; state[k]: 0 = no END / below the cut-off /
+     * its path crosses no gap / on a path reported before, 1 = hit, 2 = rejected by the drop test; visited[k] = mask of the
+     * pieces the path of piece k runs through; drop_mask = the group's clusters whose band tasks report no hit of their own */
+    int32_t end_s[KP_JOIN_MAX_PIECES];
+    int32_t res[KP_JOIN_MAX_PIECES][9];
     int32_t state[KP_JOIN_MAX_PIECES], visited[KP_JOIN_MAX_PIECES];
+    int32_t drop_mask;
 } kpo_join;
 
-/* groups of provisional clusters -> chains of accepted clusters -> join records */
-static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks, kpo_join **out) {
+typedef struct { int32_t t, q, c; } kpo_ganchor;
+static int cmp_ganchor(const void *a, const void *b) {
+    const kpo_ganchor *x = a, *y = b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->q < y->q ? -1 : (x->q > y->q);
+}
+
+/* One GROUP: minimap2's chaining DP over all its anchors (exact: every earlier anchor within KP_CHAIN_MAX_DIST is a candidate),
+ * mg_chain_backtrack, every chain cut into PIECES; chains of 2..KP_JOIN_MAX_PIECES pieces become join records. */
+static void chain_group(const uint64_t *keys, const kpo_pcl *pcl, const int *member, int n_members, kpo_join **joins, int64_t *nj, int64_t *cap) {
     static const uint8_t pen[KP_CHAIN_PEN_SIZE] = KP_CHAIN_PEN_TABLE;
+    int64_t na = 0;
+    for (int c = 0; c < n_members; c++) na += pcl[member[c]].cnt;
+    if (na > KP_JOIN_ANCHOR_MAX || na < KP_MIN_ANCHORS) return;
+    kpo_ganchor *a = malloc((size_t)na * sizeof(kpo_ganchor));
+    int32_t *f = malloc((size_t)na * 4), *p = malloc((size_t)na * 4), *used = calloc((size_t)na, 4), *order = malloc((size_t)na * 4);
+    int64_t n = 0;
+    for (int c = 0; c < n_members; c++) {
+        const kpo_pcl *cl = &pcl[member[c]];
+        for (int64_t i = cl->first; i < cl->first + cl->cnt; i++) {
+            const int32_t q = (int32_t)KP_KEY_QPOS(keys[i]);
+            a[n].q = q; a[n].t = (int32_t)KP_KEY_DIAG(keys[i]) - KP_DIAG_BIAS + q; a[n].c = c; n++;
+        }
+    }
+    qsort(a, (size_t)n, sizeof(kpo_ganchor), cmp_ganchor); /* (target, query): no two anchors of a gene/strand share both */
+    for (int64_t i = 0; i < n; i++) {
+        int max_f = KP_K; int64_t max_j = -1;
+        for (int64_t j = i - 1; j >= 0; j--) {
+            const int dr = a[i].t - a[j].t, dq = a[i].q - a[j].q;
+            if (dr > KP_CHAIN_MAX_DIST) break;
+            if (dq <= 0 || dq > KP_CHAIN_MAX_DIST || dr == 0) continue;
+            const int dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
+            if (dd > KP_JOIN_BW) continue;
+            int sc = dg < KP_K ? dg : KP_K;
+            if (dd || dg > KP_K) sc -= pen[dd];
+            sc += f[j];
+            if (sc > max_f) { max_f = sc; max_j = j; }
+        }
+        f[i] = max_f; p[i] = (int32_t)max_j;
+    }
+    /* ends by (f descending, the later anchor first) */
+    int64_t n_ends = 0;
+    for (int64_t i = 0; i < n; i++) if (f[i] >= KP_MIN_CHAIN_SCORE) order[n_ends++] = (int32_t)i;
+    for (int64_t x = 1; x < n_ends; x++) { /* insertion sort (groups are small) */
+        const int32_t v = order[x]; int64_t y = x;
+        while (y > 0 && (f[order[y - 1]] < f[v] || (f[order[y - 1]] == f[v] && order[y - 1] < v))) { order[y] = order[y - 1]; y--; }
+        order[y] = v;
+    }
+    int32_t *chain = malloc((size_t)n * 4);
+    for (int64_t e = 0; e < n_ends; e++) {
+        const int32_t end = order[e];
+        if (used[end]) continue;
+        /* walk back until a used anchor or the start; the chain is cut where the score counted from its end peaks */
+        int32_t i = end, max_s = 0, steps = 0, cut = 0;
+        do {
+            i = p[i]; steps++;
+            const int sc = i < 0 ? f[end] : f[end] - f[i];
+            if (sc > max_s) { max_s = sc; cut = steps; }
+            else if (max_s - sc > KP_JOIN_BW) break; /* (mg_chain_backtrack's max_drop = bw) */
+        } while (i >= 0 && !used[i]);
+        int32_t len = 0;
+        for (i = end; len < cut; i = p[i]) { chain[len++] = i; used[i] = 1; }
+        if (max_s < KP_MIN_CHAIN_SCORE || len < KP_MIN_ANCHORS) continue; /* (its anchors stay used, as in mg_chain_backtrack) */
+        /* pieces, in query order (the chain was walked backwards): a new piece where the diagonal jumps by more than
+         * KP_DIAG_GAP or the piece would span more than KP_MAX_SPREAD diagonals */
+        int np = 0, dmin[KP_JOIN_MAX_PIECES + 1], dmax[KP_JOIN_MAX_PIECES + 1], cm[KP_JOIN_MAX_PIECES + 1];
+        int qlo[KP_JOIN_MAX_PIECES + 1], qhi[KP_JOIN_MAX_PIECES + 1], jump_before[KP_JOIN_MAX_PIECES + 1];
+        int prev_d = 0, over = 0;
+        for (int32_t z = len - 1; z >= 0; z--) {
+            const kpo_ganchor *x = &a[chain[z]];
+            const int d = x->t - x->q;
+            int fresh = np == 0;
+            if (!fresh) {
+                const int jump = d > prev_d ? d - prev_d : prev_d - d;
+                const int lo2 = d < dmin[np - 1] ? d : dmin[np - 1], hi2 = d > dmax[np - 1] ? d : dmax[np - 1];
+                fresh = jump > KP_DIAG_GAP || hi2 - lo2 > KP_MAX_SPREAD;
+            }
+            if (fresh) {
+                if (np == KP_JOIN_MAX_PIECES) { over = 1; break; }
+                dmin[np] = dmax[np] = d; cm[np] = 0; qlo[np] = x->q; jump_before[np] = np ? (d > prev_d ? d - prev_d : prev_d - d) : 0; np++;
+            }
+            if (d < dmin[np - 1]) dmin[np - 1] = d;
+            if (d > dmax[np - 1]) dmax[np - 1] = d;
+            cm[np - 1] |= 1 << x->c;
+            qhi[np - 1] = x->q;
+            prev_d = d;
+        }
+        if (over || np < 2) continue;
+        if (*nj == *cap) { *cap *= 2; *joins = realloc(*joins, (size_t)*cap * sizeof(kpo_join)); }
+        kpo_join *J = &(*joins)[(*nj)++];
+        memset(J, 0, sizeof *J);
+        J->gs = pcl[member[0]].gs; J->contig = pcl[member[0]].contig; J->n_pieces = np;
+        J->n_anchors = len; J->chain_score = max_s;
+        J->n_members = n_members;
+        for (int c = 0; c < n_members; c++) J->member_task[c] = pcl[member[c]].task;
+        for (int k = 0; k < np; k++) {
+            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN, w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
+            if (w > J->width) J->width = w;
+        }
+        for (int k = 0; k < np; k++) {
+            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
+            J->lo[k] = dmin[k] - KP_BAND_MARGIN - (J->width - need) / 2;
+            J->cmask[k] = cm[k];
+        }
+        J->weak_mask = kp_weak_ends(np, qlo, qhi, jump_before);
+    }
+    free(chain); free(a); free(f); free(p); free(used); free(order);
+}
+
+/* groups of clusters -> chains of anchors -> join records */
+static int64_t make_joins(const uint64_t *keys, const kpo_pcl *pcl, int64_t np, kpo_join **out) {
     int64_t cap = 64, nj = 0;
     kpo_join *joins = malloc((size_t)cap * sizeof(kpo_join));
-    /* GROUPS (kp_spec.h): per gene/strand and contig, the provisional clusters in list order; a cluster continues the open
+    /* GROUPS (kp_spec.h): per gene/strand and contig, the clusters in list order; a cluster continues the open
      * sequence of its contig iff its lowest diagonal is within KP_JOIN_BW of that sequence's last cluster's highest one and
      * the sequence holds fewer than KP_JOIN_GROUP_MAX clusters.  At most KP_JOIN_OPEN sequences of a gene/strand are open
-     * at a time: a new contig's cluster closes the open sequence whose last cluster ends lowest (lowest contig on ties). */
+     * at a time: a new contig's cluster closes the open sequence whose last cluster ends lowest (lowest contig on ties).
+     * A closed sequence of two or more clusters, one of them provisional, is a group. */
     typedef struct { int n; int member[KP_JOIN_GROUP_MAX]; } kpo_seq;
     kpo_seq open[KP_JOIN_OPEN];
     int n_open = 0;
-    int64_t gcap = 64, ng = 0;
-    kpo_seq *groups = malloc((size_t)gcap * sizeof(kpo_seq));
-#define KPO_CLOSE(slot) do { if (open[slot].n >= 2) { if (ng == gcap) { gcap *= 2; groups = realloc(groups, (size_t)gcap * sizeof(kpo_seq)); } groups[ng++] = open[slot]; } \
+#define KPO_CLOSE(slot) do { if (open[slot].n >= 2) { int any = 0; for (int z = 0; z < open[slot].n; z++) any |= pcl[open[slot].member[z]].provisional; \
+                                 if (any) chain_group(keys, pcl, open[slot].member, open[slot].n, &joins, &nj, &cap); } \
                              open[slot] = open[--n_open]; } while (0)
     for (int64_t c = 0; c <= np; c++) {
         if (c == np || (n_open > 0 && pcl[open[0].member[0]].gs != pcl[c].gs))
@@ -726,63 +837,6 @@ static int64_t make_joins(const kpo_pcl *pcl, int64_t np, const kpo_task *tasks,
         open[n_open].n = 1; open[n_open].member[0] = (int)c; n_open++;
     }
 #undef KPO_CLOSE
-    for (int64_t gi = 0; gi < ng; gi++) {
-        int node[KP_JOIN_GROUP_MAX], m = 0;
-        for (int c = 0; c < groups[gi].n; c++)
-            if (pcl[groups[gi].member[c]].task >= 0) node[m++] = groups[gi].member[c];
-        if (m >= 2) {
-            for (int i = 1; i < m; i++) { /* order by (head t, head q, list order): insertion sort, stable */
-                const int x = node[i];
-                int j = i;
-                while (j > 0 && (pcl[node[j - 1]].ht > pcl[x].ht || (pcl[node[j - 1]].ht == pcl[x].ht && pcl[node[j - 1]].hq > pcl[x].hq))) { node[j] = node[j - 1]; j--; }
-                node[j] = x;
-            }
-            int f[KP_JOIN_GROUP_MAX], p[KP_JOIN_GROUP_MAX], used[KP_JOIN_GROUP_MAX];
-            for (int i = 0; i < m; i++) {
-                const kpo_pcl *ci = &pcl[node[i]];
-                int best = 0, bj = -1;
-                for (int j = i - 1; j >= 0; j--) {
-                    const kpo_pcl *cj = &pcl[node[j]];
-                    if (cj->contig != ci->contig) continue;
-                    if (ci->d0 - cj->dmax <= KP_DIAG_GAP && cj->d0 - ci->dmax <= KP_DIAG_GAP) continue; /* one run of diagonals cut in two by another contig's anchors: the band tasks cover it */
-                    const int dq = ci->hq - cj->tq, dr = ci->ht - cj->tt;
-                    if (dq <= 0 || dr <= 0 || dq > KP_CHAIN_MAX_DIST || dr > KP_CHAIN_MAX_DIST) continue;
-                    const int dd = dr > dq ? dr - dq : dq - dr;
-                    if (dd > KP_JOIN_BW) continue;
-                    const int dg = dr < dq ? dr : dq;
-                    const int link = (dg < KP_K ? dg : KP_K) - KP_K - (int)pen[dd];
-                    if (f[j] + link > best) { best = f[j] + link; bj = j; }
-                }
-                f[i] = tasks[ci->task].chain_score + best; p[i] = bj; used[i] = 0;
-            }
-            for (;;) {
-                int end = -1;
-                for (int i = 0; i < m; i++)
-                    if (!used[i] && (end < 0 || f[i] >= f[end])) end = i;
-                if (end < 0) break;
-                int chain[KP_JOIN_MAX_PIECES], len = 0, i = end;
-                while (i >= 0 && !used[i] && len < KP_JOIN_MAX_PIECES) { chain[len++] = i; used[i] = 1; i = p[i]; }
-                if (len < 2 || f[end] - (i >= 0 ? f[i] : 0) < KP_MIN_CHAIN_SCORE) continue; /* (a branch off a used node can fall below -m) */
-                if (nj == cap) { cap *= 2; joins = realloc(joins, (size_t)cap * sizeof(kpo_join)); }
-                kpo_join *J = &joins[nj++];
-                memset(J, 0, sizeof *J);
-                J->gs = pcl[node[end]].gs; J->contig = pcl[node[end]].contig; J->n_pieces = len;
-                J->chain_score = f[end] - (i >= 0 ? f[i] : 0);
-                for (int k = 0; k < len; k++) { /* the walk went backwards: piece 0 is the last node walked */
-                    const kpo_pcl *c = &pcl[node[chain[len - 1 - k]]];
-                    const kpo_task *t = &tasks[c->task];
-                    J->task[k] = c->task; J->qmax[k] = c->qmax;
-                    J->n_anchors += t->n_anchors;
-                    if (t->width > J->width) J->width = t->width;
-                }
-                for (int k = 0; k < len; k++) {
-                    const kpo_task *t = &tasks[J->task[k]];
-                    J->lo[k] = t->lo - (J->width - t->width) / 2;
-                }
-            }
-        }
-    }
-    free(groups);
     *out = joins;
     return nj;
 }
@@ -808,9 +862,9 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
     for (int k = 0; k < m; k++) {
         kpo_xpiece *X = &P[k];
         const int lo = J->lo[k];
-        /* piece 0: local (H >= 0, restarts); later pieces: CONTINUATION -- no restart, cells that no path from piece k - 1
-         * reaches are dead (KP_NEG_INF), scores may be negative */
-        const int cont = k > 0, none = cont ? KP_NEG_INF : 0;
+        /* every piece is a local alignment (H >= 0, restarts); pieces after the first have the cross gaps from the piece
+         * before them as two more sources of H */
+        const int none = 0;
         X->H = malloc(cells * 4); X->tH = malloc(cells); X->tE = malloc(cells); X->tF = malloc(cells);
         int32_t *E = malloc(cells * 4), *F = malloc(cells * 4);
         const kpo_xpiece *prev = k > 0 ? &P[k - 1] : NULL;
@@ -821,7 +875,7 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
             X->a1 = malloc((size_t)X->xlen * 4); X->a2 = malloc((size_t)X->xlen * 4);
             for (int i = 0; i < X->xlen; i++) { X->x1[i] = X->x2[i] = INT64_MIN; X->a1[i] = X->a2[i] = 0; }
         }
-        X->end_s = KP_NEG_INF; X->end_r = X->end_b = -1;
+        X->end_s = 0; X->end_r = X->end_b = -1;
 #define VALID(r, b) ((r) >= 0 && (b) >= 0 && (b) < w && (int64_t)(r) + lo + (b) >= cstart && (int64_t)(r) + lo + (b) < cend)
         for (int r = 0; r < qlen; r++) {
             for (int b = 0; b < w; b++) {
@@ -853,12 +907,11 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
                         if (c2 > best) { best = c2; tb = XT_X2; }
                     }
                 }
-                int live;
-                if (cont) { live = !KPO_DEAD(best); if (!live) { X->H[AT(r, b)] = KP_NEG_INF; X->tH[AT(r, b)] = XT_RESTART; } }
-                else { live = best > 0; if (!live) { X->H[AT(r, b)] = 0; X->tH[AT(r, b)] = XT_RESTART; } }
+                const int live = best > 0;
+                if (!live) { X->H[AT(r, b)] = 0; X->tH[AT(r, b)] = XT_RESTART; }
                 if (live) {
                     X->H[AT(r, b)] = (int)best; X->tH[AT(r, b)] = (uint8_t)tb;
-                    if (cont && r >= J->qmax[k] + KP_K - 1 && best > X->end_s) { X->end_s = (int)best; X->end_r = r; X->end_b = b; }
+                    if (best > X->end_s) { X->end_s = (int)best; X->end_r = r; X->end_b = b; }
                     if (X->x1) { /* export (cells of this piece that lie before / above the next piece's band) */
                         const int lo_next = J->lo[k + 1];
                         if (X->horizontal ? (b < lo_next - lo) : (lo + b > lo_next + w - 1)) {
@@ -875,16 +928,21 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
 #undef VALID
         free(E); free(F);
     }
-    /* joined paths, last piece first */
-    int on_path = 0; /* mask of pieces on a path reported before */
-    for (int k = m - 1; k >= 1; k--) {
-        J->state[k] = 0; J->visited[k] = 0;
-        if ((on_path >> k) & 1) continue;
+    /* THE JOINED PATH (kp_spec.h): the pieces are tried in the order of their best cells' scores (the earlier piece on ties); a
+     * piece whose path the drop test rejects is set aside and the next one tried; the first path that is not rejected settles
+     * the chain -- a hit if it crosses at least one gap, otherwise the band task of that piece's cluster stands for it */
+    int settled = 0, hit_k = -1, alone_k = -1, any_rejected = 0;
+    for (int k = 0; k < m; k++) { J->end_s[k] = P[k].end_s; J->state[k] = 0; J->visited[k] = 0; }
+    for (;;) {
+        int k = -1;
+        for (int z = 0; z < m; z++)
+            if (!((settled >> z) & 1) && (k < 0 || P[z].end_s > P[k].end_s)) k = z;
+        if (k < 0) break;
         const kpo_xpiece *X = &P[k];
-        if (X->end_r < 0 || X->end_s < KP_MIN_DP_SCORE) continue;
+        if (X->end_r < 0 || X->end_s < KP_MIN_DP_SCORE) { alone_k = k; break; } /* (nothing to report: the best piece keeps its own task) */
         int pk = k, r = X->end_r, b = X->end_b, state = 0, matches = 0, cols = 0, gap = 0, credit = 0;
         int sr = r, sb = b, spk = k;
-        int suf = 0, sufmax = 0, rejected = 0, visited = 1 << k, bonus = 0;
+        int suf = 0, sufmax = 0, gsum = 0, rejected = 0, visited = 1 << k, bonus = 0;
         for (;;) {
             const kpo_xpiece *Y = &P[pk];
             const int lo = J->lo[pk];
@@ -893,7 +951,10 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
                 if (r < 0 || b < 0 || b >= w || t < cstart || t >= cend) break;
                 const int tb = Y->tH[AT(r, b)];
                 if (tb == XT_RESTART) break;
-                if (suf > sufmax) sufmax = suf;
+                /* the drop test: the path's score behind this cell, cross-gap costs left out, against its largest value so far --
+                 * at every cross gap, and at every cell once a gap has been crossed */
+                if (suf + gsum > sufmax) sufmax = suf + gsum;
+                else if ((tb >= XT_X1 || visited != 1 << k) && sufmax - (suf + gsum) > KP_JOIN_DROP) { rejected = 1; break; }
                 if (tb == XT_DIAG) {
                     sr = r; sb = b; spk = pk; cols++;
                     const uint8_t qc = q[r], cc = tc[t];
@@ -902,14 +963,13 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
                     r--;
                 } else if (tb == XT_E || tb == XT_F) state = tb;
                 else { /* a cross gap: on to the cell of piece pk - 1 it came from */
-                    if (sufmax - suf > KP_JOIN_DROP) { rejected = 1; break; }
                     const kpo_xpiece *Z = &P[pk - 1];
                     const int64_t xi = Z->horizontal ? r : t - Z->xbase;
                     const int32_t src = tb == XT_X1 ? Z->a1[xi] : Z->a2[xi];
                     const int n = Z->horizontal ? (int)(t - src) : r - src;
                     cols += n;
                     const int cost = tb == XT_X1 ? KP_GAP_OPEN + KP_GAP_EXT * n : KP_GAP_OPEN2 + KP_GAP_EXT2 * n;
-                    suf -= cost;
+                    suf -= cost; gsum += cost;
                     if (cost > KP_GAP_OPEN + kp_log2x2((uint32_t)n)) bonus += cost - (KP_GAP_OPEN + kp_log2x2((uint32_t)n));
                     if (Z->horizontal) b = (int)(src - r - J->lo[pk - 1]);       /* same row, column src */
                     else { b = (int)(t - src - J->lo[pk - 1]); r = src; }      /* same column, row src */
@@ -924,13 +984,26 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
             }
         }
         J->visited[k] = visited;
-        if (rejected) { J->state[k] = 2; continue; }
-        J->state[k] = 1;
-        on_path |= visited;
+        if (rejected) { J->state[k] = 2; any_rejected = 1; settled |= 1 << k; continue; }
+        if (visited == 1 << k) { alone_k = k; break; } /* crosses no gap: the band task of the piece's cluster covers it */
+        J->state[k] = 1; hit_k = k;
         J->res[k][0] = X->end_s; J->res[k][1] = sr; J->res[k][2] = X->end_r + 1;
         J->res[k][3] = (int32_t)((int64_t)sr + J->lo[spk] + sb); J->res[k][4] = (int32_t)((int64_t)X->end_r + J->lo[k] + X->end_b + 1);
         J->res[k][5] = matches; J->res[k][6] = cols; J->res[k][7] = X->end_s + credit;
         J->res[k][8] = bonus < KP_HIT_BONUS_MAX ? bonus : KP_HIT_BONUS_MAX;
+        break;
+    }
+    /* CONSUMED PIECES (kp_spec.h): the clusters of the pieces the joined hit runs through, and those of the chain's weak ends
+     * that no reported path reaches, lose the hit of their own band task */
+    {
+        const int on = hit_k >= 0 ? J->visited[hit_k] : 0, keep = alone_k >= 0 ? 1 << alone_k : 0;
+        int drop = 0;
+        for (int k = 0; k < m; k++) {
+            if ((on >> k) & 1) drop |= J->cmask[k];
+            else if (!any_rejected && ((J->weak_mask >> k) & 1) && !((keep >> k) & 1)) drop |= J->cmask[k];
+        }
+        if (alone_k >= 0) drop &= ~J->cmask[alone_k];
+        J->drop_mask = drop;
     }
 #undef AT
     for (int k = 0; k < m; k++) {
@@ -1083,8 +1156,8 @@ KPO_API int64_t kpo_sw(const kpo_db *db, const uint32_t *words, int64_t padded_l
 }
 
 /* joins of one assembly, run: caller frees *out */
-static int64_t run_joins(const kpo_db *db, const kpo_asm *a, const kpo_pcl *pcl, int64_t np, const kpo_task *tasks, kpo_join **out) {
-    kpo_join *joins; const int64_t nj = make_joins(pcl, np, tasks, &joins);
+static int64_t run_joins(const kpo_db *db, const kpo_asm *a, const uint64_t *keys, const kpo_pcl *pcl, int64_t np, kpo_join **out) {
+    kpo_join *joins; const int64_t nj = make_joins(keys, pcl, np, &joins);
     for (int64_t j = 0; j < nj; j++) {
         kpo_join *J = &joins[j];
         const int g = J->gs >> 1, qlen = db->off[g + 1] - db->off[g];
@@ -1105,7 +1178,7 @@ KPO_API int64_t kpo_joins(const kpo_db *db, const uint32_t *words, int64_t padde
     uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
     kpo_task *tasks; kpo_pcl *pcl; int64_t np = 0;
     make_tasks_x(&a, keys, n, &tasks, &pcl, &np);
-    kpo_join *joins; const int64_t nj = run_joins(db, &a, pcl, np, tasks, &joins);
+    kpo_join *joins; const int64_t nj = run_joins(db, &a, keys, pcl, np, &joins);
     for (int64_t j = 0; j < nj && j < cap; j++) {
         const kpo_join *J = &joins[j];
         int32_t *o = out + KPO_JOIN_ROW * j;
@@ -1131,16 +1204,15 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
     uint64_t *keys; int64_t n = n_ctg ? collect_anchors(db, &a, &keys) : (keys = NULL, 0);
     kpo_task *tasks; kpo_pcl *pcl; int64_t np = 0;
     int64_t nt = make_tasks_x(&a, keys, n, &tasks, &pcl, &np);
-    kpo_join *joins; const int64_t nj = run_joins(db, &a, pcl, np, tasks, &joins);
+    kpo_join *joins; const int64_t nj = run_joins(db, &a, keys, pcl, np, &joins);
     uint8_t *dropped = calloc((size_t)(nt > 0 ? nt : 1), 1); /* band tasks whose hit a joined path replaces */
     int64_t n_join_hits = 0;
-    for (int64_t j = 0; j < nj; j++)
+    for (int64_t j = 0; j < nj; j++) {
         for (int k = 1; k < joins[j].n_pieces; k++)
-            if (joins[j].state[k] == 1) {
-                n_join_hits++;
-                for (int v = 0; v < joins[j].n_pieces; v++)
-                    if ((joins[j].visited[k] >> v) & 1) dropped[joins[j].task[v]] = 1;
-            }
+            if (joins[j].state[k] == 1) n_join_hits++;
+        for (int c = 0; c < joins[j].n_members; c++)
+            if (((joins[j].drop_mask >> c) & 1) && joins[j].member_task[c] >= 0) dropped[joins[j].member_task[c]] = 1;
+    }
     kp_hit *hits = malloc((size_t)(nt + n_join_hits > 0 ? nt + n_join_hits : 1) * sizeof(kp_hit));
     int64_t nh = 0, cells = 0;
     for (int64_t i = 0; i < nt; i++) {

@@ -29,10 +29,17 @@
  *                        scores 2/-4, gaps min(4+2n, 24+n), N = -1, z-drop 400, band 1.5*bw+1
  *   mm_update_extra      blen/mlen, dp_max with the log-gap cost; leading/trailing gaps trimmed (mm_fix_cigar)
  *   mm_filter_regs       mlen >= 40 and dp_max >= 80 (-s 80); mm_hit_sort by dp_max; mm_set_parent; mm_set_mapq
- * What is NOT modelled (stated, not hidden): mm_seed_select's rescue of high-occurrence seeds, the re-chaining passes
- * (max_occ rescue, RMQ long-join with bw_long), mm_filter_bad_seeds / mm_fix_bad_ends, inversion detection, the SSE
- * kernel's approximate-max shortcut (the exact z-drop test is always used), hash-based tie order of equal scores
- * (stable order instead).  For 0.6-1.8 kb gene queries against bacterial contigs none of these is expected to act.
+ *   (round 6) mm_seed_select   high-occurrence seeds: per streak of them up to (query extent / occ_dist 500) of the least frequent are
+ *                        kept (max_max_occ 4095); rep_len of the dropped ones scales the mapping quality (uniq_ratio)
+ *   (round 6) mm_fix_bad_ends  a chain end whose anchors cover less than twice the gap that follows them is cut off before the
+ *                        alignment (the extension may still reach across); mm_filter_bad_seeds / mm_filter_bad_seeds_alt:
+ *                        anchors between two long gaps that nearly cancel, or that lie closer together than they are long, are
+ *                        skipped as fill boundaries (MM_SEED_IGNORE / MM_SEED_LONG_JOIN); mm_adjust_minier: fills start and end
+ *                        in the middle of an anchor's k-mer; extension windows reach back to the uncut chain's ends
+ * What is NOT modelled (stated, not hidden): the re-chaining passes (max_occ rescue, RMQ long-join with bw_long), MM_SEED_TANDEM
+ * (equal neighbouring minimizers of the query), inversion detection, the SSE kernel's approximate-max shortcut (the exact z-drop
+ * test is always used), hash-based tie order of equal scores (stable order instead).  For 0.6-1.8 kb gene queries against
+ * bacterial contigs none of these is expected to act.
  */
 #include <math.h>
 #include <stdint.h>
@@ -45,6 +52,10 @@
 enum { MM_K = 15, MM_W = 10, MM_A = 2, MM_B = 4, MM_Q = 4, MM_E = 2, MM_Q2 = 24, MM_E2 = 1, MM_SC_AMBI = 1 };
 enum { MM_ZDROP = 400, MM_BW = 500, MM_MAX_GAP = 5000, MM_MAX_SKIP = 25, MM_MAX_ITER = 5000, MM_MIN_CNT = 3 };
 enum { MM_MIN_CHAIN_SC = 40, MM_MIN_DP_MAX = 80, MM_MIN_KSW_LEN = 200, MM_MIN_MID_OCC = 10, MM_MAX_MID_OCC = 1000000 };
+enum { MM_MAX_MAX_OCC = 4095, MM_OCC_DIST = 500, MM_MAX_MAX_HIGH_OCC = 128 };
+#define MM_SEED_LONG_JOIN (1ULL << 40)
+#define MM_SEED_IGNORE (1ULL << 41)
+static int g_end_flt = 1, g_seed_select = 1; /* test switches (mm2_set_options): the round-5 model had neither */
 static const float MM_MID_OCC_FRAC = 2e-4f, MM_MASK_LEVEL = 0.5f, MM_CHAIN_GAP_SCALE = 0.8f;
 
 typedef struct {
@@ -381,7 +392,8 @@ typedef struct {
     int32_t parent, subsc, n_sub;
     int64_t as;
     int32_t mlen, blen, dp_score, dp_max, dp_max2;
-    int32_t order_key; /* stable tie order */
+    int32_t fuzzy_mlen; /* mm_cal_fuzzy_len on the chain: what mm_fix_bad_ends measures an end against */
+    int32_t order_key;  /* stable tie order */
     uint8_t rev, has_p, mapq, dead;
 } reg_t;
 
@@ -443,7 +455,11 @@ static void set_parent(int n, reg_t *r, int sub_diff) { /* hit.c: mm_set_parent,
     free(w), free(cov);
 }
 
-static void set_mapq(int n, reg_t *r) { /* hit.c: mm_set_mapq2 with rep_len = 0 (no seed was filtered in the query) */
+static void set_mapq(int n, reg_t *r, int rep_len) { /* hit.c: mm_set_mapq2; rep_len = query bases under filtered seeds */
+    int64_t sum_sc = 0;
+    for (int i = 0; i < n; ++i)
+        if (r[i].parent == r[i].id) sum_sc += r[i].score;
+    const float uniq_ratio = sum_sc + rep_len > 0 ? (float)sum_sc / (float)(sum_sc + rep_len) : 1.0f;
     for (int i = 0; i < n; ++i) {
         reg_t *g = &r[i];
         if (g->parent != g->id) {
@@ -451,7 +467,7 @@ static void set_mapq(int n, reg_t *r) { /* hit.c: mm_set_mapq2 with rep_len = 0 
             continue;
         }
         int mapq, subsc;
-        float pen_s1 = g->score > 100 ? 1.0f : 0.01f * (float)g->score;
+        float pen_s1 = (g->score > 100 ? 1.0f : 0.01f * (float)g->score) * uniq_ratio;
         float pen_cm = g->cnt > 10 ? 1.0f : 0.1f * (float)g->cnt;
         pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
         subsc = g->subsc > MM_MIN_CHAIN_SC ? g->subsc : MM_MIN_CHAIN_SC;
@@ -733,10 +749,141 @@ static void cig_append(cig_t *g, int n_cigar, const uint32_t *cigar) {
     }
 }
 
+/* ---- align.c: what happens to a chain before it is aligned ------------------------------------------------------------------- */
+static void cal_fuzzy_len(reg_t *r, const mm128 *a) { /* hit.c: mm_cal_fuzzy_len -- matching / aligned bases the anchors imply */
+    r->fuzzy_mlen = 0;
+    if (r->cnt <= 0) return;
+    int32_t mlen = (int32_t)(a[r->as].y >> 32 & 0xff);
+    for (int64_t i = r->as + 1; i < r->as + r->cnt; ++i) {
+        int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+        int32_t tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+    }
+    r->fuzzy_mlen = mlen;
+}
+
+/* mm_fix_bad_ends: walking in from either end of the chain, an anchor that follows a gap longer than half the length
+ * covered so far becomes the new end; the walk stops once enough of the chain has been seen */
+static void fix_bad_ends(const reg_t *r, const mm128 *a, int bw, int min_match, int64_t *as, int32_t *cnt) {
+    int64_t i;
+    int32_t l, m;
+    *as = r->as, *cnt = r->cnt;
+    if (r->cnt < 3) return;
+    m = l = (int32_t)(a[r->as].y >> 32 & 0xff);
+    for (i = r->as + 1; i < r->as + r->cnt - 1; ++i) {
+        int32_t lq, lr, min, max, q_span = (int32_t)(a[i].y >> 32 & 0xff);
+        if (a[i].y & MM_SEED_LONG_JOIN) break;
+        lr = (int32_t)a[i].x - (int32_t)a[i - 1].x;
+        lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *as = i;
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->fuzzy_mlen >> 1) break;
+    }
+    *cnt = (int32_t)(r->as + r->cnt - *as);
+    m = l = (int32_t)(a[r->as + r->cnt - 1].y >> 32 & 0xff);
+    for (i = r->as + r->cnt - 2; i > *as; --i) {
+        int32_t lq, lr, min, max, q_span = (int32_t)(a[i + 1].y >> 32 & 0xff);
+        if (a[i + 1].y & MM_SEED_LONG_JOIN) break;
+        lr = (int32_t)a[i + 1].x - (int32_t)a[i].x;
+        lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+        min = lr < lq ? lr : lq, max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *cnt = (int32_t)(i + 1 - *as);
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->fuzzy_mlen >> 1) break;
+    }
+}
+
+static int *collect_long_gaps(int64_t as1, int32_t cnt1, const mm128 *a, int min_gap, int *n_) {
+    int i, n, *K;
+    *n_ = 0;
+    for (i = 1, n = 0; i < cnt1; ++i) {
+        int gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
+        if (gap < -min_gap || gap > min_gap) ++n;
+    }
+    if (n <= 1) return 0;
+    K = (int *)malloc(sizeof(int) * (size_t)n);
+    for (i = 1, n = 0; i < cnt1; ++i) {
+        int gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
+        if (gap < -min_gap || gap > min_gap) K[n++] = i;
+    }
+    *n_ = n;
+    return K;
+}
+
+/* mm_filter_bad_seeds: between two long gaps whose insertions and deletions mostly cancel, the anchors are not to be trusted */
+static void filter_bad_seeds(int64_t as1, int32_t cnt1, mm128 *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+    int max_st, max_en, n, i, k, max, *K;
+    K = collect_long_gaps(as1, cnt1, a, min_gap, &n);
+    if (K == 0) return;
+    max = 0, max_st = max_en = -1;
+    for (k = 0;; ++k) {
+        int gap, l, n_ins = 0, n_del = 0, qs, rs, max_diff = 0, max_diff_l = -1;
+        if (k == n || k >= max_en) {
+            if (max_en > 0)
+                for (i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= MM_SEED_IGNORE;
+            max = 0, max_st = max_en = -1;
+            if (k == n) break;
+        }
+        i = K[k];
+        gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - (int32_t)(a[as1 + i].x - a[as1 + i - 1].x);
+        if (gap > 0) n_ins += gap;
+        else n_del += -gap;
+        qs = (int32_t)a[as1 + i - 1].y;
+        rs = (int32_t)a[as1 + i - 1].x;
+        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+            int j = K[l], diff;
+            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
+            gap = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
+            if (gap > 0) n_ins += gap;
+            else n_del += -gap;
+            diff = n_ins + n_del - abs(n_ins - n_del);
+            if (max_diff < diff) max_diff = diff, max_diff_l = l;
+        }
+        if (max_diff > diff_thres && max_diff > max) max = max_diff, max_st = k, max_en = max_diff_l;
+    }
+    free(K);
+}
+
+/* mm_filter_bad_seeds_alt: long gaps with less matching sequence between them than they are long become one long join */
+static void filter_bad_seeds_alt(int64_t as1, int32_t cnt1, mm128 *a, int min_gap, int max_ext) {
+    int n, k, *K;
+    K = collect_long_gaps(as1, cnt1, a, min_gap, &n);
+    if (K == 0) return;
+    for (k = 0; k < n;) {
+        int i = K[k], l;
+        int gap1 = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
+        int re1 = (int32_t)a[as1 + i].x, qe1 = (int32_t)a[as1 + i].y;
+        gap1 = gap1 > 0 ? gap1 : -gap1;
+        for (l = k + 1; l < n; ++l) {
+            int j = K[l], gap2, q_span_pre, rs2, qs2, m;
+            if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
+            gap2 = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
+            q_span_pre = (int)(a[as1 + j - 1].y >> 32 & 0xff);
+            rs2 = (int32_t)a[as1 + j - 1].x + q_span_pre;
+            qs2 = (int32_t)a[as1 + j - 1].y + q_span_pre;
+            m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+            gap2 = gap2 > 0 ? gap2 : -gap2;
+            if (m > gap1 + gap2) break;
+            re1 = (int32_t)a[as1 + j].x, qe1 = (int32_t)a[as1 + j].y;
+            gap1 = gap2;
+        }
+        if (l > k + 1) {
+            int j, end = K[l - 1];
+            for (j = K[k]; j < end; ++j) a[as1 + j].y |= MM_SEED_IGNORE;
+            a[as1 + end].y |= MM_SEED_LONG_JOIN;
+        }
+        k = l;
+    }
+    free(K);
+}
+
 /* align.c: mm_align1 for one region (anchors a[as .. as+cnt) of the compacted array, all chains of the query).
  * qcode[0] = gene, qcode[1] = its reverse complement.  On a z-drop inside a global fill the region is truncated and, if
  * at least min_cnt anchors remain, *r2 receives the rest (r2->cnt > 0). */
-static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t *r, reg_t *r2, int64_t n_a, const mm128 *a,
+static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t *r, reg_t *r2, int64_t n_a, mm128 *a,
                    ez_t *ez) {
     const int bw = (int)(MM_BW * 1.5 + 1.);
     const int rid = r->rid, rev = r->rev;
@@ -748,12 +895,23 @@ static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t
     cig_t cg = {0, 0, 0};
     r2->cnt = 0;
     if (cnt1 == 0) return;
-    rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-    qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
-    re = (int32_t)a[as1 + cnt1 - 1].x + 1;
-    qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
-    /* extension limits */
-    rs0 = rs, qs0 = qs;
+    if (g_end_flt) { /* (the default: MM_F_NO_END_FLT is off) */
+        fix_bad_ends(r, a, MM_BW, MM_MIN_CHAIN_SC * 2, &as1, &cnt1);
+        filter_bad_seeds(as1, cnt1, a, 10, 40, MM_MAX_GAP >> 1, 10);
+        filter_bad_seeds_alt(as1, cnt1, a, 30, MM_MAX_GAP >> 1);
+        /* mm_adjust_minier without homopolymer compression: fills begin and end in the middle of the anchor's k-mer */
+        rs = (int32_t)a[as1].x - (MM_K >> 1), qs = (int32_t)a[as1].y - (MM_K >> 1);
+        re = (int32_t)a[as1 + cnt1 - 1].x - (MM_K >> 1), qe = (int32_t)a[as1 + cnt1 - 1].y - (MM_K >> 1);
+    } else {
+        rs = (int32_t)a[as1].x + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+        qs = (int32_t)a[as1].y + 1 - (int32_t)(a[as1].y >> 32 & 0xff);
+        re = (int32_t)a[as1 + cnt1 - 1].x + 1;
+        qe = (int32_t)a[as1 + cnt1 - 1].y + 1;
+    }
+    /* extension limits: from the UNCUT chain's first and last anchor outwards */
+    rs0 = (int32_t)a[r->as].x + 1 - (int32_t)(a[r->as].y >> 32 & 0xff);
+    qs0 = (int32_t)a[r->as].y + 1 - (int32_t)(a[r->as].y >> 32 & 0xff);
+    if (rs0 < 0) rs0 = 0;
     rs1 = qs1 = 0;
     for (int64_t ii = r->as - 1, cntl = 0; ii >= 0 && a[ii].x >> 32 == a[r->as].x >> 32; --ii) {
         int32_t x = (int32_t)a[ii].x + 1 - (int32_t)(a[ii].y >> 32 & 0xff), y = (int32_t)a[ii].y + 1 - (int32_t)(a[ii].y >> 32 & 0xff);
@@ -766,19 +924,19 @@ static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t
             }
         }
     }
-    if (qs0 > 0 && rs0 > 0) {
-        l = qs0 < MM_MAX_GAP ? qs0 : MM_MAX_GAP;
-        qs1 = qs1 > qs0 - l ? qs1 : qs0 - l;
-        qs0 = qs1 > 0 ? qs1 : 0;
+    if (qs > 0 && rs > 0) {
+        l = qs < MM_MAX_GAP ? qs : MM_MAX_GAP;
+        qs1 = qs1 > qs - l ? qs1 : qs - l;
+        qs0 = qs0 < qs1 ? qs0 : qs1; /* at least include qs0 */
         l += l * MM_A > MM_Q ? (l * MM_A - MM_Q) / MM_E : 0;
         l = l < MM_MAX_GAP ? l : MM_MAX_GAP;
-        l = l < rs0 ? l : rs0;
-        rs1 = rs1 > rs0 - l ? rs1 : rs0 - l;
-        rs0 = rs1 > 0 ? rs1 : 0;
+        l = l < rs ? l : rs;
+        rs1 = rs1 > rs - l ? rs1 : rs - l;
+        rs0 = rs0 < rs1 ? rs0 : rs1;
         rs0 = rs0 < rs ? rs0 : rs;
     } else
         rs0 = rs, qs0 = qs;
-    re0 = re, qe0 = qe;
+    re0 = (int32_t)a[r->as + r->cnt - 1].x + 1, qe0 = (int32_t)a[r->as + r->cnt - 1].y + 1;
     re1 = tlen, qe1 = qlen;
     for (int64_t ii = r->as + r->cnt, cntl = 0; ii < n_a && a[ii].x >> 32 == a[r->as].x >> 32; ++ii) {
         int32_t x = (int32_t)a[ii].x + 1, y = (int32_t)a[ii].y + 1;
@@ -790,18 +948,19 @@ static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t
             }
         }
     }
-    if (qe0 < qlen && re0 < tlen) {
-        l = qlen - qe0 < MM_MAX_GAP ? qlen - qe0 : MM_MAX_GAP;
-        qe1 = qe1 < qe0 + l ? qe1 : qe0 + l;
-        qe0 = qe1 < qlen ? qe1 : qlen;
+    if (qe < qlen && re < tlen) {
+        l = qlen - qe < MM_MAX_GAP ? qlen - qe : MM_MAX_GAP;
+        qe1 = qe1 < qe + l ? qe1 : qe + l;
+        qe0 = qe0 > qe1 ? qe0 : qe1; /* at least include qe0 */
         l += l * MM_A > MM_Q ? (l * MM_A - MM_Q) / MM_E : 0;
         l = l < MM_MAX_GAP ? l : MM_MAX_GAP;
-        l = l < tlen - re0 ? l : tlen - re0;
-        re1 = re1 < re0 + l ? re1 : re0 + l;
-        re0 = re1 < tlen ? re1 : tlen;
-        re0 = re0 > re ? re0 : re;
+        l = l < tlen - re ? l : tlen - re;
+        re1 = re1 < re + l ? re1 : re + l;
+        re0 = re0 > re1 ? re0 : re1;
     } else
         re0 = re, qe0 = qe;
+    if (qe0 > qlen) qe0 = qlen;
+    if (re0 > tlen) re0 = tlen;
 
     const uint8_t *qseq0 = qcode[rev];
     uint8_t *tbuf = (uint8_t *)malloc((size_t)(re0 - rs0 + 1)), *qbuf = (uint8_t *)malloc((size_t)qlen + 1);
@@ -818,17 +977,20 @@ static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t
     re1 = rs, qe1 = qs;
     int dropped = 0;
     for (i = 1; i < cnt1; ++i) { /* gap filling */
-        re = (int32_t)a[as1 + i].x + 1, qe = (int32_t)a[as1 + i].y + 1;
+        if ((a[as1 + i].y & MM_SEED_IGNORE) && i != cnt1 - 1) continue;
+        if (g_end_flt) re = (int32_t)a[as1 + i].x - (MM_K >> 1), qe = (int32_t)a[as1 + i].y - (MM_K >> 1);
+        else re = (int32_t)a[as1 + i].x + 1, qe = (int32_t)a[as1 + i].y + 1;
         re1 = re, qe1 = qe;
-        if (i == cnt1 - 1 || (qe - qs >= MM_MIN_KSW_LEN && re - rs >= MM_MIN_KSW_LEN)) {
+        if (i == cnt1 - 1 || (a[as1 + i].y & MM_SEED_LONG_JOIN) || (qe - qs >= MM_MIN_KSW_LEN && re - rs >= MM_MIN_KSW_LEN)) {
             const uint8_t *qseq = qseq0 + qs, *tseq = tcode + rs;
-            ksw_extd2(qe - qs, qseq, re - rs, tseq, bw, -1, 0, 0, 0, ez);
+            const int bw1 = (a[as1 + i].y & MM_SEED_LONG_JOIN) ? (qe - qs > re - rs ? qe - qs : re - rs) : bw;
+            ksw_extd2(qe - qs, qseq, re - rs, tseq, bw1, -1, 0, 0, 0, ez);
             if (test_zdrop(qseq, tseq, ez->n_cigar, ez->cigar)) {
                 ez_t probe = {0, 0, 0, 0, 0, 0, 0, 0};
-                global_zdrop_probe(qe - qs, qseq, re - rs, tseq, bw, MM_ZDROP, &probe);
+                global_zdrop_probe(qe - qs, qseq, re - rs, tseq, bw1, MM_ZDROP, &probe);
                 if (probe.zdropped) { /* truncated by the z-drop: keep the path up to the maximum, split the rest off */
                     ez_t part = {0, 0, 0, 0, 0, 0, 0, 0};
-                    ksw_extd2(probe.max_q + 1, qseq, probe.max_t + 1, tseq, bw, -1, 0, 0, 0, &part);
+                    ksw_extd2(probe.max_q + 1, qseq, probe.max_t + 1, tseq, bw1, -1, 0, 0, 0, &part);
                     if (part.n_cigar > 0) cig_append(&cg, part.n_cigar, part.cigar);
                     free(part.cigar);
                     int32_t j;
@@ -838,12 +1000,14 @@ static void align1(const mm2_index *mi, int qlen, uint8_t *const qcode[2], reg_t
                     if (j < 0) j = 0;
                     dp_score += probe.max;
                     re1 = rs + (probe.max_t + 1), qe1 = qs + (probe.max_q + 1);
-                    if (cnt1 - (j + 1) >= MM_MIN_CNT) { /* mm_split_reg */
+                    if (cnt1 - (j + 1) >= MM_MIN_CNT) { /* mm_split_reg at anchor as1 + j + 1, counted from the uncut chain's start */
+                        const int32_t n_first = (int32_t)(as1 + j + 1 - r->as);
                         *r2 = *r;
-                        r2->as = as1 + j + 1, r2->cnt = cnt1 - (j + 1);
-                        r2->score = (int32_t)((double)r->score * ((float)r2->cnt / (float)cnt1) + .499);
-                        r->cnt = cnt1 - r2->cnt, r->score -= r2->score;
+                        r2->as = r->as + n_first, r2->cnt = r->cnt - n_first;
+                        r2->score = (int32_t)((double)r->score * ((float)r2->cnt / (float)r->cnt) + .499);
+                        r->cnt = n_first, r->score -= r2->score;
                         r2->has_p = 0, r2->parent = -1;
+                        cal_fuzzy_len(r2, a);
                     }
                     break;
                 }
@@ -931,10 +1095,69 @@ static int64_t map_one(const mm2_index *mi, int gene, const uint8_t *gseq, int q
     }
     vec128 mv = {0, 0, 0}, av = {0, 0, 0};
     sketch(qc[0], qlen, 0, &mv);
-    for (int64_t m = 0; m < mv.n; ++m) { /* mm_collect_matches + seeds -> anchors */
+    /* mm_seed_collect_all: the query minimizers that occur in the index, in query order; mm_seed_select (or the plain cut);
+     * rep_len = query bases under the seeds that were dropped */
+    int32_t n_m0 = 0, rep_len = 0;
+    int64_t *m_lo = (int64_t *)malloc(sizeof(int64_t) * (size_t)(mv.n + 1)), *m_hi = (int64_t *)malloc(sizeof(int64_t) * (size_t)(mv.n + 1));
+    int32_t *m_ix = (int32_t *)malloc(sizeof(int32_t) * (size_t)(mv.n + 1));
+    uint8_t *m_flt = (uint8_t *)calloc((size_t)mv.n + 1, 1);
+    for (int64_t m = 0; m < mv.n; ++m) {
         int64_t lo, hi;
         idx_get(mi, mv.a[m].x >> 8, &lo, &hi);
-        if (hi - lo == 0 || hi - lo > mi->mid_occ) continue;
+        if (hi - lo == 0) continue;
+        m_lo[n_m0] = lo, m_hi[n_m0] = hi, m_ix[n_m0] = (int32_t)m, ++n_m0;
+    }
+    if (g_seed_select) {
+        int n_high = 0;
+        for (int i = 0; i < n_m0; ++i) n_high += m_hi[i] - m_lo[i] > mi->mid_occ;
+        if (n_m0 > 1 && n_high > 0) {
+            for (int i = 0, last0 = -1; i <= n_m0; ++i) {
+                if (i == n_m0 || m_hi[i] - m_lo[i] <= mi->mid_occ) {
+                    if (i - last0 > 1) { /* a streak of high-occurrence seeds: (last0, i) */
+                        const int32_t ps = last0 < 0 ? 0 : (int32_t)((uint32_t)mv.a[m_ix[last0]].y >> 1);
+                        const int32_t pe = i == n_m0 ? qlen : (int32_t)((uint32_t)mv.a[m_ix[i]].y >> 1);
+                        const int st = last0 + 1, en = i;
+                        int max_high_occ = (int)((double)(pe - ps) / MM_OCC_DIST + .499);
+                        if (max_high_occ > 0) { /* the max_high_occ least frequent of the streak are kept */
+                            if (max_high_occ > MM_MAX_MAX_HIGH_OCC) max_high_occ = MM_MAX_MAX_HIGH_OCC;
+                            uint64_t bsel[MM_MAX_MAX_HIGH_OCC];
+                            int k = 0, j;
+                            for (j = st; j < en && k < max_high_occ; ++j, ++k) bsel[k] = (uint64_t)(m_hi[j] - m_lo[j]) << 32 | (uint32_t)j;
+                            for (; j < en; ++j) { /* (a max-heap in minimap2; here the largest entry is found by a scan) */
+                                int top = 0;
+                                for (int z = 1; z < k; ++z)
+                                    if (bsel[z] > bsel[top]) top = z;
+                                if ((uint64_t)(m_hi[j] - m_lo[j]) < bsel[top] >> 32) bsel[top] = (uint64_t)(m_hi[j] - m_lo[j]) << 32 | (uint32_t)j;
+                            }
+                            for (j = 0; j < k; ++j) m_flt[(uint32_t)bsel[j]] = 1;
+                        }
+                        for (int j = st; j < en; ++j) m_flt[j] ^= 1;
+                        for (int j = st; j < en; ++j)
+                            if (m_hi[j] - m_lo[j] > MM_MAX_MAX_OCC) m_flt[j] = 1;
+                    }
+                    last0 = i;
+                }
+            }
+        } else if (n_m0 == 1 && n_high > 0) { /* (mm_seed_select returns early for a single seed: it stays) */
+        }
+    } else {
+        for (int i = 0; i < n_m0; ++i)
+            if (m_hi[i] - m_lo[i] > mi->mid_occ) m_flt[i] = 1;
+    }
+    {
+        int rep_st = 0, rep_en = 0;
+        for (int i = 0; i < n_m0; ++i) {
+            if (!m_flt[i]) continue;
+            const mm128 *qm = &mv.a[m_ix[i]];
+            const int en = (int)((uint32_t)qm->y >> 1) + 1, st = en - (int)(qm->x & 0xff);
+            if (st > rep_en) rep_len += rep_en - rep_st, rep_st = st, rep_en = en;
+            else rep_en = en;
+        }
+        rep_len += rep_en - rep_st;
+    }
+    for (int mi_ = 0; mi_ < n_m0; ++mi_) { /* seeds -> anchors */
+        if (m_flt[mi_]) continue;
+        const int64_t m = m_ix[mi_], lo = m_lo[mi_], hi = m_hi[mi_];
         uint32_t q_pos = (uint32_t)mv.a[m].y, q_span = (uint32_t)(mv.a[m].x & 0xff);
         for (int64_t o = lo; o < hi; ++o) {
             uint64_t ry = mi->mz[o].y;
@@ -969,6 +1192,7 @@ static int64_t map_one(const mm2_index *mi, int gene, const uint8_t *gseq, int q
             int32_t q0 = (int32_t)f->y + 1 - (int32_t)(f->y >> 32 & 0xff), q1 = (int32_t)la->y + 1;
             if (g->rev) g->qs = qlen - q1, g->qe = qlen - q0;
             else g->qs = q0, g->qe = q1;
+            cal_fuzzy_len(g, b);
         }
         qsort(regs, (size_t)n_regs, sizeof(reg_t), cmp_reg_chain);
         set_parent(n_regs, regs, MM_A * 2 + MM_B); /* chain_post; mm_select_sub is a no-op at pri_ratio 0 */
@@ -998,7 +1222,7 @@ static int64_t map_one(const mm2_index *mi, int gene, const uint8_t *gseq, int q
         n_regs = k;
         qsort(regs, (size_t)n_regs, sizeof(reg_t), cmp_reg_dp); /* mm_hit_sort */
         set_parent(n_regs, regs, MM_A * 2 + MM_B);
-        set_mapq(n_regs, regs);
+        set_mapq(n_regs, regs, rep_len);
         for (int i = 0; i < n_regs; ++i) {
             const reg_t *g = &regs[i];
             if (n_out + n_hits < cap) {
@@ -1012,6 +1236,7 @@ static int64_t map_one(const mm2_index *mi, int gene, const uint8_t *gseq, int q
         }
         free(regs), free(ch), free(b);
     }
+    free(m_lo), free(m_hi), free(m_ix), free(m_flt);
     free(mv.a), free(av.a), free(qc[0]), free(qc[1]);
     return n_hits;
 }
@@ -1028,6 +1253,10 @@ MM_API int64_t mm2_map(void *idx, const uint8_t *genes, const int64_t *gene_off,
 }
 
 /* test hooks -------------------------------------------------------------------------------------------------------------- */
+/* end_flt: mm_fix_bad_ends + mm_filter_bad_seeds(_alt) + mm_adjust_minier (minimap2's default; 0 = the round-5 model);
+ * seed_select: mm_seed_select (0 = every seed above mid_occ is dropped) */
+MM_API void mm2_set_options(int end_flt, int seed_select) { g_end_flt = end_flt, g_seed_select = seed_select; }
+
 MM_API int64_t mm2_sketch(const uint8_t *seq, int len, uint64_t *x, uint64_t *y, int64_t cap) {
     const uint8_t *t = nt4();
     uint8_t *code = (uint8_t *)malloc((size_t)len + 1);

@@ -270,6 +270,17 @@ def _join_assemblies(db):
         SeqRecord("junk_tail", np.concatenate([flank(100), g1[:500], flank(260), g1[700:760], flank(100)]).tobytes()),
         SeqRecord("more_junk", np.concatenate([flank(100), g3[:500], flank(760), g3[1200:], flank(100)]).tobytes()),
     ]
+    # a path that the drop test REJECTS: behind a 60-base insertion the gene goes on with 520 bases at 50 % identity (every
+    # second base changed: no seeds, -520 on the later piece's diagonal, far worse on the earlier one's) before it is itself
+    # again -- the local path crosses the gap and runs through them (what lies before the gap is worth more than they cost),
+    # falling ~500 below the level it arrives at: minimap2's z-drop would have split the chain there, and the pieces report their
+    # own hits; "not_crossed": with unrelated sequence in their place the best path does not cross and both pieces stand
+    gl = max(genes, key=len)
+    half = gl[420:940].copy()
+    half[::2] = np.frombuffer(b"CGTA", np.uint8)[np.searchsorted(np.frombuffer(b"ACGT", np.uint8), half[::2])]
+    dropped = np.concatenate([flank(150), gl[:420], flank(60), half, gl[940:], flank(150)])
+    recs.append(SeqRecord("not_crossed", np.concatenate([flank(150), gl[:300], flank(60), flank(560), gl[860:], flank(150)]).tobytes()))
+    recs.append(SeqRecord("drop_rejected", dropped.tobytes()))
     with_n = np.concatenate([flank(200), edit(g2, [(len(g2) // 2, "del", 90)]), flank(200)])
     with_n[200 + len(g2) // 2 - 30 : 200 + len(g2) // 2 - 22] = ord("N")
     recs.append(SeqRecord("n_near_junction", with_n.tobytes()))
@@ -278,8 +289,9 @@ def _join_assemblies(db):
 
 
 def test_joins_across_mid_size_indels_match_oracle(ctx, small_setup, small_db):
-    """kp-align v4: groups, chains of clusters, the joined fill (local first piece, continuation pieces, cross gaps by
-    atomic maxima) and the walk-back with the drop test -- join records, band tasks and hit tables equal the oracle's."""
+    """kp-align v5: groups (weak clusters included), minimap2's chaining DP over a group's anchors, pieces, the joined fill
+    (every piece local, cross gaps by atomic maxima), the walk-back from the best cell with the drop test and the consumed
+    pieces -- join records, band tasks and hit tables equal the oracle's."""
     odb = small_setup
     asms = _join_assemblies(small_db)
     packed = [a.packed() for a in asms]
@@ -1472,7 +1484,9 @@ def test_genes_beyond_the_packed_score_range(oracle):
     for i in range(2):
         _same_records(hits[hoff[i] : hoff[i + 1]], want, "hits of genes beyond the packed range")
     joins = odb.joins(pa)
-    assert sorted(joins["n_pieces"][(joins["piece"][:, :, 0] == 1).any(axis=1)].tolist()) == [2, 3], joins["n_pieces"]
+    # (round 6: the chain of a group is made of its anchors -- up to KP_JOIN_ANCHOR_MAX = 4096 of them: the 20 kb gene's three
+    # pieces are joined, the 41 kb gene's group holds ~7 400 anchors and stays two band-task hits, on the device as in the oracle)
+    assert sorted(joins["n_pieces"][(joins["piece"][:, :, 0] == 1).any(axis=1)].tolist()) == [3], joins["n_pieces"]
     for f in joins.dtype.names:
         assert np.array_equal(np.sort(joins, order=["gs", "contig"])[f], np.sort(batch.joins(0), order=["gs", "contig"])[f]), f
     assert (want["score"] == 2 * 20_000).any() and want["score"].max() > 80_000 and (want["gene"] == 2).sum() >= 3 and (want["gene"] == 4).any()

@@ -120,3 +120,36 @@ def test_bench_ranks_hold_disjoint_consecutive_assemblies():
     whole = [(i, int(p.words.sum())) for i, p in zip(ids, packed)]
     assert per_rank[0] + per_rank[1] == whole
     assert len({i for i, _ in whole}) == 6
+
+
+def test_numa_affinity_plan_partitions_the_granted_cpus():
+    """kaptive_amd/affinity.py: eight devices on a two-socket node (four per socket) get disjoint shares of the granted CPUs,
+    each on its device's node; CPUs of a node without a device are dealt out; devices of unknown node share what is left; a
+    one-node box keeps its mask; fewer CPUs than devices means everybody shares."""
+    from kaptive_amd import affinity as A
+
+    cpu_node = {c: (0 if c < 64 else 1) for c in range(128)}
+    granted = list(range(8, 120))  # a container that was given 112 of the 128
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    shares = A.plan(granted, nodes, cpu_node)
+    assert len(shares) == 8 and sorted(c for s in shares for c in s) == granted  # a partition
+    assert all(len(set(a) & set(b)) == 0 for i, a in enumerate(shares) for b in shares[i + 1 :])
+    for s, node in zip(shares, nodes):
+        assert s and all(cpu_node[c] == node for c in s)
+    assert [len(s) for s in shares] == [14] * 8
+    # a third node with CPUs but no device: its CPUs are dealt out, still a partition
+    cpu3 = {**cpu_node, **{c: 2 for c in range(128, 144)}}
+    shares = A.plan(list(range(144)), nodes, cpu3)
+    assert sorted(c for s in shares for c in s) == list(range(144)) and all(len(s) == 18 for s in shares)
+    # unknown nodes: even shares of what nobody claimed
+    shares = A.plan(list(range(16)), [None, None], {})
+    assert shares == [list(range(8)), list(range(8, 16))]
+    shares = A.plan(list(range(128)), [0, None, 1], cpu_node)
+    assert sorted(c for s in shares for c in s) == list(range(128)) and all(shares)
+    # one node, one device: the mask itself; fewer CPUs than devices: shared
+    assert A.plan([3, 4, 5], [0], {3: 0, 4: 0, 5: 0}) == [[3, 4, 5]]
+    assert A.plan([0, 1], [0, 0, 1, 1], {0: 0, 1: 1}) == [[0, 1]] * 4
+    assert A._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    info = A.place(0)  # one device: the plan is the whole mask, nothing is asked or changed
+    assert info["applied"] is False
+    assert A.device_numa_nodes([0, 1]) == [None, None]  # (no device in the build container: unknown, not an error)

@@ -35,6 +35,10 @@ ROOT = Path(__file__).resolve().parent.parent
 FIELDS = ("Best match locus", "Best match type", "Match confidence", "Problems")
 
 MID_INDEL_SIZES = (33, 48, 64, 100, 150, 300, 450)
+END_INDEL_DISTS = (40, 70, 100)
+END_INDEL_EVENTS = (("del", 45), ("ins", 61), ("del", 150), ("ins", 200))
+INTERLEAVES = (("-40+50@400", (("del", 40, 200), ("ins", 50, 640))), ("+60-45@250", (("ins", 60, 200), ("del", 45, 450))),
+               ("-33+36@150", (("del", 33, 200), ("ins", 36, 383))))  # (the second offset counts on the unedited gene: after a deletion of n, n more)
 _STATE: dict = {}
 
 
@@ -103,6 +107,29 @@ def cases(scale: float, full_size: int):
                     kw = dict(seed=70_000 + 10_000 * di + 500 * zi + 100 * ki + i, p_is=0, p_stop=0,
                               mid_indels=((size, kind), (size + 1, kind), (size + 2, other)), **small_kw)
                     out.append((f"midindel_{size}_{kind}", [key], key, kw, ()))
+    # round 6 (the review's probes): events at an explicit distance from a gene's start or end -- the piece beyond the event is
+    # too short to be a chain of its own --, pairs of events that nearly cancel (the pieces' query ranges interleave by diagonal),
+    # storms of events anywhere in the locus, and the non-iid background
+    for di, dist in enumerate(END_INDEL_DISTS):
+        for wi, where in enumerate(("start", "end")):
+            for ei, (kind, size) in enumerate(END_INDEL_EVENTS):
+                for i in range(max(1, per // 3)):
+                    off = dist if where == "start" else -dist
+                    entry = ((kind, size, off),)
+                    kw = dict(seed=95_000 + 1000 * di + 500 * wi + 100 * ei + i, p_is=0, p_stop=0, sub_rate=0.01,
+                              placed_indels=(entry, entry, entry), **small)
+                    out.append((f"endindel_{dist}_{where}_{kind}{size}", ["k"], "k", kw, ()))
+    for ii, (name, entry) in enumerate(INTERLEAVES):
+        for i in range(max(1, per // 2)):
+            kw = dict(seed=98_000 + 100 * ii + i, p_is=0, p_stop=0, sub_rate=0.01, placed_indels=(entry, entry, entry), **small)
+            out.append((f"interleave_{name}", ["k"], "k", kw, ()))
+    for si, storm in enumerate(((6, 33, 300), (14, 33, 120))):
+        for i in range(max(1, per)):
+            kw = dict(seed=99_000 + 100 * si + i, p_is=0, p_stop=0, indel_storm=storm, **small)
+            out.append((f"storm_{storm[0]}x{storm[1]}_{storm[2]}", ["k"], "k", kw, ()))
+    for i in range(max(1, per)):
+        kw = dict(seed=99_500 + i, background="paralog", **(dict() if i < min(2, full_size) else dict(length=1_000_000, median_contigs=25)))
+        out.append(("paralog", ["k"], "k", kw, ()))
     # the occurrence cut (minimap2 -f 2e-4 with min_mid_occ 10; kp_spec.h KP_MID_OCC): a 150-300 base stretch of a gene of the
     # locus planted 12 / 20 / 40 more times -- at FULL size, where the 2e-4 quantile of the index stays at its floor of 10 -- and
     # what the floor cannot follow: 40 copies of an IS-like element lift the model's cut to ~40 (reported, not hidden)
@@ -190,6 +217,10 @@ def summarise(records: list[dict]) -> str:
     by_tag: dict[str, list[dict]] = defaultdict(list)
     for r in records:
         by_tag[r["tag"] + ("/" + r["db"] if r["tag"] == "config3" or r["tag"].startswith("midindel") else "")].append(r)
+    for r in records:  # the round-6 classes once more, pooled (24 + 3 + 2 classes of a few rows each)
+        for prefix in ("endindel_40", "endindel_70", "endindel_100", "endindel", "interleave", "storm"):
+            if r["tag"].startswith(prefix + "_"):
+                by_tag["(pooled) " + prefix].append(r)
     lines = []
     lines.append("| workload | rows | byte-identical rows | locus/type/confidence/problems identical | locus+type+confidence identical | final genes identical in coordinates | in state | raw hit spans shared / kp-only / mm2-only | scores equal on shared spans | mapq equal | chain anchors equal |")
     lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
