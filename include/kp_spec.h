@@ -207,7 +207,11 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
  * widened by KP_BAND_MARGIN on both sides --, centred on its own range:  lo[k] = dmin[k] - KP_BAND_MARGIN - (W - need[k]) / 2,
  * need[k] = dmax[k] - dmin[k] + 1 + 2 KP_BAND_MARGIN.  n_anchors and chain score of the join are the chain's.
  *
- * JOINED FILL.  Every piece is filled as a band task over the whole gene (the recurrence above: local, H >= 0, restarts); in a
+ * JOINED FILL.  Every piece is filled as a band task (the recurrence above: local, H >= 0, restarts) over the ROWS between its
+ * neighbours' anchors: piece k covers rows [R0, R1), R0 = 0 for the first piece, otherwise the query position of the LAST anchor
+ * of piece k - 1 rounded down to a multiple of 8; R1 = the gene's length for the last piece, otherwise the query position of
+ * the FIRST anchor of piece k + 1 plus KP_K (a chain's alignment runs through its anchors: a piece is left after its last
+ * anchor and entered before its first); rows outside read as outside the contig (H = 0, E = F = -inf).  In a
  * piece k > 0, H has two more candidates, the CROSS gaps from piece k - 1.  When piece k lies on higher diagonals
  * (lo[k] > lo[k-1]: an insertion in the contig) a gap along row r from a live cell (r, t') of piece k - 1 left of piece k's
  * band in that row (t' < lo[k] + r):

@@ -20,7 +20,7 @@
 #include "kp_reduce_core.h"
 
 // kp_reduce.hip
-void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
+void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results, const uint8_t *task_drop,
                             const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells, const float *ln_half,
                             const float *ln_int, const KpJoin *joins, const uint32_t *join_count, uint32_t join_cap, hipStream_t stream);
@@ -247,6 +247,7 @@ struct KpWork {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
+    DevBuf<uint8_t> d_task_drop;  // per task slot: a chain consumed the cluster, its band task reports no hit (kp_join.hip)
     DevBuf<KpSwEnd> d_ends;
     DevBuf<unsigned long long> d_trace_top;
     uint64_t trace_cap = 0;  // 16-byte units the trace buffer was sized for in the most recent pass
@@ -254,6 +255,10 @@ struct KpWork {
     // consecutive batches overlap on the device (the seed scan and the sort of one wait on the L2 and on HBM while the
     // fill kernel of the other keeps the vector ALUs busy)
     hipStream_t astream = nullptr;
+    // ... and the joined fill of its joins on a second one, beside the band tasks' fill (kp_join.hip: a few waves, each a long
+    // chain of dependent steps: 3 ms that the pass would otherwise wait for)
+    hipStream_t jstream = nullptr;
+    hipEvent_t ev_jfork = nullptr, ev_jdone = nullptr;
     DevBuf<uint4> d_trace;  // direction bits of the banded Smith-Waterman: written by the fill kernel, read by the traceback
     void *sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -282,11 +287,14 @@ struct KpWork {
     bool have_events = false;
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
-        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_order.release();
+        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_task_order.release();
         d_ends.release(); d_trace_top.release(); d_trace.release();
         d_groups.release(); d_joins.release(); d_join_counts.release();
         if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
         if (astream) { (void)hipStreamSynchronize(astream); (void)hipStreamDestroy(astream); astream = nullptr; }
+        if (jstream) { (void)hipStreamSynchronize(jstream); (void)hipStreamDestroy(jstream); jstream = nullptr; }
+        if (ev_jfork) { (void)hipEventDestroy(ev_jfork); ev_jfork = nullptr; }
+        if (ev_jdone) { (void)hipEventDestroy(ev_jdone); ev_jdone = nullptr; }
         d_hits_raw.release(); d_hits.release(); d_hit_counts.release(); d_keys.release(); d_cells.release();
         for (auto &r : runs)
             if (r) r->release();
@@ -1041,6 +1049,11 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         w->have_events = true;
     }
     if (!w->astream) KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->astream, hipStreamNonBlocking));
+    if (!w->jstream) {
+        KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->jstream, hipStreamNonBlocking));
+        KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&w->ev_jfork, hipEventDisableTiming));
+        KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&w->ev_jdone, hipEventDisableTiming));
+    }
     hipStream_t stream = w->astream;
     hipEvent_t *ev = w->ev;
     if ((uint64_t)n_asm * w->anchor_cap > 0xFFFFFFF0ull)
@@ -1054,6 +1067,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_seg.reserve(2 * n_asm));
     KP_HIP_CHECK(ctx, w->d_tasks.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_task_drop.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(2));  // [0] the streaming kernel's candidates (front), [1] the edge kernel's (back)
@@ -1097,22 +1111,30 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, stream);
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
+    // kp-align v5: the chains of a group's anchors, their joined fill and walk-back need the groups and the sorted anchors only:
+    // they fork off here and run on the work set's second stream beside the band tasks' order, fill and traceback
+    KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_task_drop.p, 0, KP_N_CLASSES * (size_t)w->task_cap, stream));
+    KP_HIP_CHECK(ctx, hipEventRecord(w->ev_jfork, stream));
+    KP_HIP_CHECK(ctx, hipStreamWaitEvent(w->jstream, w->ev_jfork, 0));
+    kp_launch_join_chain(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, w->task_cap, w->d_groups.p,
+                         w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->jstream);
+    kp_launch_join_fill(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_trace.p, w->d_trace_top.p, w->trace_cap,
+                        w->jstream);
+    kp_launch_join_trace(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_task_drop.p,
+                         w->jstream);
+    KP_HIP_CHECK(ctx, hipEventRecord(w->ev_jdone, w->jstream));
     kp_launch_task_order(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, d_task_count, w->task_cap,
                          w->d_results.p, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD, stream);
-    // kp-align v4: chains of clusters across diagonal jumps (needs the chain scores the task order has just settled)
-    kp_launch_join_chain(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, w->task_cap, w->d_groups.p,
-                         w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
     // all four band classes in one fill launch, then the traceback (kp_sw.hip): ev[3]..ev[4] is the fill, ev[4]..ev[5]
     // the traceback; the remaining event slots stay in the layout and read 0
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, w->d_task_order.p + KP_ORDER_COUNTS, w->task_cap, w->d_task_order.p + ORDER_HEAD,
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->max_gene_len > KP_FILL16_MAX_GENE_LEN,
                  stream, ev[4]);
-    // ... and their joined alignment; it marks the band tasks a joined path replaces, so it follows their traceback
-    // (ev[5]..ev[6]: the joined fill and walk-back, reported in the "sw64" slot of kp_batch_profile; the last slot reads 0)
+    // ev[5]..ev[6]: what is left of the join kernels once the band tasks are through (the "sw64" slot of kp_batch_profile; the
+    // last slot reads 0)
     KP_HIP_CHECK(ctx, hipEventRecord(ev[5], stream));
-    kp_launch_join_sw(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_trace_top.p,
-                      w->trace_cap, w->d_results.p, stream);
+    KP_HIP_CHECK(ctx, hipStreamWaitEvent(stream, w->ev_jdone, 0));
     for (int c = 2; c < KP_N_CLASSES; ++c) KP_HIP_CHECK(ctx, hipEventRecord(ev[4 + c], stream));
     KP_HIP_CHECK(ctx, hipGetLastError());
     return KP_OK;
@@ -1178,7 +1200,7 @@ static int finalise_hits_on_device(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         KP_HIP_CHECK(ctx, w->d_cells.reserve(1));
         KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_hit_counts.p, 0, 2 * n_asm * sizeof(uint32_t), ctx->post));
         KP_HIP_CHECK(ctx, hipMemsetAsync(w->d_cells.p, 0, sizeof(unsigned long long), ctx->post));
-        kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, w->d_tasks.p, w->d_results.p, w->d_counts.p + n_asm,
+        kp_launch_hit_finalise(b->view, ctx->d_gene_len.p, w->d_tasks.p, w->d_results.p, w->d_task_drop.p, w->d_counts.p + n_asm,
                                w->task_cap, w->d_hits_raw.p, w->d_hit_counts.p, w->hit_cap, w->d_keys.p, w->d_hits.p,
                                w->d_hit_counts.p + n_asm, w->d_cells.p, ctx->d_ln.p, ctx->d_ln.p + KP_MAPQ_LN_HALF_SIZE, w->d_joins.p,
                                w->d_join_counts.p + 1, w->join_cap, ctx->post);
@@ -1229,6 +1251,9 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         uint32_t max_join = 0;
         for (int c = 0; c < KP_N_CLASSES; ++c) max_join = std::max(max_join, w->h_join_counts[1 + c]);
         const uint32_t n_group = w->h_join_counts[0];
+        if (std::getenv("KAPTIVE_AMD_JOIN_STATS"))
+            std::fprintf(stderr, "[kp_batch_wait] %zu assemblies: %u groups, joins per band class %u %u %u %u\n", n_asm, n_group,
+                         w->h_join_counts[1], w->h_join_counts[2], w->h_join_counts[3], w->h_join_counts[4]);
         const unsigned long long n_cand = n_cand2[0] + n_cand2[1];
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);
@@ -1443,8 +1468,7 @@ int64_t kp_batch_task_results(kp_ctx *ctx, kp_batch *b, int32_t a, int32_t *out7
             if (out7 && n < cap) {
                 const KpSwResult &r = res[i];
                 int32_t *o = out7 + 7 * n;
-                // (a negative score marks a band task whose hit a joined path replaced, kp_join.hip: the task's own result stands)
-                o[0] = r.score < 0 ? -r.score : r.score; o[1] = r.q_start; o[2] = r.q_end; o[3] = r.t_start; o[4] = r.t_end; o[5] = r.matches; o[6] = r.block_len;
+                o[0] = r.score; o[1] = r.q_start; o[2] = r.q_end; o[3] = r.t_start; o[4] = r.t_end; o[5] = r.matches; o[6] = r.block_len;
             }
             ++n;
         }

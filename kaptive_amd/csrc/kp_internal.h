@@ -140,6 +140,14 @@ struct KpSwResult {
 // read as H = 0, E = F = -inf), so a fill that starts at r_lo from the all-zero state and stops at r_hi computes the same
 // values, the same best cell and the same direction bits for every cell a path can visit.  r_lo is a multiple of 8 (a
 // word of the packed gene holds eight rows).
+// (a piece of a join: the same, within its rows [r0, r1))
+__host__ __device__ inline void kp_task_rows(int lo, int width, int cstart, int cend, int qlen, int *r_lo, int *r_hi);
+__host__ __device__ inline void kp_piece_rows(int lo, int width, int cstart, int cend, int qlen, int r0, int r1, int *r_lo, int *r_hi) {
+    kp_task_rows(lo, width, cstart, cend, qlen, r_lo, r_hi);
+    if (*r_lo < r0) *r_lo = r0;
+    if (*r_hi > r1) *r_hi = r1;
+    if (*r_hi < *r_lo) *r_hi = *r_lo;
+}
 __host__ __device__ inline void kp_task_rows(int lo, int width, int cstart, int cend, int qlen, int *r_lo, int *r_hi) {
     int a = cstart - lo - (width - 1);
     if (a < 0) a = 0;
@@ -181,6 +189,7 @@ struct KpJoin {
     int32_t asm_id, gs, contig, n_pieces, n_anchors, chain_score, width;
     int32_t lo[KP_JOIN_MAX_PIECES];     // lowest diagonal of every piece's band, query order
     int32_t cmask[KP_JOIN_MAX_PIECES];  // bit c: the piece holds an anchor of the group's cluster c
+    int32_t r0[KP_JOIN_MAX_PIECES], r1[KP_JOIN_MAX_PIECES];  // rows [r0, r1) of the piece (kp_spec.h; r0 a multiple of 8, r1 clipped to the gene by the fill)
     int32_t n_members;
     int32_t weak_mask;                  // bit k: piece k belongs to a weak end of the chain (kp_weak_ends)
     uint32_t member_task[KP_JOIN_GROUP_MAX];  // the group's clusters: KP_TASK_REF of their band tasks or KP_REF_NONE
@@ -250,9 +259,10 @@ void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint
 void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
                           KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream);
-void kp_launch_join_sw(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
-                       uint32_t task_cap, void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, KpSwResult *results,
-                       hipStream_t stream);
+void kp_launch_join_fill(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                         void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, hipStream_t stream);
+void kp_launch_join_trace(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                          uint32_t task_cap, const void *trace, uint8_t *task_drop, hipStream_t stream);
 // kp_prot.hip
 // kp_reduce.hip: assembly a's hits with gene in [gene_lo, gene_hi) (one run: hits are sorted by gene) -> out rows, gene
 // indices relative to gene_lo; out_n[a] = how many

@@ -20,6 +20,7 @@
 // Joins are rare (a few per assembly at most on anything but constructed inputs): these kernels are written for clarity
 // in plain 32-bit arithmetic, not for the vector pipe.
 #include "kp_internal.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -38,6 +39,7 @@ __device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w =
 // the 64 lanes sharing the earlier anchors of each, the winner by a wave reduction on (score, index) --; lane 0 backtracks
 // (mg_chain_backtrack), cuts every chain into pieces and appends a KpJoin per chain of two or more pieces.
 constexpr int JA_MAX = KP_JOIN_ANCHOR_MAX;
+constexpr int JA_SMALL = 1024;  // nearly every group (a gene of up to ~5 kb): 15 KB of LDS, ten blocks a CU; the rest take the 60 KB variant
 static_assert((JA_MAX & (JA_MAX - 1)) == 0 && JA_MAX <= 4096 && KP_K * JA_MAX < 65536, "bitonic network; 13-bit indices; 16-bit scores");
 
 __device__ __forceinline__ int ja_t(uint64_t w) { return (int)(w >> 20); }
@@ -45,27 +47,29 @@ __device__ __forceinline__ int ja_q(uint64_t w) { return (int)((w >> 4) & 0xFFFF
 __device__ __forceinline__ int ja_c(uint64_t w) { return (int)(w & 15u); }
 static_assert(KP_JOIN_GROUP_MAX <= 16 && KP_MAX_GENE_LEN <= 0xFFFF, "anchor word layout");
 
+template <int JA, int JA_BELOW>  // groups of JA_BELOW < n <= JA anchors are this instance's
 __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__restrict__ keys, uint32_t cap, KpKeyBits kb,
                                                           const KpTask *__restrict__ tasks, uint32_t task_cap,
                                                           const KpGroup *__restrict__ groups, const uint32_t *__restrict__ group_count,
                                                           uint32_t group_cap, KpJoin *__restrict__ joins, uint32_t *__restrict__ join_count,
-                                                          uint32_t join_cap) {
-    __shared__ uint64_t s_a[JA_MAX];
-    __shared__ uint16_t s_f[JA_MAX];   // a chain of n anchors scores at most KP_K * n
-    __shared__ uint16_t s_pm[JA_MAX];  // prefix maximum of f: the scan for predecessors stops where nothing earlier can win
-    __shared__ int16_t s_p[JA_MAX];
-    __shared__ uint8_t s_used[JA_MAX];  // 0 free, 1 member of a chain, 2 free but already tried as a chain's end
+                                                          uint32_t join_cap, int prio) {
+    __shared__ uint64_t s_a[JA];
+    __shared__ uint16_t s_f[JA];   // a chain of n anchors scores at most KP_K * n
+    __shared__ uint16_t s_pm[JA];  // prefix maximum of f: the scan for predecessors stops where nothing earlier can win
+    __shared__ int16_t s_p[JA];
+    __shared__ uint8_t s_used[JA];  // 0 free, 1 member of a chain, 2 free but already tried as a chain's end
     int16_t *s_chain = reinterpret_cast<int16_t *>(s_pm);  // (the backtracking no longer needs the prefix maxima)
     uint32_t n_groups = *group_count;
     if (n_groups > group_cap) n_groups = group_cap;
     const int lane = threadIdx.x;
     (void)tasks; (void)task_cap;
+    if (prio) __builtin_amdgcn_s_setprio(3);  // one wave per group, a dependent step per anchor: latency, not throughput
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const KpGroup &G = groups[g];
         const int n_members = G.n;
         int n = 0;
         for (int c = 0; c < n_members; ++c) n += (int)G.cnt[c];
-        if (n > JA_MAX || n < KP_MIN_ANCHORS) continue;  // (kp_spec.h: such a group is not chained)
+        if (n > JA || n <= JA_BELOW || n < KP_MIN_ANCHORS) continue;  // (kp_spec.h: a group beyond JA_MAX anchors is not chained)
         __syncthreads();  // the group before is done with the arrays
         int base = 0;
         for (int c = 0; c < n_members; ++c) {
@@ -194,6 +198,10 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
                             J->asm_id = G.asm_id; J->gs = G.gs; J->contig = G.contig; J->n_pieces = np; J->n_anchors = len;
                             J->chain_score = max_s; J->width = width; J->n_members = n_members; J->drop_mask = 0;
                             J->weak_mask = kp_weak_ends(np, qlo, qhi, jump_before);
+                            for (int k = 0; k < KP_JOIN_MAX_PIECES; ++k) {
+                                J->r0[k] = k > 0 && k < np ? qhi[k - 1] & ~7 : 0;
+                                J->r1[k] = k + 1 < np ? qlo[k + 1] + KP_K : KP_MAX_GENE_LEN + 1;
+                            }
                             for (int c = 0; c < KP_JOIN_GROUP_MAX; ++c) J->member_task[c] = c < n_members ? G.task[c] : KP_REF_NONE;
                             for (int k = 0; k < KP_JOIN_MAX_PIECES; ++k) {
                                 if (k < np) {
@@ -255,7 +263,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             const bool cont = k > 0;  // (pieces after the first take the cross gaps of the piece before; every piece is local: H >= 0, restarts)
             const int none = 0;
             int q0 = 0, r_hi = 0;
-            if (act) kp_task_rows(lo, W, cstart, cend, qlen, &q0, &r_hi);
+            if (act) kp_piece_rows(lo, W, cstart, cend, qlen, J->r0[k], J->r1[k], &q0, &r_hi);
             const int steps = act ? (r_hi - q0) + P - 1 : 0;
             const int steps8 = (steps + 7) & ~7;
             const bool exports = act && k + 1 < n_pieces;
@@ -317,15 +325,18 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                     const int qc = (int)((qwin >> (4 * sidx)) & 15u);
                     // left neighbour of cell 0: lane l - 1's cell 3 as the previous step left it; upper neighbour of cell 3: lane
                     // l + 1's cell 0 of this step
-                    int hl = __shfl_up(H[3], 1), el = __shfl_up(E[3], 1);
+                    // (DPP moves, one vector instruction each: a shuffle through the LDS crossbar four times a step was a good part
+                    // of a step's ~9000 cycles, the rest were the exports below)
+                    int hl = __builtin_amdgcn_update_dpp(0, H[3], 0x138, 0xf, 0xf, false), el = __builtin_amdgcn_update_dpp(0, E[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
                     if (l == 0) { hl = none; el = JNEG; }
                     const int oldH[4] = {H[0], H[1], H[2], H[3]}, oldF[4] = {F[0], F[1], F[2], F[3]};
                     uint32_t word = 0;
                     int hu_d = none, fu_d = JNEG;
+                    unsigned long long ex1 = 0ull, ex2 = 0ull;  // a row's offers to the next piece from this lane's four cells (insertion)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (c == 3) {  // (every lane has computed its cell 0 by now)
-                            hu_d = __shfl_down(H[0], 1); fu_d = __shfl_down(F[0], 1);
+                            hu_d = __builtin_amdgcn_update_dpp(0, H[0], 0x130, 0xf, 0xf, false); fu_d = __builtin_amdgcn_update_dpp(0, F[0], 0x130, 0xf, 0xf, false);  // wave_shl:1
                             if (l == P - 1) { hu_d = none; fu_d = JNEG; }
                         }
                         const int t = tb0 + sidx + c;
@@ -375,11 +386,18 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                             if (exports && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
                                 const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
                                 const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
-                                atomicMax(&exp[2 * xi], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low);
-                                atomicMax(&exp[2 * xi + 1], ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low);
+                                const unsigned long long k1 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low;
+                                const unsigned long long k2 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low;
+                                if (exp_horizontal) {  // the lane's four cells lie in one row: one pair of atomics per lane and step, not
+                                    ex1 = k1 > ex1 ? k1 : ex1; ex2 = k2 > ex2 ? k2 : ex2;  // four on the same two words (what the L2 serialises)
+                                } else {
+                                    atomicMax(&exp[2 * xi], k1);
+                                    atomicMax(&exp[2 * xi + 1], k2);
+                                }
                             }
                         }
                     }
+                    if (ex1) { atomicMax(&exp[2 * r], ex1); atomicMax(&exp[2 * r + 1], ex2); }
                     if (fits && m < steps8) tr[(size_t)m * P + l] = word;
                 }
             }
@@ -405,11 +423,14 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
 __global__ __launch_bounds__(64) void kp_join_fill_kernel(KpBatchView b, KpGenes genes, KpJoin *__restrict__ joins,
                                                           const uint32_t *__restrict__ join_count, uint32_t join_cap,
                                                           uint4 *__restrict__ trace, unsigned long long *__restrict__ trace_top,
-                                                          uint64_t trace_cap) {
+                                                          uint64_t trace_cap, int prio) {
     const int c = blockIdx.y;
     uint32_t n = join_count[c];
     if (n > join_cap) n = join_cap;
     if (n == 0) return;
+    // A handful of waves, each a chain of a few thousand dependent steps, on a device that other passes keep full: at the
+    // default priority a step waits its turn behind eight other waves of its SIMD (8 ms per pass for 19 joins).  They go first.
+    if (prio) __builtin_amdgcn_s_setprio(3);
     KpJoin *list = joins + (size_t)c * join_cap;
     if (c == 3) join_fill_class<32>(b, genes, list, n, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
     else if (c == 2) join_fill_class<16>(b, genes, list, n, trace, trace_top, trace_cap, blockIdx.x, gridDim.x);
@@ -420,15 +441,16 @@ __global__ __launch_bounds__(64) void kp_join_fill_kernel(KpBatchView b, KpGenes
 // ---- walk-back: one lane per join -------------------------------------------------------------------------------------------------
 // THE JOINED PATH and the CONSUMED PIECES of kp_spec.h (oracle: join_run): the pieces are tried in the order of their best cells'
 // scores; the first path the drop test does not reject settles the chain -- a hit if it crosses a gap --, and the band tasks of
-// the group's clusters that the chain's pieces hold anchors of lose their own hits (sign of the result's score flipped).
+// the group's clusters that the chain's pieces hold anchors of lose their own hits (task_drop).
 __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGenes genes, KpJoin *__restrict__ joins,
                                                            const uint32_t *__restrict__ join_count, uint32_t join_cap,
                                                            uint32_t task_cap, const uint4 *__restrict__ trace,
-                                                           KpSwResult *__restrict__ results) {
+                                                           uint8_t *__restrict__ task_drop, int prio) {
     const int cls = blockIdx.y;
     uint32_t n = join_count[cls];
     if (n > join_cap) n = join_cap;
     const int P = 4 << cls, W = 4 * P;
+    if (prio) __builtin_amdgcn_s_setprio(3);  // (as the joined fill: few lanes, long dependent walks)
     for (uint32_t ji = blockIdx.x * blockDim.x + threadIdx.x; ji < n; ji += gridDim.x * blockDim.x) {
         KpJoin *J = joins + (size_t)cls * join_cap + ji;
         const int m = J->n_pieces, gs = J->gs, gene = gs >> 1, asm_id = J->asm_id;
@@ -452,11 +474,12 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                 if (!((settled >> z) & 1) && (k < 0 || J->end_s[z] > J->end_s[k])) k = z;
             if (k < 0) break;
             if (J->end_r[k] < 0 || J->end_s[k] < KP_MIN_DP_SCORE) { alone_k = k; break; }
+            if (k == 0) { J->visited[0] = 1; alone_k = 0; break; }  // (the first piece has no gap to cross: its path need not be walked to know that)
             int pk = k, r = J->end_r[k], bi = J->end_b[k], state = 0, matches = 0, cols = 0, gap = 0, credit = 0;
             int sr = r, sb = bi, spk = k, suf = 0, sufmax = 0, gsum = 0, visited = 1 << k, bonus = 0;
             bool rejected = false;
             int lo = J->lo[pk], q0 = 0, r_hi = 0;
-            kp_task_rows(lo, W, cstart, cend, qlen, &q0, &r_hi);
+            kp_piece_rows(lo, W, cstart, cend, qlen, J->r0[pk], J->r1[pk], &q0, &r_hi);
             const uint32_t *tr = reinterpret_cast<const uint32_t *>(trace + J->trace_off[pk]);
             for (;;) {
                 const int t = r + lo + bi;
@@ -502,7 +525,7 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
                         else { bi = t - pos - lo_prev; r = pos; }   // same column, row pos
                         --pk; visited |= 1 << pk;
                         lo = lo_prev;
-                        kp_task_rows(lo, W, cstart, cend, qlen, &q0, &r_hi);
+                        kp_piece_rows(lo, W, cstart, cend, qlen, J->r0[pk], J->r1[pk], &q0, &r_hi);
                         tr = reinterpret_cast<const uint32_t *>(trace + J->trace_off[pk]);
                     }
                 } else if (state == XT_E) {
@@ -536,32 +559,54 @@ __global__ __launch_bounds__(64) void kp_join_trace_kernel(KpBatchView b, KpGene
         for (int c = 0; c < J->n_members; ++c) {
             const uint32_t ref = J->member_task[c];
             if (!((drop >> c) & 1) || ref == KP_REF_NONE || KP_REF_SLOT(ref) >= task_cap) continue;
-            KpSwResult &R = results[(size_t)KP_REF_CLS(ref) * task_cap + KP_REF_SLOT(ref)];
-            if (R.score > 0) R.score = -R.score;
+            task_drop[(size_t)KP_REF_CLS(ref) * task_cap + KP_REF_SLOT(ref)] = 1;  // (read by the hit compaction: kp_reduce.hip)
         }
     }
 }
 
 }  // namespace
 
+// grids and wave priority of the join kernels (KAPTIVE_AMD_JOIN_GRID = "fill,walk,chain,chain_large" blocks (per band class for the
+// first two), KAPTIVE_AMD_JOIN_PRIO = 0 | 1: experiments; the defaults are what tools/experiments/join_cost_ab.sh measured)
+struct JoinLaunch { int fill = 2048, walk = 512, chain = 2560, chain_large = 512, prio = 1; };  // (blocks without work leave at once: a large grid costs nothing measurable)
+static const JoinLaunch &join_launch() {
+    static const JoinLaunch cfg = [] {
+        JoinLaunch c;
+        if (const char *e = std::getenv("KAPTIVE_AMD_JOIN_GRID")) std::sscanf(e, "%d,%d,%d,%d", &c.fill, &c.walk, &c.chain, &c.chain_large);
+        if (const char *e = std::getenv("KAPTIVE_AMD_JOIN_PRIO")) c.prio = std::atoi(e);
+        return c;
+    }();
+    return cfg;
+}
+
 void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
                           KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream) {
     (void)b; (void)genes;
     if (const char *e = std::getenv("KAPTIVE_AMD_SKIP_JOINS")) if (std::atoi(e) & 1) return;  // (debugging aid: bit 0 chaining, 1 fill, 2 walk-back)
-    hipLaunchKernelGGL(kp_join_chain_kernel, dim3(512), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
-                       group_count, group_cap, joins, join_count, join_cap);
+    const JoinLaunch &L = join_launch();
+    hipLaunchKernelGGL((kp_join_chain_kernel<JA_SMALL, 0>), dim3(L.chain), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
+                       group_count, group_cap, joins, join_count, join_cap, L.prio);
+    hipLaunchKernelGGL((kp_join_chain_kernel<JA_MAX, JA_SMALL>), dim3(L.chain_large), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
+                       group_count, group_cap, joins, join_count, join_cap, L.prio);
 }
 
-void kp_launch_join_sw(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
-                       uint32_t task_cap, void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, KpSwResult *results,
-                       hipStream_t stream) {
+// The join kernels need nothing of the band tasks' fill and traceback: they run beside them, on a stream of their own
+// (kp_capi.hip); the walk-back marks the band tasks whose hits a chain consumes (task_drop), which the hit compaction reads.
+void kp_launch_join_fill(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                         void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, hipStream_t stream) {
     const char *skip_env = std::getenv("KAPTIVE_AMD_SKIP_JOINS");
-    const int skip = skip_env ? std::atoi(skip_env) : 0;
-    if (!(skip & 2))
-    hipLaunchKernelGGL(kp_join_fill_kernel, dim3(128, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap,
-                       reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units);
-    if (!(skip & 4))
-    hipLaunchKernelGGL(kp_join_trace_kernel, dim3(32, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap, task_cap,
-                       reinterpret_cast<const uint4 *>(trace), results);
+    if (skip_env && (std::atoi(skip_env) & 2)) return;
+    const JoinLaunch &L = join_launch();
+    hipLaunchKernelGGL(kp_join_fill_kernel, dim3(L.fill, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap,
+                       reinterpret_cast<uint4 *>(trace), trace_top, trace_cap_units, L.prio);
+}
+
+void kp_launch_join_trace(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
+                          uint32_t task_cap, const void *trace, uint8_t *task_drop, hipStream_t stream) {
+    const char *skip_env = std::getenv("KAPTIVE_AMD_SKIP_JOINS");
+    if (skip_env && (std::atoi(skip_env) & 4)) return;
+    const JoinLaunch &L = join_launch();
+    hipLaunchKernelGGL(kp_join_trace_kernel, dim3(L.walk, KP_N_CLASSES), dim3(64), 0, stream, b, genes, joins, join_count, join_cap, task_cap,
+                       reinterpret_cast<const uint4 *>(trace), task_drop, L.prio);
 }

@@ -20,7 +20,7 @@ constexpr int SORT_LDS = 4096;  // sort keys staged in LDS per assembly (more hi
 // ---- 1. band-task results -> per-assembly raw hit lists ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, const int32_t *__restrict__ gene_len,
                                                              const KpTask *__restrict__ tasks,
-                                                             const KpSwResult *__restrict__ results,
+                                                             const KpSwResult *__restrict__ results, const uint8_t *__restrict__ task_drop,
                                                              const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                              kp_hit *__restrict__ raw, uint32_t *__restrict__ n_raw,
                                                              uint32_t hit_cap, unsigned long long *__restrict__ cells) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void kp_hit_compact_kernel(KpBatchView b, cons
             qlen = gene_len[t.gs >> 1];
             if (t.n_anchors) my_cells += (unsigned long long)qlen * (unsigned)t.width;  // (0: rejected by the chaining)
         }
-        const bool hit = i < n && r.score >= KP_MIN_DP_SCORE;
+        const bool hit = i < n && r.score >= KP_MIN_DP_SCORE && !task_drop[(size_t)cls * task_cap + i];  // (dropped: a chain consumed it, kp_join.hip)
         uint32_t slot = 0;
         unsigned long long todo = __ballot(hit);
         while (todo) {
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(64) void kp_join_hits_kernel(KpBatchView b, const i
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const KpJoin &J = joins[(size_t)cls * join_cap + i];
         const int qlen = gene_len[J.gs >> 1];
-        atomicAdd(cells, (unsigned long long)qlen * (unsigned)J.width * (unsigned)J.n_pieces);
+        unsigned long long rows = 0;  // (every piece over its own rows: kp_spec.h, JOINED FILL)
+        for (int k = 0; k < J.n_pieces; ++k) rows += (unsigned long long)max(0, min(J.r1[k], qlen) - J.r0[k]);
+        atomicAdd(cells, rows * (unsigned)J.width);
         for (int k = 1; k < J.n_pieces; ++k) {
             if (J.state[k] != 1) continue;
             const uint32_t slot = atomicAdd(&n_raw[J.asm_id], 1u);
@@ -567,12 +569,12 @@ void kp_launch_pack_rows(const uint32_t *src, size_t src_pitch, uint32_t *dst, s
 }
 
 void kp_launch_hit_finalise(const KpBatchView &b, const int32_t *gene_len, const KpTask *tasks, const KpSwResult *results,
-                            const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
+                            const uint8_t *task_drop, const uint32_t *task_count, uint32_t task_cap, kp_hit *raw, uint32_t *n_raw, uint32_t hit_cap,
                             uint64_t *keys, kp_hit *hits, uint32_t *n_hits, unsigned long long *cells,
                             const float *ln_half, const float *ln_int, const KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
                             hipStream_t stream) {
     if (b.n_asm == 0) return;
-    hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_count,
+    hipLaunchKernelGGL(kp_hit_compact_kernel, dim3(512, KP_N_CLASSES), dim3(256), 0, stream, b, gene_len, tasks, results, task_drop, task_count,
                        task_cap, raw, n_raw, hit_cap, cells);
     hipLaunchKernelGGL(kp_join_hits_kernel, dim3(16, KP_N_CLASSES), dim3(64), 0, stream, b, gene_len, joins, join_count, join_cap, raw,
                        n_raw, hit_cap, cells);

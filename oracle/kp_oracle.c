@@ -678,6 +678,7 @@ static void sw_task(const uint8_t *q, int qlen, const uint8_t *tc, int64_t cstar
 typedef struct kpo_join {
     int32_t gs, contig, n_pieces, n_anchors, chain_score, width;
     int32_t lo[KP_JOIN_MAX_PIECES];    /* lowest diagonal of every piece's band, query order */
+    int32_t r0[KP_JOIN_MAX_PIECES], r1[KP_JOIN_MAX_PIECES]; /* rows [r0, r1) of the piece (r1 is clipped to the gene's length by the fill) */
     int32_t cmask[KP_JOIN_MAX_PIECES]; /* bit c: the piece holds an anchor of the group's cluster c */
     int32_t n_members, member_task[KP_JOIN_GROUP_MAX]; /* the group's clusters: their band tasks (-1 = none) */
     int32_t weak_mask; /* bit k: piece k belongs to a WEAK END of the chain (kp_spec.h) */
@@ -796,6 +797,10 @@ static void chain_group(const uint64_t *keys, const kpo_pcl *pcl, const int *mem
             J->cmask[k] = cm[k];
         }
         J->weak_mask = kp_weak_ends(np, qlo, qhi, jump_before);
+        for (int k = 0; k < np; k++) {
+            J->r0[k] = k ? qhi[k - 1] & ~7 : 0;
+            J->r1[k] = k + 1 < np ? qlo[k + 1] + KP_K : KP_MAX_GENE_LEN + 1;
+        }
     }
     free(chain); free(a); free(f); free(p); free(used); free(order);
 }
@@ -876,11 +881,12 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
             for (int i = 0; i < X->xlen; i++) { X->x1[i] = X->x2[i] = INT64_MIN; X->a1[i] = X->a2[i] = 0; }
         }
         X->end_s = 0; X->end_r = X->end_b = -1;
-#define VALID(r, b) ((r) >= 0 && (b) >= 0 && (b) < w && (int64_t)(r) + lo + (b) >= cstart && (int64_t)(r) + lo + (b) < cend)
+        const int R0 = J->r0[k], R1 = J->r1[k] < qlen ? J->r1[k] : qlen;
+#define VALID(r, b) ((r) >= R0 && (r) < R1 && (b) >= 0 && (b) < w && (int64_t)(r) + lo + (b) >= cstart && (int64_t)(r) + lo + (b) < cend)
         for (int r = 0; r < qlen; r++) {
             for (int b = 0; b < w; b++) {
                 const int64_t t = (int64_t)r + lo + b;
-                if (t < cstart || t >= cend) { X->H[AT(r, b)] = none; E[AT(r, b)] = F[AT(r, b)] = KP_NEG_INF; X->tH[AT(r, b)] = XT_RESTART; X->tE[AT(r, b)] = X->tF[AT(r, b)] = 0; continue; }
+                if (t < cstart || t >= cend || r < R0 || r >= R1) { X->H[AT(r, b)] = none; E[AT(r, b)] = F[AT(r, b)] = KP_NEG_INF; X->tH[AT(r, b)] = XT_RESTART; X->tE[AT(r, b)] = X->tF[AT(r, b)] = 0; continue; }
                 int hl = none, el = KP_NEG_INF, hu = none, fu = KP_NEG_INF, hd = none;
                 if (VALID(r, b - 1)) { hl = X->H[AT(r, b - 1)]; el = E[AT(r, b - 1)]; }
                 if (VALID(r - 1, b + 1)) { hu = X->H[AT(r - 1, b + 1)]; fu = F[AT(r - 1, b + 1)]; }
@@ -948,7 +954,7 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
             const int lo = J->lo[pk];
             if (state == 0) {
                 const int64_t t = (int64_t)r + lo + b;
-                if (r < 0 || b < 0 || b >= w || t < cstart || t >= cend) break;
+                if (r < J->r0[pk] || b < 0 || b >= w || t < cstart || t >= cend) break;
                 const int tb = Y->tH[AT(r, b)];
                 if (tb == XT_RESTART) break;
                 /* the drop test: the path's score behind this cell, cross-gap costs left out, against its largest value so far --
@@ -1238,7 +1244,7 @@ KPO_API int64_t kpo_align(const kpo_db *db, const uint32_t *words, int64_t padde
         const kpo_join *J = &joins[j];
         const int g = J->gs >> 1, rev = J->gs & 1, qlen = db->off[g + 1] - db->off[g];
         const int64_t cs = ctg_start[J->contig];
-        cells += (int64_t)qlen * J->width * J->n_pieces;
+        for (int k = 0; k < J->n_pieces; k++) { const int R1 = J->r1[k] < qlen ? J->r1[k] : qlen; if (R1 > J->r0[k]) cells += (int64_t)(R1 - J->r0[k]) * J->width; }
         for (int k = 1; k < J->n_pieces; k++) {
             if (J->state[k] != 1) continue;
             const int32_t *r = J->res[k];

@@ -251,7 +251,7 @@ def main() -> None:
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--procs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--full-size", type=int, default=6)
-    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r5"))
+    ap.add_argument("--out", default=str(ROOT / "profiles" / "concordance_r6"))
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     cs = cases(a.scale, a.full_size)
