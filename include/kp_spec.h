@@ -58,13 +58,18 @@
  * same x make one ANCHOR: same strand if zq == zt, query position qs; otherwise the gene's reverse complement, query
  * position gene_len - KP_K - qs.
  *
- * OCCURRENCE CUT (v4).  minimap2 drops a query seed that occurs more than mid_occ times in the index -- here: among the
- * assembly's minimizers, both strands -- with mid_occ = max(min_mid_occ = 10, the (1 - 2e-4) quantile of the occurrence
- * counts of the index's distinct minimizers).  v4 applies the floor: a gene seed with more than KP_MID_OCC anchors in an
- * assembly (one anchor per occurrence, whichever strand) loses all of them.  Exact whenever the quantile is <= 10, i.e.
- * unless more than 2 in 10 000 of an assembly's distinct minimizers occur more than ten times (tools/mid_occ_hist.py counts
- * how often that is); minimap2's rescue of high-occurrence seeds in seed-poor stretches (mm_seed_select) is not restated. */
+ * OCCURRENCE CUT (v4; round 6: the quantile).  minimap2 drops a query seed that occurs more than mid_occ times in the index --
+ * here: among the assembly's minimizers, both strands -- with mid_occ = max(min_mid_occ = 10, 1 + the count at position
+ * (int)((1 - 2e-4f) n) of the sorted occurrence counts of the index's n distinct minimizers) (mm_idx_cal_max_occ).  A gene
+ * seed with more than mid_occ anchors in an assembly (one anchor per occurrence, whichever strand) loses all of them.  The
+ * quantile is only ever needed for an assembly in which some gene seed has more than KP_MID_OCC anchors -- mid_occ >= 10
+ * whatever the assembly holds -- and is worked out for those alone (kp_chain.hip: the block that meets such a seed sketches
+ * its assembly once more and counts every minimizer).  Counts are capped at KP_MID_OCC_HIST - 1 (minimap2's own cap,
+ * max_mid_occ, is 10^6; an assembly whose 2e-4 quantile is a minimizer in 2 000 copies is not a bacterial genome).
+ * minimap2's rescue of high-occurrence seeds in seed-poor stretches (mm_seed_select) is not restated. */
 #define KP_MID_OCC 10
+#define KP_MID_OCC_FRAC 2e-4f
+#define KP_MID_OCC_HIST 2048
 #define KP_K 15
 #define KP_W 10
 #define KP_KMER_MASK 0x3FFFFFFFu

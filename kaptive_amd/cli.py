@@ -209,6 +209,14 @@ class _TypingPipeline:
                 self._early.append((k, self.submit_read(paths)))
             self._unread = len(chunks) - len(self._early)
         self._own_typer = typer is None
+        early_ctx = None
+        if typer is None:
+            # the HIP runtime and the device context come up on a thread of their own (0.2 s, interpreter lock released) while this
+            # one reads and unpacks the database file (0.12 s): the context is waiting when the Serotyper asks for it
+            from kaptive_amd import _native
+
+            self._ctx_pool = ThreadPoolExecutor(max_workers=1)
+            early_ctx = self._ctx_pool.submit(_native.Context, device)
         try:
             if typer is None:
                 self.db = load_database(args.database)
@@ -216,12 +224,15 @@ class _TypingPipeline:
                 typer = Serotyper(self.db, max_other_genes=args.max_other_genes, min_completeness=args.min_completeness,
                                   allow_below_threshold=args.below_threshold, partial_edge_tolerance=args.partial_edge_tolerance,
                                   device=device)  # fmt: skip
+                typer._ctx_early = early_ctx
             self.typer = typer
             self.engine = self.typer.engine  # the context is created here, on the thread that will drive it
         except BaseException:
             # a bad database path, no device, no memory: the reads queued above must not be drained (gigabytes of FASTA) by
             # the interpreter's exit hook before the error is reported
             self._abandon_reads()
+            if early_ctx is not None:
+                self._ctx_pool.shutdown(wait=False, cancel_futures=True)
             raise
         self.marks["context_ready"] = time.perf_counter()
         self.want_tsv = bool(getattr(args, "out", None))
@@ -280,7 +291,7 @@ class _TypingPipeline:
     def close(self, fast: bool = False) -> None:
         """``fast``: the process is about to exit (the command line): reads are cancelled, nothing is waited for or freed --
         the operating system takes the page-locked memory and the device context back faster than the runtime unwinds them."""
-        for pool in (self.readers, self.shard_readers, self.copiers, self.formatters, self.janitor):
+        for pool in (self.readers, self.shard_readers, self.copiers, self.formatters, self.janitor, *([self._ctx_pool] if getattr(self, "_ctx_pool", None) else [])):
             pool.shutdown(wait=not fast, cancel_futures=True)
         if fast:
             return

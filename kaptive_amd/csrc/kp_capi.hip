@@ -247,7 +247,10 @@ struct KpWork {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
-    DevBuf<uint8_t> d_task_drop;  // per task slot: a chain consumed the cluster, its band task reports no hit (kp_join.hip)
+    DevBuf<uint8_t> d_task_drop;
+    // counting tables of the occurrence cut's quantile (kp_chain.hip: block_mid_occ): occ_slots tables of 2^occ_log2 entries
+    DevBuf<uint32_t> d_occ_keys, d_occ_cnts;
+    uint32_t occ_slots = 0, occ_log2 = 0;  // per task slot: a chain consumed the cluster, its band task reports no hit (kp_join.hip)
     DevBuf<KpSwEnd> d_ends;
     DevBuf<unsigned long long> d_trace_top;
     uint64_t trace_cap = 0;  // 16-byte units the trace buffer was sized for in the most recent pass
@@ -287,7 +290,7 @@ struct KpWork {
     bool have_events = false;
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
-        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_task_order.release();
+        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_occ_keys.release(); d_occ_cnts.release(); d_task_order.release();
         d_ends.release(); d_trace_top.release(); d_trace.release();
         d_groups.release(); d_joins.release(); d_join_counts.release();
         if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
@@ -328,6 +331,7 @@ struct kp_ctx {
                                  // work set that meets a slightly larger batch than before does not re-allocate (and stall)
     uint64_t trace_units_per_asm = 0;  // trace buffer of a pass = n_asm * this many 16-byte units
     uint32_t group_cap = 0, join_cap = 0;  // group / join lists of a pass (entries; joins per band class)
+    uint32_t occ_slots = 2;                // counting tables of the occurrence cut's quantile a pass may use (learnt like the list sizes)
     // resident database
     bool has_db = false;
     int32_t n_genes = 0;
@@ -1068,6 +1072,14 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_tasks.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_task_drop.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    {   // a table holds every distinct minimizer of the longest assembly (2 / 11 of its bases) at a load of at most a half
+        uint32_t lg = 12;
+        while (((uint64_t)1 << lg) < (uint64_t)b->max_asm_bases * 2 / 5 + 1 && lg < 31) ++lg;
+        w->occ_log2 = lg;
+        w->occ_slots = std::max<uint32_t>(ctx->occ_slots, 2u);
+        KP_HIP_CHECK(ctx, w->d_occ_keys.reserve((size_t)w->occ_slots << lg));
+        KP_HIP_CHECK(ctx, w->d_occ_cnts.reserve((size_t)w->occ_slots << lg));
+    }
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
     KP_HIP_CHECK(ctx, w->d_cand_count.reserve(2));  // [0] the streaming kernel's candidates (front), [1] the edge kernel's (back)
@@ -1108,7 +1120,8 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         if (rc) return rc;
     }
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
-    kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, stream);
+    kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_occ_keys.p, w->d_occ_cnts.p,
+                      w->d_trace_top.p + 3, w->occ_slots, w->occ_log2, stream);  // (words 1-2 of trace_top are the fill kernel's quad counters)
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
     // kp-align v5: the chains of a group's anchors, their joined fill and walk-back need the groups and the sorted anchors only:
@@ -1238,16 +1251,17 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         // the post stream picks up where this batch's alignment pass ends; later passes on ctx->stream are not waited for
         KP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->post, w->ev[3 + KP_N_CLASSES], 0));
         w->h_counts.resize(2 * n_asm + KP_N_CLASSES);
-        unsigned long long n_cand2[2] = {0, 0}, trace_need = 0;
+        unsigned long long n_cand2[2] = {0, 0}, trace_top2[4] = {0, 0, 0, 0};
         {
             Fetch f(ctx, ctx->post);
             int frc;
-            if ((frc = f.begin((2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t) + sizeof n_cand2 + sizeof trace_need + sizeof w->h_join_counts)) ||
+            if ((frc = f.begin((2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t) + sizeof n_cand2 + sizeof trace_top2 + sizeof w->h_join_counts)) ||
                 (frc = f.add(w->h_counts.data(), w->d_counts.p, (2 * n_asm + KP_N_CLASSES) * sizeof(uint32_t))) ||
-                (frc = f.add(n_cand2, w->d_cand_count.p, sizeof n_cand2)) || (frc = f.add(&trace_need, w->d_trace_top.p, sizeof trace_need)) ||
+                (frc = f.add(n_cand2, w->d_cand_count.p, sizeof n_cand2)) || (frc = f.add(trace_top2, w->d_trace_top.p, sizeof trace_top2)) ||
                 (frc = f.add(w->h_join_counts, w->d_join_counts.p, sizeof w->h_join_counts)) || (frc = f.finish()))
                 return frc;
         }
+        const unsigned long long trace_need = trace_top2[0], occ_need = trace_top2[3];  // (assemblies that needed their mid_occ)
         uint32_t max_join = 0;
         for (int c = 0; c < KP_N_CLASSES; ++c) max_join = std::max(max_join, w->h_join_counts[1 + c]);
         const uint32_t n_group = w->h_join_counts[0];
@@ -1260,7 +1274,7 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         for (int c = 0; c < KP_N_CLASSES; ++c) max_task = std::max(max_task, w->h_counts[n_asm + c]);
         const uint32_t sub_cap = w->anchor_cap / KP_ANCHOR_SUBS;
         if (max_slice <= sub_cap && max_task <= w->task_cap && n_cand <= w->cand_cap && trace_need <= w->trace_cap &&
-            n_group <= w->group_cap && max_join <= w->join_cap) {
+            n_group <= w->group_cap && max_join <= w->join_cap && occ_need <= w->occ_slots) {
             // Everything fitted.  What came close makes room for the passes after this one: the sub-slice an anchor
             // lands in depends on the order in which the scan's waves flushed, so the fullest slice varies from pass to
             // pass on the same input, and a rerun costs a whole pass.
@@ -1295,6 +1309,7 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
             ctx->trace_units_per_asm = std::max<uint64_t>(ctx->trace_units_per_asm, (w->trace_cap + n_asm - 1) / std::max<size_t>(n_asm, 1));
         }
         if (n_group > w->group_cap) { w->group_cap = n_group + n_group / 4 + 64; ctx->group_cap = std::max(ctx->group_cap, w->group_cap); }
+        if (occ_need > w->occ_slots) ctx->occ_slots = std::max<uint32_t>(ctx->occ_slots, (uint32_t)std::min<unsigned long long>(occ_need + occ_need / 4 + 1, 1u << 16));
         if (max_join > w->join_cap) { w->join_cap = max_join + max_join / 4 + 64; ctx->join_cap = std::max(ctx->join_cap, w->join_cap); }
         if (max_task > w->task_cap) {
             w->task_cap = (max_task + max_task / 8 + 1023u) & ~1023u;

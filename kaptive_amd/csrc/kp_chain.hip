@@ -16,6 +16,7 @@
 // have to meet in one place for the joins of kp-align v4 (open sequences of clusters within KP_JOIN_BW diagonals,
 // JoinWave below; kp_join.hip chains and aligns them).
 #include "kp_internal.h"
+#include "kp_sketch.h"
 
 namespace {
 
@@ -431,18 +432,115 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
 constexpr int OCC_WAVES = KP_OCC_WAVES, OCC_BINS = KP_OCC_BINS;
 constexpr uint64_t OCC_TOMB = ~0ull;
 
-__global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_t *__restrict__ gene_len, uint64_t *__restrict__ keys,
-                                                                  uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb) {
+// ---- minimap2's mid_occ of one assembly (kp_spec.h, OCCURRENCE CUT), by the block that found a seed beyond the floor ----------------
+// The assembly's minimizers are not kept anywhere (the scan probes them against the genes' filter and forgets them), so the block
+// sketches the assembly once more -- kp_spec.h's state machine (kp_sketch.h) over chunks of OCC_CHUNK positions per thread, every
+// chunk after a warm-up from a fresh state as kp_edge_kernel's right flanks --, counts every seed value in an open-addressing
+// table in global scratch (one of `sc.n_slots` tables; their demand is counted, the host grows the scratch and reruns the pass
+// when more assemblies of a batch need one), builds the histogram of the counts in LDS and reads the quantile off it.
+// A few milliseconds for one block; assemblies that need it are rare (a gene seed in more than ten copies).
+struct OccScratch {
+    uint32_t *keys;       // [n_slots << log2_size] seed values, 0xFFFFFFFF = empty
+    uint32_t *cnts;       // [n_slots << log2_size]
+    unsigned long long *demand;  // assemblies of the pass that asked for a table
+    uint32_t n_slots, log2_size;
+};
+constexpr int OCC_CHUNK = 512;
+constexpr int OCC_WARM = 48 + 2 * (KP_K + KP_W);
+
+__device__ __forceinline__ void block_mid_occ(const KpBatchView &b, int a, const OccScratch &sc, uint32_t *s_hist, uint32_t *s_slot,
+                                              uint32_t *s_distinct, uint32_t *s_mid) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) { *s_slot = (uint32_t)atomicAdd(sc.demand, 1ull); *s_distinct = 0; }
+    for (int i = tid; i < KP_MID_OCC_HIST; i += nthr) s_hist[i] = 0;
+    __syncthreads();
+    if (*s_slot >= sc.n_slots) return;  // (no table left: the floor for now; the host sees the demand and reruns the pass)
+    const uint32_t size = 1u << sc.log2_size, mask = size - 1u;
+    uint32_t *tk = sc.keys + ((size_t)*s_slot << sc.log2_size), *tc = sc.cnts + ((size_t)*s_slot << sc.log2_size);
+    for (uint32_t i = tid; i < size; i += nthr) { tk[i] = 0xFFFFFFFFu; tc[i] = 0u; }
+    __syncthreads();
+    const uint32_t *aw = b.words + b.asm_word_off[a];
+    const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
+    const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
+    const int32_t *runs = b.n_runs + 2 * (size_t)r0;
+    for (int c = 0; c < nc; ++c) {
+        const int64_t cs = b.ctg_start[c0 + c], ce = cs + b.ctg_len[c0 + c];
+        const int64_t n_chunks = (ce - cs + OCC_CHUNK - 1) / OCC_CHUNK;
+        for (int64_t ch = tid; ch < n_chunks; ch += nthr) {
+            const int64_t s0 = cs + ch * OCC_CHUNK, e0 = min(ce, s0 + OCC_CHUNK);  // seeds whose 15-mer starts in [s0, e0) are this chunk's
+            const int64_t from = max(cs, s0 - OCC_WARM), to = min(ce, e0 + KP_K + KP_W + 1);  // (a seed is emitted at most K + W steps after its start)
+            int ri = 0;  // first N run that ends after `from`
+            {
+                int lo = 0, hi = nr;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (runs[2 * mid + 1] <= from) lo = mid + 1; else hi = mid; }
+                ri = lo;
+            }
+            auto emit = [&](int64_t t, uint32_t z, uint32_t x) {
+                (void)z;
+                if (t < s0 || t >= e0) return;
+                uint32_t slot = (x * 2654435769u) >> (32 - sc.log2_size);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&tk[slot], 0xFFFFFFFFu, x);
+                    if (old == 0xFFFFFFFFu || old == x) { atomicAdd(&tc[slot], 1u); break; }
+                    slot = (slot + 1) & mask;
+                }
+            };
+            KpSketchState st;
+            kp_sketch_reset(st);
+            for (int64_t i = from; i < to; ++i) {
+                while (ri < nr && runs[2 * ri + 1] <= i) ++ri;
+                const bool is_n = ri < nr && runs[2 * ri] <= i;
+                const uint32_t code = is_n ? 4u : ((aw[i >> 4] >> (2 * (i & 15))) & 3u);
+                kp_sketch_step(st, i, code, emit);
+            }
+            if (to == ce) kp_sketch_final(st, ce - 1, emit);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < size; i += nthr) {
+        if (tk[i] == 0xFFFFFFFFu) continue;
+        const uint32_t c = tc[i];
+        atomicAdd(&s_hist[c < (uint32_t)KP_MID_OCC_HIST - 1u ? c : (uint32_t)KP_MID_OCC_HIST - 1u], 1u);
+        atomicAdd(s_distinct, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t n = *s_distinct;
+        uint32_t mid = KP_MID_OCC;
+        if (n > 0) {
+            uint32_t kth = (uint32_t)((1. - (double)KP_MID_OCC_FRAC) * (double)n);
+            if (kth >= n) kth = n - 1;
+            uint32_t cum = 0, q = 0;
+            for (uint32_t c = 0; c < (uint32_t)KP_MID_OCC_HIST; ++c) {
+                cum += s_hist[c];
+                if (cum > kth) { q = c; break; }
+            }
+            mid = max(mid, q + 1u);
+        }
+        *s_mid = mid;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView b, const int32_t *__restrict__ gene_len, uint64_t *__restrict__ keys,
+                                                                  uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb, OccScratch sc) {
     __shared__ uint32_t s_cnt[OCC_WAVES][OCC_BINS];
     __shared__ uint32_t s_dropped, s_base, s_wave_n[OCC_WAVES];
+    __shared__ uint32_t s_over, s_mid, s_slot, s_distinct;
     const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t n = count[a];
     if (n > cap) n = cap;
     uint64_t *k = keys + (size_t)a * cap;
     uint32_t *cnt = s_cnt[wave];
     for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
-    if (threadIdx.x == 0) { s_dropped = 0; s_base = 0; }
+    if (threadIdx.x == 0) { s_dropped = 0; s_base = 0; s_over = 0; s_mid = KP_MID_OCC; }
     __syncthreads();
+    // Two passes over the assembly's anchors at most (kp_spec.h, OCCURRENCE CUT): the first only looks for a seed with more than
+    // KP_MID_OCC anchors; nearly every assembly has none and is done.  One that has is sketched once more by this block, every
+    // minimizer counted (block_mid_occ below): that gives minimap2's mid_occ, and the second pass drops what exceeds it.
+    for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t thr = pass == 0 ? (uint32_t)KP_MID_OCC : s_mid;
+    const bool apply = pass == 1;
     const uint32_t per = (((n + OCC_WAVES - 1) / OCC_WAVES) + 63u) & ~63u;
     const uint32_t lo = (uint32_t)wave * per, hi = min(n, lo + per);
     uint32_t cur = lo;
@@ -478,13 +576,13 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
                 const uint32_t i = i0 + lane;
                 const uint64_t key = i < end ? k[i] : OCC_TOMB;
                 const int qf = key != OCC_TOMB ? qf_of(key) - w0 : -1;
-                const bool drop = qf >= 0 && qf < OCC_BINS && cnt[qf] > (uint32_t)KP_MID_OCC;
-                if (drop) k[i] = OCC_TOMB;  // (the counters are read, not changed: every anchor of the seed sees the same count)
+                const bool drop = qf >= 0 && qf < OCC_BINS && cnt[qf] > thr;
+                if (drop && apply) k[i] = OCC_TOMB;  // (the counters are read, not changed: every anchor of the seed sees the same count)
                 any_drop = any_drop || __any(drop);
             }
             wave_sync();
             if (any_drop) {  // rare: the dropped anchors no longer tell which counters they touched
-                if (lane == 0) s_dropped = 1;
+                if (lane == 0) { if (apply) s_dropped = 1; else s_over = 1; }
                 for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
             } else {
                 for (uint32_t i = cur + lane; i < end; i += 64) {
@@ -529,7 +627,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
         if (open) {  // the carried stretch goes on for `first_head` anchors of this round
             open_diags += (uint32_t)__builtin_popcountll(diags & (first_head == 64 ? ~0ull : ((1ull << first_head) - 1ull)));
             if (first_head < n_valid || n_valid < 64) {  // ... and ends here
-                if (open_diags > (uint32_t)KP_MID_OCC) exact_cut(open_start, w + (uint32_t)first_head);
+                if (open_diags > thr) exact_cut(open_start, w + (uint32_t)first_head);
                 open = false;
             }
         }
@@ -540,7 +638,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
             const unsigned long long range = (my_end == 64 ? ~0ull : ((1ull << my_end) - 1ull)) & ~((1ull << lane) - 1ull) & valid_mask;
             const uint32_t my_diags = (uint32_t)__builtin_popcountll((diags | (1ull << lane)) & range);
             const bool closed = head && (later != 0ull || n_valid < 64);  // ends inside the round (or with the wave's anchors)
-            unsigned long long todo = __ballot(closed && my_diags > (uint32_t)KP_MID_OCC);
+            unsigned long long todo = __ballot(closed && my_diags > thr);
             while (todo) {  // (almost never)
                 const int pos = (int)__builtin_ctzll(todo);
                 todo &= todo - 1;
@@ -555,7 +653,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
         }
         if (n_valid < 64) break;
     }
-    if (open && open_diags > (uint32_t)KP_MID_OCC) {  // (the list ended with the carried stretch)
+    if (open && open_diags > thr) {  // (the list ended with the carried stretch)
         uint32_t end = open_start;
         const uint32_t gene = kp_ckey_gs(k[open_start], kb) >> 1;
         for (;;) {
@@ -566,6 +664,14 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(const int32_
         }
         exact_cut(open_start, end);
     }
+    __syncthreads();
+    if (pass == 0) {
+        if (!s_over) break;  // (the common case: no seed beyond the floor)
+        block_mid_occ(b, a, sc, &s_cnt[0][0], &s_slot, &s_distinct, &s_mid);
+        for (int i = threadIdx.x; i < OCC_WAVES * OCC_BINS; i += 64 * OCC_WAVES) (&s_cnt[0][0])[i] = 0;  // (the histogram lived there)
+        __syncthreads();
+    }
+    }  // passes
     __syncthreads();
     if (!s_dropped) return;
     // compaction of the whole list, in order, a block-wide chunk at a time (reads of a chunk finish before its writes: the
@@ -769,9 +875,12 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 }
 
 void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
-                       KpKeyBits key_bits, hipStream_t stream) {
+                       KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, unsigned long long *occ_demand, uint32_t occ_slots,
+                       uint32_t occ_log2_size, hipStream_t stream) {
     if (b.n_asm == 0) return;
-    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, gene_len, sorted_anchors, anchor_count, cap, key_bits);
+    OccScratch sc;
+    sc.keys = occ_keys; sc.cnts = occ_cnts; sc.demand = occ_demand; sc.n_slots = occ_slots; sc.log2_size = occ_log2_size;
+    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc);
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,

@@ -29,13 +29,15 @@ class Engine:
     typing tables as a *group* of the context and ``view(i)`` gives the engine as database ``i`` sees it.  The
     single-genome entry points (``align``, ``hits_to_alignments``) are those of a one-database engine."""
 
-    def __init__(self, db: "Database | Sequence[Database]", device: int = 0) -> None:
+    def __init__(self, db: "Database | Sequence[Database]", device: int = 0, ctx: "_native.Context | None" = None) -> None:
+        """``ctx``: a context of ``device`` the caller created ahead of time (the command line starts the runtime on a thread
+        of its own while the database file is still being read); otherwise one is created here."""
         dbs = list(db) if isinstance(db, (list, tuple)) else [db]
         self.dbs = dbs
         self.db = dbs[0]
         self.group = 0
         self.device = device
-        self.ctx = _native.Context(device)
+        self.ctx = ctx if ctx is not None else _native.Context(device)
         for d in dbs:  # KP_MAX_GENE_LEN (include/kp_spec.h): query positions are 16-bit fields of the anchor and hit keys
             too_long = np.flatnonzero(np.asarray(d.genes.lengths) > _native.MAX_GENE_LEN)
             if len(too_long):

@@ -81,7 +81,9 @@ class Serotyper:
         if self._engine is None:
             from kaptive_amd.engine import Engine
 
-            self._engine = Engine(self._db, device=self._device)
+            early = getattr(self, "_ctx_early", None)  # (a future of _native.Context: kaptive_amd/cli.py starts the runtime early)
+            self._ctx_early = None
+            self._engine = Engine(self._db, device=self._device, ctx=early.result() if early is not None else None)
         return self._engine
 
     def align(self, genome: GenomeAssembly) -> Alignments:

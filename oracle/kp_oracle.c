@@ -427,6 +427,38 @@ static void asm_seed(void *ud, int32_t start, int z, uint32_t x) {
     }
 }
 
+/* minimap2's mid_occ of an index over this assembly (mm_idx_cal_max_occ with -f 2e-4, then the floor of min_mid_occ = 10):
+ * the occurrence counts of its DISTINCT minimizers (both strands: the seed value is that of the canonical 15-mer), sorted; the
+ * count at position (int)((1 - 2e-4f) n), plus one. */
+typedef struct { uint32_t *x; int64_t n, cap; } kpo_xs;
+static void xs_seed(void *ud, int32_t start, int z, uint32_t x) {
+    kpo_xs *v = ud; (void)start; (void)z;
+    if (v->n == v->cap) { v->cap *= 2; v->x = realloc(v->x, (size_t)v->cap * sizeof(uint32_t)); }
+    v->x[v->n++] = x;
+}
+static int cmp_u32v(const void *a, const void *b) { const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : (x > y); }
+static int asm_mid_occ(const kpo_asm *a) {
+    kpo_xs v = {malloc(sizeof(uint32_t) << 16), 0, 1 << 16};
+    for (int c = 0; c < a->n_ctg; c++) kpo_sketch(a->codes + a->ctg_start[c], a->ctg_len[c], xs_seed, &v);
+    qsort(v.x, (size_t)v.n, sizeof(uint32_t), cmp_u32v);
+    int64_t n = 0;
+    uint32_t *cnt = malloc(sizeof(uint32_t) * (size_t)(v.n + 1));
+    for (int64_t i = 0, j; i < v.n; i = j) {
+        for (j = i + 1; j < v.n && v.x[j] == v.x[i]; j++) {}
+        cnt[n++] = (uint32_t)(j - i);
+    }
+    int mid = KP_MID_OCC;
+    if (n > 0) {
+        qsort(cnt, (size_t)n, sizeof(uint32_t), cmp_u32v);
+        int64_t kth = (int64_t)((1. - (double)KP_MID_OCC_FRAC) * (double)n);
+        if (kth >= n) kth = n - 1;
+        const uint32_t q = cnt[kth] < KP_MID_OCC_HIST - 1 ? cnt[kth] : KP_MID_OCC_HIST - 1; /* (counts are capped where the device's histogram ends) */
+        if ((int)q + 1 > mid) mid = (int)q + 1;
+    }
+    free(cnt); free(v.x);
+    return mid;
+}
+
 /* all anchors of one assembly, sorted by key; returns count (caller frees *out) */
 static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **out) {
     kpo_collect k = {db, 0, NULL, 0, 1 << 16, 0};
@@ -441,6 +473,7 @@ static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **ou
      * KP_MID_OCC of them is dropped with all its anchors.  Anchors are sorted by gene/strand first, so a gene's anchors are one
      * stretch of the list. */
     int64_t kept = 0;
+    int mid_occ = -1; /* the assembly's cut (kp_spec.h, OCCURRENCE CUT): worked out when the first seed beyond the floor is met */
     for (int64_t i = 0; i < k.n;) {
         const uint32_t gene = KP_KEY_GS(k.keys[i]) >> 1;
         int64_t j = i;
@@ -448,13 +481,16 @@ static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **ou
         const int glen = db->off[gene + 1] - db->off[gene];
         if (j - i > KP_MID_OCC) {
             int32_t *occ = calloc((size_t)glen + 1, sizeof(int32_t));
+            int over = 0;
             for (int64_t u = i; u < j; u++) {
                 const int q = (int)KP_KEY_QPOS(k.keys[u]);
-                occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q]++;
+                if (++occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] > KP_MID_OCC) over = 1;
             }
+            if (over && mid_occ < 0) mid_occ = asm_mid_occ(a);
+            const int cut = over ? mid_occ : KP_MID_OCC;
             for (int64_t u = i; u < j; u++) {
                 const int q = (int)KP_KEY_QPOS(k.keys[u]);
-                if (occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] <= KP_MID_OCC) k.keys[kept++] = k.keys[u];
+                if (occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] <= cut) k.keys[kept++] = k.keys[u];
             }
             free(occ);
         } else {

@@ -344,18 +344,32 @@ def test_occurrence_cut_matches_oracle(oracle):
             parts += [pad(int(rng.integers(40, 400))), u if i % 2 else revcomp(u)]
         return np.concatenate(parts + [pad(100)])
 
+    # (round 6: the cut is minimap2's mid_occ of the assembly -- max(10, the 2e-4 quantile of its minimizers' occurrence counts) --,
+    # worked out by the device for the assemblies that hold a gene seed beyond the floor.  It sits AT the floor only when fewer than
+    # 2 in 10 000 of an assembly's distinct minimizers are repeats: every assembly gets 2.4 Mbp of unrelated sequence for that;
+    # "tiny_x30" has none and its quantile is its most frequent minimizer: nothing is cut there, as in minimap2.)
+    big = lambda: SeqRecord("background", pad(2_400_000).tobytes())  # noqa: E731
     asms = []
     for copies in (9, 10, 11, 12, 30, 150):
         recs = [SeqRecord("gene", np.concatenate([pad(500), g3, pad(300)]).tobytes()),
                 SeqRecord("copies", repeats(g3[200:420], copies - 1).tobytes()),
-                SeqRecord("other", np.concatenate([pad(200), g7, pad(100)]).tobytes())]
+                SeqRecord("other", np.concatenate([pad(200), g7, pad(100)]).tobytes()), big()]
         asms.append(GenomeAssembly(f"repeat_x{copies}", Sequences.from_records(recs)))
-    asms.append(GenomeAssembly("whole_gene_x14", Sequences.from_records([SeqRecord("c", repeats(g7, 14).tobytes())])))
+    # (700 bases of a gene in 14 copies are ~130 repeated minimizers: safely below 2e-4 of the distinct ones on 8 Mbp)
+    asms.append(GenomeAssembly("whole_gene_x14", Sequences.from_records([SeqRecord("c", repeats(g7[:700], 14).tobytes()), big(), big(), big(), SeqRecord("more", pad(900_000).tobytes())])))
     asms.append(GenomeAssembly("long_gene_windows", Sequences.from_records([
         SeqRecord("gene", np.concatenate([pad(100), long_gene, pad(100)]).tobytes()),
         SeqRecord("second_window", repeats(long_gene[5000:5300], 15).tobytes()),
-        SeqRecord("straddles", repeats(long_gene[3950:4250], 13).tobytes())])))  # fmt: skip
+        SeqRecord("straddles", repeats(long_gene[3950:4250], 13).tobytes()), big()])))  # fmt: skip
     asms += [make_assembly(db, seed=s, length=60_000, median_contigs=4, min_contig=200) for s in (3, 4)]
+    asms.append(GenomeAssembly("tiny_x30", Sequences.from_records([SeqRecord("gene", np.concatenate([pad(500), g3, pad(300)]).tobytes()),
+                                                                   SeqRecord("copies", repeats(g3[200:420], 29).tobytes())])))
+    # an IS-like element in 40 copies lifts the quantile above the floor (to ~40): a gene stretch in 12 copies is then NOT cut
+    element = pad(1200)
+    lifted = [SeqRecord("gene", np.concatenate([pad(500), g3, pad(300)]).tobytes()), SeqRecord("copies", repeats(g3[200:420], 11).tobytes()),
+              SeqRecord("is", np.concatenate([np.concatenate([pad(int(rng.integers(500, 3000))), element]) for _ in range(40)]).tobytes()),
+              SeqRecord("background", pad(900_000).tobytes())]
+    asms.append(GenomeAssembly("quantile_lifted", Sequences.from_records(lifted)))
     packed = [a.packed() for a in asms]
     batch = c.batch(packed)
     hits, hoff = batch.align()
@@ -371,7 +385,10 @@ def test_occurrence_cut_matches_oracle(oracle):
     # seed to its own divergence keeps the others' count at ten or below for that seed), and at thirty nothing is left
     per_asm = [int(((hits[hoff[i] : hoff[i + 1]]["gene"] == 3) & (hits[hoff[i] : hoff[i + 1]]["contig"] == 1)).sum()) for i in range(6)]
     assert per_asm[0] == 8 and per_asm[1] == 9 and per_asm[4:] == [0, 0], per_asm
-    assert n_anchors[1] > n_anchors[2] > n_anchors[3] > n_anchors[4] and hoff[7] - hoff[6] == 0  # (fourteen whole copies: every seed of the gene is cut)
+    assert n_anchors[1] > n_anchors[2] > n_anchors[3] > n_anchors[4] and hoff[7] - hoff[6] == 0  # (fourteen copies of a gene's first 700 bases: every seed they share is cut)
+    tiny, lifted_i = len(asms) - 2, len(asms) - 1
+    assert int((hits[hoff[tiny] : hoff[tiny + 1]]["contig"] == 1).sum()) >= 25  # thirty copies, none cut: the quantile of a small index is its maximum
+    assert int(((hits[hoff[lifted_i] : hoff[lifted_i + 1]]["gene"] == 3) & (hits[hoff[lifted_i] : hoff[lifted_i + 1]]["contig"] == 1)).sum()) >= 9
     batch.close()
     c.close()
 
