@@ -62,9 +62,13 @@
  * here: among the assembly's minimizers, both strands -- with mid_occ = max(min_mid_occ = 10, 1 + the count at position
  * (int)((1 - 2e-4f) n) of the sorted occurrence counts of the index's n distinct minimizers) (mm_idx_cal_max_occ).  A gene
  * seed with more than mid_occ anchors in an assembly (one anchor per occurrence, whichever strand) loses all of them.  The
- * quantile is only ever needed for an assembly in which some gene seed has more than KP_MID_OCC anchors -- mid_occ >= 10
- * whatever the assembly holds -- and is worked out for those alone (kp_chain.hip: the block that meets such a seed sketches
- * its assembly once more and counts every minimizer).  Counts are capped at KP_MID_OCC_HIST - 1 (minimap2's own cap,
+ * quantile can matter only where some gene seed has more than KP_MID_OCC anchors (mid_occ >= 10 whatever the assembly holds),
+ * and it is WORKED OUT only for an assembly in which some gene has at least KP_MIN_ANCHORS such seeds (kp_chain.hip: the block
+ * that meets them sketches its assembly once more and counts every minimizer); in every other assembly the cut is the floor,
+ * KP_MID_OCC.  (One or two seeds of a gene beyond the floor -- in practice a 15-mer it shares by chance with a repeat of the
+ * genome: on a background with IS-like repeats 7 in 10 assemblies have one -- cannot make a chain on their own, minimap2's
+ * -n 3; cutting them at the floor where minimap2 would keep some of them takes at most two anchors off a chain of the gene's
+ * own copy.  Counting 0.9 M minimizers per assembly for them costs more than the rest of the pass.)  Counts are capped at KP_MID_OCC_HIST - 1 (minimap2's own cap,
  * max_mid_occ, is 10^6; an assembly whose 2e-4 quantile is a minimizer in 2 000 copies is not a bacterial genome).
  * minimap2's rescue of high-occurrence seeds in seed-poor stretches (mm_seed_select) is not restated. */
 #define KP_MID_OCC 10

@@ -249,7 +249,7 @@ struct KpWork {
     DevBuf<KpSwResult> d_results;
     DevBuf<uint8_t> d_task_drop;
     // counting tables of the occurrence cut's quantile (kp_chain.hip: block_mid_occ): occ_slots tables of 2^occ_log2 entries
-    DevBuf<uint32_t> d_occ_keys, d_occ_cnts;
+    DevBuf<uint32_t> d_occ_keys, d_occ_cnts, d_occ_state;
     uint32_t occ_slots = 0, occ_log2 = 0;  // per task slot: a chain consumed the cluster, its band task reports no hit (kp_join.hip)
     DevBuf<KpSwEnd> d_ends;
     DevBuf<unsigned long long> d_trace_top;
@@ -290,7 +290,7 @@ struct KpWork {
     bool have_events = false;
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
-        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_occ_keys.release(); d_occ_cnts.release(); d_task_order.release();
+        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_occ_keys.release(); d_occ_cnts.release(); d_occ_state.release(); d_task_order.release();
         d_ends.release(); d_trace_top.release(); d_trace.release();
         d_groups.release(); d_joins.release(); d_join_counts.release();
         if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
@@ -1079,6 +1079,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         w->occ_slots = std::max<uint32_t>(ctx->occ_slots, 2u);
         KP_HIP_CHECK(ctx, w->d_occ_keys.reserve((size_t)w->occ_slots << lg));
         KP_HIP_CHECK(ctx, w->d_occ_cnts.reserve((size_t)w->occ_slots << lg));
+        KP_HIP_CHECK(ctx, w->d_occ_state.reserve(2 * n_asm + w->occ_slots));
     }
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));
@@ -1121,7 +1122,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     }
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_occ_keys.p, w->d_occ_cnts.p,
-                      w->d_trace_top.p + 3, w->occ_slots, w->occ_log2, stream);  // (words 1-2 of trace_top are the fill kernel's quad counters)
+                      w->d_occ_state.p, w->d_trace_top.p + 3, w->occ_slots, w->occ_log2, stream);  // (words 1-2 of trace_top are the fill kernel's quad counters)
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
     // kp-align v5: the chains of a group's anchors, their joined fill and walk-back need the groups and the sorted anchors only:
@@ -1266,8 +1267,8 @@ int kp_batch_wait(kp_ctx *ctx, kp_batch *b) {
         for (int c = 0; c < KP_N_CLASSES; ++c) max_join = std::max(max_join, w->h_join_counts[1 + c]);
         const uint32_t n_group = w->h_join_counts[0];
         if (std::getenv("KAPTIVE_AMD_JOIN_STATS"))
-            std::fprintf(stderr, "[kp_batch_wait] %zu assemblies: %u groups, joins per band class %u %u %u %u\n", n_asm, n_group,
-                         w->h_join_counts[1], w->h_join_counts[2], w->h_join_counts[3], w->h_join_counts[4]);
+            std::fprintf(stderr, "[kp_batch_wait] %zu assemblies: %u groups, joins per band class %u %u %u %u, %llu assemblies needed their mid_occ (%u tables)\n", n_asm, n_group,
+                         w->h_join_counts[1], w->h_join_counts[2], w->h_join_counts[3], w->h_join_counts[4], occ_need, w->occ_slots);
         const unsigned long long n_cand = n_cand2[0] + n_cand2[1];
         uint32_t max_slice = 0, max_task = 0;
         for (size_t a = 0; a < n_asm; ++a) max_slice = std::max(max_slice, w->h_counts[n_asm + KP_N_CLASSES + a]);

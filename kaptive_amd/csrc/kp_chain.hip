@@ -432,57 +432,66 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
 constexpr int OCC_WAVES = KP_OCC_WAVES, OCC_BINS = KP_OCC_BINS;
 constexpr uint64_t OCC_TOMB = ~0ull;
 
-// ---- minimap2's mid_occ of one assembly (kp_spec.h, OCCURRENCE CUT), by the block that found a seed beyond the floor ----------------
-// The assembly's minimizers are not kept anywhere (the scan probes them against the genes' filter and forgets them), so the block
-// sketches the assembly once more -- kp_spec.h's state machine (kp_sketch.h) over chunks of OCC_CHUNK positions per thread, every
-// chunk after a warm-up from a fresh state as kp_edge_kernel's right flanks --, counts every seed value in an open-addressing
-// table in global scratch (one of `sc.n_slots` tables; their demand is counted, the host grows the scratch and reruns the pass
-// when more assemblies of a batch need one), builds the histogram of the counts in LDS and reads the quantile off it.
-// A few milliseconds for one block; assemblies that need it are rare (a gene seed in more than ten copies).
+// ---- minimap2's mid_occ of the assemblies that need it (kp_spec.h, OCCURRENCE CUT) ------------------------------------------------
+// The assembly's minimizers are not kept anywhere (the scan probes them against the genes' filter and forgets them), so an
+// assembly in which a gene has KP_MIN_ANCHORS seeds beyond the floor is sketched once more: the first launch of
+// kp_occ_cut_kernel (phase 0) claims it one of `n_slots` counting tables in global scratch and clears the table;
+// kp_occ_sketch_kernel -- OCC_PARTS blocks per table -- runs kp_spec.h's state machine (kp_sketch.h) over chunks of OCC_CHUNK
+// positions per thread, every chunk after a warm-up from a fresh state as kp_edge_kernel's right flanks, and counts every seed
+// value in the open-addressing table; kp_occ_quantile_kernel builds the histogram of the counts and reads the quantile off it;
+// the second launch of kp_occ_cut_kernel (phase 1) cuts at it.  Assemblies that need this are rare (a stretch of a gene in
+// more than ten copies); the launches find nothing to do otherwise.  When more assemblies of a batch ask than there are tables
+// the demand is counted and the host grows the scratch and reruns the pass.
 struct OccScratch {
     uint32_t *keys;       // [n_slots << log2_size] seed values, 0xFFFFFFFF = empty
     uint32_t *cnts;       // [n_slots << log2_size]
+    uint32_t *state;      // [n_asm] bit 0: a seed beyond the floor, bit 1: its own mid_occ decides; [n_asm] mid_occ; [n_slots] the table's assembly
     unsigned long long *demand;  // assemblies of the pass that asked for a table
     uint32_t n_slots, log2_size;
+    int32_t n_asm;
 };
 constexpr int OCC_CHUNK = 512;
 constexpr int OCC_WARM = 48 + 2 * (KP_K + KP_W);
+constexpr int OCC_PARTS = 64;
 
-__device__ __forceinline__ void block_mid_occ(const KpBatchView &b, int a, const OccScratch &sc, uint32_t *s_hist, uint32_t *s_slot,
-                                              uint32_t *s_distinct, uint32_t *s_mid) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    if (tid == 0) { *s_slot = (uint32_t)atomicAdd(sc.demand, 1ull); *s_distinct = 0; }
-    for (int i = tid; i < KP_MID_OCC_HIST; i += nthr) s_hist[i] = 0;
-    __syncthreads();
-    if (*s_slot >= sc.n_slots) return;  // (no table left: the floor for now; the host sees the demand and reruns the pass)
-    const uint32_t size = 1u << sc.log2_size, mask = size - 1u;
-    uint32_t *tk = sc.keys + ((size_t)*s_slot << sc.log2_size), *tc = sc.cnts + ((size_t)*s_slot << sc.log2_size);
-    for (uint32_t i = tid; i < size; i += nthr) { tk[i] = 0xFFFFFFFFu; tc[i] = 0u; }
-    __syncthreads();
+__global__ __launch_bounds__(256) void kp_occ_sketch_kernel(KpBatchView b, OccScratch sc) {
+    const uint32_t slot = blockIdx.y;
+    unsigned long long want = *sc.demand;
+    if (slot >= want || slot >= sc.n_slots) return;
+    const int a = (int)sc.state[2 * (size_t)sc.n_asm + slot];
+    const uint32_t mask = (1u << sc.log2_size) - 1u;
+    uint32_t *tk = sc.keys + ((size_t)slot << sc.log2_size), *tc = sc.cnts + ((size_t)slot << sc.log2_size);
     const uint32_t *aw = b.words + b.asm_word_off[a];
     const int c0 = b.asm_first_ctg[a], nc = b.asm_first_ctg[a + 1] - c0;
     const int r0 = b.asm_first_nrun[a], nr = b.asm_first_nrun[a + 1] - r0;
     const int32_t *runs = b.n_runs + 2 * (size_t)r0;
-    for (int c = 0; c < nc; ++c) {
-        const int64_t cs = b.ctg_start[c0 + c], ce = cs + b.ctg_len[c0 + c];
-        const int64_t n_chunks = (ce - cs + OCC_CHUNK - 1) / OCC_CHUNK;
-        for (int64_t ch = tid; ch < n_chunks; ch += nthr) {
-            const int64_t s0 = cs + ch * OCC_CHUNK, e0 = min(ce, s0 + OCC_CHUNK);  // seeds whose 15-mer starts in [s0, e0) are this chunk's
+    // chunks of OCC_CHUNK positions, numbered through the assembly's padded space (contigs start on 32-base boundaries, the
+    // padding between them is not sketched): every thread of the table's blocks takes every n-th chunk, whatever contig it lies in
+    const int64_t total = (int64_t)(b.asm_word_off[a + 1] - b.asm_word_off[a]) << 4;
+    const int32_t *cstarts = b.ctg_start + c0;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t s_pad = tid * OCC_CHUNK; s_pad < total; s_pad += nthr * OCC_CHUNK) {
+        int lo = 0, hi = nc;  // the contigs that overlap [s_pad, s_pad + OCC_CHUNK): from the last one that starts at or before s_pad
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cstarts[mid] <= s_pad) lo = mid + 1; else hi = mid; }
+        for (int c = max(lo - 1, 0); c < nc && cstarts[c] < s_pad + OCC_CHUNK; ++c) {
+            const int64_t cs = cstarts[c], ce = cs + b.ctg_len[c0 + c];
+            const int64_t s0 = max(cs, s_pad), e0 = min(ce, s_pad + OCC_CHUNK);  // seeds whose 15-mer starts in [s0, e0) are this chunk's
+            if (s0 >= e0) continue;
             const int64_t from = max(cs, s0 - OCC_WARM), to = min(ce, e0 + KP_K + KP_W + 1);  // (a seed is emitted at most K + W steps after its start)
             int ri = 0;  // first N run that ends after `from`
             {
-                int lo = 0, hi = nr;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (runs[2 * mid + 1] <= from) lo = mid + 1; else hi = mid; }
-                ri = lo;
+                int l2 = 0, h2 = nr;
+                while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (runs[2 * mid + 1] <= from) l2 = mid + 1; else h2 = mid; }
+                ri = l2;
             }
             auto emit = [&](int64_t t, uint32_t z, uint32_t x) {
                 (void)z;
                 if (t < s0 || t >= e0) return;
-                uint32_t slot = (x * 2654435769u) >> (32 - sc.log2_size);
+                uint32_t at = (x * 2654435769u) >> (32 - sc.log2_size);
                 for (;;) {
-                    const uint32_t old = atomicCAS(&tk[slot], 0xFFFFFFFFu, x);
-                    if (old == 0xFFFFFFFFu || old == x) { atomicAdd(&tc[slot], 1u); break; }
-                    slot = (slot + 1) & mask;
+                    const uint32_t old = atomicCAS(&tk[at], 0xFFFFFFFFu, x);
+                    if (old == 0xFFFFFFFFu || old == x) { atomicAdd(&tc[at], 1u); break; }
+                    at = (at + 1) & mask;
                 }
             };
             KpSketchState st;
@@ -496,16 +505,31 @@ __device__ __forceinline__ void block_mid_occ(const KpBatchView &b, int a, const
             if (to == ce) kp_sketch_final(st, ce - 1, emit);
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void kp_occ_quantile_kernel(OccScratch sc) {
+    __shared__ uint32_t s_hist[KP_MID_OCC_HIST];
+    __shared__ uint32_t s_distinct;
+    const uint32_t slot = blockIdx.x;
+    unsigned long long want = *sc.demand;
+    if (slot >= want || slot >= sc.n_slots) return;
+    const int a = (int)sc.state[2 * (size_t)sc.n_asm + slot];
+    const uint32_t size = 1u << sc.log2_size;
+    const uint32_t *tk = sc.keys + ((size_t)slot << sc.log2_size), *tc = sc.cnts + ((size_t)slot << sc.log2_size);
+    for (int i = threadIdx.x; i < KP_MID_OCC_HIST; i += blockDim.x) s_hist[i] = 0;
+    if (threadIdx.x == 0) s_distinct = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < size; i += nthr) {
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
         if (tk[i] == 0xFFFFFFFFu) continue;
         const uint32_t c = tc[i];
         atomicAdd(&s_hist[c < (uint32_t)KP_MID_OCC_HIST - 1u ? c : (uint32_t)KP_MID_OCC_HIST - 1u], 1u);
-        atomicAdd(s_distinct, 1u);
+        ++mine;
     }
+    if (mine) atomicAdd(&s_distinct, mine);
     __syncthreads();
-    if (tid == 0) {
-        const uint32_t n = *s_distinct;
+    if (threadIdx.x == 0) {
+        const uint32_t n = s_distinct;
         uint32_t mid = KP_MID_OCC;
         if (n > 0) {
             uint32_t kth = (uint32_t)((1. - (double)KP_MID_OCC_FRAC) * (double)n);
@@ -517,28 +541,37 @@ __device__ __forceinline__ void block_mid_occ(const KpBatchView &b, int a, const
             }
             mid = max(mid, q + 1u);
         }
-        *s_mid = mid;
+        sc.state[(size_t)sc.n_asm + a] = mid;
     }
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView b, const int32_t *__restrict__ gene_len, uint64_t *__restrict__ keys,
-                                                                  uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb, OccScratch sc) {
+                                                                  uint32_t *__restrict__ count, uint32_t cap, KpKeyBits kb, OccScratch sc,
+                                                                  int phase) {
     __shared__ uint32_t s_cnt[OCC_WAVES][OCC_BINS];
     __shared__ uint32_t s_dropped, s_base, s_wave_n[OCC_WAVES];
-    __shared__ uint32_t s_over, s_mid, s_slot, s_distinct;
+    __shared__ uint32_t s_over, s_any, s_mid, s_slot;
     const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t n = count[a];
     if (n > cap) n = cap;
     uint64_t *k = keys + (size_t)a * cap;
     uint32_t *cnt = s_cnt[wave];
     for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
-    if (threadIdx.x == 0) { s_dropped = 0; s_base = 0; s_over = 0; s_mid = KP_MID_OCC; }
+    if (threadIdx.x == 0) { s_dropped = 0; s_base = 0; s_over = 0; s_any = 0; s_mid = KP_MID_OCC; }
     __syncthreads();
-    // Two passes over the assembly's anchors at most (kp_spec.h, OCCURRENCE CUT): the first only looks for a seed with more than
-    // KP_MID_OCC anchors; nearly every assembly has none and is done.  One that has is sketched once more by this block, every
-    // minimizer counted (block_mid_occ below): that gives minimap2's mid_occ, and the second pass drops what exceeds it.
-    for (int pass = 0; pass < 2; ++pass) {
+    // Two launches (kp_spec.h, OCCURRENCE CUT).  Phase 0 only looks for seeds with more than KP_MID_OCC anchors; nearly every
+    // assembly has none.  Where a GENE has KP_MIN_ANCHORS such seeds the block claims a counting table for kp_occ_sketch_kernel /
+    // kp_occ_quantile_kernel, which work out minimap2's mid_occ of the assembly between the two launches.  Phase 1 returns at
+    // once for an assembly without a seed beyond the floor, and drops what exceeds the assembly's mid_occ -- or the floor -- in
+    // the others.
+    const int pass = phase;
+    if (phase == 1) {
+        const uint32_t st = sc.state[a];
+        if (!(st & 1u)) return;
+        if (threadIdx.x == 0) s_mid = (st & 2u) ? sc.state[(size_t)sc.n_asm + a] : (uint32_t)KP_MID_OCC;
+        __syncthreads();
+    }
+    {
     const uint32_t thr = pass == 0 ? (uint32_t)KP_MID_OCC : s_mid;
     const bool apply = pass == 1;
     const uint32_t per = (((n + OCC_WAVES - 1) / OCC_WAVES) + 63u) & ~63u;
@@ -563,6 +596,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         // positions are counted a window of OCC_BINS at a time, exactly
+        uint32_t n_over = 0;  // (first pass) seeds of this gene beyond the floor
         for (int w0 = 0; w0 < glen; w0 += OCC_BINS) {
             for (uint32_t i = cur + lane; i < end; i += 64) {
                 const uint64_t key = k[i];
@@ -582,7 +616,9 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView 
             }
             wave_sync();
             if (any_drop) {  // rare: the dropped anchors no longer tell which counters they touched
-                if (lane == 0) { if (apply) s_dropped = 1; else s_over = 1; }
+                if (!apply)  // how many of the gene's seeds are beyond the floor (the counters of this window hold them)
+                    for (int i = lane; i < OCC_BINS; i += 64) n_over += (uint32_t)__builtin_popcountll(__ballot(cnt[i] > thr));
+                if (lane == 0) { if (apply) s_dropped = 1; else s_any = 1; }
                 for (int i = lane; i < OCC_BINS; i += 64) cnt[i] = 0;
             } else {
                 for (uint32_t i = cur + lane; i < end; i += 64) {
@@ -594,6 +630,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView 
             }
             wave_sync();
         }
+        if (!apply && n_over >= (uint32_t)KP_MIN_ANCHORS && lane == 0) s_over = 1;  // (kp_spec.h: enough of them to chain on their own)
     };
     // CERTIFICATE.  The anchors of one seed lie on different (gene/strand, diagonal) pairs, so a stretch with anchors on ten or
     // fewer of them cannot hold a seed with more than ten anchors -- and a gene's anchors in an assembly sit on one or two
@@ -665,13 +702,23 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView 
         exact_cut(open_start, end);
     }
     __syncthreads();
-    if (pass == 0) {
-        if (!s_over) break;  // (the common case: no seed beyond the floor)
-        block_mid_occ(b, a, sc, &s_cnt[0][0], &s_slot, &s_distinct, &s_mid);
-        for (int i = threadIdx.x; i < OCC_WAVES * OCC_BINS; i += 64 * OCC_WAVES) (&s_cnt[0][0])[i] = 0;  // (the histogram lived there)
-        __syncthreads();
     }
-    }  // passes
+    if (phase == 0) {
+        uint32_t st = (s_any ? 1u : 0u), slot = 0;
+        if (s_over) {  // some gene has KP_MIN_ANCHORS seeds beyond the floor: the assembly's own mid_occ decides (rare)
+            if (threadIdx.x == 0) s_slot = (uint32_t)atomicAdd(sc.demand, 1ull);
+            __syncthreads();
+            slot = s_slot;
+            if (slot < sc.n_slots) {  // (no table left: the floor for now; the host sees the demand and reruns the pass)
+                st |= 2u;
+                uint32_t *tk = sc.keys + ((size_t)slot << sc.log2_size), *tc = sc.cnts + ((size_t)slot << sc.log2_size);
+                for (uint32_t i = threadIdx.x; i < (1u << sc.log2_size); i += blockDim.x) { tk[i] = 0xFFFFFFFFu; tc[i] = 0u; }
+                if (threadIdx.x == 0) { sc.state[2 * (size_t)sc.n_asm + slot] = (uint32_t)a; sc.state[(size_t)sc.n_asm + a] = KP_MID_OCC; }
+            }
+        }
+        if (threadIdx.x == 0) sc.state[a] = st;
+        return;
+    }
     __syncthreads();
     if (!s_dropped) return;
     // compaction of the whole list, in order, a block-wide chunk at a time (reads of a chunk finish before its writes: the
@@ -875,12 +922,16 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
 }
 
 void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
-                       KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, unsigned long long *occ_demand, uint32_t occ_slots,
-                       uint32_t occ_log2_size, hipStream_t stream) {
+                       KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, uint32_t *occ_state, unsigned long long *occ_demand,
+                       uint32_t occ_slots, uint32_t occ_log2_size, hipStream_t stream) {
     if (b.n_asm == 0) return;
     OccScratch sc;
-    sc.keys = occ_keys; sc.cnts = occ_cnts; sc.demand = occ_demand; sc.n_slots = occ_slots; sc.log2_size = occ_log2_size;
-    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc);
+    sc.keys = occ_keys; sc.cnts = occ_cnts; sc.state = occ_state; sc.demand = occ_demand; sc.n_slots = occ_slots; sc.log2_size = occ_log2_size;
+    sc.n_asm = b.n_asm;
+    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc, 0);
+    hipLaunchKernelGGL(kp_occ_sketch_kernel, dim3(OCC_PARTS, occ_slots), dim3(256), 0, stream, b, sc);
+    hipLaunchKernelGGL(kp_occ_quantile_kernel, dim3(occ_slots), dim3(1024), 0, stream, sc);
+    hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc, 1);
 }
 
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,

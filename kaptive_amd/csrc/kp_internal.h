@@ -229,10 +229,11 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 // kp_chain.hip: the occurrence cut on the sorted anchors (kp_spec.h, OCCURRENCE CUT): seeds with more anchors in an assembly than
 // minimap2's mid_occ of that assembly lose them; the lists are compacted in place and anchor_count updated.  occ_keys / occ_cnts:
 // `occ_slots` counting tables of 2^occ_log2_size entries for the assemblies that need their quantile worked out (a gene seed
-// beyond the floor of ten); *occ_demand (zeroed by the caller) ends up as how many asked.
+// beyond the floor of ten); occ_state: 2 * n_asm + occ_slots words of per-assembly state; *occ_demand (zeroed by the caller) ends
+// up as how many asked.
 void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
-                       KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, unsigned long long *occ_demand, uint32_t occ_slots,
-                       uint32_t occ_log2_size, hipStream_t stream);
+                       KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, uint32_t *occ_state, unsigned long long *occ_demand,
+                       uint32_t occ_slots, uint32_t occ_log2_size, hipStream_t stream);
 // kp_chain.hip: sorted anchors -> band tasks, appended per width class (class c region = tasks[c * cap ..)).
 void kp_launch_chain(const KpBatchView &b, const uint64_t *sorted_anchors, const uint32_t *anchor_count, uint32_t cap,
                      KpKeyBits key_bits, KpTask *tasks, uint32_t *task_count /*[KP_N_CLASSES]*/, uint32_t task_cap,

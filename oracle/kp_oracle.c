@@ -473,7 +473,26 @@ static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **ou
      * KP_MID_OCC of them is dropped with all its anchors.  Anchors are sorted by gene/strand first, so a gene's anchors are one
      * stretch of the list. */
     int64_t kept = 0;
-    int mid_occ = -1; /* the assembly's cut (kp_spec.h, OCCURRENCE CUT): worked out when the first seed beyond the floor is met */
+    /* the assembly's cut (kp_spec.h, OCCURRENCE CUT): minimap2's mid_occ when some gene has KP_MIN_ANCHORS seeds beyond the floor,
+     * the floor otherwise */
+    int mid_occ = KP_MID_OCC;
+    for (int64_t i = 0; i < k.n;) {
+        const uint32_t gene = KP_KEY_GS(k.keys[i]) >> 1;
+        int64_t j = i;
+        while (j < k.n && (KP_KEY_GS(k.keys[j]) >> 1) == gene) j++;
+        if (j - i > KP_MID_OCC) {
+            const int glen = db->off[gene + 1] - db->off[gene];
+            int32_t *occ = calloc((size_t)glen + 1, sizeof(int32_t));
+            int n_over = 0;
+            for (int64_t u = i; u < j; u++) {
+                const int q = (int)KP_KEY_QPOS(k.keys[u]);
+                if (++occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] == KP_MID_OCC + 1) n_over++;
+            }
+            free(occ);
+            if (n_over >= KP_MIN_ANCHORS) { mid_occ = asm_mid_occ(a); break; }
+        }
+        i = j;
+    }
     for (int64_t i = 0; i < k.n;) {
         const uint32_t gene = KP_KEY_GS(k.keys[i]) >> 1;
         int64_t j = i;
@@ -481,13 +500,11 @@ static int64_t collect_anchors(const kpo_db *db, const kpo_asm *a, uint64_t **ou
         const int glen = db->off[gene + 1] - db->off[gene];
         if (j - i > KP_MID_OCC) {
             int32_t *occ = calloc((size_t)glen + 1, sizeof(int32_t));
-            int over = 0;
             for (int64_t u = i; u < j; u++) {
                 const int q = (int)KP_KEY_QPOS(k.keys[u]);
-                if (++occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] > KP_MID_OCC) over = 1;
+                occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q]++;
             }
-            if (over && mid_occ < 0) mid_occ = asm_mid_occ(a);
-            const int cut = over ? mid_occ : KP_MID_OCC;
+            const int cut = mid_occ;
             for (int64_t u = i; u < j; u++) {
                 const int q = (int)KP_KEY_QPOS(k.keys[u]);
                 if (occ[(KP_KEY_GS(k.keys[u]) & 1) ? glen - KP_K - q : q] <= cut) k.keys[kept++] = k.keys[u];
