@@ -277,6 +277,15 @@ def gen_typing() -> None:
         # (round 5, kp-align v4) insertions and deletions of 33-450 bases inside genes: joined hits
         ("k_midindel_del", "k", dict(seed=21, p_break=0, p_is=0, p_stop=0, mid_indels=((60, "del"), (151, "del"), (300, "ins")), **small)),
         ("k_midindel_ins", "k", dict(seed=22, p_is=0, p_stop=0, mid_indels=((45, "ins"), (98, "ins"), (450, "del"), (36, "del")), **small)),
+        # (round 6, kp-align v5) events 40-100 bases from a gene's start / end, pairs of events that nearly cancel, a storm of
+        # events anywhere in the locus: chains with weak end pieces, pieces that share a diagonal, chains of three and more pieces
+        ("k_endindel_start", "k", dict(seed=23, p_break=0, p_is=0, p_stop=0, sub_rate=0.01,
+                                       placed_indels=((("del", 45, 40),), (("ins", 61, 70),), (("del", 150, 100),), (("ins", 200, 40),)), **small)),
+        ("k_endindel_end", "k", dict(seed=24, p_break=0, p_is=0, p_stop=0, sub_rate=0.01,
+                                     placed_indels=((("del", 45, -40),), (("ins", 61, -40),), (("del", 150, -70),), (("ins", 200, -100),)), **small)),
+        ("k_interleave", "k", dict(seed=25, p_break=0, p_is=0, p_stop=0, sub_rate=0.01,
+                                   placed_indels=((("del", 40, 200), ("ins", 50, 640)), (("ins", 60, 200), ("del", 45, 450)), (("del", 33, 200), ("ins", 36, 383))), **small)),
+        ("k_storm", "k", dict(seed=26, p_is=0, p_stop=0, indel_storm=(6, 33, 300), **small)),
         ("o_plain", "o", dict(seed=31, p_extra=0.0, **small)),
         ("o_extra1", "o", dict(seed=32, p_extra=3.0, **small)),
         ("o_extra2", "o", dict(seed=33, p_extra=3.0, locus=0, **small)),
