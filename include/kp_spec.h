@@ -227,7 +227,9 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
  *     X1 = max (H(r, t') + 2 t') - 4 - 2 t        X2 = max (H(r, t') + t') - 24 - t      (first / second piece of the gap cost)
  * otherwise (a deletion) a gap down column t from a live cell (r', t) of piece k - 1 on a diagonal above piece k's band
  * (t - r' > lo[k] + W - 1):   X1 = max (H(r', t) + 2 r') - 4 - 2 r,   X2 = max (H(r', t) + r') - 24 - r.
- * (Live: H > 0.)  The source cell of a maximum is the first one in increasing t' (r').  H = max(diagonal, E, F, X1, X2) with
+ * (Live: H > 0.)  A cross gap starts and ends in rows of the JUNCTION ZONE, the rows the two pieces share: r (and r') in
+ * [R0 of piece k, R1 of piece k - 1) -- the stretch of the query between the last anchor of the piece before and the first
+ * anchor of this one.  The source cell of a maximum is the first one in increasing t' (r').  H = max(diagonal, E, F, X1, X2) with
  * ties in that order (a candidate must beat everything before it); H <= 0 is a restart cell.  A path therefore crosses a gap
  * only where that pays -- which is what minimap2 comes to: it cuts a chain's end off when it is shorter than twice the gap
  * behind it (mm_fix_bad_ends) and lets the extension, a free local decision, reach across or not; an end long enough to be

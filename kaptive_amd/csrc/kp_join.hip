@@ -22,6 +22,7 @@
 #include "kp_internal.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -292,7 +293,13 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             // Eight steps at a time: what they read -- the query rows, the target bases and the keys of the cross gaps -- does not
             // depend on the cells before them, so it is all requested up front and the eight dependent steps then run from
             // registers (a step that fetched its own operands waited for memory three times: 3.3 ms for a 1300-row piece).
-            for (int m0 = 0; m0 < max_steps; m0 += 8) {
+            // The junction zones (kp_spec.h): cross gaps are taken in rows below r1 of the piece before, and offered from row r0
+            // of the piece after -- the few dozen rows between the neighbours' anchors.  Everywhere else a chunk is a plain banded
+            // fill: no key loads, no candidates, no atomics (the kernel's 800 instructions a step were mostly those).
+            const int imp_r1 = act && cont ? min(J->r1[k - 1], qlen) : 0;       // imports in rows < imp_r1
+            const int exp_r0 = exports ? J->r0[k + 1] : 0x7FFFFFFF;           // exports from rows >= exp_r0
+            auto chunk = [&](const int m0, auto io_tag, auto nr_tag) {
+                constexpr bool IO = decltype(io_tag)::value, NR = decltype(nr_tag)::value;
                 const int r0 = q0 + m0 - l;  // this lane's row at the chunk's first step
                 const int tb0 = lo + r0 + 4 * l;  // ... and the column of its cell 0 there: step s, cell c sits on tb0 + s + c
                 uint64_t qwin, twin;
@@ -306,15 +313,17 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                     const uint32_t hi_t = (fits && v0 + 1 >= 0 && v0 + 1 < asm_n_words) ? asm_words[v0 + 1] : 0u;
                     twin = (((uint64_t)hi_t << 32) | lo_t) >> (2 * (tb0 & 15));  // eleven bases: 22 of the 34 bits that are left
                 }
-                unsigned long long kx1[11], kx2[11];  // cross-gap keys: of rows r0 + s (horizontal) or of columns tb0 + j (vertical)
+                unsigned long long kx1[IO ? 11 : 1], kx2[IO ? 11 : 1];  // cross-gap keys: of rows r0 + s (horizontal) or of columns tb0 + j (vertical)
+                if constexpr (IO) {
 #pragma unroll
-                for (int j = 0; j < 11; ++j) {
-                    kx1[j] = kx2[j] = 0ull;
-                    if (fits && cont && imp) {
-                        const int xi = imp_horizontal ? r0 + j : tb0 + j - imp_lo;
-                        if ((!imp_horizontal || j < 8) && xi >= 0 && xi < imp_len) {
-                            kx1[j] = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            kx2[j] = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int j = 0; j < 11; ++j) {
+                        kx1[j] = kx2[j] = 0ull;
+                        if (fits && cont && imp) {
+                            const int xi = imp_horizontal ? r0 + j : tb0 + j - imp_lo;
+                            if ((!imp_horizontal || j < 8) && xi >= 0 && xi < imp_len) {
+                                kx1[j] = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                kx2[j] = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
                 }
@@ -324,15 +333,14 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                     const bool row_ok = fits && m < steps8 && r >= q0 && r < r_hi;
                     const int qc = (int)((qwin >> (4 * sidx)) & 15u);
                     // left neighbour of cell 0: lane l - 1's cell 3 as the previous step left it; upper neighbour of cell 3: lane
-                    // l + 1's cell 0 of this step
-                    // (DPP moves, one vector instruction each: a shuffle through the LDS crossbar four times a step was a good part
-                    // of a step's ~9000 cycles, the rest were the exports below)
+                    // l + 1's cell 0 of this step (DPP moves, one vector instruction each)
                     int hl = __builtin_amdgcn_update_dpp(0, H[3], 0x138, 0xf, 0xf, false), el = __builtin_amdgcn_update_dpp(0, E[3], 0x138, 0xf, 0xf, false);  // wave_shr:1
                     if (l == 0) { hl = none; el = JNEG; }
                     const int oldH[4] = {H[0], H[1], H[2], H[3]}, oldF[4] = {F[0], F[1], F[2], F[3]};
                     uint32_t word = 0;
                     int hu_d = none, fu_d = JNEG;
                     unsigned long long ex1 = 0ull, ex2 = 0ull;  // a row's offers to the next piece from this lane's four cells (insertion)
+                    const bool imp_row = IO && cont && imp && r < imp_r1, exp_row = IO && exports && r >= exp_r0;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (c == 3) {  // (every lane has computed its cell 0 by now)
@@ -343,13 +351,15 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                         int code = 5;  // 0..3, 4 = N, 5 = outside the contig
                         if (row_ok && t >= cstart && t < cend) {
                             code = (int)((twin >> (2 * (sidx + c))) & 3u);
-                            if (n_runs > 0) {  // (rare: assemblies with scaffold gaps)
-                                int a2 = 0, z2 = n_runs;
-                                while (a2 < z2) {
-                                    const int mid = (a2 + z2) >> 1;
-                                    if (runs[2 * mid + 1] <= t) a2 = mid + 1; else z2 = mid;
+                            if constexpr (NR) {
+                                if (n_runs > 0) {  // (rare: assemblies with scaffold gaps)
+                                    int a2 = 0, z2 = n_runs;
+                                    while (a2 < z2) {
+                                        const int mid = (a2 + z2) >> 1;
+                                        if (runs[2 * mid + 1] <= t) a2 = mid + 1; else z2 = mid;
+                                    }
+                                    if (a2 < n_runs && runs[2 * a2] <= t) code = 4;
                                 }
-                                if (a2 < n_runs && runs[2 * a2] <= t) code = 4;
                             }
                         }
                         const bool inside = code < 5;
@@ -367,14 +377,16 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                         uint32_t tb = XT_DIAG;
                         if (e > bv) { bv = e; tb = XT_E; }
                         if (f > bv) { bv = f; tb = XT_F; }
-                        if (inside && cont && imp) {
-                            const unsigned long long k1 = imp_horizontal ? kx1[sidx] : kx1[sidx + c], k2 = imp_horizontal ? kx2[sidx] : kx2[sidx + c];
-                            const int pos = imp_horizontal ? t - imp_lo : r;  // (the exporter's frame: columns count from its band's origin)
-                            if (k1) {  // (a row / column with one key has both)
-                                const int c1 = (int)(k1 >> 32) - XBIAS - KP_GAP_OPEN - KP_GAP_EXT * pos;
-                                const int c2 = (int)(k2 >> 32) - XBIAS - KP_GAP_OPEN2 - KP_GAP_EXT2 * pos;
-                                if (c1 > bv) { bv = c1; tb = XT_X1; }
-                                if (c2 > bv) { bv = c2; tb = XT_X2; }
+                        if constexpr (IO) {
+                            if (inside && imp_row) {
+                                const unsigned long long k1 = imp_horizontal ? kx1[sidx] : kx1[sidx + c], k2 = imp_horizontal ? kx2[sidx] : kx2[sidx + c];
+                                const int pos = imp_horizontal ? t - imp_lo : r;  // (the exporter's frame: columns count from its band's origin)
+                                if (k1) {  // (a row / column with one key has both)
+                                    const int c1 = (int)(k1 >> 32) - XBIAS - KP_GAP_OPEN - KP_GAP_EXT * pos;
+                                    const int c2 = (int)(k2 >> 32) - XBIAS - KP_GAP_OPEN2 - KP_GAP_EXT2 * pos;
+                                    if (c1 > bv) { bv = c1; tb = XT_X1; }
+                                    if (c2 > bv) { bv = c2; tb = XT_X2; }
+                                }
                             }
                         }
                         const bool live = inside && bv > 0;
@@ -383,22 +395,37 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                         word |= ((live ? tb : (uint32_t)XT_RESTART) | (e_extd << 3) | (f_extd << 4)) << (8 * c);
                         if (live) {
                             if (bv > best) { best = bv; best_r = r; best_b = 4 * l + c; }
-                            if (exports && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
-                                const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
-                                const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
-                                const unsigned long long k1 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low;
-                                const unsigned long long k2 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low;
-                                if (exp_horizontal) {  // the lane's four cells lie in one row: one pair of atomics per lane and step, not
-                                    ex1 = k1 > ex1 ? k1 : ex1; ex2 = k2 > ex2 ? k2 : ex2;  // four on the same two words (what the L2 serialises)
-                                } else {
-                                    atomicMax(&exp[2 * xi], k1);
-                                    atomicMax(&exp[2 * xi + 1], k2);
+                            if constexpr (IO) {
+                                if (exp_row && (exp_horizontal ? (4 * l + c < lo_next - lo) : (lo + 4 * l + c > lo_next + W - 1))) {
+                                    const int xi = exp_horizontal ? r : t - lo, pos = exp_horizontal ? t - lo : r;
+                                    const unsigned long long low = 0xFFFFFFFFull - (unsigned)pos;
+                                    const unsigned long long k1 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT * pos + XBIAS) << 32) | low;
+                                    const unsigned long long k2 = ((unsigned long long)(unsigned)(bv + KP_GAP_EXT2 * pos + XBIAS) << 32) | low;
+                                    if (exp_horizontal) {  // the lane's four cells lie in one row: one pair of atomics per lane and step, not
+                                        ex1 = k1 > ex1 ? k1 : ex1; ex2 = k2 > ex2 ? k2 : ex2;  // four on the same two words (what the L2 serialises)
+                                    } else {
+                                        atomicMax(&exp[2 * xi], k1);
+                                        atomicMax(&exp[2 * xi + 1], k2);
+                                    }
                                 }
                             }
                         }
                     }
-                    if (ex1) { atomicMax(&exp[2 * r], ex1); atomicMax(&exp[2 * r + 1], ex2); }
+                    if constexpr (IO) {
+                        if (ex1) { atomicMax(&exp[2 * r], ex1); atomicMax(&exp[2 * r + 1], ex2); }
+                    }
                     if (fits && m < steps8) tr[(size_t)m * P + l] = word;
+                }
+            };
+            const bool nr_any = __any(n_runs > 0);
+            for (int m0 = 0; m0 < max_steps; m0 += 8) {
+                // does any lane's chunk touch a junction zone?  (its rows: q0 + m0 - l .. + 7)
+                const int ra = q0 + m0 - l, rb = ra + 7;
+                const bool io = fits && m0 < steps8 && ((cont && imp && ra < imp_r1) || (exports && rb >= exp_r0));
+                if (__any(io)) {
+                    if (nr_any) chunk(m0, std::true_type{}, std::true_type{}); else chunk(m0, std::true_type{}, std::false_type{});
+                } else {
+                    if (nr_any) chunk(m0, std::false_type{}, std::true_type{}); else chunk(m0, std::false_type{}, std::false_type{});
                 }
             }
             // END of the piece: the largest score, then the first row, then the first column

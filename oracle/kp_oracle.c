@@ -956,7 +956,7 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
                 int64_t best = (int64_t)hd + s; int tb = XT_DIAG;
                 if (e > best) { best = e; tb = XT_E; }
                 if (f > best) { best = f; tb = XT_F; }
-                if (prev) { /* cross gaps from piece k - 1 */
+                if (prev && r < (J->r1[k - 1] < qlen ? J->r1[k - 1] : qlen)) { /* cross gaps from piece k - 1: taken in rows of the junction zone */
                     const int64_t xi = prev->horizontal ? r : t - prev->xbase;
                     if (xi >= 0 && xi < prev->xlen && prev->x1[xi] != INT64_MIN) {
                         const int64_t pos = prev->horizontal ? t : r;
@@ -971,7 +971,7 @@ static void join_run(kpo_join *J, const uint8_t *q, int qlen, const uint8_t *tc,
                 if (live) {
                     X->H[AT(r, b)] = (int)best; X->tH[AT(r, b)] = (uint8_t)tb;
                     if (best > X->end_s) { X->end_s = (int)best; X->end_r = r; X->end_b = b; }
-                    if (X->x1) { /* export (cells of this piece that lie before / above the next piece's band) */
+                    if (X->x1 && r >= J->r0[k + 1]) { /* export (cells of this piece, in rows of the junction zone, that lie before / above the next piece's band) */
                         const int lo_next = J->lo[k + 1];
                         if (X->horizontal ? (b < lo_next - lo) : (lo + b > lo_next + w - 1)) {
                             const int64_t xi = X->horizontal ? r : t - X->xbase, pos = X->horizontal ? t : r;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: what the join kernels cost on the headline workload (same box, same build): none / grids / wave priority
+# round 6: what the join kernels cost on the headline workload (same box, same build): with them / without them, twice
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out; mkdir -p $OUT
 N=${1:-10000}
 run() { name=$1; shift
@@ -13,7 +13,5 @@ PY
 }
 run none KAPTIVE_AMD_SKIP_JOINS=7
 run default X=1
-run small_noprio KAPTIVE_AMD_JOIN_GRID=32,8,64,8 KAPTIVE_AMD_JOIN_PRIO=0
-run small_prio KAPTIVE_AMD_JOIN_GRID=32,8,64,8 KAPTIVE_AMD_JOIN_PRIO=1
-run big_noprio KAPTIVE_AMD_JOIN_GRID=2048,512,2560,512 KAPTIVE_AMD_JOIN_PRIO=0
 run none2 KAPTIVE_AMD_SKIP_JOINS=7
+run default2 X=1
