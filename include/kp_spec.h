@@ -212,9 +212,10 @@ KP_SPEC_FN uint32_t kp_hash30(uint32_t key) { /* minimap2 sketch.c: hash64(key, 
  * PIECES.  A chain's anchors in query order fall into pieces: a new piece starts where the diagonal differs from the anchor
  * before by more than KP_DIAG_GAP, or where the piece would come to span more than KP_MAX_SPREAD diagonals.  A chain of one
  * piece is what its cluster's band task already aligns; a chain of 2..KP_JOIN_MAX_PIECES pieces is a JOIN (more pieces: none).
- * Every piece gets a band of the same width W -- the smallest of 32, 64, 128 that holds the widest piece's diagonal range
- * widened by KP_BAND_MARGIN on both sides --, centred on its own range:  lo[k] = dmin[k] - KP_BAND_MARGIN - (W - need[k]) / 2,
- * need[k] = dmax[k] - dmin[k] + 1 + 2 KP_BAND_MARGIN.  n_anchors and chain score of the join are the chain's.
+ * Every piece gets a band of the same width W and margin M -- those of a cluster's band task for the widest piece's diagonal
+ * range: 16 diagonals and KP_BAND_MARGIN_NARROW when that holds it, otherwise the smallest of 32, 64, 128 with KP_BAND_MARGIN
+ * (kp_piece_margin / kp_piece_width below) --, centred on its own range:  lo[k] = dmin[k] - M - (W - need[k]) / 2,
+ * need[k] = dmax[k] - dmin[k] + 1 + 2 M.  n_anchors and chain score of the join are the chain's.
  *
  * JOINED FILL.  Every piece is filled as a band task (the recurrence above: local, H >= 0, restarts) over the ROWS between its
  * neighbours' anchors: piece k covers rows [R0, R1), R0 = 0 for the first piece, otherwise the query position of the LAST anchor
@@ -296,6 +297,13 @@ KP_SPEC_FN int kp_log2x2(uint32_t n) { /* 2 log2(1 + n) to the nearest integer o
     while ((m >> e) > 1u) ++e;
     const uint32_t mant = e >= 4 ? (m >> (e - 4)) & 15u : (m << (4 - e)) & 15u;
     return 2 * e + (mant >= 3u) + (mant >= 11u);
+}
+/* band of a join's pieces from the widest piece's diagonal range `spread` (largest minus smallest diagonal of its anchors): the
+ * rule of a cluster's band task -- KP_BAND_MARGIN_NARROW either side when that fits 16 diagonals, KP_BAND_MARGIN otherwise */
+KP_SPEC_FN int kp_piece_margin(int spread) { return spread + 1 + 2 * KP_BAND_MARGIN_NARROW <= 16 ? KP_BAND_MARGIN_NARROW : KP_BAND_MARGIN; }
+KP_SPEC_FN int kp_piece_width(int spread) {
+    const int need = spread + 1 + 2 * kp_piece_margin(spread);
+    return need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));
 }
 #define KP_JOIN_GROUP_MAX 16
 #define KP_JOIN_ANCHOR_MAX 4096 /* groups with more anchors than this are not chained (a gene beyond ~22 kb whose group holds them all) */

@@ -170,7 +170,9 @@ __device__ __forceinline__ void close_entry(const PendEntry &E, KpGroup &G, KpTa
     if (E.in_group) {
         entry_to_group(E, G, tasks, task_count, task_cap);
         bool any = false;  // a group needs a provisional cluster (kp_spec.h): weak clusters alone chain to nothing that is reported
-        for (int i = 0; i < G.n; ++i) any = any || G.task[i] != KP_REF_NONE;
+        uint32_t total = 0;
+        for (int i = 0; i < G.n; ++i) { any = any || G.task[i] != KP_REF_NONE; total += G.cnt[i]; }
+        G.total = total;
         if (any) {
             const uint32_t g = atomicAdd(go.count, 1u);
             if (g < go.cap) go.groups[g] = G;  // beyond cap: counted, not stored (host retries)

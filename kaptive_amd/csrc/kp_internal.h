@@ -179,6 +179,7 @@ struct KpSwEnd {
 struct KpGroup {
     int32_t asm_id, n;
     int32_t gs, contig;
+    uint32_t total;                     // anchors of all its clusters (the chaining kernels pick their groups by it)
     uint32_t task[KP_JOIN_GROUP_MAX];   // KP_TASK_REF or KP_REF_NONE
     uint32_t first[KP_JOIN_GROUP_MAX];  // first anchor
     uint32_t cnt[KP_JOIN_GROUP_MAX];    // anchors of the cluster (all of them, not the chain's)

@@ -67,10 +67,9 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
     if (prio) __builtin_amdgcn_s_setprio(3);  // one wave per group, a dependent step per anchor: latency, not throughput
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const KpGroup &G = groups[g];
-        const int n_members = G.n;
-        int n = 0;
-        for (int c = 0; c < n_members; ++c) n += (int)G.cnt[c];
+        const int n = (int)G.total;
         if (n > JA || n <= JA_BELOW || n < KP_MIN_ANCHORS) continue;  // (kp_spec.h: a group beyond JA_MAX anchors is not chained)
+        const int n_members = G.n;
         __syncthreads();  // the group before is done with the arrays
         int base = 0;
         for (int c = 0; c < n_members; ++c) {
@@ -187,11 +186,9 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
                         prev_d = d;
                     }
                     if (!over && np >= 2) {
-                        int width = 0;
-                        for (int k = 0; k < np; ++k) {
-                            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
-                            width = max(width, need <= 32 ? 32 : (need <= 64 ? 64 : 128));
-                        }
+                        int spread = 0;  // the widest piece's diagonal range sets the band of all (kp_spec.h: kp_piece_margin / kp_piece_width)
+                        for (int k = 0; k < np; ++k) spread = max(spread, dmax[k] - dmin[k]);
+                        const int margin = kp_piece_margin(spread), width = kp_piece_width(spread);
                         const int cls = class_of_width(width);
                         const uint32_t slot = atomicAdd(&join_count[cls], 1u);
                         if (slot < join_cap) {  // beyond cap: counted, not stored (host retries)
@@ -206,8 +203,8 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
                             for (int c = 0; c < KP_JOIN_GROUP_MAX; ++c) J->member_task[c] = c < n_members ? G.task[c] : KP_REF_NONE;
                             for (int k = 0; k < KP_JOIN_MAX_PIECES; ++k) {
                                 if (k < np) {
-                                    const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
-                                    J->lo[k] = dmin[k] - KP_BAND_MARGIN - (width - need) / 2;
+                                    const int need = dmax[k] - dmin[k] + 1 + 2 * margin;
+                                    J->lo[k] = dmin[k] - margin - (width - need) / 2;
                                     J->cmask[k] = cm[k];
                                 } else { J->lo[k] = 0; J->cmask[k] = 0; }
                                 J->trace_off[k] = J->export_off[k] = 0xFFFFFFFFu;

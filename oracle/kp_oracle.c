@@ -840,13 +840,13 @@ static void chain_group(const uint64_t *keys, const kpo_pcl *pcl, const int *mem
         J->n_anchors = len; J->chain_score = max_s;
         J->n_members = n_members;
         for (int c = 0; c < n_members; c++) J->member_task[c] = pcl[member[c]].task;
+        int spread = 0; /* the widest piece's diagonal range */
+        for (int k = 0; k < np; k++) if (dmax[k] - dmin[k] > spread) spread = dmax[k] - dmin[k];
+        const int margin = kp_piece_margin(spread);
+        J->width = kp_piece_width(spread);
         for (int k = 0; k < np; k++) {
-            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN, w = need <= 32 ? 32 : (need <= 64 ? 64 : 128);
-            if (w > J->width) J->width = w;
-        }
-        for (int k = 0; k < np; k++) {
-            const int need = dmax[k] - dmin[k] + 1 + 2 * KP_BAND_MARGIN;
-            J->lo[k] = dmin[k] - KP_BAND_MARGIN - (J->width - need) / 2;
+            const int need = dmax[k] - dmin[k] + 1 + 2 * margin;
+            J->lo[k] = dmin[k] - margin - (J->width - need) / 2;
             J->cmask[k] = cm[k];
         }
         J->weak_mask = kp_weak_ends(np, qlo, qhi, jump_before);
