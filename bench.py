@@ -484,8 +484,8 @@ FILL_CLOCK_HZ = 2.26e9  # GRBM_GUI_ACTIVE per XCD / kernel duration (profiles/r2
 
 def offline_pmc(args) -> dict | None:
     """PMC figures of the scan kernel cannot be read from inside the process; they come from a committed offline
-    collection of this same command (profiles/scan_pmc_r5.json) and are reported only for the workload it ran."""
-    path = ROOT / "profiles" / "scan_pmc_r5.json"
+    collection of this same command (profiles/scan_pmc_r6.json) and are reported only for the workload it ran."""
+    path = ROOT / "profiles" / "scan_pmc_r6.json"
     try:
         pmc = json.loads(path.read_text())
     except OSError:

@@ -247,7 +247,7 @@ struct KpWork {
     DevBuf<uint32_t> d_seg;     // [2 * n_asm]
     DevBuf<KpTask> d_tasks;
     DevBuf<KpSwResult> d_results;
-    DevBuf<uint8_t> d_task_drop;
+    DevBuf<uint8_t> d_task_drop, d_jscratch;
     // counting tables of the occurrence cut's quantile (kp_chain.hip: block_mid_occ): occ_slots tables of 2^occ_log2 entries
     DevBuf<uint32_t> d_occ_keys, d_occ_cnts, d_occ_state;
     uint32_t occ_slots = 0, occ_log2 = 0;  // per task slot: a chain consumed the cluster, its band task reports no hit (kp_join.hip)
@@ -290,7 +290,7 @@ struct KpWork {
     bool have_events = false;
     void release() {
         d_anchors_a.release(); d_anchors_b.release(); d_counts.release(); d_sub_counts.release(); d_cand.release();
-        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_occ_keys.release(); d_occ_cnts.release(); d_occ_state.release(); d_task_order.release();
+        d_cand_count.release(); d_seg.release(); d_tasks.release(); d_results.release(); d_task_drop.release(); d_jscratch.release(); d_occ_keys.release(); d_occ_cnts.release(); d_occ_state.release(); d_task_order.release();
         d_ends.release(); d_trace_top.release(); d_trace.release();
         d_groups.release(); d_joins.release(); d_join_counts.release();
         if (sort_temp) { (void)hipFree(sort_temp); sort_temp = nullptr; sort_temp_bytes = 0; }
@@ -1072,6 +1072,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, w->d_tasks.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_results.reserve(KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_task_drop.reserve(KP_N_CLASSES * (size_t)w->task_cap));
+    KP_HIP_CHECK(ctx, w->d_jscratch.reserve(kp_join_chain_scratch_bytes()));
     {   // a table holds every distinct minimizer of the longest assembly (2 / 11 of its bases) at a load of at most a half
         uint32_t lg = 12;
         while (((uint64_t)1 << lg) < (uint64_t)b->max_asm_bases * 2 / 5 + 1 && lg < 31) ++lg;
@@ -1131,7 +1132,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipEventRecord(w->ev_jfork, stream));
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(w->jstream, w->ev_jfork, 0));
     kp_launch_join_chain(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, w->task_cap, w->d_groups.p,
-                         w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->jstream);
+                         w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_jscratch.p, w->jstream);
     kp_launch_join_fill(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_trace.p, w->d_trace_top.p, w->trace_cap,
                         w->jstream);
     kp_launch_join_trace(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_task_drop.p,

@@ -425,8 +425,10 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void kp_chain_kernel(KpBatchView 
 // the exact counts of a block took turns, and an assembly with diverged relatives of database genes -- their anchors lie on
 // more than ten diagonals per gene, the certificate fails for thousands of genes -- ran this kernel in 0.75 ms instead of 0.13.
 // Anchors to drop become tombstones and the list is compacted at the end, which almost never happens.
+// (Eight waves a block, 33 KB of tables: four blocks a CU as two of sixteen waves were, but a block now finds room beside the
+// band fill's blocks of the passes in flight -- twelve a CU at 9 KB each leave 52 KB --: +0.6 % on the overlapped step.)
 #ifndef KP_OCC_WAVES
-#define KP_OCC_WAVES 16
+#define KP_OCC_WAVES 8
 #endif
 #ifndef KP_OCC_BINS
 #define KP_OCC_BINS 1024

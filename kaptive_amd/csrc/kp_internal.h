@@ -263,7 +263,8 @@ void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint
 // whose hit a joined path replaces get the sign of their result's score flipped.
 void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
-                          KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream);
+                          KpJoin *joins, uint32_t *join_count, uint32_t join_cap, uint8_t *scratch, hipStream_t stream);
+size_t kp_join_chain_scratch_bytes();  // `scratch`: working arrays of the chaining instance for groups beyond 1024 anchors
 void kp_launch_join_fill(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,
                          void *trace, unsigned long long *trace_top, uint64_t trace_cap_units, hipStream_t stream);
 void kp_launch_join_trace(const KpBatchView &b, const KpGenes &genes, KpJoin *joins, const uint32_t *join_count, uint32_t join_cap,

@@ -40,7 +40,8 @@ __device__ __forceinline__ int class_of_width(int w) { return w == 16 ? 0 : (w =
 // the 64 lanes sharing the earlier anchors of each, the winner by a wave reduction on (score, index) --; lane 0 backtracks
 // (mg_chain_backtrack), cuts every chain into pieces and appends a KpJoin per chain of two or more pieces.
 constexpr int JA_MAX = KP_JOIN_ANCHOR_MAX;
-constexpr int JA_SMALL = 1024;  // nearly every group (a gene of up to ~5 kb): 15 KB of LDS, ten blocks a CU; the rest take the 60 KB variant
+constexpr int JA_SMALL = 1024;  // nearly every group (a gene of up to ~5 kb): 15 KB of LDS, ten blocks a CU; the rest take the variant without LDS
+constexpr size_t JOIN_CHAIN_SCRATCH = 15 * (size_t)JA_MAX;  // bytes of device memory per block of that variant
 static_assert((JA_MAX & (JA_MAX - 1)) == 0 && JA_MAX <= 4096 && KP_K * JA_MAX < 65536, "bitonic network; 13-bit indices; 16-bit scores");
 
 __device__ __forceinline__ int ja_t(uint64_t w) { return (int)(w >> 20); }
@@ -53,12 +54,29 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
                                                           const KpTask *__restrict__ tasks, uint32_t task_cap,
                                                           const KpGroup *__restrict__ groups, const uint32_t *__restrict__ group_count,
                                                           uint32_t group_cap, KpJoin *__restrict__ joins, uint32_t *__restrict__ join_count,
-                                                          uint32_t join_cap, int prio) {
-    __shared__ uint64_t s_a[JA];
-    __shared__ uint16_t s_f[JA];   // a chain of n anchors scores at most KP_K * n
-    __shared__ uint16_t s_pm[JA];  // prefix maximum of f: the scan for predecessors stops where nothing earlier can win
-    __shared__ int16_t s_p[JA];
-    __shared__ uint8_t s_used[JA];  // 0 free, 1 member of a chain, 2 free but already tried as a chain's end
+                                                          uint32_t join_cap, int prio, uint8_t *__restrict__ scratch) {
+    // working arrays: in LDS for the groups of up to JA_SMALL anchors; the instance for the rare larger ones keeps them in
+    // device memory (a slice of `scratch` per block, L2-resident) -- 60 KB of LDS a block could not be placed on a CU beside the
+    // band fill's blocks, and the join kernels behind it then started only when that fill was over (round 6: 2.7 % of the step)
+    uint64_t *s_a;
+    uint16_t *s_f;   // a chain of n anchors scores at most KP_K * n
+    uint16_t *s_pm;  // prefix maximum of f: the scan for predecessors stops where nothing earlier can win
+    int16_t *s_p;
+    uint8_t *s_used;  // 0 free, 1 member of a chain, 2 free but already tried as a chain's end
+    if constexpr (JA_BELOW == 0) {
+        __shared__ uint64_t l_a[JA];
+        __shared__ uint16_t l_f[JA], l_pm[JA];
+        __shared__ int16_t l_p[JA];
+        __shared__ uint8_t l_used[JA];
+        s_a = l_a; s_f = l_f; s_pm = l_pm; s_p = l_p; s_used = l_used;
+    } else {
+        uint8_t *base = scratch + (size_t)blockIdx.x * JOIN_CHAIN_SCRATCH;
+        s_a = reinterpret_cast<uint64_t *>(base);
+        s_f = reinterpret_cast<uint16_t *>(base + 8 * (size_t)JA);
+        s_pm = reinterpret_cast<uint16_t *>(base + 10 * (size_t)JA);
+        s_p = reinterpret_cast<int16_t *>(base + 12 * (size_t)JA);
+        s_used = base + 14 * (size_t)JA;
+    }
     int16_t *s_chain = reinterpret_cast<int16_t *>(s_pm);  // (the backtracking no longer needs the prefix maxima)
     uint32_t n_groups = *group_count;
     if (n_groups > group_cap) n_groups = group_cap;
@@ -605,15 +623,17 @@ static const JoinLaunch &join_launch() {
 
 void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
-                          KpJoin *joins, uint32_t *join_count, uint32_t join_cap, hipStream_t stream) {
+                          KpJoin *joins, uint32_t *join_count, uint32_t join_cap, uint8_t *scratch, hipStream_t stream) {
     (void)b; (void)genes;
     if (const char *e = std::getenv("KAPTIVE_AMD_SKIP_JOINS")) if (std::atoi(e) & 1) return;  // (debugging aid: bit 0 chaining, 1 fill, 2 walk-back)
     const JoinLaunch &L = join_launch();
     hipLaunchKernelGGL((kp_join_chain_kernel<JA_SMALL, 0>), dim3(L.chain), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
-                       group_count, group_cap, joins, join_count, join_cap, L.prio);
+                       group_count, group_cap, joins, join_count, join_cap, L.prio, (uint8_t *)nullptr);
     hipLaunchKernelGGL((kp_join_chain_kernel<JA_MAX, JA_SMALL>), dim3(L.chain_large), dim3(64), 0, stream, sorted_anchors, anchor_cap, kb, tasks, task_cap, groups,
-                       group_count, group_cap, joins, join_count, join_cap, L.prio);
+                       group_count, group_cap, joins, join_count, join_cap, L.prio, scratch);
 }
+
+size_t kp_join_chain_scratch_bytes() { return (size_t)join_launch().chain_large * JOIN_CHAIN_SCRATCH; }
 
 // The join kernels need nothing of the band tasks' fill and traceback: they run beside them, on a stream of their own
 // (kp_capi.hip); the walk-back marks the band tasks whose hits a chain consumes (task_drop), which the hit compaction reads.
