@@ -389,6 +389,9 @@ int kp_fail(kp_ctx *ctx, int code, const std::string &msg) {
 }
 
 namespace {
+// measurement aid (KAPTIVE_AMD_DUMMY_LAUNCHES=n: n empty launches per alignment pass): what a kernel boundary costs the kernels
+// of the other passes in flight -- every launch begins and ends with cache maintenance on the L2s
+__global__ void kp_noop_kernel() {}
 
 // Streams of the short, low-occupancy kernels that follow an alignment pass get the highest priority the device offers:
 // when another batch's alignment pass fills the chip, their waves are scheduled as soon as any slot frees up.
@@ -1054,7 +1057,11 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     }
     if (!w->astream) KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->astream, hipStreamNonBlocking));
     if (!w->jstream) {
-        KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->jstream, hipStreamNonBlocking));
+        // (KAPTIVE_AMD_JOIN_STREAM_PRIO=1: experiment -- the join kernels' blocks need 128-176 VGPRs, a SIMD with three band-fill waves
+        // has 56 free; from a queue of the highest priority they take the place of a fill wave that retires)
+        static const bool jprio = [] { const char *e = std::getenv("KAPTIVE_AMD_JOIN_STREAM_PRIO"); return e && std::atoi(e) != 0; }();
+        if (jprio) KP_HIP_CHECK(ctx, create_priority_stream(&w->jstream));
+        else KP_HIP_CHECK(ctx, hipStreamCreateWithFlags(&w->jstream, hipStreamNonBlocking));
         KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&w->ev_jfork, hipEventDisableTiming));
         KP_HIP_CHECK(ctx, hipEventCreateWithFlags(&w->ev_jdone, hipEventDisableTiming));
     }
@@ -1124,6 +1131,10 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipEventRecord(ev[2], stream));
     kp_launch_occ_cut(b->view, ctx->d_gene_len.p, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_occ_keys.p, w->d_occ_cnts.p,
                       w->d_occ_state.p, w->d_trace_top.p + 3, w->occ_slots, w->occ_log2, stream);  // (words 1-2 of trace_top are the fill kernel's quad counters)
+    {
+        static const int n_dummy = [] { const char *e = std::getenv("KAPTIVE_AMD_DUMMY_LAUNCHES"); return e ? std::atoi(e) : 0; }();
+        for (int i = 0; i < n_dummy; ++i) hipLaunchKernelGGL(kp_noop_kernel, dim3(1), dim3(64), 0, stream);
+    }
     kp_launch_chain(b->view, w->d_anchors_a.p, w->d_counts.p, w->anchor_cap, w->key_bits, w->d_tasks.p,
                     d_task_count, w->task_cap, w->d_groups.p, w->d_join_counts.p, w->group_cap, stream);
     // kp-align v5: the chains of a group's anchors, their joined fill and walk-back need the groups and the sorted anchors only:
@@ -1133,11 +1144,16 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     KP_HIP_CHECK(ctx, hipStreamWaitEvent(w->jstream, w->ev_jfork, 0));
     kp_launch_join_chain(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, w->task_cap, w->d_groups.p,
                          w->d_join_counts.p, w->group_cap, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_jscratch.p, w->jstream);
-    kp_launch_join_fill(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_trace.p, w->d_trace_top.p, w->trace_cap,
-                        w->jstream);
-    kp_launch_join_trace(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_task_drop.p,
-                         w->jstream);
-    KP_HIP_CHECK(ctx, hipEventRecord(w->ev_jdone, w->jstream));
+    static const bool join_after_fill = [] { const char *e = std::getenv("KAPTIVE_AMD_JOIN_AFTER_FILL"); return e && std::atoi(e) != 0; }();
+    auto join_fill_and_walk = [&]() -> int {
+        kp_launch_join_fill(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->d_trace.p, w->d_trace_top.p, w->trace_cap,
+                            w->jstream);
+        kp_launch_join_trace(b->view, ctx->genes, w->d_joins.p, w->d_join_counts.p + 1, w->join_cap, w->task_cap, w->d_trace.p, w->d_task_drop.p,
+                             w->jstream);
+        KP_HIP_CHECK(ctx, hipEventRecord(w->ev_jdone, w->jstream));
+        return KP_OK;
+    };
+    if (!join_after_fill) { if (int rc = join_fill_and_walk()) return rc; }
     kp_launch_task_order(b->view, ctx->genes, w->d_anchors_a.p, w->anchor_cap, w->key_bits, w->d_tasks.p, d_task_count, w->task_cap,
                          w->d_results.p, w->d_task_order.p, w->d_task_order.p + ORDER_HEAD, stream);
     KP_HIP_CHECK(ctx, hipEventRecord(ev[3], stream));
@@ -1146,6 +1162,10 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
     kp_launch_sw(b->view, ctx->genes, w->d_tasks.p, w->d_task_order.p + KP_ORDER_COUNTS, w->task_cap, w->d_task_order.p + ORDER_HEAD,
                  w->d_ends.p, w->d_trace.p, w->d_trace_top.p, w->trace_cap, w->d_results.p, ctx->max_gene_len > KP_FILL16_MAX_GENE_LEN,
                  stream, ev[4]);
+    if (join_after_fill) {  // (experiment: the joined fill dispatched once the band fill is through, beside the traceback)
+        KP_HIP_CHECK(ctx, hipStreamWaitEvent(w->jstream, ev[4], 0));
+        if (int rc = join_fill_and_walk()) return rc;
+    }
     // ev[5]..ev[6]: what is left of the join kernels once the band tasks are through (the "sw64" slot of kp_batch_profile; the
     // last slot reads 0)
     KP_HIP_CHECK(ctx, hipEventRecord(ev[5], stream));

@@ -242,6 +242,17 @@ __global__ __launch_bounds__(64) void kp_join_chain_kernel(const uint64_t *__res
 // ---- joined fill ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned nib4(unsigned word, int i) { return (word >> (4 * i)) & 15u; }
 
+// The pieces of a join are filled one after the other by the SAME lanes of one wave: what a piece exports is read by its own
+// wave only, so the exports' atomics, the loads that import them and the fences between pieces need the scope of a work group
+// (one wave here), not of the device.  A device-scope fence is an L2 write-back and invalidate on gfx950 (`buffer_wbl2 sc1`,
+// `buffer_inv sc1`: the L2s of the eight XCDs are not coherent with each other) -- two per piece, in the middle of a band fill
+// that streams 10 GB of direction bits through those L2s: the 20 joins of a headline batch cost the step 2.2 % that way
+// (tools/experiments/join_cost_bits.sh).  The walk-back is a later kernel on the same stream.
+__device__ __forceinline__ void join_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ void join_export(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Direction byte of a cell: bits 0-2 the source of H (XT_*), bit 3 "E was extended", bit 4 "F was extended".
 enum { XT_DIAG = 0, XT_E = 1, XT_F = 2, XT_RESTART = 3, XT_X1 = 4, XT_X2 = 5 };
 
@@ -296,7 +307,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             unsigned long long *exp = reinterpret_cast<unsigned long long *>(trace + toff + t_units);
             if (fits && exports) {
                 for (int i = l; i < 2 * exp_len; i += P) exp[i] = 0ull;
-                __threadfence();
+                join_fence();
             }
             int max_steps = fits ? steps8 : 0;
 #pragma unroll
@@ -313,20 +324,39 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             // fill: no key loads, no candidates, no atomics (the kernel's 800 instructions a step were mostly those).
             const int imp_r1 = act && cont ? min(J->r1[k - 1], qlen) : 0;       // imports in rows < imp_r1
             const int exp_r0 = exports ? J->r0[k + 1] : 0x7FFFFFFF;           // exports from rows >= exp_r0
-            auto chunk = [&](const int m0, auto io_tag, auto nr_tag) {
-                constexpr bool IO = decltype(io_tag)::value, NR = decltype(nr_tag)::value;
+            // (round 6) The windows of a chunk are requested while the chunk before it computes: the headline workload has some
+            // twenty joins a batch, a few waves whose chunks each waited out a memory round trip on a device full of other
+            // passes' kernels (3.5 ms per launch, 2 % of the step).  Columns inside N runs come as an eleven-bit mask per
+            // chunk, not as a binary search of the assembly's run list per cell.
+            auto load_windows = [&](const int m0, uint64_t &qwin, uint64_t &twin) {
                 const int r0 = q0 + m0 - l;  // this lane's row at the chunk's first step
                 const int tb0 = lo + r0 + 4 * l;  // ... and the column of its cell 0 there: step s, cell c sits on tb0 + s + c
-                uint64_t qwin, twin;
-                {
-                    const int w0 = r0 >> 3, nq = (qlen + 7) >> 3;  // (arithmetic shifts: rows before the gene read as N)
-                    const uint32_t lo_w = (fits && w0 >= 0 && w0 < nq) ? qnib[w0] : 0x44444444u;
-                    const uint32_t hi_w = (fits && w0 + 1 >= 0 && w0 + 1 < nq) ? qnib[w0 + 1] : 0x44444444u;
-                    qwin = (((uint64_t)hi_w << 32) | lo_w) >> (4 * (r0 & 7));
-                    const int v0 = tb0 >> 4;
-                    const uint32_t lo_t = (fits && v0 >= 0 && v0 < asm_n_words) ? asm_words[v0] : 0u;
-                    const uint32_t hi_t = (fits && v0 + 1 >= 0 && v0 + 1 < asm_n_words) ? asm_words[v0 + 1] : 0u;
-                    twin = (((uint64_t)hi_t << 32) | lo_t) >> (2 * (tb0 & 15));  // eleven bases: 22 of the 34 bits that are left
+                const int w0 = r0 >> 3, nq = (qlen + 7) >> 3;  // (arithmetic shifts: rows before the gene read as N)
+                const uint32_t lo_w = (fits && w0 >= 0 && w0 < nq) ? qnib[w0] : 0x44444444u;
+                const uint32_t hi_w = (fits && w0 + 1 >= 0 && w0 + 1 < nq) ? qnib[w0 + 1] : 0x44444444u;
+                qwin = (((uint64_t)hi_w << 32) | lo_w) >> (4 * (r0 & 7));
+                const int v0 = tb0 >> 4;
+                const uint32_t lo_t = (fits && v0 >= 0 && v0 < asm_n_words) ? asm_words[v0] : 0u;
+                const uint32_t hi_t = (fits && v0 + 1 >= 0 && v0 + 1 < asm_n_words) ? asm_words[v0 + 1] : 0u;
+                twin = (((uint64_t)hi_t << 32) | lo_t) >> (2 * (tb0 & 15));  // eleven bases: 22 of the 34 bits that are left
+            };
+            auto chunk = [&](const int m0, const uint64_t qwin, const uint64_t twin, auto io_tag, auto nr_tag) {
+                constexpr bool IO = decltype(io_tag)::value, NR = decltype(nr_tag)::value;
+                const int r0 = q0 + m0 - l;
+                const int tb0 = lo + r0 + 4 * l;
+                uint32_t nmask = 0;  // bit j: column tb0 + j lies in an N run
+                if constexpr (NR) {
+                    if (fits && n_runs > 0) {  // (rare: assemblies with scaffold gaps)
+                        int a2 = 0, z2 = n_runs;
+                        while (a2 < z2) {  // the first run that ends beyond tb0
+                            const int mid = (a2 + z2) >> 1;
+                            if (runs[2 * mid + 1] <= tb0) a2 = mid + 1; else z2 = mid;
+                        }
+                        for (; a2 < n_runs && runs[2 * a2] < tb0 + 11; ++a2) {
+                            const int s0 = max(runs[2 * a2] - tb0, 0), e0 = min(runs[2 * a2 + 1] - tb0, 11);
+                            if (e0 > s0) nmask |= ((1u << e0) - 1u) & ~((1u << s0) - 1u);
+                        }
+                    }
                 }
                 unsigned long long kx1[IO ? 11 : 1], kx2[IO ? 11 : 1];  // cross-gap keys: of rows r0 + s (horizontal) or of columns tb0 + j (vertical)
                 if constexpr (IO) {
@@ -336,8 +366,8 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                         if (fits && cont && imp) {
                             const int xi = imp_horizontal ? r0 + j : tb0 + j - imp_lo;
                             if ((!imp_horizontal || j < 8) && xi >= 0 && xi < imp_len) {
-                                kx1[j] = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                kx2[j] = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                kx1[j] = __hip_atomic_load(&imp[2 * xi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                kx2[j] = __hip_atomic_load(&imp[2 * xi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
                     }
@@ -367,14 +397,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                         if (row_ok && t >= cstart && t < cend) {
                             code = (int)((twin >> (2 * (sidx + c))) & 3u);
                             if constexpr (NR) {
-                                if (n_runs > 0) {  // (rare: assemblies with scaffold gaps)
-                                    int a2 = 0, z2 = n_runs;
-                                    while (a2 < z2) {
-                                        const int mid = (a2 + z2) >> 1;
-                                        if (runs[2 * mid + 1] <= t) a2 = mid + 1; else z2 = mid;
-                                    }
-                                    if (a2 < n_runs && runs[2 * a2] <= t) code = 4;
-                                }
+                                if ((nmask >> (sidx + c)) & 1u) code = 4;
                             }
                         }
                         const bool inside = code < 5;
@@ -405,7 +428,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                             }
                         }
                         const bool live = inside && bv > 0;
-                        if (inside) { E[c] = e; F[c] = f; } else { E[c] = F[c] = JNEG; }
+                        E[c] = inside ? e : JNEG; F[c] = inside ? f : JNEG;
                         H[c] = live ? bv : none;
                         word |= ((live ? tb : (uint32_t)XT_RESTART) | (e_extd << 3) | (f_extd << 4)) << (8 * c);
                         if (live) {
@@ -419,28 +442,32 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                                     if (exp_horizontal) {  // the lane's four cells lie in one row: one pair of atomics per lane and step, not
                                         ex1 = k1 > ex1 ? k1 : ex1; ex2 = k2 > ex2 ? k2 : ex2;  // four on the same two words (what the L2 serialises)
                                     } else {
-                                        atomicMax(&exp[2 * xi], k1);
-                                        atomicMax(&exp[2 * xi + 1], k2);
+                                        join_export(&exp[2 * xi], k1);
+                                        join_export(&exp[2 * xi + 1], k2);
                                     }
                                 }
                             }
                         }
                     }
                     if constexpr (IO) {
-                        if (ex1) { atomicMax(&exp[2 * r], ex1); atomicMax(&exp[2 * r + 1], ex2); }
+                        if (ex1) { join_export(&exp[2 * r], ex1); join_export(&exp[2 * r + 1], ex2); }
                     }
                     if (fits && m < steps8) tr[(size_t)m * P + l] = word;
                 }
             };
             const bool nr_any = __any(n_runs > 0);
+            uint64_t q_next = 0, t_next = 0;
+            if (max_steps > 0) load_windows(0, q_next, t_next);
             for (int m0 = 0; m0 < max_steps; m0 += 8) {
+                const uint64_t qwin = q_next, twin = t_next;
+                if (m0 + 8 < max_steps) load_windows(m0 + 8, q_next, t_next);
                 // does any lane's chunk touch a junction zone?  (its rows: q0 + m0 - l .. + 7)
                 const int ra = q0 + m0 - l, rb = ra + 7;
                 const bool io = fits && m0 < steps8 && ((cont && imp && ra < imp_r1) || (exports && rb >= exp_r0));
                 if (__any(io)) {
-                    if (nr_any) chunk(m0, std::true_type{}, std::true_type{}); else chunk(m0, std::true_type{}, std::false_type{});
+                    if (nr_any) chunk(m0, qwin, twin, std::true_type{}, std::true_type{}); else chunk(m0, qwin, twin, std::true_type{}, std::false_type{});
                 } else {
-                    if (nr_any) chunk(m0, std::false_type{}, std::true_type{}); else chunk(m0, std::false_type{}, std::false_type{});
+                    if (nr_any) chunk(m0, qwin, twin, std::false_type{}, std::true_type{}); else chunk(m0, qwin, twin, std::false_type{}, std::false_type{});
                 }
             }
             // END of the piece: the largest score, then the first row, then the first column
@@ -455,7 +482,7 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
                 J->export_off[k] = fits && exports ? (uint32_t)(toff + t_units) : 0xFFFFFFFFu;
                 J->end_s[k] = fits && best_r >= 0 ? best : 0; J->end_r[k] = fits ? best_r : -1; J->end_b[k] = best_b;
             }
-            __threadfence();  // this piece's exports are in memory before the next piece reads them
+            join_fence();  // this piece's exports are in memory before the next piece reads them
             imp = fits && exports ? exp : nullptr;
             imp_horizontal = exp_horizontal; imp_len = exp_len; imp_lo = lo;
         }

@@ -281,7 +281,8 @@ __device__ __forceinline__ Result protein_pair_strips(RowBuf rb, int (*s_chunk)[
         const int j_lo = max(1, i0 - shift - k), j_hi = min(len2, i0 + 63 - shift + k);
         const int width = j_hi - j_lo + 1;
         const bool last_strip = i0 + 64 > len1;
-        __threadfence();  // the previous strip's row-buffer stores (lane 63) are visible to every lane's loads
+        __threadfence_block();  // the previous strip's row-buffer stores (lane 63) are visible to every lane's loads (one block: a
+                                // device-scope fence here is an L2 write-back and invalidate per strip, kp_join.hip)
         __syncthreads();
         for (int x = lane; x < min(width, S2_CAP); x += 64) {
             const uint8_t c = s2[j_lo - 1 + x];

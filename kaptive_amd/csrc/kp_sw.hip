@@ -599,6 +599,9 @@ constexpr uint32_t NARROW_BLOCKS_PER_CU = KP_SW_NARROW_BLOCKS_PER_CU;  // blocks
                        // the per-quad set-up spilled 17 VGPRs; round 4, same box: 46.8-47.0 k assemblies/s at 3 against 46.2-46.4 k at 4,
                        // fill alone 7.36 ms either way: the kernel is bound by vector issue, not by latency)
 #endif
+#ifndef KP_SW_LDS_PAD
+#define KP_SW_LDS_PAD 0
+#endif
 __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, KpGenes genes, const KpTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ task_count, uint32_t task_cap,
                                                    const uint32_t *__restrict__ order, KpSwEnd *__restrict__ ends,
@@ -608,6 +611,12 @@ __global__ __launch_bounds__(64, KP_SW_WAVES) void kp_sw_kernel(KpBatchView b, K
     __shared__ __attribute__((aligned(16))) uint16_t s_t[TCODE_HALVES];
     __shared__ uint32_t s_tw[TWORD_WORDS];
     __shared__ uint32_t s_spread[SPREAD_WORDS];
+#if KP_SW_LDS_PAD
+    // LDS that is never used: it limits the blocks of this kernel a CU holds (160 KB / (9 KB + pad)), so that a SIMD per CU keeps
+    // room for a wave of the kernels that run beside it -- the persistent blocks of this one give their slots up only at its end
+    __shared__ uint32_t s_pad[KP_SW_LDS_PAD / 4];
+    if (task_cap == 0xFFFFFFFFu) { s_pad[threadIdx.x] = blockIdx.x; __syncthreads(); trace_top[3] = s_pad[63 - threadIdx.x]; }  // (never)
+#endif
     for (uint32_t v = threadIdx.x; v < SPREAD_WORDS; v += 64)
         s_spread[v] = 3u * ((v & 3u) | ((v & 0xCu) << 6) | ((v & 0x30u) << 12) | ((v & 0xC0u) << 18));
     // (every use comes after the first chunk's barriers)

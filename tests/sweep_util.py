@@ -46,6 +46,9 @@ def assembly_kwargs(config: str, i: int) -> dict:
         size = 33 + (41 * i) % 448
         kind, other = ("del", "ins") if i % 8 == 3 else ("ins", "del")
         kw["mid_indels"] = ((size, kind), (size + 1, kind), (33 + (size * 7) % 448, other))
+    if i % 10 == 7:  # (round 6) events 40-100 bases from a gene's start or end and a pair that nearly cancels: weak end pieces,
+        off = (40, 70, 100)[(i // 10) % 3] * (-1 if (i // 30) % 2 else 1)  # pieces that share a diagonal (kp_spec.h, kp-align v5)
+        kw["placed_indels"] = ((("del", 45 + i % 60, off),), (("ins", 61 + i % 140, off),), (("del", 40, 200), ("ins", 50, 640)))
     return kw
 
 
