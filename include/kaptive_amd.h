@@ -230,7 +230,7 @@ KP_API int64_t kp_batch_tasks(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, i
  * int32 (score, q_start, q_end, t_start, t_end, matches, block_len).  Tasks whose best cell stays below the score
  * cut-off (KP_MIN_DP_SCORE) are not traced back: their row holds the score and zeros. */
 KP_API int64_t kp_batch_task_results(kp_ctx *ctx, kp_batch *batch, int32_t asm_index, int32_t *out7, int64_t cap);
-/* ... and the JOINS of one assembly (kp_spec.h, kp-align v4: chains of clusters across diagonal jumps of up to KP_JOIN_BW, the
+/* ... and the JOINS of one assembly (kp_spec.h, kp-align v5: chains of a group's anchors across diagonal jumps of up to KP_JOIN_BW, the
  * stand-in for minimap2's bw = 500 chaining inside rammappy's map_batch, src/kaptive/serotyping/core.py:147-155), in device
  * order, KP_JOIN_ROW_INTS x int32 each: gs, contig, n_pieces, n_anchors, chain_score, width, lo[KP_JOIN_MAX_PIECES], then per
  * piece 11 values -- state (0 nothing, 1 joined hit, 2 rejected by the drop test), mask of the pieces its path visits, cell

@@ -893,7 +893,7 @@ class Batch:
 
 
     def joins(self, asm_index: int) -> np.ndarray:
-        """The joins of one assembly (kp_spec.h, kp-align v4) as JOIN_DTYPE rows, in device order (kp_batch_joins)."""
+        """The joins of one assembly (kp_spec.h, kp-align v5) as JOIN_DTYPE rows, in device order (kp_batch_joins)."""
         n = lib().kp_batch_joins(self.ctx._h, self._h, C.c_int32(asm_index), None, C.c_int64(0))
         self.ctx._check(n, "kp_batch_joins")
         out = np.zeros(n, JOIN_DTYPE)

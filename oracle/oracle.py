@@ -218,7 +218,7 @@ class OracleDB:
         return out
 
     def joins(self, pa) -> np.ndarray:
-        """Joins of the assembly (kp_spec.h, v4), one JOIN_DTYPE row each, in the order the oracle finds them."""
+        """Joins of the assembly (kp_spec.h, v5), one JOIN_DTYPE row each, in the order the oracle finds them."""
         keep, args = self._asm_args(pa)
         n = lib().kpo_joins(*args, None, C.c_int64(0))
         out = np.zeros(n, JOIN_DTYPE)

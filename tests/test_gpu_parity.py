@@ -237,7 +237,7 @@ def test_anchor_task_hit_stages_match_oracle(ctx, small_setup, small_db):
 
 
 def _join_assemblies(db):
-    """Genes with insertions and deletions of 33-480 bases (kp_spec.h, kp-align v4): planted by the generator in whole
+    """Genes with insertions and deletions of 33-480 bases (kp_spec.h, kp-align v4, v5): planted by the generator in whole
     assemblies, and hand-made contigs for what it does not reach -- three pieces in one gene, a short piece before a long
     gap (the continuation starts below zero), both strands, an N run next to the junction, a junction at a contig end,
     two copies of the edited gene on one contig, and a tail of unrelated sequence before a chance piece."""
@@ -1251,7 +1251,7 @@ def test_config4_acinetobacter_at_full_size(oracle):
 def test_parity_sweep_at_full_size(oracle):
     """Many full-size assemblies per configuration (KAPTIVE_AMD_SWEEP of them, default 128: BASELINE configs 2/3 -- 5 Mbp, K
     and O databases -- and config 4 -- 240 loci, 4 Mbp in ~1500 contigs), with divergence from 0 to 12 %, indels, N runs,
-    second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v4), and as
+    second loci, tandem copies and insertions / deletions of 33-480 bases inside genes (joined hits, kp-align v5), and as
     many small assemblies whose locus copy carries 2-24 insertions / deletions of 1-520 bases anywhere ("storm"), and as many full-size ones on the
     background that is not iid ("paralog"): the device's hit tables equal the oracle's record for record and its report rows equal the
     host reduction's byte for byte, for every assembly and database.  The oracle runs in spawned workers; the summary of a large run is kept under profiles/."""
@@ -1489,7 +1489,7 @@ def test_genes_beyond_the_packed_score_range(oracle):
             SeqRecord("n_run", np.concatenate([pad(10), with_n, pad(10), revcomp(small[1])]).tobytes()),
             SeqRecord("tail_only", huge[25_000:].tobytes()),
             SeqRecord("head_only", np.concatenate([pad(5), revcomp(huge[:17_000])]).tobytes()),
-            # ... and with insertions / deletions beyond a band's reach: joined alignments (kp-align v4) whose pieces are tasks
+            # ... and with insertions / deletions beyond a band's reach: joined alignments (kp-align v5) whose pieces are tasks
             # of the 32-bit fill, three pieces over 20 000 rows and two over 41 000
             SeqRecord("big_joined", np.concatenate([pad(40), big[:8000], big[8200:15_000], pad(90), big[15_000:], pad(40)]).tobytes()),
             SeqRecord("huge_joined_rc", revcomp(np.concatenate([pad(40), huge[:22_000], huge[22_450:], pad(40)])).tobytes())]  # fmt: skip
