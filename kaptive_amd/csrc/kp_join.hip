@@ -298,7 +298,9 @@ __device__ __forceinline__ void join_fill_class(const KpBatchView &b, const KpGe
             const int exp_len = exports ? (exp_horizontal ? qlen : qlen + W) : 0;
             const int lo_next = exports ? J->lo[k + 1] : 0;
             // room: direction bytes (a word per lane and step) and the export array (two 64-bit keys per index)
-            const unsigned long long t_units = (unsigned long long)steps8 * P / 4, x_units = (unsigned long long)exp_len;
+            // (both multiples of eight 16-byte units: the band fill's task blocks -- same buffer, same bump counter -- count on
+            // starting on 128-byte lines, kp_sw.hip; an export array of an odd length shifted every block allocated after it)
+            const unsigned long long t_units = (unsigned long long)steps8 * P / 4, x_units = ((unsigned long long)exp_len + 7ull) & ~7ull;
             unsigned long long toff = 0;
             if (act && l == 0) toff = atomicAdd(trace_top, t_units + x_units);
             toff = ((unsigned long long)__shfl((unsigned)(toff >> 32), g * P) << 32) | __shfl((unsigned)toff, g * P);
