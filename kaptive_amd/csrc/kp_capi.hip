@@ -1087,7 +1087,7 @@ static int enqueue_align(kp_ctx *ctx, kp_batch *b, KpWork *w) {
         w->occ_slots = std::max<uint32_t>(ctx->occ_slots, 2u);
         KP_HIP_CHECK(ctx, w->d_occ_keys.reserve((size_t)w->occ_slots << lg));
         KP_HIP_CHECK(ctx, w->d_occ_cnts.reserve((size_t)w->occ_slots << lg));
-        KP_HIP_CHECK(ctx, w->d_occ_state.reserve(2 * n_asm + w->occ_slots));
+        KP_HIP_CHECK(ctx, w->d_occ_state.reserve(kp_occ_state_words(n_asm, w->occ_slots)));
     }
     KP_HIP_CHECK(ctx, w->d_task_order.reserve(ORDER_HEAD + KP_N_CLASSES * (size_t)w->task_cap));
     KP_HIP_CHECK(ctx, w->d_cand.reserve(w->cand_cap));

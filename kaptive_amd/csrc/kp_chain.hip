@@ -449,14 +449,15 @@ constexpr uint64_t OCC_TOMB = ~0ull;
 struct OccScratch {
     uint32_t *keys;       // [n_slots << log2_size] seed values, 0xFFFFFFFF = empty
     uint32_t *cnts;       // [n_slots << log2_size]
-    uint32_t *state;      // [n_asm] bit 0: a seed beyond the floor, bit 1: its own mid_occ decides; [n_asm] mid_occ; [n_slots] the table's assembly
+    uint32_t *state;      // [n_asm] bit 0: a seed beyond the floor, bit 1: its own mid_occ decides; [n_asm] mid_occ; [n_slots] the table's assembly;
+                          // [n_slots][KP_MID_OCC_HIST + 2] the quantile kernel's histogram, distinct values and blocks done (kp_occ_state_words)
     unsigned long long *demand;  // assemblies of the pass that asked for a table
     uint32_t n_slots, log2_size;
     int32_t n_asm;
 };
-constexpr int OCC_CHUNK = 512;
+constexpr int OCC_CHUNK = 256;  // (5 Mbp = 19 500 chunks for the 32 768 threads of a table's blocks: with 512 and 64 blocks a thread ran 640 steps, 1.4 ms)
 constexpr int OCC_WARM = 48 + 2 * (KP_K + KP_W);
-constexpr int OCC_PARTS = 64;
+constexpr int OCC_PARTS = 128;
 
 __global__ __launch_bounds__(256) void kp_occ_sketch_kernel(KpBatchView b, OccScratch sc) {
     const uint32_t slot = blockIdx.y;
@@ -500,10 +501,12 @@ __global__ __launch_bounds__(256) void kp_occ_sketch_kernel(KpBatchView b, OccSc
             };
             KpSketchState st;
             kp_sketch_reset(st);
+            uint32_t word = aw[from >> 4];
             for (int64_t i = from; i < to; ++i) {
+                if ((i & 15) == 0) word = aw[i >> 4];  // (one load per sixteen steps)
                 while (ri < nr && runs[2 * ri + 1] <= i) ++ri;
                 const bool is_n = ri < nr && runs[2 * ri] <= i;
-                const uint32_t code = is_n ? 4u : ((aw[i >> 4] >> (2 * (i & 15))) & 3u);
+                const uint32_t code = is_n ? 4u : ((word >> (2 * (i & 15))) & 3u);
                 kp_sketch_step(st, i, code, emit);
             }
             if (to == ce) kp_sketch_final(st, ce - 1, emit);
@@ -511,29 +514,63 @@ __global__ __launch_bounds__(256) void kp_occ_sketch_kernel(KpBatchView b, OccSc
     }
 }
 
+constexpr int OCC_QPARTS = 32;  // blocks per table in the quantile kernel
+// words per table behind the state arrays: the histogram the table's blocks add up, the number of distinct values, blocks done
+constexpr size_t OCC_QWORDS = (size_t)KP_MID_OCC_HIST + 2;
+__device__ __forceinline__ uint32_t *occ_qwords(const OccScratch &sc, uint32_t slot) {
+    return sc.state + 2 * (size_t)sc.n_asm + sc.n_slots + (size_t)slot * OCC_QWORDS;
+}
+
 __global__ __launch_bounds__(1024) void kp_occ_quantile_kernel(OccScratch sc) {
     __shared__ uint32_t s_hist[KP_MID_OCC_HIST];
-    __shared__ uint32_t s_distinct;
-    const uint32_t slot = blockIdx.x;
+    __shared__ uint32_t s_distinct, s_last;
+    const uint32_t slot = blockIdx.y;
     unsigned long long want = *sc.demand;
     if (slot >= want || slot >= sc.n_slots) return;
     const int a = (int)sc.state[2 * (size_t)sc.n_asm + slot];
     const uint32_t size = 1u << sc.log2_size;
-    const uint32_t *tk = sc.keys + ((size_t)slot << sc.log2_size), *tc = sc.cnts + ((size_t)slot << sc.log2_size);
+    const uint32_t *tc = sc.cnts + ((size_t)slot << sc.log2_size);
+    uint32_t *gq = occ_qwords(sc, slot);  // (zeroed by the block that claimed the table)
     for (int i = threadIdx.x; i < KP_MID_OCC_HIST; i += blockDim.x) s_hist[i] = 0;
-    if (threadIdx.x == 0) s_distinct = 0;
+    if (threadIdx.x == 0) { s_distinct = 0; s_last = 0; }
     __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
-        if (tk[i] == 0xFFFFFFFFu) continue;
-        const uint32_t c = tc[i];
-        atomicAdd(&s_hist[c < (uint32_t)KP_MID_OCC_HIST - 1u ? c : (uint32_t)KP_MID_OCC_HIST - 1u], 1u);
+    // (an empty slot has the count 0: the claiming block cleared both arrays.  Nearly every minimizer of an assembly occurs once
+    // or twice: those are counted in registers -- with an LDS atomic per slot a block's 1024 threads queued up at two bins, 2.0 ms
+    // a table in one block --, the counts come four to a load, and OCC_QPARTS blocks share a table: 0.1 ms.)
+    uint32_t mine = 0, n1 = 0, n2 = 0;
+    auto take = [&](uint32_t c) {
+        if (c == 0) return;
         ++mine;
+        if (c == 1) ++n1;
+        else if (c == 2) ++n2;
+        else atomicAdd(&s_hist[c < (uint32_t)KP_MID_OCC_HIST - 1u ? c : (uint32_t)KP_MID_OCC_HIST - 1u], 1u);
+    };
+    if (size >= 4) {
+        const uint4 *tc4 = reinterpret_cast<const uint4 *>(tc);  // (tables are 2^log2_size entries apart: 16-byte aligned)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < size / 4; i += gridDim.x * blockDim.x) {
+            const uint4 v = tc4[i];
+            take(v.x); take(v.y); take(v.z); take(v.w);
+        }
+    } else if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) take(tc[i]);
     }
+    if (n1) atomicAdd(&s_hist[1], n1);
+    if (n2) atomicAdd(&s_hist[2], n2);
     if (mine) atomicAdd(&s_distinct, mine);
     __syncthreads();
+    for (int i = threadIdx.x; i < KP_MID_OCC_HIST; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&gq[i], s_hist[i]);
+    if (threadIdx.x == 0 && s_distinct) atomicAdd(&gq[KP_MID_OCC_HIST], s_distinct);
+    __threadfence();  // (device scope: the table's blocks run on any XCD)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&gq[KP_MID_OCC_HIST + 1], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int i = threadIdx.x; i < KP_MID_OCC_HIST; i += blockDim.x) s_hist[i] = __hip_atomic_load(&gq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t n = s_distinct;
+        const uint32_t n = __hip_atomic_load(&gq[KP_MID_OCC_HIST], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t mid = KP_MID_OCC;
         if (n > 0) {
             uint32_t kth = (uint32_t)((1. - (double)KP_MID_OCC_FRAC) * (double)n);
@@ -717,6 +754,7 @@ __global__ __launch_bounds__(64 * OCC_WAVES) void kp_occ_cut_kernel(KpBatchView 
                 st |= 2u;
                 uint32_t *tk = sc.keys + ((size_t)slot << sc.log2_size), *tc = sc.cnts + ((size_t)slot << sc.log2_size);
                 for (uint32_t i = threadIdx.x; i < (1u << sc.log2_size); i += blockDim.x) { tk[i] = 0xFFFFFFFFu; tc[i] = 0u; }
+                for (uint32_t i = threadIdx.x; i < (uint32_t)OCC_QWORDS; i += blockDim.x) occ_qwords(sc, slot)[i] = 0u;
                 if (threadIdx.x == 0) { sc.state[2 * (size_t)sc.n_asm + slot] = (uint32_t)a; sc.state[(size_t)sc.n_asm + a] = KP_MID_OCC; }
             }
         }
@@ -925,6 +963,8 @@ void kp_launch_segments(const uint32_t *count, uint32_t cap, int n_asm, uint32_t
                        seg_end);
 }
 
+size_t kp_occ_state_words(size_t n_asm, uint32_t occ_slots) { return 2 * n_asm + occ_slots + (size_t)occ_slots * OCC_QWORDS; }
+
 void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
                        KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, uint32_t *occ_state, unsigned long long *occ_demand,
                        uint32_t occ_slots, uint32_t occ_log2_size, hipStream_t stream) {
@@ -934,7 +974,7 @@ void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *
     sc.n_asm = b.n_asm;
     hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc, 0);
     hipLaunchKernelGGL(kp_occ_sketch_kernel, dim3(OCC_PARTS, occ_slots), dim3(256), 0, stream, b, sc);
-    hipLaunchKernelGGL(kp_occ_quantile_kernel, dim3(occ_slots), dim3(1024), 0, stream, sc);
+    hipLaunchKernelGGL(kp_occ_quantile_kernel, dim3(OCC_QPARTS, occ_slots), dim3(1024), 0, stream, sc);
     hipLaunchKernelGGL(kp_occ_cut_kernel, dim3(b.n_asm), dim3(64 * OCC_WAVES), 0, stream, b, gene_len, sorted_anchors, anchor_count, cap, key_bits, sc, 1);
 }
 

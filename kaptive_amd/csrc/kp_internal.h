@@ -232,6 +232,7 @@ void kp_launch_anchor_compact(const KpBatchView &b, const uint64_t *sliced, cons
 // `occ_slots` counting tables of 2^occ_log2_size entries for the assemblies that need their quantile worked out (a gene seed
 // beyond the floor of ten); occ_state: 2 * n_asm + occ_slots words of per-assembly state; *occ_demand (zeroed by the caller) ends
 // up as how many asked.
+size_t kp_occ_state_words(size_t n_asm, uint32_t occ_slots);  // 32-bit words of the occurrence cut's `occ_state`
 void kp_launch_occ_cut(const KpBatchView &b, const int32_t *gene_len, uint64_t *sorted_anchors, uint32_t *anchor_count, uint32_t cap,
                        KpKeyBits key_bits, uint32_t *occ_keys, uint32_t *occ_cnts, uint32_t *occ_state, unsigned long long *occ_demand,
                        uint32_t occ_slots, uint32_t occ_log2_size, hipStream_t stream);
