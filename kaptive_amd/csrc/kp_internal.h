@@ -259,9 +259,9 @@ void kp_launch_sw(const KpBatchView &b, const KpGenes &genes, const KpTask *task
 void kp_launch_task_order(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t cap, KpKeyBits key_bits,
                           KpTask *tasks, const uint32_t *task_count, uint32_t task_cap, KpSwResult *results, uint32_t *hist,
                           uint32_t *order, hipStream_t stream);
-// kp_join.hip (kp-align v4): groups -> joins (one list per band class: joins[c * join_cap ..), join_count[c]); the joined fill and
-// walk-back of every join (direction bytes and exports come out of the same trace buffer as the band tasks'); band tasks
-// whose hit a joined path replaces get the sign of their result's score flipped.
+// kp_join.hip (kp-align v5): groups -> joins (one list per band class: joins[c * join_cap ..), join_count[c]); the joined fill and
+// walk-back of every join (direction bytes and exports come out of the same trace buffer as the band tasks', in multiples of
+// 128 bytes); band tasks whose clusters a chain consumes get their flag in `task_drop` (one byte per task slot and class).
 void kp_launch_join_chain(const KpBatchView &b, const KpGenes &genes, const uint64_t *sorted_anchors, uint32_t anchor_cap, KpKeyBits kb,
                           const KpTask *tasks, uint32_t task_cap, const KpGroup *groups, const uint32_t *group_count, uint32_t group_cap,
                           KpJoin *joins, uint32_t *join_count, uint32_t join_cap, uint8_t *scratch, hipStream_t stream);

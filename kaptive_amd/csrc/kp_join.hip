@@ -1,24 +1,26 @@
-// kp_join.hip -- kp-align v4: chains of clusters across diagonal jumps of up to KP_JOIN_BW, and their joined alignment.
+// kp_join.hip -- kp-align v5: chains of a group's anchors across diagonal jumps of up to KP_JOIN_BW, and their joined alignment.
 //
 // minimap2 (which the reference's aligner wraps: src/kaptive/serotyping/core.py:147-155, docs/serotyping/method.md:23-28)
 // chains anchors whose diagonals differ by up to bw = 500 and aligns through the gap, so a gene with an insertion or
 // deletion of 33-500 bases is one hit there.  The band tasks of kp_chain.hip / kp_sw.hip stop at KP_DIAG_GAP = 32 diagonals;
-// this file puts the join on top of them (include/kp_spec.h, "kp-align v4", is the specification; oracle/kp_oracle.c
-// make_joins / join_run the CPU statement):
+// this file puts the join on top of them (include/kp_spec.h, GROUPS .. CONSUMED PIECES, is the specification;
+// oracle/kp_oracle.c chain_group / make_joins / join_run the CPU statement):
 //
-//   kp_join_chain_kernel   one wave per GROUP of clusters (kp_chain.hip finds them; round 6: weak clusters are members): minimap2's
+//   kp_join_chain_kernel   one wave per GROUP of clusters (kp_chain.hip finds them; weak clusters are members): minimap2's
 //                          chaining DP over all the group's ANCHORS, the backtracking, every chain cut into pieces where its
 //                          diagonal jumps: one KpJoin per chain of two or more pieces
 //   kp_join_fill_kernel    P lanes per join (band of 4P diagonals, the mapping of kp_sw.hip's 32-bit kernel): the pieces one
-//                          after the other -- piece 0 as a local alignment, the later ones as CONTINUATIONS that only the
-//                          cross gaps from the piece before can enter; what a piece offers the next one (per row or per
-//                          column: the best H + e * position for both pieces of the gap cost) is collected with 64-bit
-//                          atomic maxima in memory, direction bytes go to the trace buffer
-//   kp_join_trace_kernel   one lane per join: walks back from the END of the last piece through the cross gaps, applies the
-//                          drop test, writes the joined hit and flips the sign of the replaced band tasks' scores
+//                          after the other, every one a local alignment over the rows between its neighbours' anchors; in
+//                          the junction zones a piece takes the cross gaps the piece before offers (per row or per column:
+//                          the best H + e * position for both pieces of the gap cost, collected with 64-bit atomic maxima
+//                          in memory); direction bytes go to the trace buffer
+//   kp_join_trace_kernel   one lane per join: the pieces in the order of their best cells, the walk back through the cross
+//                          gaps with the two-sided drop test, the joined hit; band tasks whose clusters a chain consumes get
+//                          their drop flag (task_drop: read by the hit compaction -- the band fill is writing the task
+//                          results while this runs)
 //
-// Joins are rare (a few per assembly at most on anything but constructed inputs): these kernels are written for clarity
-// in plain 32-bit arithmetic, not for the vector pipe.
+// All of it runs on a stream of its own beside the band tasks' fill and traceback (kp_capi.hip).  Plain 32-bit arithmetic:
+// some twenty joins per thousand assemblies on the headline workload, 55 per assembly on `bench.py --mix joins`.
 #include "kp_internal.h"
 #include <cstdio>
 #include <cstdlib>
