@@ -252,6 +252,27 @@ def test_occurrence_cut_follows_the_model_at_its_floor(dbs):
             assert fk == fm
 
 
+def test_occurrence_cut_follows_the_models_quantile_when_repeats_lift_it(dbs):
+    """Round 6 (kp_spec.h, OCCURRENCE CUT): an IS-like element in 40 copies lifts minimap2's mid_occ -- the 2e-4 quantile of the
+    assembly's minimizer counts -- far above its floor; a 220-base stretch of a gene in 12 more copies is then NOT cut.  The
+    oracle works the assembly's quantile out where a gene has three seeds beyond the floor: same raw hits as the model (round
+    5's floor-only rule dropped every copy's seeds: 0 of 3 such rows, profiles/concordance_r5.md)."""
+    db, odb, typer = _db(dbs, "kpsc_k", 100)
+    genome = make_assembly(db, seed=91_100, p_is=0, p_stop=0, is_copies=(40, 1200), repeat_segment=(220, 12))
+    packed = genome.packed()
+    index = mm2.Mm2Index.from_contigs(genome.contigs)
+    assert index.mid_occ > 20
+    hk, hm = odb.align(packed), index.map(db.genes)
+    sk, sm = {_span(h) for h in hk}, {_span(h) for h in hm}
+    assert len(sk ^ sm) <= 4, (len(sk - sm), len(sm - sk))
+    plain = len(odb.align(make_assembly(db, seed=91_100, p_is=0, p_stop=0, is_copies=(40, 1200)).packed()))
+    assert len(hk) > plain + 200, (len(hk), plain)  # the copies are reported (measured: 1659 hits against 1220 without them)
+    rk = typer.reduce(genome, hits_to_alignments(db, genome, hk))
+    rm = typer.reduce(genome, hits_to_alignments(db, genome, hm))
+    for field in ("best_locus_name", "phenotype", "typeable"):
+        assert getattr(rk, field) == getattr(rm, field), field
+
+
 # ---- seeds: the oracle's state machine against the model's mm_sketch -----------------------------------------------------------
 _CODE = np.full(256, 4, np.uint8)
 for _i, _c in enumerate(b"ACGT"):
